@@ -1,0 +1,446 @@
+"""numpy restatement of the reference's util/ hot path -- TEST INFRASTRUCTURE ONLY.
+
+This module is the *checker* for the HIP product path.  Nothing under
+``pyaudiorestoration_amd/`` may import it; only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg do.
+
+Parity status: PINNED.  Every function below is checked in
+``tests/test_oracle_golden.py`` against golden vectors captured by importing the
+real reference (``oracle/gen_golden.py``, run in the build container where
+``/root/reference`` exists; numpy 2.2.6 + scipy 1.15.3 are the de-facto pin of the
+reference's un-versioned third-party arithmetic).
+
+Each function cites the reference lines it restates (paths relative to the
+reference checkout).  Third-party arithmetic the reference itself delegates to
+(``numpy.fft``, ``scipy.signal.get_window/butter/sosfiltfilt/correlate``,
+``scipy.interpolate.interp1d``) is called directly here as well: it is the same
+dependency, not reference code.
+"""
+import numpy as np
+import scipy.signal
+import scipy.interpolate
+
+
+# --------------------------------------------------------------------------- STFT
+
+def frame_count(n, n_fft, hop):
+    """S1  util/fourier.py:78-82 -- frames of a reflect-padded signal (integer exact)."""
+    return (n + 2 * (n_fft // 2) - n_fft) // hop + 1
+
+
+def stft(x, n_fft=1024, step=512, window_name="blackmanharris", zeropad=1):
+    """S0-S3  util/fourier.py:37-75 with the numpy backend :136-157.
+
+    reflect-pad n_fft//2, frame i = window * xpad[i*step : i*step+n_fft], zero
+    extension at the END up to n_fft*zeropad, rfft in float32 (pocketfft), then a
+    float64 division by sqrt(n_fft) (so: complex128 container, c64-precision values).
+    """
+    n_fft = int(n_fft)
+    step = max(n_fft // 2, 1) if step is None else int(step)
+    x = np.asarray(x)
+    if x.ndim != 1:
+        raise ValueError("x must be 1D")
+    win = scipy.signal.get_window(window_name, n_fft).astype(np.float32)
+    xp = np.pad(x, n_fft // 2, mode="reflect")
+    n_frames = (len(xp) - n_fft) // step + 1
+    idx = np.arange(n_frames)[:, None] * step + np.arange(n_fft)[None, :]
+    frames = (win[None, :] * xp[idx]).astype(np.float32)
+    spec = np.fft.rfft(frames, n=n_fft * zeropad, axis=1).T
+    return spec / np.sqrt(n_fft)
+
+
+def to_mag(spec):
+    """S4  util/fourier.py:23-24."""
+    return np.abs(spec) + 0.0000001
+
+
+def get_mag(*a, **k):
+    """S4  util/fourier.py:27-29."""
+    return to_mag(stft(*a, **k))
+
+
+def fft_freqs(n_fft, fs):
+    """S5  util/fourier.py:690-700."""
+    return np.arange(0, n_fft // 2 + 1) / float(n_fft) * float(fs)
+
+
+def fix_length(data, size):
+    """S5  util/fourier.py:440-478 (1-D / leading-axis use only)."""
+    data = np.asarray(data)
+    n = data.shape[0]
+    if n > size:
+        return data[:size]
+    if n < size:
+        pad = [(0, size - n)] + [(0, 0)] * (data.ndim - 1)
+        return np.pad(data, pad, mode="constant")
+    return data
+
+
+def window_sumsquare(window_name, n_frames, hop_length, n_fft, dtype=np.float64):
+    """util/fourier.py:481-546 (win_length == n_fft, norm=None)."""
+    n = n_fft + hop_length * (n_frames - 1)
+    env = np.zeros(n, dtype=dtype)
+    wsq = scipy.signal.get_window(window_name, n_fft) ** 2
+    for f in range(n_frames):
+        s = f * hop_length
+        env[s:min(n, s + n_fft)] += wsq[:max(0, min(n_fft, n - s))]
+    return env
+
+
+def istft(stft_matrix, hop_length=None, window_name="blackmanharris", length=None):
+    """S6  util/fourier.py:314-437 (center=True, win_length=n_fft).
+
+    Unlike the reference this does NOT mutate its argument (quirk 9); the
+    denormalisation by sqrt(n_fft) is applied to a copy.
+    """
+    S = np.array(stft_matrix) * 1  # copy
+    n_fft = 2 * (S.shape[0] - 1)
+    S = S * np.sqrt(n_fft)
+    if hop_length is None:
+        hop_length = n_fft // 4
+    win = scipy.signal.get_window(window_name, n_fft, fftbins=True)
+    if length:
+        n_frames = min(S.shape[1], int(np.ceil((length + n_fft) / hop_length)))
+    else:
+        n_frames = S.shape[1]
+    real_dtype = np.float32 if S.dtype == np.complex64 else np.float64
+    y = np.zeros(n_fft + hop_length * (n_frames - 1), dtype=real_dtype)
+    frames = win[:, None] * np.fft.irfft(S[:, :n_frames], axis=0)
+    for f in range(n_frames):
+        y[f * hop_length:f * hop_length + n_fft] += frames[:, f]
+    env = window_sumsquare(window_name, n_frames, hop_length, n_fft, dtype=real_dtype)
+    nz = env > np.finfo(env.dtype).tiny
+    y[nz] /= env[nz]
+    if length is None:
+        return y[n_fft // 2:-(n_fft // 2)]
+    return fix_length(y[n_fft // 2:], length)
+
+
+# --------------------------------------------------------------------- resampling
+
+def speed_to_pos(sampletimes, speeds, num_input_samples):
+    """R1  util/resampling.py:93-137.
+
+    Returns the *written prefix* (quirk 2): when no segment straddles
+    ``num_input_samples`` the reference returns a buffer whose tail is
+    uninitialised memory; the defined result is the first sum(n_i) entries.
+    The second return value says whether the trim branch fired.
+    """
+    sampletimes = np.asarray(sampletimes, dtype=np.float64)
+    speeds = np.asarray(speeds, dtype=np.float64)
+    periods = np.diff(sampletimes)
+    err = 0.0
+    offset = sampletimes[0]
+    cap = int(np.mean(speeds) * (sampletimes[-1] - sampletimes[0]) * 1.01)
+    out = np.empty(cap)
+    w = 0
+    for i in range(len(speeds) - 1):
+        want = periods[i] * np.mean(speeds[i:i + 2]) + err
+        n = int(round(want))
+        err = want - n
+        ramp = np.arange(n) / (n - 1) * (speeds[i + 1] - speeds[i]) + speeds[i]
+        seg = np.cumsum(1 / ramp) + offset
+        offset = seg[-1]
+        out[w:w + n] = seg
+        if out[w] <= num_input_samples <= out[w + n - 1]:
+            end = w + int(np.argmin(np.abs(seg - num_input_samples)))
+            return out[:end].copy(), True
+        w += n
+    return out[:w].copy(), False
+
+
+def sinc_resample(sample_at, signal, NT, chunk=1 << 15):
+    """R2+R3  util/resampling.py:21-27, 51-90 (sinc_wrapper -> sinc_core), vectorised.
+
+    Canonical delta definition (quirk 3): period_to[i] = max(1e-12, p[i+1]-p[i])
+    for every i but the last, which reuses the previous one -- exactly what the
+    single-threaded ``sinc_wrapper`` does.  Tap k of output i multiplies
+    ``signal[lower+k]`` (quirk 1: bug-compatible leading edge).  All math float64,
+    result cast to float32.
+    """
+    p = np.asarray(sample_at, dtype=np.float64)
+    sig = np.asarray(signal)
+    len_in = len(sig)
+    n_out = len(p)
+    if n_out < 2:
+        raise ValueError("reference raises UnboundLocalError for len_out < 2")
+    N = np.arange(-NT, NT + 1, dtype=np.float32)[:2 * NT].astype(np.float64)
+    win = np.hanning(2 * NT + 1).astype(np.float32)[:2 * NT].astype(np.float64)
+    dp = np.empty(n_out)
+    dp[:-1] = np.maximum(1e-12, p[1:] - p[:-1])
+    dp[-1] = dp[-2]
+    fc = np.minimum(1.0 / dp, 1.0)
+    out = np.empty(n_out, dtype=np.float32)
+    k = np.arange(2 * NT)
+    for a in range(0, n_out, chunk):
+        b = min(n_out, a + chunk)
+        pc = p[a:b]
+        ind = np.rint(pc).astype(np.int64)
+        lower = np.maximum(0, ind - NT)
+        upper = np.minimum(ind + NT, len_in)
+        shift = pc - ind
+        idx = lower[:, None] + k[None, :]
+        live = idx < upper[:, None]
+        taps = np.where(live, sig[np.minimum(idx, len_in - 1)].astype(np.float64), 0.0)
+        w = np.sinc((N[None, :] - shift[:, None]) * fc[a:b, None]) * fc[a:b, None]
+        out[a:b] = np.sum(taps * w * win[None, :], axis=1)
+    return out
+
+
+def linear_resample(sample_at, signal):
+    """R4 'Linear' mode  util/resampling.py:229."""
+    return np.interp(sample_at, np.arange(len(signal)), signal, left=0.0, right=0.0).astype(np.float32)
+
+
+def lag_to_positions(lag_curve, sr, len_signal):
+    """R4 lag-curve branch  util/resampling.py:189-206."""
+    sampletimes = lag_curve[:, 0] * sr
+    lags = lag_curve[:, 1] * sr
+    num_out = len_signal + abs(lags[-1])
+    pos = np.interp(np.arange(num_out), sampletimes, sampletimes - lags)
+    hit = np.nonzero(pos >= len_signal)[0]
+    if len(hit):
+        pos = pos[:hit[0]]
+    return np.clip(pos, 0, None)
+
+
+# ------------------------------------------------------------ correlation / filters
+
+def parabolic(f, x):
+    """X1  util/correlation.py:42-46."""
+    xv = 1 / 2. * (f[x - 1] - f[x + 1]) / (f[x - 1] - 2 * f[x] + f[x + 1]) + x
+    yv = f[x] - 1 / 4. * (f[x - 1] - f[x + 1]) * (xv - x)
+    return xv, yv
+
+
+def xcorr(a, b, mode="full"):
+    """X2  util/correlation.py:6-13."""
+    a = a / np.linalg.norm(a)
+    b = b / np.linalg.norm(b)
+    return scipy.signal.correlate(a, b, mode=mode, method="auto")
+
+
+def find_delay(a, b, ignore_phase=False, window_name=None):
+    """X2  util/correlation.py:16-39 (does not mutate a/b)."""
+    a = np.array(a, dtype=np.float64)
+    b = np.array(b, dtype=np.float64)
+    if window_name:
+        a = a * scipy.signal.get_window(window_name, len(a))
+        b = b * scipy.signal.get_window(window_name, len(b))
+    res = xcorr(a, b, mode="same")
+    peak = np.argmax(np.abs(res)) if ignore_phase else np.argmax(res)
+    i_peak, corr = parabolic(res, peak)
+    return i_peak - len(res) // 2, corr
+
+
+def butter_bandpass_filter(data, lowcut, highcut, fs, order=5):
+    """F1  util/filters.py:7-24."""
+    nyq = 0.5 * fs
+    low, high = lowcut / nyq, highcut / nyq
+    lo_ok, hi_ok = 0 < low < 1, 0 < high < 1
+    if lo_ok and hi_ok:
+        sos = scipy.signal.butter(order, [low, high], btype="band", output="sos")
+    elif lo_ok:
+        sos = scipy.signal.butter(order, low, btype="high", output="sos")
+    elif hi_ok:
+        sos = scipy.signal.butter(order, high, btype="low", output="sos")
+    else:
+        return data
+    return scipy.signal.sosfiltfilt(sos, data)
+
+
+def moving_average(a, n=3):
+    """F2  util/filters.py:27-30."""
+    c = np.cumsum(a, dtype=float)
+    c[n:] = c[n:] - c[:-n]
+    return c[n - 1:] / n
+
+
+# ------------------------------------------------------------------------ trackers
+
+def _interp_nans(y):
+    """util/wow_detection.py:14-22."""
+    bad = np.isnan(y)
+    if bad.any():
+        y[bad] = np.interp(bad.nonzero()[0], (~bad).nonzero()[0], y[~bad])
+
+
+class _TrackGeometry:
+    """W1  util/wow_detection.py:28-117 -- trail sampling and band -> bin arithmetic."""
+
+    def __init__(self, spectrum, trail, fft_size, hop, sr, tolerance_st):
+        self.spectrum = spectrum
+        self.fft_size, self.hop, self.sr = fft_size, hop, sr
+        self.num_bins, n_frames = spectrum.shape
+        trail = sorted(trail, key=lambda t: t[0])
+        t_raw = [t[0] for t in trail]
+        f_raw = [t[1] for t in trail]
+        self.frame_0, self.frame_1 = 0, n_frames
+        if t_raw[0]:
+            self.frame_0 = max(self.frame_0, int(t_raw[0] * sr / hop))
+        if t_raw[-1]:
+            self.frame_1 = min(self.frame_1, int(t_raw[-1] * sr / hop))
+        self.times = np.linspace(self.frame_0 * hop / sr, self.frame_1 * hop / sr,
+                                 self.frame_1 - self.frame_0)
+        self.freqs = np.interp(self.times, t_raw, f_raw)
+        self.tol = tolerance_st / 12
+        self.NL = self.NU = 0
+
+    def f2b(self, f):
+        return max(1, min(self.num_bins - 1, int(round(f * self.fft_size / self.sr))))
+
+    def band(self, freq, tol=None):
+        tol = self.tol if tol is None else tol
+        lf = np.log2(freq)
+        return np.power(2, lf - tol), np.power(2, lf + tol)
+
+    def limits(self, fL, fU):
+        fL = max(1.0, fL)
+        fU = min(self.sr / 2, fU)
+        self.NL, self.NU = self.f2b(fL), self.f2b(fU)
+        while self.NU - self.NL < 4:
+            self.NL -= 1
+            self.NU += 1
+
+    def peak(self, i):
+        """util/wow_detection.py:119-139 (allow_window is never True in shipped code)."""
+        col = self.spectrum[:, self.frame_0 + i]
+        b = self.NL + int(np.argmax(col[self.NL:self.NU]))
+        if col[b - 1] < col[b] > col[b + 1]:
+            b, _ = parabolic(col, b)
+        return b / self.fft_size * self.sr
+
+
+def track_peak(spectrum, trail, fft_size, hop, sr, tolerance_st=1):
+    """W2 PeakTracker  util/wow_detection.py:294-304."""
+    g = _TrackGeometry(spectrum, trail, fft_size, hop, sr, tolerance_st)
+    for i in range(len(g.freqs)):
+        g.limits(*g.band(g.freqs[i]))
+        g.freqs[i] = g.peak(i)
+    _interp_nans(g.freqs)
+    return g.times, g.freqs
+
+
+def track_peak_track(spectrum, trail, fft_size, hop, sr, tolerance_st=1):
+    """W2 PeakTrackTracker  util/wow_detection.py:307-327 (band stays on freqs[0];
+    tolerance halves from the 4th frame on)."""
+    g = _TrackGeometry(spectrum, trail, fft_size, hop, sr, tolerance_st)
+    f0 = g.freqs[0]
+    for i in range(len(g.freqs)):
+        g.limits(*g.band(f0, g.tol / 2 if i > 2 else g.tol))
+        g.freqs[i] = g.peak(i)
+    _interp_nans(g.freqs)
+    return g.times, g.freqs
+
+
+def track_cog(spectrum, trail, fft_size, hop, sr, tolerance_st=1):
+    """W2 CenterOfGravity  util/wow_detection.py:256-291."""
+    g = _TrackGeometry(spectrum, trail, fft_size, hop, sr, tolerance_st)
+    ff = fft_freqs(fft_size, sr)
+    g.limits(*g.band(g.freqs[0]))
+    for i in range(len(g.freqs)):
+        w = np.hanning(g.NU - g.NL) * spectrum[g.NL:g.NU, g.frame_0 + i]
+        g.freqs[i] = 2 ** (np.sum(w * np.log2(ff[g.NL:g.NU])) / np.sum(w))
+        g.limits(*g.band(g.freqs[i]))
+    _interp_nans(g.freqs)
+    return g.times, g.freqs
+
+
+def track_freehand(spectrum, trail, fft_size, hop, sr, tolerance_st=1):
+    """W2 FreehandTracker  util/wow_detection.py:390-394."""
+    g = _TrackGeometry(spectrum, trail, fft_size, hop, sr, tolerance_st)
+    return g.times, g.freqs
+
+
+def zero_crossings(a):
+    """util/wow_detection.py:448-450."""
+    pos = a > 0
+    return np.where(np.bitwise_xor(pos[1:], pos[:-1]))[0]
+
+
+def track_zero_crossing(spectrum, signal, trail, fft_size, hop, sr, tolerance_st=1):
+    """W3 ZeroCrossingTracker  util/wow_detection.py:330-358 (signal is (n, ch))."""
+    g = _TrackGeometry(spectrum, trail, fft_size, hop, sr, tolerance_st)
+    fL, _ = g.band(np.min(g.freqs))
+    _, fU = g.band(np.max(g.freqs))
+    s0, s1 = int(g.times[0] * sr), int(g.times[-1] * sr)
+    filt = butter_bandpass_filter(signal[s0:s1, 0], fL, fU, sr, order=3)
+    cr = zero_crossings(filt)
+    d = np.diff(cr).astype(np.float32)
+    size = int(sr / 100 / np.mean(d))
+    padded = np.pad(d, size, mode="reflect")
+    w = scipy.signal.get_window("hann", size)
+    dc = np.convolve(padded, w / size * 2, mode="same")[size:-size]
+    g.freqs[:] = np.interp(g.times, cr[:len(dc)] / sr + g.times[0], sr / 2 / dc)
+    _interp_nans(g.freqs)
+    return g.times, g.freqs
+
+
+def track_correlation(spectrum, trail, fft_size, hop, sr, tolerance_st=1):
+    """W4 CorrelationTracker  util/wow_detection.py:396-436 (reads columns 0.. -- the
+    reference ignores frame_0 here, quirk kept)."""
+    g = _TrackGeometry(spectrum, trail, fft_size, hop, sr, tolerance_st)
+    ff = fft_freqs(fft_size, sr)
+    fL, fU = min(g.freqs), max(g.freqs)
+    g.limits(fL, fU)
+    ns = (g.NU - g.NL) * 4
+    lf = np.log2(ff[g.NL:g.NU])
+    grid = np.linspace(lf[0], lf[-1], ns)
+    nf = len(g.freqs)
+    res = np.ones((ns, nf + 1))
+    for i in range(nf):
+        res[:, i] = scipy.interpolate.interp1d(lf, spectrum[g.NL:g.NU, i], kind="quadratic")(grid)
+    wind = np.hanning(ns)
+    changes = np.ones(nf)
+    for i in range(nf):
+        r = xcorr(res[:, i] * wind, res[:, i + 1] * wind, mode="same")
+        ip, _ = parabolic(r, int(np.argmax(r)))
+        changes[i] = (ns // 2) - ip
+    speed = np.cumsum(changes) / ns * (lf[-1] - lf[0])
+    g.freqs[:] = np.power(2, np.log2((fL + fU) / 2) + speed)
+    _interp_nans(g.freqs)
+    return g.times, g.freqs
+
+
+TRACKERS = {
+    "Peak": track_peak,
+    "Peak Track": track_peak_track,
+    "Center of Gravity": track_cog,
+    "Freehand Draw": track_freehand,
+    "Correlation": track_correlation,
+}
+
+
+# ------------------------------------------------- P0: headless pyrespeeder data flow
+
+def trace_to_speed(freqs):
+    """util/markers.py:197-199 (TraceLine, offset 0): log2 speed centred on 0."""
+    s = np.log2(freqs)
+    return s - np.mean(s)
+
+
+def master_speed_curve(lines, duration, sr, hop, bands=(0, 20)):
+    """P0  util/markers.py:585-639 (MasterSpeedLine.update + get_linspace).
+
+    ``lines`` is a list of (times, log2speed).  Returns the (num, 2) array
+    [[t_seconds, linear speed], ...] handed to resampling.run.
+    Note out[] is float32 inside sample_lines (util/markers.py:609).
+    """
+    marker_sr = sr / hop
+    num = int(duration * marker_sr)
+    times = np.linspace(0, duration, num=num)
+    cols = np.zeros((len(times), len(lines)), dtype=np.float32)
+    for i, (lt, lv) in enumerate(lines):
+        cols[:, i] = np.interp(times, lt, lv, left=np.nan, right=np.nan)
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mean = np.nanmean(cols, axis=1)
+    _interp_nans(mean)
+    lo, hi = sorted(bands)
+    filt = butter_bandpass_filter(mean, lo, hi, marker_sr, order=3)
+    data = np.stack((times, filt), axis=-1)
+    out = np.array(data)
+    np.power(2, out[:, 1], out[:, 1])
+    return out

@@ -1,0 +1,179 @@
+"""Pins oracle/oracle_np.py (the CPU restatement) to golden vectors captured from the
+real reference by oracle/gen_golden.py.  CPU-only."""
+import numpy as np
+import pytest
+
+import inputs
+from oracle import oracle_np as O
+
+
+def relerr(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+STFT_CASES = ["kat1", "bh", "small_vec", "odd_len", "zp2", "zp2_big", "n2048", "n64", "n4096", "hop_eq", "hop_odd"]
+
+
+@pytest.mark.parametrize("name", STFT_CASES)
+def test_stft(golden, name):
+    g = golden["stft"]
+    n, seed, n_fft, hop, zp = (int(v) for v in g[name + "_cfg"])
+    x = inputs.noise(n, seed)
+    assert inputs.checksum(x) == float(g[name + "_insum"])
+    S = O.stft(x, n_fft, hop, str(g[name + "_win"]), zp)
+    assert S.shape == g[name + "_S"].shape == (n_fft * zp // 2 + 1, O.frame_count(n, n_fft, hop))
+    assert relerr(S, g[name + "_S"]) < 2e-6
+    assert abs(np.abs(S).sum() - float(g[name + "_sum_abs"])) < 1e-5 * float(g[name + "_sum_abs"])
+
+
+def test_stft_kat_values(golden):
+    """SURVEY 8c KAT1/KAT2 literal values."""
+    x = inputs.noise(4096, 0)
+    S = O.stft(x, 1024, 256, "hann", 1)
+    assert abs(S[0, 0] - (-0.19117718935012817)) < 1e-6
+    assert abs(S[100, 8] - (-0.9019840955734253 - 0.008981410413980484j)) < 1e-6
+    assert abs(np.abs(S).sum() - 4672.315581462234) < 1e-2
+    m = O.get_mag(x, 1024, 256, "blackmanharris", 1)
+    assert abs(m[5, 3] - 0.44975326198697824) < 1e-6
+    assert relerr(m, golden["stft"]["kat2_mag"]) < 2e-6
+
+
+def test_stft_strided(golden):
+    st = np.stack((inputs.noise(3000, 10), inputs.noise(3000, 11)), axis=-1)
+    assert relerr(O.stft(st[:, 1], 512, 128, "blackmanharris", 1), golden["stft"]["strided_S"]) < 2e-6
+
+
+@pytest.mark.parametrize("name", ["rt512", "rt1024", "rt256"])
+def test_istft(golden, name):
+    g = golden["istft"]
+    n, seed, n_fft, hop = (int(v) for v in g[name + "_cfg"])
+    x = inputs.noise(n, seed)
+    S = O.stft(x, n_fft, hop)
+    S2 = S.copy()
+    S2[5:40, 3:9] *= 0.25
+    assert relerr(O.istft(S, hop_length=hop, length=n), g[name + "_y"]) < 2e-6
+    assert relerr(O.istft(S2, hop_length=hop, length=n), g[name + "_ymod"]) < 2e-6
+    assert relerr(O.istft(S, hop_length=hop), g[name + "_ynolen"]) < 2e-6
+    assert relerr(O.istft(S, hop_length=hop, length=n), x) < 1e-5     # round trip
+
+
+def test_istft_heal_framing(golden):
+    g = golden["istft"]
+    x = inputs.noise(5000, 15)
+    S = O.stft(O.fix_length(x, len(x) + 256), 512, 32)
+    assert tuple(g["heal_shape"]) == S.shape
+    assert relerr(O.istft(S, hop_length=32, length=len(x)), g["heal_y"]) < 2e-6
+
+
+def test_speed_to_pos(golden):
+    g = golden["speed_to_pos"]
+    n = 8192
+    st = np.linspace(0, n, 33)
+    sp = 1 + 0.01 * np.sin(2 * np.pi * np.arange(33) / 16 + 0.7)
+    pos, trimmed = O.speed_to_pos(st, sp, n)
+    assert trimmed and len(pos) == 8191
+    assert np.array_equal(pos, g["kat3_pos"])                      # bit-exact float64
+    assert abs(pos[4000] - 4001.554017502851) < 1e-9 and abs(pos[-1] - 8191.0160396801675) < 1e-9
+    pos, _ = O.speed_to_pos(np.array((0.0, 20000.0)), np.array((0.5, 2.0)), 20000)
+    assert np.array_equal(pos, g["ramp_pos"])
+    sc = inputs.bench_speed_curve(2.0, 48000)
+    pos, _ = O.speed_to_pos(sc[:, 0] * 48000, sc[:, 1], 96000)
+    assert np.array_equal(pos, g["bench_pos"])
+    pos, _ = O.speed_to_pos(g["wobble_st"], g["wobble_sp"], 30000)
+    assert np.array_equal(pos, g["wobble_pos"])
+    pos, trimmed = O.speed_to_pos(g["untrimmed_st"], g["untrimmed_sp"], 10000)
+    assert not trimmed and len(pos) < int(g["untrimmed_buflen"])
+    assert np.array_equal(pos, g["untrimmed_pos"])
+
+
+def test_sinc(golden):
+    g = golden["sinc"]
+    gp = golden["speed_to_pos"]
+    tol = 3e-7      # f32 output; summation order differs (np.sum pairwise vs axis-sum)
+    y = O.sinc_resample(gp["kat3_pos"], inputs.sine(8192, 440, 44100), 32)
+    assert relerr(y, g["kat4_y"]) < tol
+    assert abs(float(y.sum(dtype=np.float64)) - 24.03584675192542) < 1e-3
+    sig = inputs.noise(600, 30)
+    y = O.sinc_resample(np.arange(600, dtype=np.float64), sig, 8)
+    assert relerr(y, g["ident_y"]) < tol
+    assert np.all(np.abs(y[8:] - sig[8:]) < 1e-6) and np.any(np.abs(y[:8] - sig[:8]) > 1e-3)   # quirk 1
+    sig = (inputs.sine(20000, 440, 44100, 0.5) + inputs.sine(20000, 21000, 44100, 0.1)).astype(np.float32)
+    assert relerr(O.sinc_resample(gp["ramp_pos"], sig, 50), g["ramp_y"]) < tol
+    bsig = inputs.bench_signal(0, 96000, 48000)
+    yb = O.sinc_resample(gp["bench_pos"], bsig, 32)
+    assert relerr(yb, g["bench_y"]) < tol
+    assert relerr(yb, g["bench_y_mt"]) < 1e-6           # the reference's own mt == single invariant
+    assert relerr(O.sinc_resample(g["tail_pos"], inputs.noise(1000, 31), 16), g["tail_y"]) < tol
+    sig = inputs.noise(3000, 32)
+    pos = np.cumsum(np.full(2500, 1.013)) - 0.4
+    assert relerr(O.sinc_resample(pos, sig, 1), g["nt1_y"]) < tol
+    assert relerr(O.sinc_resample(pos, sig, 100), g["nt100_y"]) < tol
+    assert relerr(O.sinc_resample(g["down_pos"], sig, 24), g["down_y"]) < tol
+
+
+def test_filters(golden):
+    g = golden["filters"]
+    x = inputs.noise(4096, 0).astype(np.float64)
+    assert np.allclose(O.butter_bandpass_filter(x, 1000, 4000, 44100, order=3), g["band"], rtol=0, atol=1e-12)
+    assert abs(g["band"][100] - (-0.16118795506647626)) < 1e-12          # KAT5
+    assert np.allclose(O.butter_bandpass_filter(x, 0, 20, 172.265625, order=3), g["low"], rtol=0, atol=1e-12)
+    assert abs(g["low"][100] - (-0.24571490040224575)) < 1e-12           # KAT6
+    assert np.allclose(O.butter_bandpass_filter(x, 300, 0, 44100, order=3), g["high"], rtol=0, atol=1e-12)
+    assert np.allclose(O.butter_bandpass_filter(x, 500, 2000, 44100), g["band5"], rtol=0, atol=1e-12)
+    assert bool(g["pass_is_identity"]) and O.butter_bandpass_filter(x, 0, 0, 44100) is x
+    assert np.allclose(O.moving_average(x[:100], 5), g["mavg"])
+
+
+def test_correlation(golden):
+    g = golden["correlation"]
+    assert O.parabolic([1, 3, 2], 1) == (1.1666666666666667, 3.0416666666666665) == tuple(g["parabolic"])   # KAT7
+    aa = np.sin(np.arange(521) * 1.0)
+    bb = np.sin(np.arange(521) * 1.0 + 3)
+    assert np.allclose(O.find_delay(aa, bb, window_name="hann"), g["find_delay"])
+    assert np.allclose(O.xcorr(inputs.noise(200, 40).astype(np.float64), inputs.noise(200, 41).astype(np.float64),
+                               mode="same"), g["xcorr_same"])
+
+
+def test_trackers(golden):
+    g = golden["trackers"]
+    sr, n, n_fft, hop = (int(v) for v in g["cfg"])
+    x = inputs.pilot(n, sr)
+    spec = O.get_mag(x, n_fft, hop, "blackmanharris", 1)
+    trail = [(0.2, 4000.0), (1.3, 4000.0)]
+    for name, key in (("Peak", "peak"), ("Peak Track", "peak_track"), ("Center of Gravity", "center_of_gravity"),
+                      ("Correlation", "correlation"), ("Freehand Draw", "freehand_draw")):
+        t, f = O.TRACKERS[name](spec, list(trail), n_fft, hop, sr, 0.5)
+        assert np.array_equal(t, g[key + "_times"]), name
+        assert relerr(f, g[key + "_freqs"]) < 1e-6, name
+    t, f = O.track_zero_crossing(spec, x[:, None], list(trail), n_fft, hop, sr, 0.5)
+    assert np.array_equal(t, g["zero_crossing_times"]) and relerr(f, g["zero_crossing_freqs"]) < 1e-9
+    t, f = O.track_peak(spec, [(1.2, 4030.0), (0.1, 3980.0), (0.6, 4010.0)], n_fft, hop, sr, 2.0)
+    assert np.array_equal(t, g["peak2_times"]) and relerr(f, g["peak2_freqs"]) < 1e-6
+    # sanity: the pilot's FM is recovered (8 Hz, +-0.5 %)
+    assert abs(np.mean(g["peak_freqs"]) - 4000) < 5 and 10 < np.ptp(g["peak_freqs"]) < 60
+
+
+def test_pipeline(golden):
+    g = golden["pipeline"]
+    sr, n, n_fft, hop = (int(v) for v in g["cfg"])
+    x = inputs.pilot(n, sr)
+    spec = O.get_mag(x, n_fft, hop, "blackmanharris", 1)
+    t, f = O.track_peak(spec, [(0.05, 4000.0), (1.45, 4000.0)], n_fft, hop, sr, 0.5)
+    assert np.array_equal(t, g["track_times"]) and relerr(f, g["track_freqs"]) < 1e-6
+    curve = O.master_speed_curve([(t, O.trace_to_speed(f))], n / sr, sr, hop, bands=(0, 20))
+    assert curve.shape == g["curve"].shape and relerr(curve[:, 1], g["curve"][:, 1]) < 1e-7
+    pos, _ = O.speed_to_pos(curve[:, 0] * sr, curve[:, 1], n)
+    assert len(pos) == len(g["pos"]) and np.max(np.abs(pos - g["pos"])) < 1e-5
+    y = O.sinc_resample(g["pos"], x, 32)
+    assert relerr(y, g["y"]) < 3e-7
+
+
+def test_linear_and_lag(golden):
+    g = golden["linear_lag"]
+    sig = inputs.noise(5000, 50)
+    pos = O.lag_to_positions(g["lag"], int(g["sr"]), len(sig))
+    assert np.array_equal(pos, g["pos"])
+    assert np.array_equal(O.linear_resample(pos, sig), g["lin"])
