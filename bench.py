@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- north-star benchmark: Msamples/s resampled, 192 kHz varispeed, 64-tap sinc.
+
+One "step" = one pass of the varispeed hot path over one file that is already resident in HBM:
+speed curve -> segment plan -> float64 positions (K_pos) -> Hann-windowed sinc interpolation
+(K_sinc) -> float32 output in HBM.  Workload (BASELINE.json configs[1] at the metric's 192 kHz):
+60-min mono float32, speed 1 + 0.01 sin(2 pi 0.55 t + 0.7) sampled every 256 samples, NT = 32
+(SURVEY 8d).  Inputs are synthesised on the device (closed form + stateless hash noise).
+
+N > 1: one process per GPU (torch.distributed.run), every rank resamples its OWN file (seed = rank)
+-- files/channels are independent in the reference (util/resampling.py:168,225), so there is no
+data-path collective; the only communication is the timing barrier / MAX reduction.  Weak scaling.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event-timed
+K_sinc launches vs the 8 TB/s HBM peak, 8 algorithmic bytes per output sample) and `cpu_baseline`
+(the plain-C oracle port timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALGO_BYTES_PER_SAMPLE = 8.0    # 4 B signal read + 4 B output write
+
+
+def cpu_baseline(sr, nt, budget_s=15.0):
+    """Oracle C port (oracle/par_oracle.c) on the host cores: speed_to_pos (1 thread, serial like the
+    reference) + sinc_mt (one contiguous chunk per core, like sinc_wrapper_mt)."""
+    import numpy as np
+    from oracle import oracle_c as C
+    cores = os.cpu_count() or 1
+
+    def run(seconds):
+        n = int(sr * seconds)
+        sig = C.synth_signal(0, n, float(sr))
+        m = int(seconds * sr / 256)
+        st, sp = C.synth_curve(m, seconds, float(sr))
+        t0 = time.perf_counter()
+        pos, _ = C.speed_to_pos(st, sp, n)
+        out = C.sinc(pos, sig, nt, threads=cores)
+        dt = time.perf_counter() - t0
+        return len(out), dt
+
+    n1, t1 = run(0.5)                               # probe
+    rate = n1 / t1
+    seconds = max(1.0, min(600.0, budget_s * rate / sr))
+    n2, t2 = run(seconds)
+    return {"value": round(n2 / t2 / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{seconds:.1f} s of the same 192 kHz workload ({n2} output samples, {t2:.1f} s wall): "
+                      f"C speed_to_pos on 1 thread + C sinc on {cores} threads (contiguous chunks like sinc_wrapper_mt)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--seconds", type=float, default=3600.0, help="file duration (default: the 60-min config)")
+    ap.add_argument("--sr", type=int, default=192000)
+    ap.add_argument("--nt", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    from pyaudiorestoration_amd import _dev, _lib, resampling
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    else:
+        dist = None
+        torch.cuda.set_device(local)
+    dev = local
+    L = _lib.lib()
+    sp_ = _dev.stream_ptr(dev)
+
+    n_in = int(a.sr * a.seconds)
+    m = int(a.seconds * a.sr / 256)
+    sig = torch.empty(n_in, dtype=torch.float32, device=f"cuda:{dev}")
+    st = torch.empty(m, dtype=torch.float64, device=f"cuda:{dev}")
+    spd = torch.empty(m, dtype=torch.float64, device=f"cuda:{dev}")
+    _lib.check(L.par_synth_signal_f32(dev, _dev.ptr(sig), 0, n_in, float(a.sr), 0x5EED ^ rank, sp_))
+    _lib.check(L.par_synth_speed_curve_f64(dev, _dev.ptr(st), _dev.ptr(spd), m, a.seconds, float(a.sr), 0.01, 0.55,
+                                           0.7 + rank, sp_))
+    nbytes = int(L.par_speed_plan_bytes(m))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{dev}")
+    cap = int(n_in * 1.02) + 1024
+    pos = torch.empty(cap, dtype=torch.float64, device=f"cuda:{dev}")
+    out = torch.empty(cap, dtype=torch.float32, device=f"cuda:{dev}")
+    torch.cuda.synchronize()
+
+    ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(L.par_event_create(ctypes.byref(ev0)))
+    _lib.check(L.par_event_create(ctypes.byref(ev1)))
+    sinc_ms = []
+    len_out = ctypes.c_int64(0)
+    trimmed = ctypes.c_int(0)
+
+    def step(timed):
+        _lib.check(L.par_speed_to_pos_plan(dev, _dev.ptr(st), _dev.ptr(spd), m, n_in, _dev.ptr(work), nbytes,
+                                           ctypes.byref(len_out), ctypes.byref(trimmed), sp_))
+        assert 2 <= len_out.value <= cap
+        _lib.check(L.par_speed_to_pos_fill(dev, _dev.ptr(spd), m, _dev.ptr(work), _dev.ptr(pos), len_out.value, sp_))
+        _lib.check(L.par_event_record(ev0, sp_))
+        _lib.check(L.par_sinc_resample_f32(dev, _dev.ptr(pos), len_out.value, _dev.ptr(sig), 1, n_in, a.nt,
+                                           _dev.ptr(out), 1, sp_))
+        _lib.check(L.par_event_record(ev1, sp_))
+        if timed:
+            ms = ctypes.c_float(0)
+            _lib.check(L.par_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)))     # waits for this step's kernel only
+            sinc_ms.append(ms.value)
+
+    for _ in range(a.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        cnt = torch.tensor([len_out.value], dtype=torch.float64, device=f"cuda:{dev}")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_per_step = float(cnt.item())
+    else:
+        total_per_step = float(len_out.value)
+
+    if rank == 0:
+        ms_step = dt / a.steps * 1e3
+        value = total_per_step * a.steps / dt / 1e6
+        k_ms = sum(sinc_ms) / len(sinc_ms)
+        achieved = ALGO_BYTES_PER_SAMPLE * len_out.value / (k_ms * 1e-3) / 1e9
+        res = {
+            "metric": "Msamples/sec resampled (192 kHz varispeed)", "value": round(value, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.seconds:g}-s {a.sr} Hz mono float32 varispeed resample, +-1% sinusoidal speed "
+                                   f"curve (0.55 Hz, hop 256), {2 * a.nt}-tap Hann sinc; one file per GPU",
+                       "samples_in_per_gpu": n_in, "samples_out_per_gpu": int(len_out.value), "NT": a.nt,
+                       "step": "plan + positions (K_pos, f64) + K_sinc, inputs resident in HBM"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "k_sinc",
+                         "kernel_ms": round(k_ms, 4),
+                         "note": "8 algorithmic B/output sample (4 B in + 4 B out); the kernel is VALU-bound "
+                                 "(64 taps/sample), see DESIGN.md"},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(a.sr, a.nt)
+        print(json.dumps(res), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+/*
+ * par_hip.h -- C ABI of libpar_hip.so, the MI355X (gfx950) implementation of the
+ * pyaudiorestoration util/ hot path.  This is the drop-in boundary: plain pointers
+ * and sizes, no torch / numpy / C++ types.  Every DEVICE pointer is caller-owned
+ * HBM (the Python host layer allocates it through torch-ROCm tensors); `stream`
+ * is a hipStream_t passed as void* (NULL = the default stream).  The library keeps
+ * no global state except small per-device constant tables (twiddles, sinc tap
+ * tables) keyed by (device, size).
+ *
+ * All functions return an int status (0 = PAR_OK), never throw, and record a
+ * message retrievable with par_last_error() (thread-local).  Functions are
+ * re-entrant and call hipSetDevice(device) themselves, so they may be driven from
+ * one host thread per GPU (ctypes releases the GIL).
+ *
+ * Citations are file:line in the reference checkout (HENDRIX-ZT2/pyaudiorestoration).
+ */
+#ifndef PAR_HIP_H
+#define PAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAR_OK 0
+#define PAR_ERR_ARG 1            /* bad argument (the reference would raise or misbehave) */
+#define PAR_ERR_HIP 2            /* a HIP runtime call failed */
+#define PAR_ERR_UNSUPPORTED 3    /* valid for the reference, not implemented here (caller falls through) */
+#define PAR_ERR_WORKSPACE 4      /* caller-provided workspace too small */
+
+/* ---- library / device ---------------------------------------------------------- */
+int par_version(void);
+int par_device_count(void);
+int par_last_error(char* buf, int n);
+/* stream-ordered helper used by the host layer and bench to time kernels with HIP events
+ * on the stream the kernels are launched on (torch.cuda.Event only sees torch's stream). */
+int par_event_create(void** ev);
+int par_event_destroy(void* ev);
+int par_event_record(void* ev, void* stream);
+int par_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+int par_stream_sync(int device, void* stream);
+
+/* ---- S0-S4: STFT / magnitude ---------------------------------------------------
+ * Replaces the backend slot of util/fourier.py:67-75, i.e. a callable
+ * (n_fft, step, window, x, zeropad) like pyfftw_rfft2 (:124-133) / np_rfft_pick (:136-157):
+ * reflect-pad n_fft/2 (estimate_and_center :78-82), frame i = window * xpad[i*hop : i*hop+n_fft]
+ * zero-extended at the END to n_fft*zeropad (segment_array :160-166), real FFT, / sqrt(n_fft)
+ * (numpy/torch normalisation).  mode 1 fuses to_mag (:23-24): |X| + 1e-7.
+ *
+ *   x        device f32, logical length n, element stride x_stride (channel view of an (n,ch) array)
+ *   window   device f32[n_fft] (scipy.signal.get_window(name, n_fft) as float32, :66)
+ *   out      device, FRAME-MAJOR: mode 0 -> complex64 [frames][bins] interleaved re,im
+ *                                 mode 1 -> float32   [frames][bins]
+ *            bins = n_fft*zeropad/2+1, frames = par_stft_frames(n, n_fft, hop)
+ * n_fft*zeropad must be a power of two in [16, 8192]; otherwise PAR_ERR_UNSUPPORTED.
+ */
+int64_t par_stft_frames(int64_t n, int n_fft, int hop);
+int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad,
+                 const float* window, float* out, int mode, void* stream);
+
+/* ---- S6: ISTFT -----------------------------------------------------------------
+ * Replaces util/fourier.py:314-437 (istft, center=True, win_length=n_fft) incl.
+ * window_sumsquare (:492-546) and __overlap_add (:677-687).  Does NOT mutate `spec`.
+ *   spec     device complex64 [n_frames][bins] frame-major (bins = n_fft/2+1)
+ *   window   device f32[n_fft]  (get_window(name, n_fft, fftbins=True))
+ *   frames   device f32 scratch [n_frames][n_fft]
+ *   y        device f32[y_len]; y[t] = ola[t + skip] / sumsq[t + skip] (0 beyond the ola length),
+ *            skip = n_fft/2 and y_len = `length` reproduce fix_length(y[n_fft//2:], length) (:430-435).
+ */
+int par_istft_f32(int device, const float* spec, int64_t n_frames, int n_fft, int hop, const float* window,
+                  float* frames, float* y, int64_t y_len, int64_t skip, void* stream);
+
+/* ---- R1: speed curve -> fractional read positions ----------------------------------
+ * Replaces resampling.speed_to_pos (util/resampling.py:93-137).  Two calls because the
+ * caller must allocate the position array:
+ *   plan : segment lengths n_i (error-diffused rounding :111-118), per-segment reciprocal sums,
+ *          the float64 offset chain (:125-126) and the end-trim (:129-135).  Returns len_out
+ *          (= the written prefix when no trim fires) and whether the trim fired.
+ *          Synchronises `stream`.
+ *   fill : writes pos[0..len_out) as float64, bit-identical to the reference's array.
+ * sampletimes/speeds are DEVICE float64[m].  work is caller-owned device scratch of at least
+ * par_speed_plan_bytes(m) bytes and must stay untouched between plan and fill (or the fused
+ * resampler below).
+ */
+size_t par_speed_plan_bytes(int64_t m);
+int par_speed_to_pos_plan(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
+                          void* work, size_t work_bytes, int64_t* len_out, int* trimmed, void* stream);
+int par_speed_to_pos_fill(int device, const double* speeds, int64_t m, const void* work,
+                          double* pos, int64_t len_out, void* stream);
+
+/* ---- R2/R3: windowed-sinc varispeed interpolation --------------------------------------
+ * Replaces sinc_wrapper / sinc_wrapper_mt / sinc_core (util/resampling.py:21-90), operator
+ * slot #2: out[i] = sum_k signal[lower+k] * sinc((N_k-shift)*fc)*fc * hanning(2NT+1)[k].
+ * Canonical period definition: period_to[i] = max(1e-12, pos[i+1]-pos[i])
+ * for all but the global last sample (which reuses the previous one) == single-thread
+ * sinc_wrapper.  Bug-compatible leading edge (quirk 1).  len_out >= 2, 1 <= NT <= 512.
+ *   pos   device f64[len_out];  sig device f32 (len_in, stride sig_stride);
+ *   out   device f32 (len_out, stride out_stride)  -- strided column views of (n,ch) arrays.
+ */
+int par_sinc_resample_f32(int device, const double* pos, int64_t len_out, const float* sig, int64_t sig_stride,
+                          int64_t len_in, int NT, float* out, int64_t out_stride, void* stream);
+
+/* "Linear" mode of resampling.run (util/resampling.py:229): np.interp(pos, arange(len), sig, 0, 0). */
+int par_linear_resample_f32(int device, const double* pos, int64_t len_out, const float* sig, int64_t sig_stride,
+                            int64_t len_in, float* out, int64_t out_stride, void* stream);
+
+/* ---- synthetic workload generators, so bench inputs are born in HBM ---------- */
+int par_synth_signal_f32(int device, float* out, int64_t start, int64_t count, double sr, uint64_t seed, void* stream);
+int par_synth_speed_curve_f64(int device, double* sampletimes, double* speeds, int64_t m, double duration_s,
+                              double sr, double depth, double rate_hz, double phase, void* stream);
+
+/* ---- W1/W2: per-frame peak trackers on a device magnitude spectrogram ---------------------
+ * Replaces the trace() loops of PeakTracker / PeakTrackTracker (util/wow_detection.py:294-327)
+ * with Track.set_bin_limits (:97-107), get_peak (:119-134), is_peak (:136-139) and
+ * correlation.parabolic (util/correlation.py:42-46).
+ *   mag      device f32 frame-major [n_frames][bins]
+ *   freqs    device f64[count]: in = sampled trail (sample_trail :66-76), out = traced frequencies
+ *   mode 0   PeakTracker: band re-centred on freqs[i] every frame
+ *   mode 1   PeakTrackTracker: band fixed on freqs[0]; tolerance halves for i > 2
+ */
+int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
+                       double* freqs, int fft_size, double sr, double tolerance_oct, int mode, void* stream);
+/* CenterOfGravity.trace (util/wow_detection.py:256-291): sequential band adaptation. */
+int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
+                      double* freqs, int fft_size, double sr, double tolerance_oct, void* stream);
+
+/* ---- F1: zero-phase SOS filtering ------------------------------------------------------
+ * Replaces scipy.signal.sosfiltfilt(sos, data) as called by butter_bandpass_filter
+ * (util/filters.py:24): odd extension of padlen samples, sosfilt_zi initial state scaled by the
+ * first sample, forward pass, backward pass, trim.  The filter DESIGN (scipy.signal.butter,
+ * sosfilt_zi; O(order) work) stays in the host layer; the O(n) recurrences run on the GPU.
+ *   sos HOST f64[n_sections][6] (a0 == 1), zi HOST f64[n_sections][2] (= scipy.signal.sosfilt_zi(sos))
+ *   x, y DEVICE f64[n];  work DEVICE f64[work_len], work_len >= par_sosfiltfilt_work_len(n, padlen)
+ *   padlen = 3*(2*n_sections+1 - min(#(sos[:,2]==0), #(sos[:,5]==0)))  (scipy default), n > padlen.
+ */
+int64_t par_sosfiltfilt_work_len(int64_t n, int64_t padlen);
+int par_sosfiltfilt_f64(int device, const double* sos, const double* zi, int n_sections, const double* x, int64_t n,
+                        int64_t padlen, double* work, int64_t work_len, double* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAR_HIP_H */

@@ -1,0 +1,248 @@
+/*
+ * par_oracle.c -- plain-C CPU restatement of the reference's varispeed hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY: the checker for the HIP path at sizes numpy would be too slow for, and
+ * the `cpu_baseline` ("kind": "port") of bench.py.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it; nothing under pyaudiorestoration_amd/ does.
+ *
+ * Parity status: PINNED -- tests/test_oracle_golden.py checks every function here against golden
+ * vectors captured from the real reference (oracle/gen_golden.py).
+ *
+ * Restates (reference file:line, HENDRIX-ZT2/pyaudiorestoration):
+ *   oracle_speed_to_pos   util/resampling.py:93-137   speed_to_pos
+ *   oracle_sinc           util/resampling.py:21-27, 51-90  sinc_wrapper -> sinc_core (float64 math like numba)
+ *   oracle_sinc_mt        util/resampling.py:30-46    sinc_wrapper_mt: one contiguous chunk per thread
+ *   oracle_stft_mag       util/fourier.py:23-29, 37-82, 136-166  get_mag via the numpy framing
+ *   oracle_synth_*        SURVEY 8d closed-form workload (same as tests/inputs.py)
+ * Build: gcc -O2 -fPIC -shared -pthread par_oracle.c -lm   (no -ffast-math: numpy order is kept)
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------ speed_to_pos */
+/* returns 0 ok; *len_out = written prefix (or trimmed length), *trimmed = 1 when the end trim fired.
+ * out must hold at least `cap` doubles; positions beyond cap -> -2 (the reference raises there). */
+int oracle_speed_to_pos(const double* st, const double* sp, int64_t m, int64_t n_in, double* out, int64_t cap,
+                        int64_t* len_out, int* trimmed) {
+  double err = 0.0, offset = st[0];
+  int64_t w = 0;
+  *trimmed = 0;
+  for (int64_t i = 0; i + 1 < m; ++i) {
+    const double period = st[i + 1] - st[i];
+    const double mean = (sp[i] + sp[i + 1]) / 2.0;
+    const double inerr = period * mean + err;
+    const double r = nearbyint(inerr);                /* Python round(): half to even */
+    if (r < 2.0) return -1;
+    const int64_t n = (int64_t)r;
+    err = inerr - r;
+    if (w + n > cap) return -2;
+    const double ds = sp[i + 1] - sp[i], nm1 = (double)(n - 1);
+    double c = 0.0;
+    for (int64_t k = 0; k < n; ++k) {
+      const double bs = ((double)k / nm1) * ds + sp[i];
+      c += 1.0 / bs;
+      out[w + k] = c + offset;
+    }
+    offset = out[w + n - 1];
+    if (out[w] <= (double)n_in && (double)n_in <= out[w + n - 1]) {
+      int64_t arg = 0;
+      double best = INFINITY;
+      for (int64_t k = 0; k < n; ++k) {
+        const double d = fabs(out[w + k] - (double)n_in);
+        if (d < best) {
+          best = d;
+          arg = k;
+        }
+      }
+      *len_out = w + arg;
+      *trimmed = 1;
+      return 0;
+    }
+    w += n;
+  }
+  *len_out = w;
+  return 0;
+}
+
+/* int(mean(speeds) * (st[-1]-st[0]) * 1.01): the reference's buffer size (:108-109), sequential mean */
+int64_t oracle_end_guess(const double* st, const double* sp, int64_t m) {
+  double s = 0.0;
+  for (int64_t i = 0; i < m; ++i) s += sp[i];
+  return (int64_t)((s / (double)m) * (st[m - 1] - st[0]) * 1.01) + 8;   /* +8: pairwise-vs-sequential slack */
+}
+
+/* ------------------------------------------------------------------ sinc_core */
+static float hann32(int k, int NT) { return (float)(0.5 + 0.5 * cos(M_PI * (double)(k - NT) / (double)NT)); }
+
+static void sinc_range(const double* pos, int64_t len_out, int64_t a, int64_t b, const float* sig, int64_t sig_stride,
+                       int64_t len_in, int NT, const float* win, float* out, int64_t out_stride) {
+  for (int64_t i = a; i < b; ++i) {
+    const double p = pos[i];
+    const int64_t ind = (int64_t)nearbyint(p);
+    const int64_t lower = ind - NT > 0 ? ind - NT : 0;
+    const int64_t upper = ind + NT < len_in ? ind + NT : len_in;
+    /* canonical period: true next position for all but the global last sample */
+    double dp = (i + 1 < len_out) ? pos[i + 1] - p : p - pos[i - 1];
+    if (!(dp > 1e-12)) dp = 1e-12;
+    double fc = 1.0 / dp;
+    if (fc > 1.0) fc = 1.0;
+    const double shift = p - (double)ind;
+    double acc = 0.0;
+    for (int64_t k = 0; k < upper - lower; ++k) {
+      double x = ((double)(k - NT) - shift) * fc;
+      double y = M_PI * (x == 0.0 ? 1e-20 : x);
+      acc += (double)sig[(lower + k) * sig_stride] * (sin(y) / y * fc) * (double)win[k];
+    }
+    out[i * out_stride] = (float)acc;
+  }
+}
+
+int oracle_sinc(const double* pos, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in, int NT,
+                float* out, int64_t out_stride) {
+  if (len_out < 2 || NT < 1) return -1;
+  float* win = (float*)malloc(sizeof(float) * (2 * NT + 1));
+  for (int k = 0; k <= 2 * NT; ++k) win[k] = hann32(k, NT);
+  sinc_range(pos, len_out, 0, len_out, sig, sig_stride, len_in, NT, win, out, out_stride);
+  free(win);
+  return 0;
+}
+
+typedef struct {
+  const double* pos;
+  int64_t len_out, a, b;
+  const float* sig;
+  int64_t sig_stride, len_in;
+  int NT;
+  const float* win;
+  float* out;
+  int64_t out_stride;
+} sinc_job;
+
+static void* sinc_worker(void* v) {
+  sinc_job* j = (sinc_job*)v;
+  sinc_range(j->pos, j->len_out, j->a, j->b, j->sig, j->sig_stride, j->len_in, j->NT, j->win, j->out, j->out_stride);
+  return NULL;
+}
+
+/* contiguous chunks of ceil(len/nthreads), exactly like sinc_wrapper_mt (:33-46) */
+int oracle_sinc_mt(const double* pos, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in, int NT,
+                   float* out, int64_t out_stride, int nthreads) {
+  if (len_out < 2 || NT < 1 || nthreads < 1) return -1;
+  float* win = (float*)malloc(sizeof(float) * (2 * NT + 1));
+  for (int k = 0; k <= 2 * NT; ++k) win[k] = hann32(k, NT);
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
+  sinc_job* jobs = (sinc_job*)malloc(sizeof(sinc_job) * nthreads);
+  const int64_t chunk = (len_out + nthreads - 1) / nthreads;
+  int started = 0;
+  for (int t = 0; t < nthreads; ++t) {
+    int64_t a = t * chunk, b = a + chunk < len_out ? a + chunk : len_out;
+    if (a >= b) break;
+    sinc_job jb = {pos, len_out, a, b, sig, sig_stride, len_in, NT, win, out, out_stride};
+    jobs[t] = jb;
+    pthread_create(&th[t], NULL, sinc_worker, &jobs[t]);
+    ++started;
+  }
+  for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+  free(th);
+  free(jobs);
+  free(win);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ STFT magnitude */
+static int64_t reflect_idx(int64_t q, int64_t n) {
+  if (n == 1) return 0;
+  const int64_t P = 2 * (n - 1);
+  q %= P;
+  if (q < 0) q += P;
+  return q < n ? q : P - q;
+}
+
+/* iterative radix-2 complex FFT, float64 */
+static void fft_c(double* re, double* im, int n) {
+  for (int i = 1, j = 0; i < n; ++i) {
+    int bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) {
+      double t = re[i]; re[i] = re[j]; re[j] = t;
+      t = im[i]; im[i] = im[j]; im[j] = t;
+    }
+  }
+  for (int len = 2; len <= n; len <<= 1) {
+    const double ang = -2.0 * M_PI / len;
+    for (int i = 0; i < n; i += len) {
+      for (int k = 0; k < len / 2; ++k) {
+        const double wr = cos(ang * k), wi = sin(ang * k);
+        const int a = i + k, b = i + k + len / 2;
+        const double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+        re[b] = re[a] - xr; im[b] = im[a] - xi;
+        re[a] += xr; im[a] += xi;
+      }
+    }
+  }
+}
+
+/* out: frame-major [frames][bins]; mode 0 complex interleaved (re,im) float, mode 1 |X|+1e-7 float */
+int oracle_stft(const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad, const float* window,
+                float* out, int mode) {
+  const int M = n_fft * zeropad;
+  if (M < 2 || (M & (M - 1))) return -1;
+  const int bins = M / 2 + 1;
+  const int64_t frames = (n + 2 * (int64_t)(n_fft / 2) - n_fft) / hop + 1;
+  double* re = (double*)malloc(sizeof(double) * M);
+  double* im = (double*)malloc(sizeof(double) * M);
+  const double scale = 1.0 / sqrt((double)n_fft);
+  for (int64_t f = 0; f < frames; ++f) {
+    for (int t = 0; t < M; ++t) {
+      im[t] = 0.0;
+      re[t] = t < n_fft ? (double)(window[t] * x[reflect_idx(f * hop - n_fft / 2 + t, n) * x_stride]) : 0.0;
+    }
+    fft_c(re, im, M);
+    for (int k = 0; k < bins; ++k) {
+      const double a = re[k] * scale, b = im[k] * scale;
+      if (mode == 0) {
+        out[2 * (f * bins + k)] = (float)a;
+        out[2 * (f * bins + k) + 1] = (float)b;
+      } else {
+        out[f * bins + k] = (float)(sqrt(a * a + b * b) + 1e-7);
+      }
+    }
+  }
+  free(re);
+  free(im);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ synthetic workload */
+static double splitmix_uniform(uint64_t idx, uint64_t seed) {
+  uint64_t z = (idx ^ seed) + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
+void oracle_synth_signal(float* out, int64_t start, int64_t count, double sr, uint64_t seed) {
+  const double w1 = 2.0 * M_PI * 1000.0, w2 = 2.0 * M_PI * (0.45 * sr / 2.0);
+  for (int64_t i = 0; i < count; ++i) {
+    const double n = (double)(start + i);
+    out[i] = (float)(0.25 * sin(w1 * n / sr) + 0.25 * sin(w2 * n / sr) + 0.1 * splitmix_uniform((uint64_t)(start + i), seed));
+  }
+}
+
+void oracle_synth_curve(double* st, double* sp, int64_t m, double dur, double sr, double depth, double rate, double phase) {
+  const double step = dur / (double)(m - 1);
+  for (int64_t i = 0; i < m; ++i) {
+    const double t = (i == m - 1) ? dur : (double)i * step;
+    st[i] = t * sr;
+    sp[i] = 1.0 + depth * sin(2.0 * M_PI * rate * t + phase);
+  }
+}

@@ -1,0 +1,39 @@
+"""Device plumbing: PyTorch-ROCm is used ONLY to own HBM buffers and name streams."""
+import ctypes
+
+import numpy as np
+import torch
+
+
+def device_index(device=None):
+    """Resolve a device argument to an ordinal.  Raises when no GPU is visible: the
+    product path never falls back to the CPU."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("pyaudiorestoration_amd: no ROCm GPU visible (torch.cuda.is_available() is False); "
+                           "the HIP path has no CPU fallback")
+    if device is None:
+        return torch.cuda.current_device()
+    if isinstance(device, int):
+        return device
+    d = torch.device(device)
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+def stream_ptr(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def to_dev(a, dtype, dev):
+    """numpy (any stride) / torch -> contiguous device tensor of `dtype`."""
+    if isinstance(a, torch.Tensor):
+        return a.to(device=f"cuda:{dev}", dtype=dtype).contiguous()
+    np_dtype = {torch.float32: np.float32, torch.float64: np.float64, torch.complex64: np.complex64}[dtype]
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np_dtype)).to(f"cuda:{dev}")
+
+
+def empty(shape, dtype, dev):
+    return torch.empty(shape, dtype=dtype, device=f"cuda:{dev}")
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())

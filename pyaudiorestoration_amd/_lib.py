@@ -1,0 +1,88 @@
+"""ctypes binding of libpar_hip.so (the C ABI declared in include/par_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call
+fails, an exception is raised (inside the reference's own backend chain,
+util/fourier.py:67-75, that exception is what makes it try the next backend).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpar_hip.so")
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_vp = ctypes.c_void_p
+c_dbl = ctypes.c_double
+c_sz = ctypes.c_size_t
+c_u64 = ctypes.c_uint64
+
+# name -> (restype, argtypes); mirrors include/par_hip.h one to one
+SIGNATURES = {
+    "par_version": (c_int, []),
+    "par_device_count": (c_int, []),
+    "par_last_error": (c_int, [ctypes.c_char_p, c_int]),
+    "par_event_create": (c_int, [ctypes.POINTER(c_vp)]),
+    "par_event_destroy": (c_int, [c_vp]),
+    "par_event_record": (c_int, [c_vp, c_vp]),
+    "par_event_elapsed_ms": (c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_float)]),
+    "par_stream_sync": (c_int, [c_int, c_vp]),
+    "par_stft_frames": (c_i64, [c_i64, c_int, c_int]),
+    "par_stft_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
+    "par_istft_f32": (c_int, [c_int, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "par_speed_plan_bytes": (c_sz, [c_i64]),
+    "par_speed_to_pos_plan": (c_int, [c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_sz, ctypes.POINTER(c_i64),
+                                      ctypes.POINTER(c_int), c_vp]),
+    "par_speed_to_pos_fill": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "par_sinc_resample_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp]),
+    "par_linear_resample_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    "par_synth_signal_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_dbl, c_u64, c_vp]),
+    "par_synth_speed_curve_f64": (c_int, [c_int, c_vp, c_vp, c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_vp]),
+    "par_track_peak_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_int, c_vp]),
+    "par_sosfiltfilt_work_len": (c_i64, [c_i64, c_i64]),
+    "par_sosfiltfilt_f64": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "par_track_cog_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_vp]),
+}
+
+_lib = None
+
+
+class ParError(RuntimeError):
+    """A libpar_hip call returned a non-zero status."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libpar_hip status {code}: {msg}")
+        self.code = code
+
+
+class ParUnsupported(ParError):
+    """Valid for the reference but not implemented by the HIP path (status PAR_ERR_UNSUPPORTED)."""
+
+
+def lib():
+    """Load the shared library once.  Raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    lib().par_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc):
+    if rc != 0:
+        msg = last_error()
+        raise (ParUnsupported if rc == 3 else ParError)(rc, msg)

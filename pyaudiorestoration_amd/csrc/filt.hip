@@ -1,0 +1,166 @@
+// K_sosfiltfilt -- zero-phase cascaded-biquad filtering of one long float64 signal.
+//
+// Semantics: scipy.signal.sosfiltfilt(sos, data) exactly as butter_bandpass_filter calls it
+// (reference util/filters.py:24; scipy 1.15 _filter_design/_signaltools):
+//     ext = odd_ext(x, padlen)            # 2*x[0]-x[padlen:0:-1] | x | 2*x[-1]-x[-2:-padlen-2:-1]
+//     y, _ = sosfilt(sos, ext,     zi = sosfilt_zi(sos) * ext[0])
+//     y, _ = sosfilt(sos, y[::-1], zi = sosfilt_zi(sos) * y[-1]);  return y[::-1][padlen:-padlen]
+// with the transposed direct-form-II biquad  y = b0*x + z0; z0 = b1*x - a1*y + z1; z1 = b2*x - a2*y.
+//
+// An IIR is a serial recurrence, but a LINEAR one: state' = A*state + B*x.  So the signal is cut into
+// blocks of kFiltBlock samples; every block (one lane each) computes its zero-state end state in
+// parallel, a tiny serial pass chains  s[b+1] = A^blk * s[b] + r[b]  over the blocks, and every block
+// is then re-run from its true initial state writing the outputs.  Results equal scipy's up to
+// floating-point re-association of the state propagation (~1e-15 relative).
+#include "par_common.h"
+#include <math.h>
+#include <vector>
+
+namespace par {
+
+constexpr int kFiltBlock = 256;
+
+struct Biquad {
+  double b0, b1, b2, a1, a2;
+};
+
+// element k of the pass (forward: k, backward: L-1-k)
+__device__ __forceinline__ int64_t pass_index(int64_t k, int64_t L, int reverse) { return reverse ? L - 1 - k : k; }
+
+__global__ void k_odd_ext(const double* __restrict__ x, int64_t n, int64_t pad, double* __restrict__ ext) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t L = n + 2 * pad;
+  if (i >= L) return;
+  double v;
+  if (i < pad) v = 2.0 * x[0] - x[pad - i];
+  else if (i < pad + n) v = x[i - pad];
+  else v = 2.0 * x[n - 1] - x[n - 2 - (i - pad - n)];
+  ext[i] = v;
+}
+
+// zero-state response end state of each block
+__global__ void k_sos_block_zero(const double* __restrict__ u, int64_t L, int reverse, Biquad q, int64_t nblk,
+                                 double* __restrict__ r) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblk) return;
+  const int64_t k0 = b * kFiltBlock;
+  const int64_t k1 = k0 + kFiltBlock < L ? k0 + kFiltBlock : L;
+  double z0 = 0.0, z1 = 0.0;
+  for (int64_t k = k0; k < k1; ++k) {
+    const double xv = u[pass_index(k, L, reverse)];
+    const double y = q.b0 * xv + z0;
+    z0 = q.b1 * xv - q.a1 * y + z1;
+    z1 = q.b2 * xv - q.a2 * y;
+  }
+  r[2 * b] = z0;
+  r[2 * b + 1] = z1;
+}
+
+// serial chain over block boundaries: s[b+1] = P * s[b] + r[b],  P = A^kFiltBlock (host-computed)
+__global__ void k_sos_chain(const double* __restrict__ r, int64_t nblk, double p00, double p01, double p10, double p11,
+                            double zi0, double zi1, const double* __restrict__ scale_sample, double* __restrict__ s) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double sc = *scale_sample;
+  double z0 = zi0 * sc, z1 = zi1 * sc;
+  for (int64_t b = 0; b < nblk; ++b) {
+    s[2 * b] = z0;
+    s[2 * b + 1] = z1;
+    const double n0 = p00 * z0 + p01 * z1 + r[2 * b];
+    const double n1 = p10 * z0 + p11 * z1 + r[2 * b + 1];
+    z0 = n0;
+    z1 = n1;
+  }
+}
+
+__global__ void k_sos_block_run(const double* __restrict__ u, int64_t L, int reverse, Biquad q, int64_t nblk,
+                                const double* __restrict__ s, double* __restrict__ y) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblk) return;
+  const int64_t k0 = b * kFiltBlock;
+  const int64_t k1 = k0 + kFiltBlock < L ? k0 + kFiltBlock : L;
+  double z0 = s[2 * b], z1 = s[2 * b + 1];
+  for (int64_t k = k0; k < k1; ++k) {
+    const int64_t idx = pass_index(k, L, reverse);
+    const double xv = u[idx];
+    const double yv = q.b0 * xv + z0;
+    z0 = q.b1 * xv - q.a1 * yv + z1;
+    z1 = q.b2 * xv - q.a2 * yv;
+    y[idx] = yv;
+  }
+}
+
+__global__ void k_copy_mid(const double* __restrict__ src, int64_t pad, int64_t n, double* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i + pad];
+}
+
+}  // namespace par
+
+extern "C" {
+
+int64_t par_sosfiltfilt_work_len(int64_t n, int64_t padlen) {
+  const int64_t L = n + 2 * padlen;
+  const int64_t nblk = (L + par::kFiltBlock - 1) / par::kFiltBlock;
+  return 2 * L + 4 * nblk + 8;
+}
+
+int par_sosfiltfilt_f64(int device, const double* sos, const double* zi, int n_sections, const double* x, int64_t n,
+                        int64_t padlen, double* work, int64_t work_len, double* y, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(sos && zi && x && work && y && n_sections >= 1 && n_sections <= 64, PAR_ERR_ARG,
+              "par_sosfiltfilt_f64: bad args");
+  PAR_REQUIRE(n > padlen && padlen >= 0, PAR_ERR_ARG,
+              "par_sosfiltfilt_f64: the length of the input vector x must be greater than padlen, which is %lld",
+              (long long)padlen);   // scipy's own ValueError text
+  PAR_REQUIRE(work_len >= par_sosfiltfilt_work_len(n, padlen), PAR_ERR_WORKSPACE, "par_sosfiltfilt_f64: workspace too small");
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipStream_t st = as_stream(stream);
+  const int64_t L = n + 2 * padlen;
+  const int64_t nblk = ceil_div(L, kFiltBlock);
+  double* bufA = work;
+  double* bufB = work + L;
+  double* r = work + 2 * L;
+  double* s = r + 2 * nblk;
+  hipLaunchKernelGGL(k_odd_ext, dim3((unsigned)ceil_div(L, 256)), dim3(256), 0, st, x, n, padlen, bufA);
+  double* cur = bufA;
+  double* nxt = bufB;
+  for (int dir = 0; dir < 2; ++dir) {
+    // zi scales with the first sample this pass consumes: ext[0] forward, y[L-1] backward
+    for (int sec = 0; sec < n_sections; ++sec) {
+      const double* c = sos + 6 * sec;
+      PAR_REQUIRE(c[3] == 1.0, PAR_ERR_ARG, "par_sosfiltfilt_f64: sos[%d,3] (a0) must be 1", sec);
+      Biquad q{c[0], c[1], c[2], c[4], c[5]};
+      // P = A^kFiltBlock, A = [[-a1, 1], [-a2, 0]]
+      double p00 = 1, p01 = 0, p10 = 0, p11 = 1;
+      double a00 = -q.a1, a01 = 1.0, a10 = -q.a2, a11 = 0.0;
+      for (int e = kFiltBlock; e > 0; e >>= 1) {
+        if (e & 1) {
+          const double t00 = p00 * a00 + p01 * a10, t01 = p00 * a01 + p01 * a11;
+          const double t10 = p10 * a00 + p11 * a10, t11 = p10 * a01 + p11 * a11;
+          p00 = t00; p01 = t01; p10 = t10; p11 = t11;
+        }
+        const double s00 = a00 * a00 + a01 * a10, s01 = a00 * a01 + a01 * a11;
+        const double s10 = a10 * a00 + a11 * a10, s11 = a10 * a01 + a11 * a11;
+        a00 = s00; a01 = s01; a10 = s10; a11 = s11;
+      }
+      // the scale sample is the first element of the CASCADE input of this direction; after the first
+      // section `cur` no longer holds it, so it is latched into work[-1] region (s tail) per direction.
+      double* latch = s + 2 * nblk + (dir ? 1 : 0);
+      if (sec == 0) {
+        PAR_HIP_CHECK(hipMemcpyAsync(latch, cur + (dir ? L - 1 : 0), sizeof(double), hipMemcpyDeviceToDevice, st));
+      }
+      hipLaunchKernelGGL(k_sos_block_zero, dim3((unsigned)ceil_div(nblk, 64)), dim3(64), 0, st, cur, L, dir, q, nblk, r);
+      hipLaunchKernelGGL(k_sos_chain, dim3(1), dim3(1), 0, st, r, nblk, p00, p01, p10, p11, zi[2 * sec], zi[2 * sec + 1],
+                         latch, s);
+      hipLaunchKernelGGL(k_sos_block_run, dim3((unsigned)ceil_div(nblk, 64)), dim3(64), 0, st, cur, L, dir, q, nblk, s, nxt);
+      double* t = cur;
+      cur = nxt;
+      nxt = t;
+    }
+  }
+  hipLaunchKernelGGL(k_copy_mid, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, cur, padlen, n, y);
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// Shared host/device helpers for libpar_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include "../../include/par_hip.h"
+
+namespace par {
+
+void set_error(const char* fmt, ...);
+
+#define PAR_HIP_CHECK(call)                                                              \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      par::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return PAR_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+
+#define PAR_REQUIRE(cond, code, ...)   \
+  do {                                 \
+    if (!(cond)) {                     \
+      par::set_error(__VA_ARGS__);     \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kMaxDevices = 16;
+
+// wave-level reductions (64 lanes)
+__device__ inline long long wave_min_ll(long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    long long t = __shfl_xor(v, o, kWave);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+__device__ inline long long wave_max_ll(long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    long long t = __shfl_xor(v, o, kWave);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace par

@@ -1,0 +1,147 @@
+// K_track -- wow/flutter pitch trackers on a device-resident magnitude spectrogram.
+//
+// Semantics (reference util/wow_detection.py): Track.freq_plus_tolerance :109-117, set_bin_limits
+// :97-107, freq_2_bin :81-82, get_peak :119-134, is_peak :136-139, PeakTracker.trace :298-304,
+// PeakTrackTracker.trace :310-327, CenterOfGravity :259-291; correlation.parabolic
+// (util/correlation.py:42-46).  The spectrogram is FRAME-MAJOR float32 (what K_stft writes), so a
+// frame's band is a contiguous run.  Band/bin arithmetic is float64 like the reference.
+#include "par_common.h"
+#include <math.h>
+
+namespace par {
+
+struct Band {
+  int NL, NU;
+};
+
+__device__ __forceinline__ int freq_to_bin(double f, int fft_size, double sr, int bins) {
+  long long b = llrint(f * (double)fft_size / sr);        // Python round(): half-to-even
+  if (b > bins - 1) b = bins - 1;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__device__ __forceinline__ Band band_limits(double freq, double tol, int fft_size, double sr, int bins) {
+  const double lf = log2(freq);
+  double fL = exp2(lf - tol), fU = exp2(lf + tol);
+  fL = fL > 1.0 ? fL : 1.0;                                // max(1.0, fL)
+  fU = fU < sr / 2 ? fU : sr / 2;                          // min(sr/2, fU)
+  Band b;
+  b.NL = freq_to_bin(fL, fft_size, sr, bins);
+  b.NU = freq_to_bin(fU, fft_size, sr, bins);
+  while (b.NU - b.NL < 4) {                                // min_bins = 4
+    b.NL -= 1;
+    b.NU += 1;
+  }
+  if (b.NL < 0) b.NL = 0;                                  // (numpy would wrap a negative slice start)
+  if (b.NU > bins) b.NU = bins;
+  return b;
+}
+
+__device__ __forceinline__ double peak_freq(const float* __restrict__ col, Band b, int bins, int fft_size, double sr) {
+  int arg = b.NL;
+  float best = col[b.NL];
+  for (int k = b.NL + 1; k < b.NU; ++k) {
+    const float v = col[k];
+    if (v > best) {                                        // first occurrence of the maximum (np.argmax)
+      best = v;
+      arg = k;
+    }
+  }
+  double x = (double)arg;
+  const double fm = (double)col[(arg - 1 + bins) % bins], f0 = (double)col[arg], fp = (double)col[(arg + 1) % bins];
+  if (fm < f0 && f0 > fp) {
+    // parabolic(): xv = 1/2*(f[x-1]-f[x+1]) / (f[x-1]-2f[x]+f[x+1]) + x
+    x = 0.5 * (fm - fp) / (fm - 2.0 * f0 + fp) + x;
+  }
+  return x / (double)fft_size * sr;
+}
+
+__global__ void k_track_peak(const float* __restrict__ mag, int bins, int64_t frame_0, int64_t count,
+                             double* __restrict__ freqs, int fft_size, double sr, double tol) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const Band b = band_limits(freqs[i], tol, fft_size, sr, bins);     // PeakTracker: band follows the drawn trail
+  freqs[i] = peak_freq(mag + (frame_0 + i) * bins, b, bins, fft_size, sr);
+}
+
+// PeakTrackTracker: band fixed on the first trail frequency (read back by the host entry point).
+__global__ void k_track_peak_fixed(const float* __restrict__ mag, int bins, int64_t frame_0, int64_t count,
+                                   double centre, double* __restrict__ freqs, int fft_size, double sr, double tol) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const Band b = band_limits(centre, i > 2 ? tol / 2 : tol, fft_size, sr, bins);
+  freqs[i] = peak_freq(mag + (frame_0 + i) * bins, b, bins, fft_size, sr);
+}
+
+// CenterOfGravity: the band of frame i+1 depends on the result of frame i -> one wave walks the frames,
+// its 64 lanes share the bins of the current band.
+__global__ __launch_bounds__(64) void k_track_cog(const float* __restrict__ mag, int bins, int64_t frame_0, int64_t count,
+                                                   double* __restrict__ freqs, int fft_size, double sr, double tol) {
+  const int lane = threadIdx.x;
+  Band b = band_limits(freqs[0], tol, fft_size, sr, bins);
+  for (int64_t i = 0; i < count; ++i) {
+    const float* col = mag + (frame_0 + i) * bins;
+    const int L = b.NU - b.NL;
+    double num = 0.0, den = 0.0;
+    for (int k = lane; k < L; k += kWave) {
+      // np.hanning(L)[k] = 0.5 - 0.5*cos(2*pi*k/(L-1));  hanning(1) == [1.]
+      const double w = (L == 1) ? 1.0 : 0.5 - 0.5 * cos(2.0 * M_PI * (double)k / (double)(L - 1));
+      const double wm = w * (double)col[b.NL + k];
+      const double fr = (double)(b.NL + k) / (double)fft_size * sr;
+      num += wm * log2(fr);
+      den += wm;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      num += __shfl_xor(num, o, kWave);
+      den += __shfl_xor(den, o, kWave);
+    }
+    const double f = exp2(num / den);
+    if (lane == 0) freqs[i] = f;
+    b = band_limits(f, tol, fft_size, sr, bins);
+  }
+}
+
+}  // namespace par
+
+extern "C" {
+
+int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
+                       double* freqs, int fft_size, double sr, double tolerance_oct, int mode, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(mag && freqs && bins >= 3 && count >= 0 && frame_0 >= 0 && frame_0 + count <= n_frames, PAR_ERR_ARG,
+              "par_track_peak_f64: bad args (frame_0=%lld count=%lld n_frames=%lld)", (long long)frame_0,
+              (long long)count, (long long)n_frames);
+  PAR_REQUIRE(mode == 0 || mode == 1, PAR_ERR_ARG, "par_track_peak_f64: mode must be 0 or 1");
+  if (count == 0) return PAR_OK;
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipStream_t s = as_stream(stream);
+  if (mode == 0) {
+    hipLaunchKernelGGL(k_track_peak, dim3((unsigned)ceil_div(count, 64)), dim3(64), 0, s, mag, bins, frame_0, count,
+                       freqs, fft_size, sr, tolerance_oct);
+  } else {
+    double centre = 0.0;
+    PAR_HIP_CHECK(hipMemcpyAsync(&centre, freqs, sizeof(double), hipMemcpyDeviceToHost, s));
+    PAR_HIP_CHECK(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(k_track_peak_fixed, dim3((unsigned)ceil_div(count, 64)), dim3(64), 0, s, mag, bins, frame_0, count,
+                       centre, freqs, fft_size, sr, tolerance_oct);
+  }
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
+int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
+                      double* freqs, int fft_size, double sr, double tolerance_oct, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(mag && freqs && bins >= 3 && count >= 0 && frame_0 >= 0 && frame_0 + count <= n_frames, PAR_ERR_ARG,
+              "par_track_cog_f64: bad args");
+  if (count == 0) return PAR_OK;
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipLaunchKernelGGL(k_track_cog, dim3(1), dim3(64), 0, as_stream(stream), mag, bins, frame_0, count, freqs, fft_size, sr,
+                     tolerance_oct);
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+"""Mirror of reference util/fourier.py -- same names, arguments and error behaviour, HIP inside.
+
+stft :37-75, get_mag :27-29, to_mag :23-24, istft :314-437, fix_length :440-478,
+fft_freqs :690-700.  `hip_rfft2` has the exact backend-slot signature
+``(n_fft, step, window, x, zeropad)`` of util/fourier.py:67-70, so a maintainer can put it first in
+that tuple.  Arrays are returned with the reference's logical shape
+``(n_freqs, n_frames)``; memory is frame-major (a transposed view), which the reference's own numpy
+backend also produces for n_fft > 512 (util/fourier.py:147).
+"""
+import contextlib
+import logging
+import time
+
+import numpy as np
+import torch
+from scipy import signal as dsp
+
+from . import _dev, _lib
+
+# kept for API parity (util/fourier.py:20-21); the HIP ISTFT needs no column blocking
+MAX_MEM_BLOCK = 2 ** 8 * 2 ** 10
+
+
+def to_mag(spectrum):
+    return abs(spectrum) + .0000001
+
+
+def get_mag(*args, **kwargs):
+    """Get the magnitude spectrum from complex input (fused: |X|+1e-7 never round-trips a complex
+    spectrogram through HBM)."""
+    return stft(*args, _mode=1, **kwargs)
+
+
+@contextlib.contextmanager
+def timed_log(method_name):
+    start = time.time()
+    yield
+    logging.info(f"{method_name} {time.time() - start:0.2f}s")
+
+
+def stft_dev(x_t, n_fft, step, window_t, zeropad=1, mode=0, x_stride=1, n=None, dev=None):
+    """Device-resident STFT.  x_t: float32 tensor (element stride x_stride, logical length n).
+    Returns a tensor with logical shape (bins, frames) that is a transposed view of the frame-major
+    [frames][bins] buffer the kernel wrote (complex64 for mode 0, float32 magnitude for mode 1)."""
+    dev = _dev.device_index(dev if dev is not None else x_t.device)
+    L = _lib.lib()
+    if n is None:
+        n = x_t.numel() // x_stride
+    bins = (n_fft * zeropad) // 2 + 1
+    frames = int(L.par_stft_frames(n, n_fft, step))
+    out = _dev.empty((frames, bins), torch.complex64 if mode == 0 else torch.float32, dev)
+    _lib.check(L.par_stft_f32(dev, _dev.ptr(x_t), n, x_stride, n_fft, step, zeropad, _dev.ptr(window_t), _dev.ptr(out),
+                              mode, _dev.stream_ptr(dev)))
+    return out.T
+
+
+def hip_rfft2(n_fft, step, window, x, zeropad, _mode=0):
+    """Backend-slot callable (util/fourier.py:67-70).  Raises on any failure so that the
+    reference's chain falls through to its next backend."""
+    with timed_log("hip"):
+        dev = _dev.device_index(None)
+        x_t = _dev.to_dev(x, torch.float32, dev)
+        w_t = _dev.to_dev(window, torch.float32, dev)
+        res = stft_dev(x_t, n_fft, step, w_t, zeropad, _mode, dev=dev)
+        return res.cpu().numpy()
+
+
+def stft(x, n_fft=1024, step=512, window_name='blackmanharris', zeropad=1, _mode=0):
+    """Compute the STFT; returns ndarray of shape (n_freqs, n_steps) like the reference."""
+    n_fft = int(n_fft)
+    step = max(n_fft // 2, 1) if step is None else int(step)
+    if isinstance(x, torch.Tensor):
+        if x.ndim != 1:
+            raise ValueError('x must be 1D')
+        dev = _dev.device_index(x.device)
+        window = _dev.to_dev(dsp.get_window(window_name, n_fft).astype(np.float32), torch.float32, dev)
+        xs = x if x.dtype == torch.float32 else x.to(torch.float32)
+        stride = xs.stride(0) if xs.numel() > 1 else 1
+        return stft_dev(xs, n_fft, step, window, zeropad, _mode, x_stride=max(stride, 1), n=xs.shape[0], dev=dev)
+    x = np.asarray(x)
+    if x.ndim != 1:
+        raise ValueError('x must be 1D')
+    window = dsp.get_window(window_name, n_fft).astype(np.float32)
+    return hip_rfft2(n_fft, step, window, x, zeropad, _mode)
+
+
+def istft_dev(spec_t, hop_length, window_t, length=None, dev=None):
+    """spec_t: complex64 tensor with logical shape (bins, frames), frame-major memory preferred."""
+    dev = _dev.device_index(dev if dev is not None else spec_t.device)
+    L = _lib.lib()
+    bins, total_frames = spec_t.shape
+    n_fft = 2 * (bins - 1)
+    fm = spec_t.T.contiguous()                      # [frames][bins]; no copy when it came from stft_dev
+    if fm.dtype != torch.complex64:
+        fm = fm.to(torch.complex64)
+    if length:
+        n_frames = min(total_frames, int(np.ceil((length + n_fft) / hop_length)))
+    else:
+        n_frames = total_frames
+    frames = _dev.empty((n_frames, n_fft), torch.float32, dev)
+    if length is None:
+        y_len = hop_length * (n_frames - 1)         # y[n_fft//2 : -(n_fft//2)]
+    else:
+        y_len = int(length)
+    y = _dev.empty(max(y_len, 0), torch.float32, dev)
+    _lib.check(L.par_istft_f32(dev, _dev.ptr(fm), n_frames, n_fft, hop_length, _dev.ptr(window_t), _dev.ptr(frames),
+                               _dev.ptr(y), y.numel(), n_fft // 2, _dev.stream_ptr(dev)))
+    return y
+
+
+def istft(stft_matrix, hop_length=None, win_length=None, window_name='blackmanharris', center=True, dtype=None,
+          length=None):
+    """Inverse STFT (least squares, window-sumsquare normalised), reference util/fourier.py:314-437.
+
+    Differences, both documented in DESIGN.md: the argument is NOT mutated (the reference scales it
+    by sqrt(n_fft) in place) and the result is float32 unless `dtype` says otherwise.
+    Only the shipped call pattern is supported: center=True, win_length in (None, n_fft)."""
+    n_fft = 2 * (stft_matrix.shape[0] - 1)
+    if win_length is None:
+        win_length = n_fft
+    if not center or win_length != n_fft:
+        raise NotImplementedError("HIP istft supports center=True and win_length == n_fft (the shipped call sites)")
+    if hop_length is None:
+        hop_length = int(win_length // 4)
+    window = dsp.get_window(window_name, win_length, fftbins=True).astype(np.float32)
+    if isinstance(stft_matrix, torch.Tensor):
+        dev = _dev.device_index(stft_matrix.device)
+        return istft_dev(stft_matrix, hop_length, _dev.to_dev(window, torch.float32, dev), length, dev)
+    dev = _dev.device_index(None)
+    S = np.asarray(stft_matrix)
+    spec_t = _dev.to_dev(S.T, torch.complex64, dev).T
+    y = istft_dev(spec_t, hop_length, _dev.to_dev(window, torch.float32, dev), length, dev).cpu().numpy()
+    if dtype is not None:
+        y = y.astype(dtype)
+    return y
+
+
+def fix_length(data, size, axis=-1, **kwargs):
+    """Fix the length of an array to exactly `size` along an axis (trailing zero pad / trim)."""
+    kwargs.setdefault('mode', 'constant')
+    n = data.shape[axis]
+    if n > size:
+        slices = [slice(None)] * data.ndim
+        slices[axis] = slice(0, size)
+        return data[tuple(slices)]
+    elif n < size:
+        lengths = [(0, 0)] * data.ndim
+        lengths[axis] = (0, size - n)
+        return np.pad(data, lengths, **kwargs)
+    return data
+
+
+def fft_freqs(n_fft, fs):
+    """Return frequencies for DFT"""
+    return np.arange(0, (n_fft // 2 + 1)) / float(n_fft) * float(fs)

@@ -1,0 +1,72 @@
+"""P0 -- headless restatement of the pyrespeeder data flow (BASELINE config 3).
+
+The reference spreads these ~30 lines of array math over GUI classes that cannot run headless:
+pyrespeeder_gui.py:119-140 (run_resample / get_speed_curve), :165-191 (tracker invocation),
+util/markers.py:182-226 (TraceLine: log2 speed centred on 0), :585-639 (BaseLine.get_times,
+marker_sr, sample_lines, filter_bandpass, MasterSpeedLine.update, get_linspace) and
+util/spectrum.py:384-385 (spectra are computed with 'blackmanharris').
+Here: STFT magnitude (K_stft) -> tracker (K_track) -> master speed curve (K_sosfiltfilt) ->
+positions (K_pos) -> sinc resample (K_sinc), with the signal and spectrogram resident in HBM.
+"""
+import warnings
+
+import numpy as np
+import torch
+
+from . import _dev, filters, fourier, resampling, wow_detection
+
+
+def trace_to_speed(freqs):
+    """TraceLine.__init__ (util/markers.py:197-199): log2 speed, centred on 0 (offset 0)."""
+    speed = np.log2(freqs)
+    return speed - np.mean(speed)
+
+
+def master_speed_curve(lines, duration, sr, hop, bands=(0, 20)):
+    """MasterSpeedLine.update + get_linspace (util/markers.py:585-639).
+    lines: list of (times, log2_speed).  Returns [[t_seconds, linear_speed], ...]."""
+    marker_sr = sr / hop
+    times = np.linspace(0, duration, num=int(duration * marker_sr))
+    out = np.zeros((len(times), len(lines)), dtype=np.float32)
+    for i, (line_times, line_values) in enumerate(lines):
+        out[:, i] = np.interp(times, line_times, line_values, left=np.nan, right=np.nan)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", category=RuntimeWarning)
+        mean_with_nans = np.nanmean(out, axis=1)
+    wow_detection.interp_nans(mean_with_nans)
+    lowcut, highcut = sorted(bands)
+    filtered = filters.butter_bandpass_filter(mean_with_nans, lowcut, highcut, marker_sr, order=3)
+    data = np.stack((times, filtered), axis=-1)
+    curve = np.array(data)
+    np.power(2, curve[:, 1], curve[:, 1])
+    return curve
+
+
+def respeed(signal, sr, trail, fft_size=1024, hop=256, zeropad=1, mode="Peak", tolerance_st=0.5, bands=(0, 20),
+            sinc_quality=32, resampling_mode="Sinc", device=None):
+    """signal: float32 (n,) or (n, ch).  Returns dict with every intermediate the reference's GUI
+    would hold: spectrum (device), track times/freqs, speed curve, positions (device), output."""
+    dev = _dev.device_index(device)
+    sig2d = signal[:, None] if signal.ndim == 1 else signal
+    n = sig2d.shape[0]
+    sig_t = _dev.to_dev(sig2d, torch.float32, dev)                       # (n, ch) resident in HBM
+    ch = sig2d.shape[1]
+    spec = fourier.get_mag(sig_t.reshape(-1)[0::ch] if ch > 1 else sig_t.reshape(-1), fft_size, hop,
+                           "blackmanharris", zeropad)                      # device tensor (bins, frames)
+    track = wow_detection.wow_detectors[mode](spec, sig2d, list(trail), fft_size * zeropad, hop, sr, tolerance_st,
+                                              "Linear")
+    curve = master_speed_curve([(track.times, trace_to_speed(track.freqs))], n / sr, sr, hop, bands)
+    st_t = _dev.to_dev(curve[:, 0] * sr, torch.float64, dev)
+    sp_t = _dev.to_dev(np.ascontiguousarray(curve[:, 1]), torch.float64, dev)
+    pos_t = resampling.speed_to_pos_dev(st_t, sp_t, n, dev)
+    out_t = _dev.empty((pos_t.numel(), ch), torch.float32, dev)
+    for c in range(ch):
+        fn = resampling.sinc_resample_dev if resampling_mode == "Sinc" else None
+        if fn is not None:
+            fn(pos_t, sig_t.reshape(-1)[c:], sinc_quality, out_t.reshape(-1)[c:], sig_stride=ch, len_in=n,
+               out_stride=ch, dev=dev)
+        else:
+            resampling.linear_resample_dev(pos_t, sig_t.reshape(-1)[c:], out_t.reshape(-1)[c:], sig_stride=ch, len_in=n,
+                                           out_stride=ch, dev=dev)
+    return {"spectrum": spec, "times": track.times, "freqs": track.freqs, "speed_curve": curve, "positions": pos_t,
+            "output": out_t}

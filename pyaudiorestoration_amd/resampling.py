@@ -1,0 +1,178 @@
+"""Mirror of reference util/resampling.py -- same names, arguments and behaviour, HIP inside.
+
+sinc_wrapper :21-27, sinc_wrapper_mt :30-46, sinc_core :51-90, speed_to_pos :93-137,
+find_cutoff :14-18, run :162-240.  The `*_dev` functions keep everything in HBM (torch tensors
+only own the buffers); the numpy-signature functions wrap them with H2D/D2H copies.
+"""
+import ctypes
+import logging
+import os
+from time import time
+
+import numpy as np
+import torch
+
+from . import _dev, _lib
+from .timing import log_duration
+
+
+def find_cutoff(array, cutoff):
+    """First index with array[idx] >= cutoff, as a 1-tuple like np.ndenumerate yields; else None."""
+    hit = np.nonzero(np.asarray(array) >= cutoff)[0]
+    return (int(hit[0]),) if len(hit) else None
+
+
+# ----------------------------------------------------------------------------- positions
+
+def speed_to_pos_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None):
+    """Device speed curve (float64 tensors) -> float64 position tensor (the written prefix)."""
+    dev = _dev.device_index(dev if dev is not None else sampletimes_t.device)
+    L = _lib.lib()
+    m = sampletimes_t.numel()
+    if speeds_t.numel() != m:
+        raise ValueError("sampletimes and speeds must have the same length")
+    nbytes = int(L.par_speed_plan_bytes(m))
+    work = _dev.empty(nbytes, torch.uint8, dev)
+    len_out = ctypes.c_int64(0)
+    trimmed = ctypes.c_int(0)
+    sp = _dev.stream_ptr(dev)
+    _lib.check(L.par_speed_to_pos_plan(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m, int(num_imput_samples),
+                                       _dev.ptr(work), nbytes, ctypes.byref(len_out), ctypes.byref(trimmed), sp))
+    pos = _dev.empty(len_out.value, torch.float64, dev)
+    _lib.check(L.par_speed_to_pos_fill(dev, _dev.ptr(speeds_t), m, _dev.ptr(work), _dev.ptr(pos), len_out.value, sp))
+    return pos
+
+
+def speed_to_pos(sampletimes, speeds, num_imput_samples):
+    """
+    sampletimes: 1D array of sample numbers at which speeds is sampled; must have even spacing
+    speeds: 1D array of speed samples
+    num_imput_samples: int
+    Returns the float64 read positions (bit-identical to the reference's array; when the reference's
+    end trim does not fire its buffer tail is uninitialised -- only the written prefix is returned).
+    """
+    dev = _dev.device_index(None)
+    st = _dev.to_dev(np.asarray(sampletimes, dtype=np.float64), torch.float64, dev)
+    sp = _dev.to_dev(np.asarray(speeds, dtype=np.float64), torch.float64, dev)
+    return speed_to_pos_dev(st, sp, num_imput_samples, dev).cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- interpolation
+
+def sinc_resample_dev(pos_t, sig_t, NT, out_t=None, sig_stride=1, len_in=None, out_stride=1, dev=None):
+    """pos_t float64[len_out], sig_t float32 (stride sig_stride) -> float32 out (stride out_stride)."""
+    dev = _dev.device_index(dev if dev is not None else pos_t.device)
+    L = _lib.lib()
+    len_out = pos_t.numel()
+    if len_in is None:
+        len_in = sig_t.numel() // sig_stride
+    if out_t is None:
+        out_t = _dev.empty(len_out * out_stride, torch.float32, dev)
+    _lib.check(L.par_sinc_resample_f32(dev, _dev.ptr(pos_t), len_out, _dev.ptr(sig_t), sig_stride, len_in, int(NT),
+                                       _dev.ptr(out_t), out_stride, _dev.stream_ptr(dev)))
+    return out_t
+
+
+def linear_resample_dev(pos_t, sig_t, out_t=None, sig_stride=1, len_in=None, out_stride=1, dev=None):
+    dev = _dev.device_index(dev if dev is not None else pos_t.device)
+    L = _lib.lib()
+    len_out = pos_t.numel()
+    if len_in is None:
+        len_in = sig_t.numel() // sig_stride
+    if out_t is None:
+        out_t = _dev.empty(len_out * out_stride, torch.float32, dev)
+    _lib.check(L.par_linear_resample_f32(dev, _dev.ptr(pos_t), len_out, _dev.ptr(sig_t), sig_stride, len_in,
+                                         _dev.ptr(out_t), out_stride, _dev.stream_ptr(dev)))
+    return out_t
+
+
+def sinc_wrapper(sample_at, signal, lowpass, NT):
+    """Returns float32[len(sample_at)].  `lowpass` is ignored, as in the reference (dead argument)."""
+    dev = _dev.device_index(None)
+    if len(sample_at) < 2:
+        raise UnboundLocalError("local variable 'period_to' referenced before assignment")   # reference behaviour
+    pos_t = _dev.to_dev(np.asarray(sample_at, dtype=np.float64), torch.float64, dev)
+    sig_t = _dev.to_dev(signal, torch.float32, dev)
+    return sinc_resample_dev(pos_t, sig_t, NT, dev=dev).cpu().numpy()
+
+
+def sinc_wrapper_mt(output, sample_at, signal, lowpass, NT):
+    """In-place variant: fills caller-owned `output` (may be a strided column view), returns None.
+    Uses the canonical period definition (every chunk boundary reads the true next position), so the
+    result does not depend on os.cpu_count() the way the reference's chunked threads do."""
+    output[:] = sinc_wrapper(sample_at, signal, lowpass, NT)
+
+
+def sinc_core(sample_at, signal, lowpass, output, win_func, N):
+    """Reference-signature entry (util/resampling.py:52): NT from len(N); window/N are recomputed on
+    the device side from NT exactly as sinc_wrapper builds them."""
+    NT = (len(N) - 1) // 2
+    output[:] = sinc_wrapper(sample_at, signal, lowpass, NT)
+
+
+# ----------------------------------------------------------------------------- run
+
+def run(filenames, signal_data=None, speed_curve=None, resampling_mode="Linear", sinc_quality=50, use_channels=(),
+        prog_sig=None, lag_curve=None, suffix=""):
+    """Drop-in for resampling.run (util/resampling.py:162-240): same progress callbacks, channel
+    filtering and output naming; positions and all channels stay in HBM until the final D2H."""
+    from . import io_ops
+    if prog_sig:
+        prog_sig.notifyProgress.emit(0)
+    if signal_data is None:
+        signal_data = [None for filename in filenames]
+    dev = _dev.device_index(None)
+    for filename, sig_data in zip(filenames, signal_data):
+        with log_duration("Preparing"):
+            logging.info(f"Resampling '{os.path.basename(filename)}'... {resampling_mode}, {sinc_quality}, {use_channels}")
+            if sig_data:
+                signal, sr = sig_data
+                num_channels = signal.shape[1]
+            else:
+                signal, sr, num_channels = io_ops.read_file(filename)
+            sig_t = _dev.to_dev(signal, torch.float32, dev)          # (n, ch) C-order in HBM
+            n_in, n_ch_in = signal.shape
+            if speed_curve is not None:
+                sampletimes = speed_curve[:, 0] * sr
+                speeds = speed_curve[:, 1]
+                pos_t = speed_to_pos_dev(_dev.to_dev(np.asarray(sampletimes, dtype=np.float64), torch.float64, dev),
+                                         _dev.to_dev(np.asarray(speeds, dtype=np.float64), torch.float64, dev), n_in, dev)
+            elif lag_curve is not None:
+                sampletimes = lag_curve[:, 0] * sr
+                lags = lag_curve[:, 1] * sr
+                num_output_samples = n_in + abs(lags[-1])
+                sample_at = np.interp(np.arange(num_output_samples), sampletimes, sampletimes - lags)
+                trim_end = find_cutoff(sample_at, n_in)
+                if trim_end is not None:
+                    logging.debug(f"Trimmed to sample {trim_end[0]}")
+                    sample_at = sample_at[:trim_end[0]]
+                np.clip(sample_at, 0, None, out=sample_at)
+                pos_t = _dev.to_dev(sample_at, torch.float64, dev)
+            else:
+                raise UnboundLocalError("local variable 'sample_at' referenced before assignment")  # reference behaviour
+        if use_channels:
+            use_channels = [channel for channel in use_channels if channel < signal.shape[1]]
+        else:
+            use_channels = tuple(range(num_channels))
+        with log_duration("Resampling"):
+            length = pos_t.numel()
+            num_channels = len(use_channels)
+            out_t = _dev.empty((length, num_channels), torch.float32, dev)
+            for out_channel, in_channel in enumerate(use_channels):
+                sig_view = sig_t.reshape(-1)[in_channel:]
+                out_view = out_t.reshape(-1)[out_channel:]
+                if resampling_mode == "Sinc":
+                    sinc_resample_dev(pos_t, sig_view, sinc_quality, out_view, sig_stride=n_ch_in, len_in=n_in,
+                                      out_stride=num_channels, dev=dev)
+                elif resampling_mode == "Linear":
+                    linear_resample_dev(pos_t, sig_view, out_view, sig_stride=n_ch_in, len_in=n_in,
+                                        out_stride=num_channels, dev=dev)
+                if prog_sig:
+                    prog_sig.notifyProgress.emit((out_channel + 1) / num_channels * 100)
+            output = out_t.cpu().numpy()
+        with log_duration("Writing"):
+            out_file_path = f"{os.path.splitext(filename)[0]}_res{suffix}.wav"
+            io_ops.write_wav_float(out_file_path, output, sr)
+            if prog_sig:
+                prog_sig.notifyProgress.emit(100)
+    logging.info("Done!")

@@ -1,0 +1,327 @@
+"""GPU parity tests: the HIP path (through the Python mirror -> ctypes -> C ABI) against
+ (1) golden vectors captured from the real reference, (2) the pinned CPU oracle on seeded inputs,
+ (3) size-independent properties at larger sizes.
+Tolerances: float outputs within 1e-5 relative (norm-wise) -- most are ~1e-6;
+positions, lengths and frame counts exact."""
+import numpy as np
+import pytest
+import scipy.signal
+
+import inputs
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def relerr(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def par():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from pyaudiorestoration_amd import _lib, fourier, resampling, wow_detection, filters, pipeline
+    assert _lib.lib().par_device_count() >= 1
+
+    class P:
+        pass
+    p = P()
+    p.fourier, p.resampling, p.wow, p.filters, p.pipeline, p.torch = fourier, resampling, wow_detection, filters, pipeline, torch
+    return p
+
+
+# ------------------------------------------------------------------------------------ STFT
+STFT_CASES = ["kat1", "bh", "small_vec", "odd_len", "zp2", "zp2_big", "n2048", "n64", "n4096", "hop_eq", "hop_odd"]
+
+
+@pytest.mark.parametrize("name", STFT_CASES)
+def test_stft_golden(par, golden, name):
+    g = golden["stft"]
+    n, seed, n_fft, hop, zp = (int(v) for v in g[name + "_cfg"])
+    x = inputs.noise(n, seed)
+    S = par.fourier.stft(x, n_fft, hop, str(g[name + "_win"]), zp)
+    assert S.shape == g[name + "_S"].shape                      # integer frame/bin arithmetic exact
+    assert relerr(S, g[name + "_S"]) < TOL
+    m = par.fourier.get_mag(x, n_fft, hop, str(g[name + "_win"]), zp)
+    assert relerr(m, np.abs(g[name + "_S"].astype(np.complex128)) + 1e-7) < TOL
+
+
+def test_stft_kat_and_strided(par, golden):
+    x = inputs.noise(4096, 0)
+    S = par.fourier.stft(x, 1024, 256, "hann", 1)
+    assert abs(S[0, 0] - (-0.19117718935012817)) < 1e-5 and abs(S[100, 8] - (-0.9019840955734253 - 0.008981410413980484j)) < 1e-5
+    m = par.fourier.get_mag(x, 1024, 256, "blackmanharris", 1)
+    assert relerr(m, golden["stft"]["kat2_mag"]) < TOL
+    st = np.stack((inputs.noise(3000, 10), inputs.noise(3000, 11)), axis=-1)
+    assert relerr(par.fourier.stft(st[:, 1], 512, 128, "blackmanharris", 1), golden["stft"]["strided_S"]) < TOL
+    # device-resident channel view: element stride 2, no host copy
+    t = par.torch.from_numpy(st).cuda()
+    Sd = par.fourier.stft(t[:, 1], 512, 128, "blackmanharris", 1)
+    assert relerr(Sd.cpu().numpy(), golden["stft"]["strided_S"]) < TOL
+    with pytest.raises(ValueError):
+        par.fourier.stft(st, 512, 128)
+    from pyaudiorestoration_amd import _lib
+    with pytest.raises(_lib.ParUnsupported):                    # reference chain would fall through here
+        par.fourier.stft(x, 1000, 250)
+
+
+def test_stft_vs_c_oracle_larger(par):
+    from oracle import oracle_c as C
+    x = inputs.pilot(200000, 192000)
+    for n_fft, hop, wname in ((1024, 256, "blackmanharris"), (512, 32, "hann"), (4096, 512, "hann"), (8192, 2048, "hamming")):
+        win = scipy.signal.get_window(wname, n_fft).astype(np.float32)
+        ref = C.stft(x, n_fft, hop, win, 1, mode=1)
+        got = par.fourier.get_mag(x, n_fft, hop, wname)
+        assert got.shape == ref.shape and relerr(got, ref) < TOL, (n_fft, hop)
+
+
+def test_stft_short_and_edge_inputs(par):
+    from oracle import oracle_np as O
+    for n, n_fft, hop in ((40, 64, 16), (33, 64, 16), (700, 1024, 256), (1024, 1024, 1024)):
+        x = inputs.noise(n, 77)
+        assert relerr(par.fourier.stft(x, n_fft, hop, "hann"), O.stft(x, n_fft, hop, "hann")) < TOL, (n, n_fft)
+
+
+# ----------------------------------------------------------------------------------- ISTFT
+@pytest.mark.parametrize("name", ["rt512", "rt1024", "rt256"])
+def test_istft_golden(par, golden, name):
+    g = golden["istft"]
+    n, seed, n_fft, hop = (int(v) for v in g[name + "_cfg"])
+    x = inputs.noise(n, seed)
+    S = par.fourier.stft(x, n_fft, hop)
+    S2 = S.copy()
+    S2[5:40, 3:9] *= 0.25
+    keep = S.copy()
+    y = par.fourier.istft(S, hop_length=hop, length=n)
+    assert np.array_equal(S, keep)                              # not mutated (quirk 9 decision)
+    assert relerr(y, g[name + "_y"]) < TOL and relerr(y, x) < TOL
+    assert relerr(par.fourier.istft(S2, hop_length=hop, length=n), g[name + "_ymod"]) < TOL
+    assert relerr(par.fourier.istft(S, hop_length=hop), g[name + "_ynolen"]) < TOL
+
+
+def test_istft_heal_framing_and_device_roundtrip(par, golden):
+    g = golden["istft"]
+    x = inputs.noise(5000, 15)
+    S = par.fourier.stft(par.fourier.fix_length(x, len(x) + 256), 512, 32)
+    assert tuple(g["heal_shape"]) == S.shape
+    assert relerr(par.fourier.istft(S, hop_length=32, length=len(x)), g["heal_y"]) < TOL
+    xt = par.torch.from_numpy(inputs.noise(100000, 16)).cuda()
+    St = par.fourier.stft(xt, 1024, 256)                        # stays in HBM
+    yt = par.fourier.istft(St, hop_length=256, length=xt.numel())
+    assert relerr(yt.cpu().numpy(), xt.cpu().numpy()) < TOL
+
+
+# ------------------------------------------------------------------------------- positions
+def test_speed_to_pos_golden_bit_exact(par, golden):
+    g = golden["speed_to_pos"]
+    n = 8192
+    st = np.linspace(0, n, 33)
+    sp = 1 + 0.01 * np.sin(2 * np.pi * np.arange(33) / 16 + 0.7)
+    pos = par.resampling.speed_to_pos(st, sp, n)
+    assert len(pos) == 8191 and np.array_equal(pos, g["kat3_pos"])          # KAT3, float64 bit-exact
+    assert np.array_equal(par.resampling.speed_to_pos(np.array((0.0, 20000.0)), np.array((0.5, 2.0)), 20000), g["ramp_pos"])
+    sc = inputs.bench_speed_curve(2.0, 48000)
+    assert np.array_equal(par.resampling.speed_to_pos(sc[:, 0] * 48000, sc[:, 1], 96000), g["bench_pos"])
+    assert np.array_equal(par.resampling.speed_to_pos(g["wobble_st"], g["wobble_sp"], 30000), g["wobble_pos"])
+    assert np.array_equal(par.resampling.speed_to_pos(g["untrimmed_st"], g["untrimmed_sp"], 10000), g["untrimmed_pos"])
+
+
+def test_speed_to_pos_vs_c_oracle_long(par):
+    from oracle import oracle_c as C
+    sr, dur = 192000, 20.0
+    sc = inputs.bench_speed_curve(dur, sr)
+    n = int(sr * dur)
+    ref, trimmed = C.speed_to_pos(sc[:, 0] * sr, sc[:, 1], n)
+    pos = par.resampling.speed_to_pos(sc[:, 0] * sr, sc[:, 1], n)
+    assert len(pos) == len(ref) and np.array_equal(pos, ref)
+    assert np.all(np.diff(pos) > 0)                                           # property: monotone
+    from pyaudiorestoration_amd import _lib
+    with pytest.raises(_lib.ParError):
+        par.resampling.speed_to_pos(np.array([0.0, 3.0, 6.0]), np.array([0.2, 0.2, 0.2]), 100)    # n_i < 2
+
+
+# ------------------------------------------------------------------------------------ sinc
+def test_sinc_golden(par, golden):
+    g = golden["sinc"]
+    gp = golden["speed_to_pos"]
+    y = par.resampling.sinc_wrapper(gp["kat3_pos"], inputs.sine(8192, 440, 44100), 0, 32)
+    assert relerr(y, g["kat4_y"]) < TOL
+    assert abs(y[4000] - (-0.45488033)) < 1e-5 and abs(y[100] - 0.004950763) < 1e-5      # KAT4
+    assert np.allclose(y[:3], [0.91083026, 0.903764, 0.91026634], atol=1e-5)              # edge-quirk region
+    sig = inputs.noise(600, 30)
+    y = par.resampling.sinc_wrapper(np.arange(600, dtype=np.float64), sig, 0, 8)
+    assert relerr(y, g["ident_y"]) < TOL and np.all(np.abs(y[8:] - sig[8:]) < 1e-5)      # quirk 1 kept
+    sig = (inputs.sine(20000, 440, 44100, 0.5) + inputs.sine(20000, 21000, 44100, 0.1)).astype(np.float32)
+    assert relerr(par.resampling.sinc_wrapper(gp["ramp_pos"], sig, 0, 50), g["ramp_y"]) < TOL
+    bsig = inputs.bench_signal(0, 96000, 48000)
+    yb = par.resampling.sinc_wrapper(gp["bench_pos"], bsig, 0, 32)
+    assert relerr(yb, g["bench_y"]) < TOL
+    assert relerr(par.resampling.sinc_wrapper(g["tail_pos"], inputs.noise(1000, 31), 0, 16), g["tail_y"]) < TOL
+    sig = inputs.noise(3000, 32)
+    pos = np.cumsum(np.full(2500, 1.013)) - 0.4
+    assert relerr(par.resampling.sinc_wrapper(pos, sig, 0, 1), g["nt1_y"]) < TOL
+    assert relerr(par.resampling.sinc_wrapper(pos, sig, 0, 100), g["nt100_y"]) < TOL
+    assert relerr(par.resampling.sinc_wrapper(g["down_pos"], sig, 0, 24), g["down_y"]) < TOL
+
+
+def test_sinc_wrapper_mt_and_core_signatures(par, golden):
+    g = golden["sinc"]
+    gp = golden["speed_to_pos"]
+    bsig = inputs.bench_signal(0, 96000, 48000)
+    buf = np.zeros((len(gp["bench_pos"]), 2), dtype=np.float32)
+    assert par.resampling.sinc_wrapper_mt(buf[:, 1], gp["bench_pos"], bsig, 0, 32) is None
+    assert relerr(buf[:, 1], g["bench_y"]) < TOL and not buf[:, 0].any()
+    out = np.empty(len(gp["bench_pos"]), dtype=np.float32)
+    N = np.arange(-32, 33, dtype="float32")
+    par.resampling.sinc_core(gp["bench_pos"], bsig, 0, out, np.hanning(65).astype("float32"), N)
+    assert relerr(out, g["bench_y"]) < TOL
+    with pytest.raises(UnboundLocalError):
+        par.resampling.sinc_wrapper(np.array([5.0]), bsig, 0, 32)
+
+
+@pytest.mark.parametrize("NT", [4, 32, 50])
+def test_sinc_vs_c_oracle_regimes(par, NT):
+    """fc == 1, fc < 1, mixed waves, big speeds (LDS span overflow -> global path), all vs the C oracle."""
+    from oracle import oracle_c as C
+    rng = np.random.default_rng(5)
+    sig = inputs.bench_signal(0, 400000, 96000)
+    n_out = 150000
+    for name, speed in (("slow", np.full(n_out, 0.97)), ("fast", np.full(n_out, 1.031)),
+                        ("mixed", 1 + 0.02 * np.sin(np.arange(n_out) * 2e-3)),
+                        ("jitter", 1 + 0.3 * rng.random(n_out)), ("x2.5", np.full(n_out, 2.5)),
+                        ("x9", np.full(40000, 9.0))):
+        pos = 40.25 + np.cumsum(speed)
+        ref = C.sinc(pos, sig, NT, threads=8)
+        got = par.resampling.sinc_wrapper(pos, sig, 0, NT)
+        assert relerr(got, ref) < TOL, (name, NT, relerr(got, ref))
+
+
+def test_sinc_exact_integer_positions_and_repeats(par):
+    from oracle import oracle_c as C
+    sig = inputs.noise(5000, 9)
+    pos = np.concatenate((np.arange(100, 2100, dtype=np.float64), [2100.5, 2100.5, 2100.5, 2101.0],
+                          np.arange(2101.0, 2600.0, 0.5)))
+    assert relerr(par.resampling.sinc_wrapper(pos, sig, 0, 32), C.sinc(pos, sig, 32)) < TOL
+
+
+def test_linear_and_lag_golden(par, golden):
+    g = golden["linear_lag"]
+    sig = inputs.noise(5000, 50)
+    t = par.torch
+    got = par.resampling.linear_resample_dev(t.from_numpy(g["pos"]).cuda(), t.from_numpy(sig).cuda()).cpu().numpy()
+    assert relerr(got, g["lin"]) < 1e-6
+
+
+def test_run_writes_res_wav_like_reference(par, golden, tmp_path):
+    """resampling.run drop-in: progress callbacks, channel filtering, output naming, FLOAT wav."""
+    from pyaudiorestoration_amd import io_ops
+    g, gp = golden["sinc"], golden["speed_to_pos"]
+    sr = 48000
+    sig = np.stack((inputs.bench_signal(0, 96000, sr), inputs.noise(96000, 1)), axis=-1)
+    curve = inputs.bench_speed_curve(2.0, sr)
+    seen = []
+
+    class Sig:
+        class notifyProgress:
+            emit = staticmethod(seen.append)
+    fn = str(tmp_path / "tape.flac")
+    par.resampling.run((fn,), signal_data=((sig, sr),), speed_curve=curve, resampling_mode="Sinc", sinc_quality=32,
+                       use_channels=(0, 5), prog_sig=Sig, suffix="_x")
+    y, sr2, ch = io_ops.read_file(str(tmp_path / "tape_res_x.wav"))
+    assert sr2 == sr and ch == 1 and y.shape == (len(gp["bench_pos"]), 1)
+    assert relerr(y[:, 0], g["bench_y"]) < TOL
+    assert seen[0] == 0 and seen[-1] == 100 and 100.0 in seen
+    par.resampling.run((fn,), signal_data=((sig, sr),), speed_curve=curve, resampling_mode="Linear")
+    y, _, ch = io_ops.read_file(str(tmp_path / "tape_res.wav"))
+    assert ch == 2 and relerr(y[:, 0], np.interp(gp["bench_pos"], np.arange(96000), sig[:, 0], left=0, right=0)) < 1e-6
+
+
+# --------------------------------------------------------------------------------- filters
+def test_filters_golden(par, golden):
+    g = golden["filters"]
+    x = inputs.noise(4096, 0).astype(np.float64)
+    f = par.filters.butter_bandpass_filter
+    assert relerr(f(x, 1000, 4000, 44100, order=3), g["band"]) < 1e-9
+    assert relerr(f(x, 0, 20, 172.265625, order=3), g["low"]) < 1e-9
+    assert relerr(f(x, 300, 0, 44100, order=3), g["high"]) < 1e-9
+    assert relerr(f(x, 500, 2000, 44100), g["band5"]) < 1e-9
+    assert f(x, 0, 0, 44100) is x
+    with pytest.raises(ValueError):
+        f(x[:10], 0, 20, 172.0, order=3)
+    big = inputs.noise(1350000, 3).astype(np.float64)           # C2-sized speed curve
+    assert relerr(f(big, 0, 20, 375.0, order=3), scipy.signal.sosfiltfilt(scipy.signal.butter(3, 20 / 187.5, btype="low", output="sos"), big)) < 1e-9
+
+
+# -------------------------------------------------------------------------------- trackers
+def test_trackers_golden(par, golden):
+    g = golden["trackers"]
+    sr, n, n_fft, hop = (int(v) for v in g["cfg"])
+    x = inputs.pilot(n, sr)
+    spec = par.fourier.get_mag(x, n_fft, hop, "blackmanharris", 1)
+    trail = [(0.2, 4000.0), (1.3, 4000.0)]
+    for name, key, tol in (("Peak", "peak", 1e-6), ("Peak Track", "peak_track", 1e-6), ("Center of Gravity", "center_of_gravity", 1e-6),
+                           ("Correlation", "correlation", 1e-5), ("Freehand Draw", "freehand_draw", 1e-12),
+                           ("Zero-Crossing", "zero_crossing", 1e-6)):
+        tr = par.wow.wow_detectors[name](spec, x[:, None], list(trail), n_fft, hop, sr, 0.5, "Linear")
+        assert np.array_equal(tr.times, g[key + "_times"]), name
+        assert relerr(tr.freqs, g[key + "_freqs"]) < tol, (name, relerr(tr.freqs, g[key + "_freqs"]))
+    tr = par.wow.wow_detectors["Peak"](spec, x[:, None], [(1.2, 4030.0), (0.1, 3980.0), (0.6, 4010.0)], n_fft, hop, sr, 2.0)
+    assert np.array_equal(tr.times, g["peak2_times"]) and relerr(tr.freqs, g["peak2_freqs"]) < 1e-6
+    # device-resident spectrogram (no D2H/H2D of the spectrogram)
+    xt = par.torch.from_numpy(x).cuda()
+    spec_t = par.fourier.get_mag(xt, n_fft, hop, "blackmanharris", 1)
+    tr = par.wow.wow_detectors["Peak"](spec_t, x[:, None], list(trail), n_fft, hop, sr, 0.5)
+    assert relerr(tr.freqs, g["peak_freqs"]) < 1e-6
+
+
+def test_pipeline_config3_flow(par, golden):
+    g = golden["pipeline"]
+    sr, n, n_fft, hop = (int(v) for v in g["cfg"])
+    x = inputs.pilot(n, sr)
+    r = par.pipeline.respeed(x, sr, [(0.05, 4000.0), (1.45, 4000.0)], n_fft, hop, 1, "Peak", 0.5, (0, 20), 32)
+    assert np.array_equal(r["times"], g["track_times"]) and relerr(r["freqs"], g["track_freqs"]) < 1e-6
+    assert r["speed_curve"].shape == g["curve"].shape and relerr(r["speed_curve"][:, 1], g["curve"][:, 1]) < 1e-7
+    pos = r["positions"].cpu().numpy()
+    assert len(pos) == len(g["pos"]) and np.max(np.abs(pos - g["pos"])) < 1e-4
+    assert relerr(r["output"].cpu().numpy()[:, 0], g["y"]) < 5e-5      # speed curve differs ~1e-7 -> positions ~1e-5
+
+
+# ------------------------------------------------------------- properties at bench-like sizes
+def test_large_properties(par):
+    """10 s @192 kHz: device-born signal == oracle generator; sampled outputs == oracle at random
+    indices; chunk invariance (resampling a slice of the position array gives the same samples)."""
+    from oracle import oracle_c as C
+    import ctypes
+    from pyaudiorestoration_amd import _lib, _dev
+    t = par.torch
+    sr, dur = 192000, 10.0
+    n = int(sr * dur)
+    L = _lib.lib()
+    sig_t = t.empty(n, dtype=t.float32, device="cuda")
+    _lib.check(L.par_synth_signal_f32(0, _dev.ptr(sig_t), 0, n, float(sr), 0x5EED, _dev.stream_ptr(0)))
+    sig = sig_t.cpu().numpy()
+    assert np.max(np.abs(sig - C.synth_signal(0, n, sr))) < 1e-6
+    m = int(dur * sr / 256)
+    st_t = t.empty(m, dtype=t.float64, device="cuda")
+    sp_t = t.empty(m, dtype=t.float64, device="cuda")
+    _lib.check(L.par_synth_speed_curve_f64(0, _dev.ptr(st_t), _dev.ptr(sp_t), m, dur, float(sr), 0.01, 0.55, 0.7,
+                                           _dev.stream_ptr(0)))
+    st, sp = st_t.cpu().numpy(), sp_t.cpu().numpy()
+    rst, rsp = C.synth_curve(m, dur, sr)
+    assert np.allclose(st, rst, rtol=0, atol=1e-6) and np.allclose(sp, rsp, rtol=0, atol=1e-14)
+    pos_t = par.resampling.speed_to_pos_dev(st_t, sp_t, n)
+    ref_pos, _ = C.speed_to_pos(st, sp, n)
+    pos = pos_t.cpu().numpy()
+    assert np.array_equal(pos, ref_pos)
+    out = par.resampling.sinc_resample_dev(pos_t, sig_t, 32).cpu().numpy()
+    idx = np.sort(np.random.default_rng(0).choice(len(pos) - 70000, 40, replace=False))
+    for i in idx:                                         # oracle on 40 windows of 2000 outputs
+        ref = C.sinc(pos[i:i + 2001], sig, 32)[:2000]
+        assert relerr(out[i:i + 2000], ref) < TOL
+    part = par.resampling.sinc_resample_dev(pos_t[123457:323457], sig_t, 32).cpu().numpy()
+    assert np.array_equal(part[:-1], out[123457:323456])  # chunk invariance (last sample: period reuse)

@@ -177,3 +177,67 @@ def test_linear_and_lag(golden):
     pos = O.lag_to_positions(g["lag"], int(g["sr"]), len(sig))
     assert np.array_equal(pos, g["pos"])
     assert np.array_equal(O.linear_resample(pos, sig), g["lin"])
+
+
+# ----------------------------------------------------------------- plain-C oracle (oracle/par_oracle.c)
+
+def test_c_oracle_speed_to_pos(golden):
+    from oracle import oracle_c as C
+    g = golden["speed_to_pos"]
+    n = 8192
+    st = np.linspace(0, n, 33)
+    sp = 1 + 0.01 * np.sin(2 * np.pi * np.arange(33) / 16 + 0.7)
+    pos, trimmed = C.speed_to_pos(st, sp, n)
+    assert trimmed and np.array_equal(pos, g["kat3_pos"])
+    pos, _ = C.speed_to_pos(np.array((0.0, 20000.0)), np.array((0.5, 2.0)), 20000)
+    assert np.array_equal(pos, g["ramp_pos"])
+    sc = inputs.bench_speed_curve(2.0, 48000)
+    pos, _ = C.speed_to_pos(sc[:, 0] * 48000, sc[:, 1], 96000)
+    assert np.array_equal(pos, g["bench_pos"])
+    pos, _ = C.speed_to_pos(g["wobble_st"], g["wobble_sp"], 30000)
+    assert np.array_equal(pos, g["wobble_pos"])
+    pos, trimmed = C.speed_to_pos(g["untrimmed_st"], g["untrimmed_sp"], 10000)
+    assert not trimmed and np.array_equal(pos, g["untrimmed_pos"])
+
+
+def test_c_oracle_sinc(golden):
+    from oracle import oracle_c as C
+    g = golden["sinc"]
+    gp = golden["speed_to_pos"]
+    tol = 3e-7
+    assert relerr(C.sinc(gp["kat3_pos"], inputs.sine(8192, 440, 44100), 32), g["kat4_y"]) < tol
+    assert relerr(C.sinc(np.arange(600, dtype=np.float64), inputs.noise(600, 30), 8), g["ident_y"]) < tol
+    sig = (inputs.sine(20000, 440, 44100, 0.5) + inputs.sine(20000, 21000, 44100, 0.1)).astype(np.float32)
+    assert relerr(C.sinc(gp["ramp_pos"], sig, 50), g["ramp_y"]) < tol
+    bsig = inputs.bench_signal(0, 96000, 48000)
+    assert relerr(C.sinc(gp["bench_pos"], bsig, 32), g["bench_y"]) < tol
+    assert relerr(C.sinc(gp["bench_pos"], bsig, 32, threads=5), g["bench_y"]) < tol     # mt == single
+    assert relerr(C.sinc(g["tail_pos"], inputs.noise(1000, 31), 16), g["tail_y"]) < tol
+    sig = inputs.noise(3000, 32)
+    pos = np.cumsum(np.full(2500, 1.013)) - 0.4
+    assert relerr(C.sinc(pos, sig, 1), g["nt1_y"]) < tol
+    assert relerr(C.sinc(pos, sig, 100), g["nt100_y"]) < tol
+    assert relerr(C.sinc(g["down_pos"], sig, 24), g["down_y"]) < tol
+
+
+@pytest.mark.parametrize("name", ["kat1", "small_vec", "odd_len", "zp2", "n2048", "n64", "hop_odd"])
+def test_c_oracle_stft(golden, name):
+    from oracle import oracle_c as C
+    import scipy.signal
+    g = golden["stft"]
+    n, seed, n_fft, hop, zp = (int(v) for v in g[name + "_cfg"])
+    win = scipy.signal.get_window(str(g[name + "_win"]), n_fft).astype(np.float32)
+    S = C.stft(inputs.noise(n, seed), n_fft, hop, win, zp, mode=0)
+    assert relerr(S, g[name + "_S"]) < 2e-6
+    m = C.stft(inputs.noise(n, seed), n_fft, hop, win, zp, mode=1)
+    assert relerr(m, np.abs(g[name + "_S"]) + 1e-7) < 2e-6
+
+
+def test_c_oracle_synth_matches_numpy_generators():
+    from oracle import oracle_c as C
+    a = C.synth_signal(12345, 5000, 192000.0)
+    b = inputs.bench_signal(12345, 5000, 192000.0)
+    assert np.max(np.abs(a - b)) <= 6e-8            # last-ulp libm differences before the f32 cast
+    sc = inputs.bench_speed_curve(3.0, 48000)
+    st, sp = C.synth_curve(len(sc), 3.0, 48000.0)
+    assert np.allclose(st, sc[:, 0] * 48000, rtol=0, atol=1e-7) and np.allclose(sp, sc[:, 1], rtol=0, atol=1e-15)
