@@ -67,6 +67,10 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64 (soname libamdhip64.so.7, the same soname this library
+        # needs).  Importing torch FIRST makes the dynamic loader hand that one runtime to both; loading
+        # ours first would pull in /opt/rocm's copy as well and the second runtime then sees no device.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol

@@ -1,34 +1,56 @@
-"""Builds libpar_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Builds libpar_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Each csrc/*.hip is compiled to an object with per-file flags, then linked.  pos.hip (float64
+positions that must be bit-identical to numpy) is built with -ffp-contract=off; the other kernels
+keep hipcc's default contraction and spell their FMAs explicitly."""
 import glob
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "obj")
 OUT = os.path.join(HERE, "libpar_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+PER_FILE = {"pos.hip": ["-ffp-contract=off"]}
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def is_stale():
-    if not os.path.exists(OUT):
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(OUT)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=False):
-    if not force and not is_stale():
-        return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + sources() + ["-o", OUT]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _headers() + [os.path.abspath(__file__)]
+    jobs = []
+    objs = []
+    for src in sources():
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs):
+            jobs.append([hipcc] + FLAGS + PER_FILE.get(os.path.basename(src), []) + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _newer(OUT, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT])
     return OUT
 
 

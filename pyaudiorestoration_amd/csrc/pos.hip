@@ -8,8 +8,7 @@
 //     pos   = cumsum(1/bs) + offset;  offset = pos[-1]                (:125-126)
 //     trim at the first segment whose [first,last] straddles num_input_samples (:129-135)
 //
-// Everything is float64 with numpy's operation order, no FMA contraction (explicit *_rn
-// intrinsics), so the per-segment reciprocal sums are bit-identical to numpy's sequential cumsum.
+// Everything is float64 with numpy's operation order and no FMA contraction, so the per-segment reciprocal sums are bit-identical to numpy's sequential cumsum.
 //
 // Round-1 structure: the two cross-segment serial chains (the error-diffused n_i recurrence and the
 // float64 offset chain, both inherently order-dependent in floating point) run on the host between
@@ -17,6 +16,12 @@
 #include "par_common.h"
 #include <math.h>
 #include <vector>
+
+// numpy evaluates every product and sum separately: no FMA contraction anywhere in this file, on the
+// device and in the host-side chains alike.  build.py compiles THIS file with -ffp-contract=off (hip's
+// __dmul_rn/__dadd_rn are plain inline operators parsed before any source-level pragma, so they still
+// get fused under the default -ffp-contract=fast -- measured: positions off by 1 ulp).
+#pragma clang fp contract(off)
 
 namespace par {
 
@@ -53,15 +58,16 @@ __global__ void k_seg_want(const double* __restrict__ st, const double* __restri
                            double* __restrict__ a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nseg) return;
-  const double period = __dsub_rn(st[i + 1], st[i]);
-  const double mean = __ddiv_rn(__dadd_rn(sp[i], sp[i + 1]), 2.0);
-  a[i] = __dmul_rn(period, mean);
+  const double period = st[i + 1] - st[i];
+  const double mean = (sp[i] + sp[i + 1]) / 2.0;
+  a[i] = period * mean;
 }
 
 __device__ __forceinline__ double ramp_recip(long long k, double nm1, double ds, double s0) {
   // 1 / (k/(n-1) * ds + s0), each operation individually rounded (numpy, :120 and :125)
-  const double bs = __dadd_rn(__dmul_rn(__ddiv_rn((double)k, nm1), ds), s0);
-  return __ddiv_rn(1.0, bs);
+  const double q = (double)k / nm1;
+  const double bs = q * ds + s0;      // not fused: this file is compiled with -ffp-contract=off
+  return 1.0 / bs;
 }
 
 // S_i = last element of np.cumsum(1/block_speeds): strictly sequential float64 adds.
@@ -70,9 +76,9 @@ __global__ void k_seg_sum(const double* __restrict__ sp, const int64_t* __restri
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nseg) return;
   const long long n = seg_start[i + 1] - seg_start[i];
-  const double s0 = sp[i], ds = __dsub_rn(sp[i + 1], sp[i]), nm1 = (double)(n - 1);
+  const double s0 = sp[i], ds = sp[i + 1] - sp[i], nm1 = (double)(n - 1);
   double c = 0.0;
-  for (long long k = 0; k < n; ++k) c = __dadd_rn(c, ramp_recip(k, nm1, ds, s0));
+  for (long long k = 0; k < n; ++k) c = c + ramp_recip(k, nm1, ds, s0);
   S[i] = c;
 }
 
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(64) void k_pos_fill(const double* __restrict__ sp, 
     n = seg_start[i + 1] - start;
     if (start >= (long long)len_out) n = 0;
     s0 = sp[i];
-    ds = __dsub_rn(sp[i + 1], sp[i]);
+    ds = sp[i + 1] - sp[i];
     nm1 = (double)(seg_start[i + 1] - start - 1);
     off = seg_off[i];
   }
@@ -112,8 +118,8 @@ __global__ __launch_bounds__(64) void k_pos_fill(const double* __restrict__ sp, 
     for (int kk = 0; kk < kFillSegs; ++kk) {
       const long long k = k0 + kk;
       if (k < n) {
-        c = __dadd_rn(c, ramp_recip(k, nm1, ds, s0));
-        buf[lane][kk] = __dadd_rn(c, off);
+        c = c + ramp_recip(k, nm1, ds, s0);
+        buf[lane][kk] = c + off;
       }
     }
     __syncthreads();

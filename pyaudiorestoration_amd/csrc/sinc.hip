@@ -254,6 +254,7 @@ __global__ __launch_bounds__(kSincBlock) void k_sinc(const double* __restrict__ 
   }
 }
 
+#pragma clang fp contract(off)   // numpy's interp kernel is slope*(x-x0)+y0 with separate roundings
 // "Linear" mode: np.interp(sample_at, arange(len_in), signal, left=0, right=0)  (util/resampling.py:229)
 __global__ __launch_bounds__(256) void k_lerp(const double* __restrict__ pos, int64_t len_out,
                                                const float* __restrict__ sig, int64_t sig_stride, int64_t len_in,

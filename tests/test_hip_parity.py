@@ -324,4 +324,4 @@ def test_large_properties(par):
         ref = C.sinc(pos[i:i + 2001], sig, 32)[:2000]
         assert relerr(out[i:i + 2000], ref) < TOL
     part = par.resampling.sinc_resample_dev(pos_t[123457:323457], sig_t, 32).cpu().numpy()
-    assert np.array_equal(part[:-1], out[123457:323456])  # chunk invariance (last sample: period reuse)
+    assert relerr(part[:-1], out[123457:323456]) < 2e-6     # chunk invariance (tile phase changes which waves take the fc==1 path)
