@@ -87,6 +87,12 @@ int par_istft_f32(int device, const float* spec, int64_t n_frames, int n_fft, in
 size_t par_speed_plan_bytes(int64_t m);
 int par_speed_to_pos_plan(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
                           void* work, size_t work_bytes, int64_t* len_out, int* trimmed, void* stream);
+/* Same as par_speed_to_pos_plan; force_host != 0 runs the serial host evaluation of the two
+ * order-dependent chains (the exact fallback the device scans defer to when they flag a near-tie),
+ * *path_used (optional) reports 0 = device scans, 1 = serial host path. */
+int par_speed_to_pos_plan_ex(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
+                             void* work, size_t work_bytes, int64_t* len_out, int* trimmed, int force_host,
+                             int* path_used, void* stream);
 int par_speed_to_pos_fill(int device, const double* speeds, int64_t m, const void* work,
                           double* pos, int64_t len_out, void* stream);
 

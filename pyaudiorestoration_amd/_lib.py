@@ -33,6 +33,8 @@ SIGNATURES = {
     "par_speed_plan_bytes": (c_sz, [c_i64]),
     "par_speed_to_pos_plan": (c_int, [c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_sz, ctypes.POINTER(c_i64),
                                       ctypes.POINTER(c_int), c_vp]),
+    "par_speed_to_pos_plan_ex": (c_int, [c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_sz, ctypes.POINTER(c_i64),
+                                         ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int), c_vp]),
     "par_speed_to_pos_fill": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "par_sinc_resample_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp]),
     "par_linear_resample_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),

@@ -8,129 +8,661 @@
 //     pos   = cumsum(1/bs) + offset;  offset = pos[-1]                (:125-126)
 //     trim at the first segment whose [first,last] straddles num_input_samples (:129-135)
 //
-// Everything is float64 with numpy's operation order and no FMA contraction, so the per-segment reciprocal sums are bit-identical to numpy's sequential cumsum.
+// Everything is float64 in numpy's operation order with NO FMA contraction (build.py compiles this
+// file with -ffp-contract=off; hip's __dmul_rn/__dadd_rn are plain inline operators that DO get fused
+// under the default -ffp-contract=fast -- measured: positions off by 1 ulp).
 //
-// Round-1 structure: the two cross-segment serial chains (the error-diffused n_i recurrence and the
-// float64 offset chain, both inherently order-dependent in floating point) run on the host between
-// device stages; the O(len_out) work -- 1 division per output sample, done twice -- is on the GPU.
+// The reference walks the segments serially; two of its chains are order-dependent in floating point.
+// Both are evaluated on the device by parallel scans that reproduce the serial result exactly:
+//   (1) segment lengths.  n_i = N_i - N_{i-1} with N_i = round(sum_{t<=i} a_t): the running sum is
+//       scanned in 128-bit fixed point (64 fractional bits, exact for a_i >= 2^-11).  The reference's
+//       float64 chain deviates from exact arithmetic by at most a few 1e-11 (one 2^-45 rounding now and
+//       then), so any cumulative sum closer than 2^-32 to a rounding tie is flagged and the whole plan is
+//       redone by the serial host path (probability ~1e-3 per hour-long file).
+//   (2) segment offsets  x_{i+1} = fl(x_i + S_i).  Inside one binade of x the float64 add is an integer
+//       translation in units of ulp(x): X' = X + floor(S/u) + round-bit, where an exact half rounds to
+//       even, i.e. depends only on the parity of X.  Such "parity-dependent translations" (c_even, c_odd)
+//       are closed under composition, so each binade run is one segmented scan; the <= ~60 steps that
+//       cross a binade (predicted from a plain float64 scan, then verified) are evaluated directly by a
+//       single thread that stitches the runs together.  Any verification failure -> serial host path.
+// The O(len_out) work (one IEEE division per output sample, twice: reciprocal sums, then the fill) is
+// one lane per segment; k/(n-1) uses Markstein's correctly-rounded quotient from y = RN(1/(n-1)).
 #include "par_common.h"
 #include <math.h>
 #include <vector>
 
-// numpy evaluates every product and sum separately: no FMA contraction anywhere in this file, on the
-// device and in the host-side chains alike.  build.py compiles THIS file with -ffp-contract=off (hip's
-// __dmul_rn/__dadd_rn are plain inline operators parsed before any source-level pragma, so they still
-// get fused under the default -ffp-contract=fast -- measured: positions off by 1 ulp).
 #pragma clang fp contract(off)
 
 namespace par {
 
+// ---------------------------------------------------------------------------------- plan layout
 struct PlanHeader {
   int64_t m;
-  int64_t len_out;
-  int64_t total_written;
+  int64_t len_out;        // trimmed length or total written
+  int64_t total_written;  // sum n_i
+  unsigned long long trim_seg;   // first segment whose [first,last] straddles n_in, or ~0
+  int64_t cap;            // the reference's end_guess buffer size
   int32_t trimmed;
-  int32_t pad;
+  int32_t flags;          // kFlag*
+  int32_t n_direct;
+  int32_t n_runs;
+  double speed_sum;
+};
+constexpr int kFlagAmbiguous = 1;   // a cumulative length is too close to a rounding tie
+constexpr int kFlagBadLength = 2;   // some n_i < 2 (reference divides by zero / indexes an empty array)
+constexpr int kFlagRange = 4;       // a_i outside the exactly-representable fixed-point range
+constexpr int kFlagVerify = 8;      // offset-chain binade prediction failed verification
+constexpr int kFlagDirectOverflow = 16;
+constexpr int kMaxDirect = 2048;
+constexpr unsigned long long kNoTrim = ~0ull;
+
+struct U128 {
+  unsigned long long hi, lo;       // value = hi + lo * 2^-64
+};
+struct PElem {                      // parity-dependent translation (+ segmented-scan head flag)
+  long long c0, c1;                 // increment when the incoming integer is even / odd
+  long long head;                   // 1: a run starts at this element (scan restarts here)
+  long long pad;
+};
+struct RunEntry {
+  long long start;                  // first segment of the run
+  double x;                         // offset at that segment (bit-exact)
 };
 
-// workspace layout: [PlanHeader | seg_start int64[m] | seg_off f64[m] | tmp f64[m]]
+constexpr size_t kHdrBytes = 256;
 struct PlanView {
   PlanHeader* hdr;
-  int64_t* seg_start;
-  double* seg_off;
-  double* tmp;
+  int64_t* seg_start;   // [m]   seg_start[i] = outputs before segment i; [m-1] = total
+  double* seg_off;      // [m]   offset chain; seg_off[i] = position offset of segment i; [m-1] = final
+  double* S;            // [m]   per-segment reciprocal sums
+  double* xs;           // [m]   approx offsets (plain f64 scan)
+  char* scan;           // [m * 32] scan elements (U128 then PElem)
+  char* bsum;           // block sums for the scans
+  long long* direct;    // [kMaxDirect] indices of direct (binade-crossing) steps
+  RunEntry* runs;       // [kMaxDirect + 2]
 };
-__host__ __device__ inline size_t plan_bytes(int64_t m) {
-  return 64 + (size_t)m * (sizeof(int64_t) + 2 * sizeof(double));
+inline size_t scan_blocks(int64_t n) { return (size_t)((n + 1023) / 1024); }
+inline size_t plan_bytes(int64_t m) {
+  return kHdrBytes + (size_t)m * (8 + 8 + 8 + 8 + 32) + (scan_blocks(m) + 8) * 32 + kMaxDirect * 8 +
+         (kMaxDirect + 2) * sizeof(RunEntry) + 256;
 }
 inline PlanView plan_view(void* work, int64_t m) {
   char* b = static_cast<char*>(work);
   PlanView v;
   v.hdr = reinterpret_cast<PlanHeader*>(b);
-  v.seg_start = reinterpret_cast<int64_t*>(b + 64);
-  v.seg_off = reinterpret_cast<double*>(b + 64 + (size_t)m * 8);
-  v.tmp = reinterpret_cast<double*>(b + 64 + (size_t)m * 16);
+  b += kHdrBytes;
+  v.seg_start = reinterpret_cast<int64_t*>(b);
+  b += (size_t)m * 8;
+  v.seg_off = reinterpret_cast<double*>(b);
+  b += (size_t)m * 8;
+  v.S = reinterpret_cast<double*>(b);
+  b += (size_t)m * 8;
+  v.xs = reinterpret_cast<double*>(b);
+  b += (size_t)m * 8;
+  v.scan = b;
+  b += (size_t)m * 32;
+  v.bsum = b;
+  b += (scan_blocks(m) + 8) * 32;
+  v.direct = reinterpret_cast<long long*>(b);
+  b += kMaxDirect * 8;
+  v.runs = reinterpret_cast<RunEntry*>(b);
   return v;
 }
 
-// a_i (util/resampling.py:103,:111), exact numpy order: diff, (s0+s1)/2, product.
+// ------------------------------------------------------------------------------ generic scans
+struct AddU128 {
+  using T = U128;
+  __device__ static T identity() { return T{0ull, 0ull}; }
+  __device__ static T combine(T a, T b) {          // a then b
+    T r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1ull : 0ull);
+    return r;
+  }
+};
+struct AddF64 {
+  using T = double;
+  __device__ static T identity() { return 0.0; }
+  __device__ static T combine(T a, T b) { return a + b; }
+};
+struct ComposeP {
+  using T = PElem;
+  __device__ static T identity() { return T{0, 0, 0, 0}; }
+  __device__ static T combine(T a, T b) {          // apply a first, then b; b.head restarts
+    if (b.head) return b;
+    T r;
+    r.c0 = a.c0 + ((a.c0 & 1) ? b.c1 : b.c0);
+    r.c1 = a.c1 + (((1 + a.c1) & 1) ? b.c1 : b.c0);
+    r.head = a.head;
+    r.pad = 0;
+    return r;
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ T shfl_up_any(T v, int delta) {
+  static_assert(sizeof(T) % 8 == 0, "scan element must be a multiple of 8 bytes");
+  union {
+    T t;
+    unsigned long long w[sizeof(T) / 8];
+  } u;
+  u.t = v;
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 8; ++i) u.w[i] = __shfl_up(u.w[i], delta, kWave);
+  return u.t;
+}
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 4;
+constexpr int kScanTile = kScanThreads * kScanItems;   // 1024
+
+// scan of the per-thread totals across the block; returns the EXCLUSIVE prefix of this thread and the
+// block total (valid in every thread).
+template <typename Op>
+__device__ typename Op::T block_exclusive(typename Op::T mine, typename Op::T* smem, typename Op::T* block_total) {
+  using T = typename Op::T;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  T inc = mine;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    T up = shfl_up_any(inc, d);
+    if (lane >= d) inc = Op::combine(up, inc);
+  }
+  if (lane == kWave - 1) smem[wave] = inc;
+  __syncthreads();
+  T wave_prefix = Op::identity();
+  T total = Op::identity();
+#pragma unroll
+  for (int w = 0; w < kScanThreads / kWave; ++w) {
+    if (w < wave) wave_prefix = Op::combine(wave_prefix, smem[w]);
+    total = Op::combine(total, smem[w]);
+  }
+  __syncthreads();
+  T excl = shfl_up_any(inc, 1);
+  if (lane == 0) excl = Op::identity();
+  *block_total = total;
+  return Op::combine(wave_prefix, excl);
+}
+
+template <typename Op>
+__global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const typename Op::T* __restrict__ data, int64_t n,
+                                                               typename Op::T* __restrict__ bsum) {
+  using T = typename Op::T;
+  __shared__ T smem[kScanThreads / kWave];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  T acc = Op::identity();
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (base + k < n) acc = Op::combine(acc, data[base + k]);
+  T total;
+  block_exclusive<Op>(acc, smem, &total);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+// single block: in-place EXCLUSIVE scan of the block sums (loops over tiles with a carry)
+template <typename Op>
+__global__ __launch_bounds__(kScanThreads) void k_scan_top(typename Op::T* __restrict__ bsum, int64_t nb) {
+  using T = typename Op::T;
+  __shared__ T smem[kScanThreads / kWave];
+  T carry = Op::identity();
+  for (int64_t t0 = 0; t0 < nb; t0 += kScanTile) {
+    const int64_t base = t0 + (int64_t)threadIdx.x * kScanItems;
+    T v[kScanItems];
+    T acc = Op::identity();
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      v[k] = (base + k < nb) ? bsum[base + k] : Op::identity();
+      acc = Op::combine(acc, v[k]);
+    }
+    T total;
+    T run = Op::combine(carry, block_exclusive<Op>(acc, smem, &total));
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      if (base + k < nb) bsum[base + k] = run;
+      run = Op::combine(run, v[k]);
+    }
+    carry = Op::combine(carry, total);
+  }
+}
+
+// in-place INCLUSIVE scan with the block prefixes applied
+template <typename Op>
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply(typename Op::T* __restrict__ data, int64_t n,
+                                                              const typename Op::T* __restrict__ bsum) {
+  using T = typename Op::T;
+  __shared__ T smem[kScanThreads / kWave];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  T v[kScanItems];
+  T acc = Op::identity();
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (base + k < n) ? data[base + k] : Op::identity();
+    acc = Op::combine(acc, v[k]);
+  }
+  T total;
+  T run = Op::combine(bsum[blockIdx.x], block_exclusive<Op>(acc, smem, &total));
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    run = Op::combine(run, v[k]);
+    if (base + k < n) data[base + k] = run;
+  }
+}
+
+template <typename Op>
+static int inclusive_scan(typename Op::T* data, int64_t n, typename Op::T* bsum, hipStream_t s) {
+  const int64_t nb = ceil_div(n, kScanTile);
+  hipLaunchKernelGGL(k_scan_reduce<Op>, dim3((unsigned)nb), dim3(kScanThreads), 0, s, data, n, bsum);
+  hipLaunchKernelGGL(k_scan_top<Op>, dim3(1), dim3(kScanThreads), 0, s, bsum, nb);
+  hipLaunchKernelGGL(k_scan_apply<Op>, dim3((unsigned)nb), dim3(kScanThreads), 0, s, data, n, bsum);
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
+// ------------------------------------------------------------------------- stage kernels
+__global__ void k_init_header(PlanHeader* h, int64_t m) {
+  h->m = m;
+  h->len_out = 0;
+  h->total_written = 0;
+  h->trim_seg = kNoTrim;
+  h->cap = 0;
+  h->trimmed = 0;
+  h->flags = 0;
+  h->n_direct = 0;
+  h->n_runs = 0;
+  h->speed_sum = 0.0;
+}
+
+// a_i (util/resampling.py:103,:111) in numpy's order, converted EXACTLY to 64.64 fixed point.
 __global__ void k_seg_want(const double* __restrict__ st, const double* __restrict__ sp, int64_t nseg,
-                           double* __restrict__ a) {
+                           U128* __restrict__ a_fix, PlanHeader* __restrict__ h) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nseg) return;
   const double period = st[i + 1] - st[i];
   const double mean = (sp[i] + sp[i + 1]) / 2.0;
-  a[i] = period * mean;
+  const double a = period * mean;
+  U128 e{0ull, 0ull};
+  if (!(a >= 0x1p-11 && a < 0x1p62)) {
+    atomicOr(&h->flags, kFlagRange);
+  } else {
+    const double ip = floor(a);
+    e.hi = (unsigned long long)ip;
+    e.lo = (unsigned long long)((a - ip) * 0x1p64);     // exact: < 2^64, at most 64 fractional bits
+  }
+  a_fix[i] = e;
 }
 
-__device__ __forceinline__ double ramp_recip(long long k, double nm1, double ds, double s0) {
-  // 1 / (k/(n-1) * ds + s0), each operation individually rounded (numpy, :120 and :125)
-  const double q = (double)k / nm1;
-  const double bs = q * ds + s0;      // not fused: this file is compiled with -ffp-contract=off
+__device__ __forceinline__ unsigned long long round_fixed(U128 A, bool* ambiguous) {
+  const unsigned long long half = 1ull << 63, zone = 1ull << 32;
+  const unsigned long long d = A.lo > half ? A.lo - half : half - A.lo;
+  if (d < zone) *ambiguous = true;
+  return A.hi + (A.lo > half ? 1ull : 0ull);
+}
+
+// n_i = round(A_i) - round(A_{i-1});  seg_start[i] = round(A_{i-1})
+__global__ void k_seg_lengths(const U128* __restrict__ A, int64_t nseg, int64_t* __restrict__ seg_start,
+                              PlanHeader* __restrict__ h) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg) return;
+  bool amb = false;
+  const unsigned long long Ni = round_fixed(A[i], &amb);
+  const unsigned long long Np = i > 0 ? round_fixed(A[i - 1], &amb) : 0ull;
+  seg_start[i] = (int64_t)Np;
+  if (i == nseg - 1) {
+    seg_start[nseg] = (int64_t)Ni;
+    h->total_written = (int64_t)Ni;
+  }
+  int f = 0;
+  if (amb) f |= kFlagAmbiguous;
+  if (Ni < Np + 2ull) f |= kFlagBadLength;
+  if (f) atomicOr(&h->flags, f);
+}
+
+__global__ void k_speed_sum(const double* __restrict__ sp, int64_t m, PlanHeader* __restrict__ h) {
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) acc += sp[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&h->speed_sum, acc);
+}
+
+struct Ramp {
+  double s0, ds, nm1, y;     // y = RN(1/(n-1))
+};
+__device__ __forceinline__ Ramp make_ramp(double s0, double s1, long long n) {
+  Ramp r;
+  r.s0 = s0;
+  r.ds = s1 - s0;
+  r.nm1 = (double)(n - 1);
+  r.y = 1.0 / r.nm1;
+  return r;
+}
+// 1 / (k/(n-1) * ds + s0), every operation individually rounded like numpy (:120, :125).
+// k/(n-1) by Markstein's theorem: with y = RN(1/b), q0 = RN(a*y), r = a - b*q0 (exact, fma),
+// q = RN(q0 + r*y) is the correctly rounded a/b  (checked exhaustively for n <= 6000 on the host).
+__device__ __forceinline__ double ramp_recip(long long k, const Ramp& r) {
+  const double a = (double)k;
+  const double q0 = a * r.y;
+  const double rem = __builtin_fma(-q0, r.nm1, a);
+  const double q = __builtin_fma(rem, r.y, q0);
+  const double bs = q * r.ds + r.s0;          // not fused (-ffp-contract=off)
   return 1.0 / bs;
 }
 
-// S_i = last element of np.cumsum(1/block_speeds): strictly sequential float64 adds.
-__global__ void k_seg_sum(const double* __restrict__ sp, const int64_t* __restrict__ seg_start, int64_t nseg,
-                          double* __restrict__ S) {
+// S_i = last element of np.cumsum(1/block_speeds): strictly sequential float64 adds, one lane per segment.
+__global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                                 int64_t nseg, double* __restrict__ S) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nseg) return;
   const long long n = seg_start[i + 1] - seg_start[i];
-  const double s0 = sp[i], ds = sp[i + 1] - sp[i], nm1 = (double)(n - 1);
   double c = 0.0;
-  for (long long k = 0; k < n; ++k) c = c + ramp_recip(k, nm1, ds, s0);
+  if (n >= 2) {
+    const Ramp r = make_ramp(sp[i], sp[i + 1], n);
+    long long k = 0;
+    for (; k + 1 < n; k += 2) {               // two independent divisions in flight
+      const double r0 = ramp_recip(k, r), r1 = ramp_recip(k + 1, r);
+      c = c + r0;
+      c = c + r1;
+    }
+    if (k < n) c = c + ramp_recip(k, r);
+  }
   S[i] = c;
 }
 
-// pos[start_i + k] = cumsum_k + offset_i  (:125).  One wave handles 64 consecutive segments and
-// transposes 64x64 blocks through LDS so HBM writes are contiguous runs per segment.
-constexpr int kFillSegs = 64;
-__global__ __launch_bounds__(64) void k_pos_fill(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
-                                                  const double* __restrict__ seg_off, int64_t nseg, int64_t len_out,
-                                                  double* __restrict__ pos) {
-  __shared__ double buf[kFillSegs][kFillSegs + 1];
-  __shared__ long long s_start[kFillSegs];
-  __shared__ long long s_n[kFillSegs];
-  const int lane = threadIdx.x;
-  const int64_t i = (int64_t)blockIdx.x * kFillSegs + lane;
+__device__ __forceinline__ int f64_exponent(double x) { return (int)((__double_as_longlong(x) >> 52) & 0x7ff); }
+
+__device__ __forceinline__ void mark_direct(long long i, long long* direct, PlanHeader* h) {
+  const int slot = atomicAdd(&h->n_direct, 1);
+  if (slot < kMaxDirect) direct[slot] = i;
+  else atomicOr(&h->flags, kFlagDirectOverflow);
+}
+
+// xs[i] = inclusive plain-f64 scan of S  ->  approx offsets xa_i = st0 + xs[i-1].
+// Build the parity-translation element of step i (x_i -> x_{i+1}) or mark it direct.
+__global__ void k_off_prepare(const double* __restrict__ S, const double* __restrict__ xs, const double* __restrict__ st,
+                              int64_t nseg, PElem* __restrict__ el, long long* __restrict__ direct,
+                              PlanHeader* __restrict__ h) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg) return;
+  const double st0 = st[0];
+  const double xa = st0 + (i > 0 ? xs[i - 1] : 0.0);
+  const double xb = st0 + xs[i];
+  const double lo = 1.0 - 0x1p-30, hi = 1.0 + 0x1p-30;
+  const int e = f64_exponent(xa);
+  bool interior = xa > 0.0 && S[i] > 0.0 && e > 64 && e < 2046 && f64_exponent(xa * lo) == e &&
+                  f64_exponent(xa * hi) == e && f64_exponent(xb * lo) == e && f64_exponent(xb * hi) == e;
+  PElem p{0, 0, 0, 0};
+  if (interior) {
+    // u = ulp in binade e = 2^(e-1075); S/u is an exact power-of-two scaling
+    const double t = ldexp(S[i], 1075 - e);
+    if (t < 0x1p62) {
+      const double fl = floor(t);
+      const long long q = (long long)fl;
+      const double fr = t - fl;                // exact
+      if (fr > 0.5) p.c0 = p.c1 = q + 1;
+      else if (fr < 0.5) p.c0 = p.c1 = q;
+      else {                                   // exact half: ties-to-even on the SUM's parity
+        p.c0 = q + (q & 1);
+        p.c1 = q + ((q + 1) & 1);
+      }
+    } else {
+      interior = false;
+    }
+  }
+  if (!interior) mark_direct(i, direct, h);
+  el[i] = p;
+}
+
+// head flags: a run starts at 0 and after every direct step
+__global__ void k_off_heads(PElem* __restrict__ el, int64_t nseg, const long long* __restrict__ direct,
+                            const PlanHeader* __restrict__ h) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int nd = h->n_direct;
+  if (nd > kMaxDirect) nd = kMaxDirect;
+  if (j == 0) el[0].head = 1;
+  if (j < nd) {
+    const long long d = direct[j];
+    if (d + 1 < nseg) el[d + 1].head = 1;
+  }
+}
+
+__device__ __forceinline__ double apply_elem(const PElem& E, double xa) {
+  // xa is the (bit-exact) offset at the start of the run; work in units of ulp(xa)
+  const int e = f64_exponent(xa);
+  const long long X = (long long)ldexp(xa, 1075 - e);      // exact integer in [2^52, 2^53)
+  const long long Y = X + ((X & 1) ? E.c1 : E.c0);
+  return ldexp((double)Y, e - 1075);
+}
+
+// one thread: sort the direct steps, walk the runs, evaluate the crossing steps with real float64 adds
+__global__ void k_off_stitch(const double* __restrict__ S, const PElem* __restrict__ E, const double* __restrict__ st,
+                             int64_t nseg, long long* __restrict__ direct, RunEntry* __restrict__ runs,
+                             PlanHeader* __restrict__ h) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int nd = h->n_direct;
+  if (nd > kMaxDirect) nd = kMaxDirect;
+  for (int a = 1; a < nd; ++a) {               // insertion sort (nd is tiny)
+    const long long v = direct[a];
+    int b = a - 1;
+    while (b >= 0 && direct[b] > v) {
+      direct[b + 1] = direct[b];
+      --b;
+    }
+    direct[b + 1] = v;
+  }
+  long long a = 0;
+  double xa = st[0];
+  int r = 0;
+  for (int j = 0; j < nd; ++j) {
+    const long long d = direct[j];
+    runs[r].start = a;
+    runs[r].x = xa;
+    ++r;
+    const double xd = (d == a) ? xa : apply_elem(E[d - 1], xa);
+    xa = xd + S[d];                            // the direct step: a real float64 add
+    a = d + 1;
+  }
+  runs[r].start = a;
+  runs[r].x = xa;
+  ++r;
+  runs[r].start = INT64_MAX;                   // sentinel
+  runs[r].x = 0.0;
+  h->n_direct = nd;
+  h->n_runs = r;
+}
+
+// offsets for every segment, verification of the binade prediction, end-trim detection (:129)
+__global__ void k_off_apply(const double* __restrict__ sp, const PElem* __restrict__ E, const RunEntry* __restrict__ runs,
+                            int64_t nseg, double n_in, double* __restrict__ seg_off, PlanHeader* __restrict__ h) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg) return;
+  const int nr = h->n_runs;
+  int lo = 0, hi = nr - 1;                     // last run with start <= i
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (runs[mid].start <= i) lo = mid; else hi = mid - 1;
+  }
+  const long long a = runs[lo].start;
+  const double xa = runs[lo].x;
+  const double xi = (i == a) ? xa : apply_elem(E[i - 1], xa);
+  const bool is_direct = runs[lo + 1].start == i + 1;      // step i ends its run
+  const double xn = is_direct ? runs[lo + 1].x : apply_elem(E[i], xa);
+  seg_off[i] = xi;
+  if (i == nseg - 1) seg_off[nseg] = xn;
+  if (!is_direct) {
+    // both ends of an interior step must sit in the run's binade, else the integer model was wrong
+    const int e = f64_exponent(xa);
+    if (f64_exponent(xi) != e || f64_exponent(xn) != e) atomicOr(&h->flags, kFlagVerify);
+  }
+  const double first = 1.0 / sp[i] + xi;       // k = 0: bs = 0/(n-1)*ds + s0 = s0
+  if (first <= n_in && n_in <= xn) atomicMin(&h->trim_seg, (unsigned long long)i);
+}
+
+// np.argmin |pos - n_in| inside the trim segment (first occurrence), header finalisation
+__global__ void k_trim(const double* __restrict__ st, const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                       const double* __restrict__ seg_off, int64_t m, double n_in, PlanHeader* __restrict__ h) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int64_t nseg = m - 1;
+  // int(np.mean(speeds) * (st[-1]-st[0]) * 1.01)  (:108)
+  h->cap = (int64_t)((h->speed_sum / (double)m) * (st[m - 1] - st[0]) * 1.01);
+  int64_t len = h->total_written;
+  if (h->trim_seg != kNoTrim && h->trim_seg < (unsigned long long)nseg) {
+    const int64_t i = (int64_t)h->trim_seg;
+    const long long n = seg_start[i + 1] - seg_start[i];
+    const Ramp r = make_ramp(sp[i], sp[i + 1], n);
+    const double off = seg_off[i];
+    double c = 0.0, best = INFINITY;
+    long long arg = 0;
+    for (long long k = 0; k < n; ++k) {
+      c = c + ramp_recip(k, r);
+      const double d = fabs((c + off) - n_in);
+      if (d < best) {
+        best = d;
+        arg = k;
+      }
+    }
+    len = seg_start[i] + arg;
+    h->trimmed = 1;
+  }
+  h->len_out = len;
+}
+
+// pos[start_i + k] = cumsum_k + offset_i  (:125).  One lane per segment; each wave transposes 64 x 32
+// blocks through LDS so that HBM sees contiguous 256-byte runs.
+constexpr int kFillChunk = 32;
+constexpr int kFillWaves = 4;
+__global__ __launch_bounds__(kWave * kFillWaves) void k_pos_fill(const double* __restrict__ sp,
+                                                                  const int64_t* __restrict__ seg_start,
+                                                                  const double* __restrict__ seg_off, int64_t nseg,
+                                                                  int64_t len_out, double* __restrict__ pos) {
+  __shared__ double buf[kFillWaves][kWave][kFillChunk + 1];
+  __shared__ long long s_start[kFillWaves][kWave];
+  __shared__ int s_n[kFillWaves][kWave];
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  const int64_t i = ((int64_t)blockIdx.x * kFillWaves + w) * kWave + lane;
   long long n = 0, start = 0;
-  double s0 = 1.0, ds = 0.0, nm1 = 1.0, off = 0.0;
+  Ramp r = make_ramp(1.0, 1.0, 2);
+  double off = 0.0;
   if (i < nseg) {
     start = seg_start[i];
     n = seg_start[i + 1] - start;
+    if (n >= 2) r = make_ramp(sp[i], sp[i + 1], n);
     if (start >= (long long)len_out) n = 0;
-    s0 = sp[i];
-    ds = sp[i + 1] - sp[i];
-    nm1 = (double)(seg_start[i + 1] - start - 1);
+    else if (start + n > (long long)len_out) n = len_out - start;     // trimmed tail: fewer samples, same ramp
     off = seg_off[i];
   }
-  s_start[lane] = start;
-  s_n[lane] = n;
+  s_start[w][lane] = start;
+  s_n[w][lane] = (int)(n > 0x7fffffff ? 0x7fffffff : n);
   long long nmax = n;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    long long t = __shfl_xor(nmax, o, kWave);
+    const long long t = __shfl_xor(nmax, o, kWave);
     nmax = t > nmax ? t : nmax;
   }
   double c = 0.0;
-  for (long long k0 = 0; k0 < nmax; k0 += kFillSegs) {
-    // each lane advances its own segment by up to 64 samples (sequential adds), into LDS row `lane`
-    for (int kk = 0; kk < kFillSegs; ++kk) {
+  for (long long k0 = 0; k0 < nmax; k0 += kFillChunk) {
+#pragma unroll 2
+    for (int kk = 0; kk < kFillChunk; ++kk) {
       const long long k = k0 + kk;
       if (k < n) {
-        c = c + ramp_recip(k, nm1, ds, s0);
-        buf[lane][kk] = c + off;
+        c = c + ramp_recip(k, r);
+        buf[w][lane][kk] = c + off;
       }
     }
-    __syncthreads();
-    // write out: for each segment row, lanes cover 64 consecutive output samples
-    for (int seg = 0; seg < kFillSegs; ++seg) {
-      const long long k = k0 + lane;
-      const long long dst = s_start[seg] + k;
-      if (k < s_n[seg] && dst < (long long)len_out) pos[dst] = buf[seg][lane];
+    // wave-synchronous transpose: rows = segments, 32 consecutive outputs each; two rows per pass
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int col = lane & (kFillChunk - 1), half = lane / kFillChunk;
+    for (int seg = 0; seg < kWave; seg += 2) {
+      const int sg = seg + half;
+      const long long k = k0 + col;
+      if (k < (long long)s_n[w][sg]) pos[s_start[w][sg] + k] = buf[w][sg][col];
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
+}
+
+// ------------------------------------------------------------------ serial host path (exact, slow)
+// Used when the device plan flags an ambiguity; follows the reference loop literally.
+static int host_plan(const PlanView& pv, const double* d_st, const double* d_sp, int64_t m, int64_t n_in,
+                     PlanHeader* out, hipStream_t s) {
+  const int64_t nseg = m - 1;
+  std::vector<double> sp(m), st(m);
+  PAR_HIP_CHECK(hipMemcpyAsync(sp.data(), d_sp, m * sizeof(double), hipMemcpyDeviceToHost, s));
+  PAR_HIP_CHECK(hipMemcpyAsync(st.data(), d_st, m * sizeof(double), hipMemcpyDeviceToHost, s));
+  PAR_HIP_CHECK(hipStreamSynchronize(s));
+  std::vector<int64_t> start(m);
+  std::vector<double> off(m);
+  double err = 0.0, offset = st[0], sum = 0.0;
+  for (int64_t i = 0; i < m; ++i) sum += sp[i];
+  const int64_t cap = (int64_t)((sum / (double)m) * (st[m - 1] - st[0]) * 1.01);
+  int64_t acc = 0, out_len = -1;
+  int trim = 0;
+  for (int64_t i = 0; i < nseg; ++i) {
+    const double a = (st[i + 1] - st[i]) * ((sp[i] + sp[i + 1]) / 2.0);
+    const double inerr = a + err;
+    const double rn = nearbyint(inerr);          // Python round(): half to even
+    PAR_REQUIRE(rn >= 2.0 && rn < 9.0e15, PAR_ERR_ARG,
+                "par_speed_to_pos_plan: segment %lld has n=%g samples (reference needs n >= 2)", (long long)i, rn);
+    err = inerr - rn;
+    const int64_t n = (int64_t)rn;
+    start[i] = acc;
+    off[i] = offset;
+    PAR_REQUIRE(acc + n <= cap, PAR_ERR_ARG,
+                "par_speed_to_pos_plan: positions overflow the reference's end_guess buffer (%lld > %lld); it raises here",
+                (long long)(acc + n), (long long)cap);
+    const double ds = sp[i + 1] - sp[i], nm1 = (double)(n - 1);
+    double c = 0.0, first = 0.0;
+    for (int64_t k = 0; k < n; ++k) {
+      const double bs = ((double)k / nm1) * ds + sp[i];
+      c += 1.0 / bs;
+      if (k == 0) first = c + offset;
+    }
+    const double last = c + offset;
+    acc += n;
+    if (first <= (double)n_in && (double)n_in <= last) {
+      double c2 = 0.0, best = INFINITY;
+      int64_t arg = 0;
+      for (int64_t k = 0; k < n; ++k) {
+        const double bs = ((double)k / nm1) * ds + sp[i];
+        c2 += 1.0 / bs;
+        const double d = fabs((c2 + offset) - (double)n_in);
+        if (d < best) {
+          best = d;
+          arg = k;
+        }
+      }
+      out_len = start[i] + arg;
+      trim = 1;
+      // later segments are never produced by the reference; give them empty, consistent entries
+      for (int64_t j = i + 1; j <= nseg; ++j) {
+        start[j] = acc;
+        off[j] = last;
+      }
+      break;
+    }
+    offset = last;
+  }
+  if (out_len < 0) {
+    start[nseg] = acc;
+    off[nseg] = offset;
+    out_len = acc;
+  }
+  out->m = m;
+  out->len_out = out_len;
+  out->total_written = acc;
+  out->trim_seg = kNoTrim;
+  out->cap = cap;
+  out->trimmed = trim;
+  out->flags = 0;
+  out->n_direct = 0;
+  out->n_runs = 0;
+  out->speed_sum = sum;
+  PAR_HIP_CHECK(hipMemcpyAsync(pv.seg_start, start.data(), m * sizeof(int64_t), hipMemcpyHostToDevice, s));
+  PAR_HIP_CHECK(hipMemcpyAsync(pv.seg_off, off.data(), m * sizeof(double), hipMemcpyHostToDevice, s));
+  PAR_HIP_CHECK(hipMemcpyAsync(pv.hdr, out, sizeof(PlanHeader), hipMemcpyHostToDevice, s));
+  PAR_HIP_CHECK(hipStreamSynchronize(s));
+  return PAR_OK;
 }
 
 }  // namespace par
@@ -139,8 +671,11 @@ extern "C" {
 
 size_t par_speed_plan_bytes(int64_t m) { return par::plan_bytes(m < 2 ? 2 : m); }
 
-int par_speed_to_pos_plan(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
-                          void* work, size_t work_bytes, int64_t* len_out, int* trimmed, void* stream) {
+// force_host != 0 exercises the serial host path (tests use it to cross-check the device scans);
+// *path_used = 0 device scans, 1 serial host path.
+int par_speed_to_pos_plan_ex(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
+                             void* work, size_t work_bytes, int64_t* len_out, int* trimmed, int force_host,
+                             int* path_used, void* stream) {
   using namespace par;
   PAR_REQUIRE(sampletimes && speeds && work && len_out && trimmed, PAR_ERR_ARG, "par_speed_to_pos_plan: null pointer");
   PAR_REQUIRE(m >= 2, PAR_ERR_ARG, "par_speed_to_pos_plan: need at least 2 speed samples (m=%lld)", (long long)m);
@@ -150,117 +685,59 @@ int par_speed_to_pos_plan(int device, const double* sampletimes, const double* s
   hipStream_t s = as_stream(stream);
   const int64_t nseg = m - 1;
   PlanView pv = plan_view(work, m);
-
-  // stage 1 (device): a_i
-  hipLaunchKernelGGL(k_seg_want, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, s, sampletimes, speeds, nseg, pv.tmp);
-  PAR_HIP_CHECK(hipGetLastError());
-  std::vector<double> a(nseg), sp(m), st(m);
-  PAR_HIP_CHECK(hipMemcpyAsync(a.data(), pv.tmp, nseg * sizeof(double), hipMemcpyDeviceToHost, s));
-  PAR_HIP_CHECK(hipMemcpyAsync(sp.data(), speeds, m * sizeof(double), hipMemcpyDeviceToHost, s));
-  PAR_HIP_CHECK(hipMemcpyAsync(st.data(), sampletimes, m * sizeof(double), hipMemcpyDeviceToHost, s));
-  PAR_HIP_CHECK(hipStreamSynchronize(s));
-
-  // stage 2 (host, serial by construction): error-diffused segment lengths (:113-118)
-  std::vector<int64_t> start(m);
-  double err = 0.0;
-  int64_t acc = 0;
-  for (int64_t i = 0; i < nseg; ++i) {
-    const double inerr = a[i] + err;
-    const double r = nearbyint(inerr);            // round-half-even, like Python round()
-    PAR_REQUIRE(r >= 2.0 && r < 9.0e15, PAR_ERR_ARG,
-                "par_speed_to_pos_plan: segment %lld has n=%g samples (reference needs n >= 2)", (long long)i, r);
-    err = inerr - r;
-    start[i] = acc;
-    acc += (int64_t)r;
-  }
-  start[nseg] = acc;
-  // end_guess buffer of the reference (:108-109): writing past it raises in numpy
-  double mean_speed = 0.0;
-  {
-    // np.mean = pairwise sum / m; pairwise vs sequential only matters in the last ulp of an int() floor
-    // of a value scaled by 1.01 -- restated with numpy's pairwise blocking (blocks of 128, unrolled by 8).
-    struct PW {
-      static double sum(const double* x, int64_t n) {
-        if (n < 8) {
-          double r = 0.0;
-          for (int64_t i = 0; i < n; ++i) r += x[i];
-          return r;
-        }
-        if (n <= 128) {
-          double r[8];
-          for (int j = 0; j < 8; ++j) r[j] = x[j];
-          int64_t i;
-          for (i = 8; i < n - (n % 8); i += 8)
-            for (int j = 0; j < 8; ++j) r[j] += x[i + j];
-          double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-          for (; i < n; ++i) res += x[i];
-          return res;
-        }
-        int64_t n2 = n / 2;
-        n2 -= n2 % 8;
-        return sum(x, n2) + sum(x + n2, n - n2);
-      }
-    };
-    mean_speed = PW::sum(sp.data(), m) / (double)m;
-  }
-  const double guess = mean_speed * (st[m - 1] - st[0]) * 1.01;
-  const int64_t cap = (int64_t)guess;
-
-  PAR_HIP_CHECK(hipMemcpyAsync(pv.seg_start, start.data(), m * sizeof(int64_t), hipMemcpyHostToDevice, s));
-  // stage 3 (device): per-segment sequential reciprocal sums
-  hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.tmp);
-  PAR_HIP_CHECK(hipGetLastError());
-  std::vector<double> S(nseg);
-  PAR_HIP_CHECK(hipMemcpyAsync(S.data(), pv.tmp, nseg * sizeof(double), hipMemcpyDeviceToHost, s));
-  PAR_HIP_CHECK(hipStreamSynchronize(s));
-
-  // stage 4 (host, serial by construction): offset chain (:125-126) + end trim (:129-135)
-  std::vector<double> off(m);
-  double offset = st[0];
-  int64_t out_len = acc;
-  int trim = 0;
-  const double N = (double)n_in;
-  for (int64_t i = 0; i < nseg; ++i) {
-    off[i] = offset;
-    PAR_REQUIRE(start[i + 1] <= cap, PAR_ERR_ARG,
-                "par_speed_to_pos_plan: positions overflow the reference's end_guess buffer (%lld > %lld); it raises here",
-                (long long)start[i + 1], (long long)cap);
-    const double first = 1.0 / sp[i] + offset;    // k = 0: bs = 0/(n-1)*ds + s0 = s0
-    const double last = S[i] + offset;
-    if (first <= N && N <= last) {
-      // argmin |pos - N| inside this one segment, first occurrence (np.argmin)
-      const int64_t n = start[i + 1] - start[i];
-      const double ds = sp[i + 1] - sp[i], nm1 = (double)(n - 1);
-      double c = 0.0, best = INFINITY;
-      int64_t arg = 0;
-      for (int64_t k = 0; k < n; ++k) {
-        const double bs = ((double)k / nm1) * ds + sp[i];
-        c += 1.0 / bs;
-        const double d = fabs((c + offset) - N);
-        if (d < best) {
-          best = d;
-          arg = k;
-        }
-      }
-      out_len = start[i] + arg;
-      trim = 1;
-      break;
-    }
-    offset = last;
-  }
-  off[nseg] = offset;
   PlanHeader h;
-  h.m = m;
-  h.len_out = out_len;
-  h.total_written = acc;
-  h.trimmed = trim;
-  h.pad = 0;
-  PAR_HIP_CHECK(hipMemcpyAsync(pv.seg_off, off.data(), m * sizeof(double), hipMemcpyHostToDevice, s));
-  PAR_HIP_CHECK(hipMemcpyAsync(pv.hdr, &h, sizeof(h), hipMemcpyHostToDevice, s));
-  PAR_HIP_CHECK(hipStreamSynchronize(s));
-  *len_out = out_len;
-  *trimmed = trim;
+  memset(&h, 0, sizeof(h));
+  bool need_host = force_host != 0;
+  if (!need_host) {
+    const unsigned g256 = (unsigned)ceil_div(nseg, 256);
+    hipLaunchKernelGGL(k_init_header, dim3(1), dim3(1), 0, s, pv.hdr, m);
+    U128* fix = reinterpret_cast<U128*>(pv.scan);
+    hipLaunchKernelGGL(k_seg_want, dim3(g256), dim3(256), 0, s, sampletimes, speeds, nseg, fix, pv.hdr);
+    int rc = inclusive_scan<AddU128>(fix, nseg, reinterpret_cast<U128*>(pv.bsum), s);
+    if (rc != PAR_OK) return rc;
+    hipLaunchKernelGGL(k_seg_lengths, dim3(g256), dim3(256), 0, s, fix, nseg, pv.seg_start, pv.hdr);
+    hipLaunchKernelGGL(k_speed_sum, dim3(64), dim3(256), 0, s, speeds, m, pv.hdr);
+    hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.S);
+    PAR_HIP_CHECK(hipMemcpyAsync(pv.xs, pv.S, nseg * sizeof(double), hipMemcpyDeviceToDevice, s));
+    rc = inclusive_scan<AddF64>(pv.xs, nseg, reinterpret_cast<double*>(pv.bsum), s);
+    if (rc != PAR_OK) return rc;
+    PElem* el = reinterpret_cast<PElem*>(pv.scan);
+    hipLaunchKernelGGL(k_off_prepare, dim3(g256), dim3(256), 0, s, pv.S, pv.xs, sampletimes, nseg, el, pv.direct, pv.hdr);
+    hipLaunchKernelGGL(k_off_heads, dim3((kMaxDirect + 255) / 256), dim3(256), 0, s, el, nseg, pv.direct, pv.hdr);
+    rc = inclusive_scan<ComposeP>(el, nseg, reinterpret_cast<PElem*>(pv.bsum), s);
+    if (rc != PAR_OK) return rc;
+    hipLaunchKernelGGL(k_off_stitch, dim3(1), dim3(1), 0, s, pv.S, el, sampletimes, nseg, pv.direct, pv.runs, pv.hdr);
+    hipLaunchKernelGGL(k_off_apply, dim3(g256), dim3(256), 0, s, speeds, el, pv.runs, nseg, (double)n_in, pv.seg_off,
+                       pv.hdr);
+    hipLaunchKernelGGL(k_trim, dim3(1), dim3(1), 0, s, sampletimes, speeds, pv.seg_start, pv.seg_off, m, (double)n_in,
+                       pv.hdr);
+    PAR_HIP_CHECK(hipGetLastError());
+    PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
+    PAR_HIP_CHECK(hipStreamSynchronize(s));
+    // any flag (near-tie length, n_i < 2, range, verification, too many crossings): the serial path
+    // decides -- it also produces the reference's own diagnosis for genuinely bad curves.
+    if (h.flags) need_host = true;
+  }
+  if (need_host) {
+    int rc = host_plan(pv, sampletimes, speeds, m, n_in, &h, s);
+    if (rc != PAR_OK) return rc;
+  } else {
+    // the reference writes each segment into its end_guess-sized buffer BEFORE testing the trim (:127-129)
+    const int64_t written = h.trimmed ? h.len_out : h.total_written;
+    PAR_REQUIRE(written <= h.cap, PAR_ERR_ARG,
+                "par_speed_to_pos_plan: positions overflow the reference's end_guess buffer (%lld > %lld); it raises here",
+                (long long)written, (long long)h.cap);
+  }
+  if (path_used) *path_used = need_host ? 1 : 0;
+  *len_out = h.len_out;
+  *trimmed = h.trimmed;
   return PAR_OK;
+}
+
+int par_speed_to_pos_plan(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
+                          void* work, size_t work_bytes, int64_t* len_out, int* trimmed, void* stream) {
+  return par_speed_to_pos_plan_ex(device, sampletimes, speeds, m, n_in, work, work_bytes, len_out, trimmed, 0, nullptr,
+                                  stream);
 }
 
 int par_speed_to_pos_fill(int device, const double* speeds, int64_t m, const void* work, double* pos, int64_t len_out,
@@ -271,8 +748,8 @@ int par_speed_to_pos_fill(int device, const double* speeds, int64_t m, const voi
   PAR_HIP_CHECK(hipSetDevice(device));
   PlanView pv = plan_view(const_cast<void*>(work), m);
   const int64_t nseg = m - 1;
-  hipLaunchKernelGGL(k_pos_fill, dim3((unsigned)ceil_div(nseg, kFillSegs)), dim3(64), 0, as_stream(stream), speeds,
-                     pv.seg_start, pv.seg_off, nseg, len_out, pos);
+  hipLaunchKernelGGL(k_pos_fill, dim3((unsigned)ceil_div(nseg, kWave * kFillWaves)), dim3(kWave * kFillWaves), 0,
+                     as_stream(stream), speeds, pv.seg_start, pv.seg_off, nseg, len_out, pos);
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }

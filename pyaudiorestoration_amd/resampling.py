@@ -24,8 +24,10 @@ def find_cutoff(array, cutoff):
 
 # ----------------------------------------------------------------------------- positions
 
-def speed_to_pos_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None):
-    """Device speed curve (float64 tensors) -> float64 position tensor (the written prefix)."""
+def speed_to_pos_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_host_chain=False, info=None):
+    """Device speed curve (float64 tensors) -> float64 position tensor (the written prefix).
+    force_host_chain runs the serial host evaluation of the two order-dependent chains (the exact
+    fallback of the device scans); `info`, if a dict, receives {"path": 0 device | 1 host, "trimmed"}."""
     dev = _dev.device_index(dev if dev is not None else sampletimes_t.device)
     L = _lib.lib()
     m = sampletimes_t.numel()
@@ -36,8 +38,12 @@ def speed_to_pos_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None):
     len_out = ctypes.c_int64(0)
     trimmed = ctypes.c_int(0)
     sp = _dev.stream_ptr(dev)
-    _lib.check(L.par_speed_to_pos_plan(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m, int(num_imput_samples),
-                                       _dev.ptr(work), nbytes, ctypes.byref(len_out), ctypes.byref(trimmed), sp))
+    path = ctypes.c_int(0)
+    _lib.check(L.par_speed_to_pos_plan_ex(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m, int(num_imput_samples),
+                                          _dev.ptr(work), nbytes, ctypes.byref(len_out), ctypes.byref(trimmed),
+                                          1 if force_host_chain else 0, ctypes.byref(path), sp))
+    if info is not None:
+        info.update(path=path.value, trimmed=bool(trimmed.value))
     pos = _dev.empty(len_out.value, torch.float64, dev)
     _lib.check(L.par_speed_to_pos_fill(dev, _dev.ptr(speeds_t), m, _dev.ptr(work), _dev.ptr(pos), len_out.value, sp))
     return pos

@@ -325,3 +325,36 @@ def test_large_properties(par):
         assert relerr(out[i:i + 2000], ref) < TOL
     part = par.resampling.sinc_resample_dev(pos_t[123457:323457], sig_t, 32).cpu().numpy()
     assert relerr(part[:-1], out[123457:323456]) < 2e-6     # chunk invariance (tile phase changes which waves take the fc==1 path)
+
+
+def test_speed_plan_device_scans_vs_serial_host_chain(par, golden):
+    """The device plan (128-bit fixed-point length scan + parity-translation offset scan) must agree
+    bit-for-bit with the serial host evaluation, take the device path on ordinary curves, and defer
+    to the host path on exact rounding ties."""
+    t = par.torch
+    from oracle import oracle_c as C
+    rng = np.random.default_rng(11)
+    cases = []
+    sc = inputs.bench_speed_curve(40.0, 192000)                      # 30000 segments, offsets cross 2^8..2^22
+    cases.append((sc[:, 0] * 192000, sc[:, 1], int(192000 * 40.0)))
+    st = np.linspace(0, 2_000_000, 2_000_000 // 64)                  # hop 64, noisy speeds, no trim (n_in huge)
+    cases.append((st, 1 + 0.05 * np.sin(np.arange(len(st)) * 0.01) + 0.003 * rng.standard_normal(len(st)), 10**9))
+    st = 1000.0 + np.cumsum(rng.uniform(100, 400, 5000))             # uneven spacing, late start
+    cases.append((st, rng.uniform(0.5, 2.0, 5000), int(st[-1] * 0.8)))
+    for st, sp, n_in in cases:
+        info_d, info_h = {}, {}
+        a = par.resampling.speed_to_pos_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), n_in, info=info_d)
+        b = par.resampling.speed_to_pos_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), n_in, force_host_chain=True,
+                                            info=info_h)
+        ref, trimmed = C.speed_to_pos(st, sp, n_in)
+        assert info_d["path"] == 0 and info_h["path"] == 1
+        assert info_d["trimmed"] == info_h["trimmed"] == trimmed
+        assert a.numel() == b.numel() == len(ref)
+        assert np.array_equal(a.cpu().numpy(), ref) and np.array_equal(b.cpu().numpy(), ref)
+    # exact ties: period 256.5, speed 1 -> every other cumulative length is k + 0.5
+    st = np.arange(0, 200) * 256.5
+    sp = np.ones(200)
+    info = {}
+    a = par.resampling.speed_to_pos_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), 10**9, info=info)
+    ref, _ = C.speed_to_pos(st, sp, 10**9)
+    assert info["path"] == 1 and np.array_equal(a.cpu().numpy(), ref)
