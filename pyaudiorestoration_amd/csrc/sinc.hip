@@ -17,12 +17,14 @@
 //    without any per-tap sin: the numerator obeys the 3-term recurrence u[n+1] = 2cos(theta)u[n]-u[n-1]
 //    (theta = pi*fc), seeded at the window centre and run outwards in both directions (its error
 //    grows ~n while the weight decays ~1/n); when a whole wave has fc == 1 (speed <= 1) the numerator
-//    collapses to (-1)^(n+1) sin(pi*shift) and is factored out of the sum.  The denominator is one
-//    v_fma_f32 (x folded with pi/win_k from a wave-uniform table held in SGPRs) + one v_rcp_f32.
+//    collapses to (-1)^(n+1) sin(pi*shift) and is factored out of the sum.  Taps +n and -n share ONE
+//    v_rcp_f32 (the quarter-rate instruction that bounds this kernel): their denominators combine to
+//    (n^2 - shift^2)*pi/win_n, one v_fma_f32 against a wave-uniform table held in SGPRs.
 //  * positions stay float64 end to end (a 345.6 M-sample index does not fit float32); only the
 //    sub-sample shift in [-0.5, 0.5] and fc drop to float32.
 #include "par_common.h"
 #include <math.h>
+#include <stdlib.h>
 #include <map>
 #include <vector>
 
@@ -61,7 +63,7 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 // Fully general float64 evaluation of ONE output straight from global memory.  Used for the
 // leading-edge outputs (ind < NT), for tiles whose input span does not fit LDS, and as the
 // in-library cross-check of the fast path.  Follows util/resampling.py:66-90 line by line.
-__device__ float sinc_one_f64(double p, double dp, const float* __restrict__ sig, int64_t sig_stride,
+__device__ __noinline__ float sinc_one_f64(double p, double dp, const float* __restrict__ sig, int64_t sig_stride,
                               int64_t len_in, int NT) {
   const long long ind = llrint(p);
   const long long lower = ind - NT > 0 ? ind - NT : 0;
@@ -83,51 +85,85 @@ __device__ float sinc_one_f64(double p, double dp, const float* __restrict__ sig
   return (float)acc;
 }
 
-// fc == 1 for every lane of the wave: numerator (-1)^(n+1) sin(pi*s) factored out.
+// ---- tap loops ------------------------------------------------------------------------------------
+// Taps +n and -n share one reciprocal:  with q = s^2 and R_n = (win_n/pi)/(n^2 - q) = rcp(q*b_n + a2_n)
+//   sig[+n]*w(+n) + sig[-n]*w(-n) = R_n * ( n*(G + H) + s*(G - H) ),   G = sig[+n]*U_n,  H = sig[-n]*V_n
+// where U_n = sin(theta*(n-s)), V_n = sin(theta*(n+s)) (theta = pi*fc) are the sinc numerators.
+// The n loop runs in chunks of kChunk taps so that LDS offsets inside a chunk are instruction immediates,
+// the chunk's table entries arrive in one scalar load, and the (-1)^n sign is a free operand modifier.
+constexpr int kChunk = 4;
+
+// fc == 1 for every lane of the wave: U_n = -(-1)^n sin(pi s), V_n = +(-1)^n sin(pi s) -> factored out.
+// Accumulates e = sum (-1)^n (sig[+n]+sig[-n]) R_n  and  d = sum (-1)^n n (sig[+n]-sig[-n]) R_n.
 template <int R>
 __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const int (&c)[R], const float (&s)[R],
-                                           int NT, const float* __restrict__ tabA, const float* __restrict__ tabB,
-                                           float (&res)[R]) {
-  float accE[R], accO[R];
-  const float b0 = tabB[0];
+                                           int NT, const float2* __restrict__ tab, float (&res)[R]) {
+  float q[R], e[R], d[R];
+  int tp[R], tm[R];                          // LDS word indices (kept as indices so the loads stay ds_read)
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    accE[r] = tile[c[r]] * fast_rcp(s[r] * b0);
-    accO[r] = 0.0f;
+    q[r] = s[r] * s[r];
+    e[r] = d[r] = 0.0f;
+    tp[r] = c[r] + 1;                        // -> t[+n0]
+    tm[r] = c[r] - kChunk;                   // -> t[-(n0 + kChunk - 1)]
   }
-  int n = 1;
-  for (; n + 1 < NT; n += 2) {
-    const float a1 = tabA[n], b1 = tabB[n], a2 = tabA[n + 1], b2 = tabB[n + 1];
+  int n0 = 1;
+#pragma unroll 1
+  for (; n0 + kChunk <= NT; n0 += kChunk) {  // n0 is odd: n0+k is odd for even k
+    float2 ab[kChunk];
+#pragma unroll
+    for (int k = 0; k < kChunk; ++k) ab[k] = tab[n0 + k];
+#pragma unroll
+    for (int k = 0; k < kChunk; ++k) {
+      const float fn = (float)(n0 + k);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float sp = tile[tp[r] + k], sm = tile[tm[r] + (kChunk - 1 - k)];
+        const float D = sp - sm, E = sp + sm;
+        const float Rn = fast_rcp(fmaf(q[r], ab[k].y, ab[k].x));
+        const float DR = D * Rn;
+        if (k & 1) {                         // even n: +
+          e[r] = fmaf(E, Rn, e[r]);
+          d[r] = fmaf(DR, fn, d[r]);
+        } else {                             // odd n: -
+          e[r] = fmaf(-E, Rn, e[r]);
+          d[r] = fmaf(-DR, fn, d[r]);
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float* t = tile + c[r];
-      accO[r] = fmaf(t[n], fast_rcp(fmaf(s[r], b1, a1)), accO[r]);
-      accO[r] = fmaf(t[-n], fast_rcp(fmaf(s[r], b1, -a1)), accO[r]);
-      accE[r] = fmaf(t[n + 1], fast_rcp(fmaf(s[r], b2, a2)), accE[r]);
-      accE[r] = fmaf(t[-n - 1], fast_rcp(fmaf(s[r], b2, -a2)), accE[r]);
+      tp[r] += kChunk;
+      tm[r] -= kChunk;
     }
   }
-  if (n < NT) {   // n is odd here
-    const float a1 = tabA[n], b1 = tabB[n];
+  for (; n0 < NT; ++n0) {                    // <= kChunk-1 leftover taps
+    const float2 ab = tab[n0];
+    const float sgn = (n0 & 1) ? -1.0f : 1.0f, fn = sgn * (float)n0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float* t = tile + c[r];
-      accO[r] = fmaf(t[n], fast_rcp(fmaf(s[r], b1, a1)), accO[r]);
-      accO[r] = fmaf(t[-n], fast_rcp(fmaf(s[r], b1, -a1)), accO[r]);
+      const float sp = tile[c[r] + n0], sm = tile[c[r] - n0];
+      const float Rn = fast_rcp(fmaf(q[r], ab.y, ab.x));
+      e[r] = fmaf((sp + sm) * sgn, Rn, e[r]);
+      d[r] = fmaf((sp - sm) * Rn, fn, d[r]);
     }
   }
+  const float b0 = tab[0].y;
 #pragma unroll
-  for (int r = 0; r < R; ++r) res[r] = -sinpi_half(s[r]) * (accE[r] - accO[r]);
+  for (int r = 0; r < R; ++r) {
+    const float centre = tile[c[r]] * fast_rcp(s[r] * b0);
+    res[r] = -sinpi_half(s[r]) * (centre + fmaf(s[r], e[r], d[r]));
+  }
 }
 
-// general fc in (0, 1]: numerator by the two-sided 3-term recurrence seeded at the centre.
+// general fc in (0, 1]: numerators by 3-term recurrences seeded at the centre and run outwards.
 template <int R>
 __device__ __forceinline__ void taps_general(const float* __restrict__ tile, const int (&c)[R], const float (&s)[R],
                                              const float (&fc)[R], const float (&dd)[R], int NT,
-                                             const float* __restrict__ tabA, const float* __restrict__ tabB,
-                                             float (&res)[R]) {
-  float acc[R], up[R], upp[R], um[R], umm[R], c2[R];
-  const float b0 = tabB[0];
+                                             const float2* __restrict__ tab, float (&res)[R]) {
+  float q[R], accP[R], accM[R], U[R], Up[R], V[R], Vp[R], c2[R], centre[R];
+  int tp[R], tm[R];
+  const float b0 = tab[0].y;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const float h = fc[r] * s[r];                    // phi / pi, |h| <= 0.5
@@ -140,38 +176,71 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
       sth = sinpi_half(fc[r]);
       cth = cospi_half(fc[r]);
     }
-    const float u0 = -sphi;
-    up[r] = fmaf(sth, cphi, -cth * sphi);             // u[+1]
-    um[r] = -fmaf(sth, cphi, cth * sphi);             // u[-1]
-    upp[r] = u0;
-    umm[r] = u0;
+    Up[r] = -sphi;                                    // U_0 = sin(-phi)
+    Vp[r] = sphi;                                     // V_0 = sin(+phi)
+    U[r] = fmaf(sth, cphi, -cth * sphi);              // U_1 = sin(theta - phi)
+    V[r] = fmaf(sth, cphi, cth * sphi);               // V_1 = sin(theta + phi)
     c2[r] = 2.0f * cth;
-    acc[r] = tile[c[r]] * (u0 * fast_rcp(s[r] * b0));
+    q[r] = s[r] * s[r];
+    centre[r] = tile[c[r]] * (Up[r] * fast_rcp(s[r] * b0));
+    accP[r] = accM[r] = 0.0f;
+    tp[r] = c[r] + 1;
+    tm[r] = c[r] - kChunk;
   }
-  for (int n = 1; n < NT; ++n) {
-    const float a = tabA[n], b = tabB[n];
+  int n0 = 1;
+#pragma unroll 1
+  for (; n0 + kChunk <= NT; n0 += kChunk) {
+    float2 ab[kChunk];
+#pragma unroll
+    for (int k = 0; k < kChunk; ++k) ab[k] = tab[n0 + k];
+#pragma unroll
+    for (int k = 0; k < kChunk; ++k) {
+      const float fn = (float)(n0 + k);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float G = tile[tp[r] + k] * U[r], H = tile[tm[r] + (kChunk - 1 - k)] * V[r];
+        const float Rn = fast_rcp(fmaf(q[r], ab[k].y, ab[k].x));
+        accM[r] = fmaf(G - H, Rn, accM[r]);
+        accP[r] = fmaf((G + H) * Rn, fn, accP[r]);
+        const float un = fmaf(c2[r], U[r], -Up[r]);
+        Up[r] = U[r];
+        U[r] = un;
+        const float vn = fmaf(c2[r], V[r], -Vp[r]);
+        Vp[r] = V[r];
+        V[r] = vn;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float* t = tile + c[r];
-      acc[r] = fmaf(t[n], up[r] * fast_rcp(fmaf(s[r], b, a)), acc[r]);
-      acc[r] = fmaf(t[-n], um[r] * fast_rcp(fmaf(s[r], b, -a)), acc[r]);
-      const float un = fmaf(c2[r], up[r], -upp[r]);
-      upp[r] = up[r];
-      up[r] = un;
-      const float vn = fmaf(c2[r], um[r], -umm[r]);
-      umm[r] = um[r];
-      um[r] = vn;
+      tp[r] += kChunk;
+      tm[r] -= kChunk;
+    }
+  }
+  for (; n0 < NT; ++n0) {
+    const float2 ab = tab[n0];
+    const float fn = (float)n0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float G = tile[c[r] + n0] * U[r], H = tile[c[r] - n0] * V[r];
+      const float Rn = fast_rcp(fmaf(q[r], ab.y, ab.x));
+      accM[r] = fmaf(G - H, Rn, accM[r]);
+      accP[r] = fmaf((G + H) * Rn, fn, accP[r]);
+      const float un = fmaf(c2[r], U[r], -Up[r]);
+      Up[r] = U[r];
+      U[r] = un;
+      const float vn = fmaf(c2[r], V[r], -Vp[r]);
+      Vp[r] = V[r];
+      V[r] = vn;
     }
   }
 #pragma unroll
-  for (int r = 0; r < R; ++r) res[r] = acc[r];
+  for (int r = 0; r < R; ++r) res[r] = centre[r] + fmaf(s[r], accM[r], accP[r]);
 }
 
 __global__ __launch_bounds__(kSincBlock) void k_sinc(const double* __restrict__ pos, int64_t len_out,
                                                       const float* __restrict__ sig, int64_t sig_stride,
-                                                      int64_t len_in, int NT, const float* __restrict__ tabA,
-                                                      const float* __restrict__ tabB, float* __restrict__ out,
-                                                      int64_t out_stride) {
+                                                      int64_t len_in, int NT, const float2* __restrict__ tab,
+                                                      float* __restrict__ out, int64_t out_stride) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   __shared__ long long red[2 * (kSincBlock / kWave)];
   const int t = threadIdx.x;
@@ -242,8 +311,8 @@ __global__ __launch_bounds__(kSincBlock) void k_sinc(const double* __restrict__ 
     res[r] = 0.0f;
   }
   if (__any(anyfast)) {
-    if (__all(unity)) taps_unity<kSincR>(tile, c, s, NT, tabA, tabB, res);
-    else taps_general<kSincR>(tile, c, s, fc, dd, NT, tabA, tabB, res);
+    if (__all(unity)) taps_unity<kSincR>(tile, c, s, NT, tab, res);
+    else taps_general<kSincR>(tile, c, s, fc, dd, NT, tab, res);
   }
 #pragma unroll
   for (int r = 0; r < kSincR; ++r) {
@@ -278,8 +347,7 @@ __global__ __launch_bounds__(256) void k_lerp(const double* __restrict__ pos, in
 
 // ---- host side: per-(device, NT) tap tables -------------------------------------------------------
 struct SincTable {
-  float* a = nullptr;
-  float* b = nullptr;
+  float2* ab = nullptr;      // ab[n] = (pi*n^2/win_n, -pi/win_n)
 };
 static std::mutex g_tab_mu;
 static std::map<std::pair<int, int>, SincTable> g_tabs;
@@ -292,18 +360,15 @@ static int get_sinc_table(int device, int NT, SincTable* out) {
     *out = it->second;
     return PAR_OK;
   }
-  // a[n] = pi*n/win, b[n] = -pi/win with win = float32(np.hanning(2NT+1)[NT+n]), n = 0..NT-1
-  std::vector<float> a(NT), b(NT);
-  for (int n = 0; n < NT; ++n) {
-    float win = (float)(0.5 + 0.5 * cos(M_PI * (double)n / (double)NT));
-    a[n] = (float)(M_PI * (double)n / (double)win);
-    b[n] = (float)(-M_PI / (double)win);
+  // a2[n] = pi*n^2/win, b[n] = -pi/win with win = float32(np.hanning(2NT+1)[NT+n]), n = 0..NT-1
+  std::vector<float2> ab(NT + kChunk);
+  for (int n = 0; n < NT + kChunk; ++n) {
+    float win = n < NT ? (float)(0.5 + 0.5 * cos(M_PI * (double)n / (double)NT)) : 1.0f;
+    ab[n] = make_float2((float)(M_PI * (double)n * (double)n / (double)win), (float)(-M_PI / (double)win));
   }
   SincTable t;
-  PAR_HIP_CHECK(hipMalloc(&t.a, NT * sizeof(float)));
-  PAR_HIP_CHECK(hipMalloc(&t.b, NT * sizeof(float)));
-  PAR_HIP_CHECK(hipMemcpy(t.a, a.data(), NT * sizeof(float), hipMemcpyHostToDevice));
-  PAR_HIP_CHECK(hipMemcpy(t.b, b.data(), NT * sizeof(float), hipMemcpyHostToDevice));
+  PAR_HIP_CHECK(hipMalloc(&t.ab, ab.size() * sizeof(float2)));
+  PAR_HIP_CHECK(hipMemcpy(t.ab, ab.data(), ab.size() * sizeof(float2), hipMemcpyHostToDevice));
   g_tabs[key] = t;
   *out = t;
   return PAR_OK;
@@ -326,8 +391,8 @@ int par_sinc_resample_f32(int device, const double* pos, int64_t len_out, const 
   int rc = get_sinc_table(device, NT, &tab);
   if (rc != PAR_OK) return rc;
   const int64_t blocks = ceil_div(len_out, kSincTile);
-  hipLaunchKernelGGL(k_sinc, dim3((unsigned)blocks), dim3(kSincBlock), kSincCap * sizeof(float), as_stream(stream), pos,
-                     len_out, sig, sig_stride, len_in, NT, tab.a, tab.b, out, out_stride);
+hipLaunchKernelGGL(k_sinc, dim3((unsigned)blocks), dim3(kSincBlock), kSincCap * sizeof(float), as_stream(stream), pos,
+                     len_out, sig, sig_stride, len_in, NT, tab.ab, out, out_stride);
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }
