@@ -526,8 +526,8 @@ __global__ void k_trim(const double* __restrict__ st, const double* __restrict__
   h->len_out = len;
 }
 
-// pos[start_i + k] = cumsum_k + offset_i  (:125).  One lane per segment; each wave transposes 64 x 32
-// blocks through LDS so that HBM sees contiguous 256-byte runs.
+// pos[start_i + k] = cumsum_k + offset_i  (:125).  One lane per segment; each wave transposes 64 x 16
+// blocks through LDS so that HBM sees contiguous 128-byte runs.
 constexpr int kFillChunk = 32;
 constexpr int kFillWaves = 4;
 __global__ __launch_bounds__(kWave * kFillWaves) void k_pos_fill(const double* __restrict__ sp,
@@ -560,19 +560,23 @@ __global__ __launch_bounds__(kWave * kFillWaves) void k_pos_fill(const double* _
   }
   double c = 0.0;
   for (long long k0 = 0; k0 < nmax; k0 += kFillChunk) {
-#pragma unroll 2
-    for (int kk = 0; kk < kFillChunk; ++kk) {
-      const long long k = k0 + kk;
-      if (k < n) {
-        c = c + ramp_recip(k, r);
-        buf[w][lane][kk] = c + off;
-      }
+    for (int kk = 0; kk < kFillChunk; kk += 4) {
+      // four independent IEEE divisions in flight; only the running sum is serial
+      const double r0 = ramp_recip(k0 + kk, r), r1 = ramp_recip(k0 + kk + 1, r);
+      const double r2 = ramp_recip(k0 + kk + 2, r), r3 = ramp_recip(k0 + kk + 3, r);
+      const double c0 = c + r0, c1 = c0 + r1, c2 = c1 + r2, c3 = c2 + r3;
+      // rows past the segment end are never read back (the store side checks k < n)
+      buf[w][lane][kk] = c0 + off;
+      buf[w][lane][kk + 1] = c1 + off;
+      buf[w][lane][kk + 2] = c2 + off;
+      buf[w][lane][kk + 3] = c3 + off;
+      c = c3;
     }
-    // wave-synchronous transpose: rows = segments, 32 consecutive outputs each; two rows per pass
+    // wave-synchronous transpose: rows = segments, kFillChunk consecutive outputs each; several rows per pass
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int col = lane & (kFillChunk - 1), half = lane / kFillChunk;
-    for (int seg = 0; seg < kWave; seg += 2) {
+    for (int seg = 0; seg < kWave; seg += kWave / kFillChunk) {
       const int sg = seg + half;
       const long long k = k0 + col;
       if (k < (long long)s_n[w][sg]) pos[s_start[w][sg] + k] = buf[w][sg][col];

@@ -97,7 +97,7 @@ constexpr int kChunk = 4;
 // Accumulates e = sum (-1)^n (sig[+n]+sig[-n]) R_n  and  d = sum (-1)^n n (sig[+n]-sig[-n]) R_n.
 template <int R>
 __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const int (&c)[R], const float (&s)[R],
-                                           int NT, const float2* __restrict__ tab, float (&res)[R]) {
+                                           int NT, const float4* __restrict__ tab, float (&res)[R]) {
   float q[R], e[R], d[R];
   int tp[R], tm[R];                          // LDS word indices (kept as indices so the loads stay ds_read)
 #pragma unroll
@@ -110,12 +110,12 @@ __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const
   int n0 = 1;
 #pragma unroll 1
   for (; n0 + kChunk <= NT; n0 += kChunk) {  // n0 is odd: n0+k is odd for even k
-    float2 ab[kChunk];
+    float4 ab[kChunk];                       // wave-uniform: one s_load_dwordx16, operands stay in SGPRs
 #pragma unroll
     for (int k = 0; k < kChunk; ++k) ab[k] = tab[n0 + k];
 #pragma unroll
     for (int k = 0; k < kChunk; ++k) {
-      const float fn = (float)(n0 + k);
+      const float fn = ab[k].z;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const float sp = tile[tp[r] + k], sm = tile[tm[r] + (kChunk - 1 - k)];
@@ -138,8 +138,8 @@ __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const
     }
   }
   for (; n0 < NT; ++n0) {                    // <= kChunk-1 leftover taps
-    const float2 ab = tab[n0];
-    const float sgn = (n0 & 1) ? -1.0f : 1.0f, fn = sgn * (float)n0;
+    const float4 ab = tab[n0];
+    const float sgn = (n0 & 1) ? -1.0f : 1.0f, fn = sgn * ab.z;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const float sp = tile[c[r] + n0], sm = tile[c[r] - n0];
@@ -160,7 +160,7 @@ __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const
 template <int R>
 __device__ __forceinline__ void taps_general(const float* __restrict__ tile, const int (&c)[R], const float (&s)[R],
                                              const float (&fc)[R], const float (&dd)[R], int NT,
-                                             const float2* __restrict__ tab, float (&res)[R]) {
+                                             const float4* __restrict__ tab, float (&res)[R]) {
   float q[R], accP[R], accM[R], U[R], Up[R], V[R], Vp[R], c2[R], centre[R];
   int tp[R], tm[R];
   const float b0 = tab[0].y;
@@ -190,12 +190,12 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
   int n0 = 1;
 #pragma unroll 1
   for (; n0 + kChunk <= NT; n0 += kChunk) {
-    float2 ab[kChunk];
+    float4 ab[kChunk];                       // wave-uniform: one s_load_dwordx16, operands stay in SGPRs
 #pragma unroll
     for (int k = 0; k < kChunk; ++k) ab[k] = tab[n0 + k];
 #pragma unroll
     for (int k = 0; k < kChunk; ++k) {
-      const float fn = (float)(n0 + k);
+      const float fn = ab[k].z;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const float G = tile[tp[r] + k] * U[r], H = tile[tm[r] + (kChunk - 1 - k)] * V[r];
@@ -217,8 +217,8 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
     }
   }
   for (; n0 < NT; ++n0) {
-    const float2 ab = tab[n0];
-    const float fn = (float)n0;
+    const float4 ab = tab[n0];
+    const float fn = ab.z;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const float G = tile[c[r] + n0] * U[r], H = tile[c[r] - n0] * V[r];
@@ -239,7 +239,7 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
 
 __global__ __launch_bounds__(kSincBlock) void k_sinc(const double* __restrict__ pos, int64_t len_out,
                                                       const float* __restrict__ sig, int64_t sig_stride,
-                                                      int64_t len_in, int NT, const float2* __restrict__ tab,
+                                                      int64_t len_in, int NT, const float4* __restrict__ tab,
                                                       float* __restrict__ out, int64_t out_stride) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   __shared__ long long red[2 * (kSincBlock / kWave)];
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_lerp(const double* __restrict__ pos, in
 
 // ---- host side: per-(device, NT) tap tables -------------------------------------------------------
 struct SincTable {
-  float2* ab = nullptr;      // ab[n] = (pi*n^2/win_n, -pi/win_n)
+  float4* ab = nullptr;      // ab[n] = (pi*n^2/win_n, -pi/win_n, n, 0)
 };
 static std::mutex g_tab_mu;
 static std::map<std::pair<int, int>, SincTable> g_tabs;
@@ -361,14 +361,14 @@ static int get_sinc_table(int device, int NT, SincTable* out) {
     return PAR_OK;
   }
   // a2[n] = pi*n^2/win, b[n] = -pi/win with win = float32(np.hanning(2NT+1)[NT+n]), n = 0..NT-1
-  std::vector<float2> ab(NT + kChunk);
+  std::vector<float4> ab(NT + kChunk);
   for (int n = 0; n < NT + kChunk; ++n) {
     float win = n < NT ? (float)(0.5 + 0.5 * cos(M_PI * (double)n / (double)NT)) : 1.0f;
-    ab[n] = make_float2((float)(M_PI * (double)n * (double)n / (double)win), (float)(-M_PI / (double)win));
+    ab[n] = make_float4((float)(M_PI * (double)n * (double)n / (double)win), (float)(-M_PI / (double)win), (float)n, 0.0f);
   }
   SincTable t;
-  PAR_HIP_CHECK(hipMalloc(&t.ab, ab.size() * sizeof(float2)));
-  PAR_HIP_CHECK(hipMemcpy(t.ab, ab.data(), ab.size() * sizeof(float2), hipMemcpyHostToDevice));
+  PAR_HIP_CHECK(hipMalloc(&t.ab, ab.size() * sizeof(float4)));
+  PAR_HIP_CHECK(hipMemcpy(t.ab, ab.data(), ab.size() * sizeof(float4), hipMemcpyHostToDevice));
   g_tabs[key] = t;
   *out = t;
   return PAR_OK;
