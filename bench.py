@@ -69,19 +69,10 @@ def main():
     a = ap.parse_args()
 
     import torch
-    from pyaudiorestoration_amd import _dev, _lib, resampling
+    from pyaudiorestoration_amd import _dev, _lib, multi_gpu
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    else:
-        dist = None
-        torch.cuda.set_device(local)
+    ctx = multi_gpu.RankContext()                      # nccl (= RCCL) when WORLD_SIZE > 1, else single process
+    world, rank, local, dist = ctx.world, ctx.rank, ctx.local, ctx.dist
     dev = local
     L = _lib.lib()
     sp_ = _dev.stream_ptr(dev)
@@ -124,25 +115,8 @@ def main():
 
     for _ in range(a.warmup):
         step(False)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(True)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        cnt = torch.tensor([len_out.value], dtype=torch.float64, device=f"cuda:{dev}")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_per_step = float(cnt.item())
-    else:
-        total_per_step = float(len_out.value)
+    dt = ctx.timed(lambda: step(True), a.steps)        # barrier+sync | K steps | sync+barrier, MAX over ranks
+    total_per_step = ctx.reduce_sum(len_out.value)     # whole-job output samples per step
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -166,8 +140,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(a.sr, a.nt)
         print(json.dumps(res), flush=True)
-    if dist:
-        dist.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -109,7 +109,7 @@ __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const
   }
   int n0 = 1;
 #pragma unroll 1
-  for (; n0 + kChunk <= NT; n0 += kChunk) {  // n0 is odd: n0+k is odd for even k
+  for (; n0 < NT; n0 += kChunk) {            // n0 is odd: n0+k is odd for even k; taps >= NT have R_n == 0
     float4 ab[kChunk];                       // wave-uniform: one s_load_dwordx16, operands stay in SGPRs
 #pragma unroll
     for (int k = 0; k < kChunk; ++k) ab[k] = tab[n0 + k];
@@ -135,17 +135,6 @@ __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const
     for (int r = 0; r < R; ++r) {
       tp[r] += kChunk;
       tm[r] -= kChunk;
-    }
-  }
-  for (; n0 < NT; ++n0) {                    // <= kChunk-1 leftover taps
-    const float4 ab = tab[n0];
-    const float sgn = (n0 & 1) ? -1.0f : 1.0f, fn = sgn * ab.z;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float sp = tile[c[r] + n0], sm = tile[c[r] - n0];
-      const float Rn = fast_rcp(fmaf(q[r], ab.y, ab.x));
-      e[r] = fmaf((sp + sm) * sgn, Rn, e[r]);
-      d[r] = fmaf((sp - sm) * Rn, fn, d[r]);
     }
   }
   const float b0 = tab[0].y;
@@ -189,7 +178,7 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
   }
   int n0 = 1;
 #pragma unroll 1
-  for (; n0 + kChunk <= NT; n0 += kChunk) {
+  for (; n0 < NT; n0 += kChunk) {
     float4 ab[kChunk];                       // wave-uniform: one s_load_dwordx16, operands stay in SGPRs
 #pragma unroll
     for (int k = 0; k < kChunk; ++k) ab[k] = tab[n0 + k];
@@ -216,28 +205,11 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
       tm[r] -= kChunk;
     }
   }
-  for (; n0 < NT; ++n0) {
-    const float4 ab = tab[n0];
-    const float fn = ab.z;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float G = tile[c[r] + n0] * U[r], H = tile[c[r] - n0] * V[r];
-      const float Rn = fast_rcp(fmaf(q[r], ab.y, ab.x));
-      accM[r] = fmaf(G - H, Rn, accM[r]);
-      accP[r] = fmaf((G + H) * Rn, fn, accP[r]);
-      const float un = fmaf(c2[r], U[r], -Up[r]);
-      Up[r] = U[r];
-      U[r] = un;
-      const float vn = fmaf(c2[r], V[r], -Vp[r]);
-      Vp[r] = V[r];
-      V[r] = vn;
-    }
-  }
 #pragma unroll
   for (int r = 0; r < R; ++r) res[r] = centre[r] + fmaf(s[r], accM[r], accP[r]);
 }
 
-__global__ __launch_bounds__(kSincBlock) void k_sinc(const double* __restrict__ pos, int64_t len_out,
+__global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict__ pos, int64_t len_out,
                                                       const float* __restrict__ sig, int64_t sig_stride,
                                                       int64_t len_in, int NT, const float4* __restrict__ tab,
                                                       float* __restrict__ out, int64_t out_stride) {
@@ -278,8 +250,10 @@ __global__ __launch_bounds__(kSincBlock) void k_sinc(const double* __restrict__ 
     mn = red[w] < mn ? red[w] : mn;
     mx = red[kSincBlock / kWave + w] > mx ? red[kSincBlock / kWave + w] : mx;
   }
-  const long long lo = mn - NT;
-  const long long span = mx + NT - lo;             // <= kSincCap for the LDS path
+  // the tap loops run in chunks of kChunk and may touch up to kChunk-1 taps beyond +-(NT-1); those
+  // carry an exactly-zero weight (R_n = rcp(inf)) but must read finite data: stage a kChunk margin.
+  const long long lo = mn - NT - kChunk;
+  const long long span = mx + NT + kChunk - lo;    // <= kSincCap for the LDS path
   const bool staged = span <= kSincCap;
   if (staged) {
     for (long long q = t; q < span; q += kSincBlock) {
@@ -289,6 +263,8 @@ __global__ __launch_bounds__(kSincBlock) void k_sinc(const double* __restrict__ 
   }
   __syncthreads();
 
+  // From here on only (c, s, fc, dd) stay live through the tap loops; the float64 position, its period
+  // and the 64-bit index are dropped (the rare float64 slow path re-reads them) to keep VGPRs low.
   float res[kSincR];
   int c[kSincR];
   float s[kSincR], fc[kSincR], dd[kSincR];
@@ -298,7 +274,7 @@ __global__ __launch_bounds__(kSincBlock) void k_sinc(const double* __restrict__ 
   for (int r = 0; r < kSincR; ++r) {
     // leading-edge outputs (ind < NT) keep the reference's mis-aligned taps: float64 path.
     fastlane[r] = valid[r] && staged && ind[r] >= NT;
-    c[r] = fastlane[r] ? (int)(ind[r] - lo) : NT;          // harmless in-range index for idle lanes
+    c[r] = fastlane[r] ? (int)(ind[r] - lo) : NT + kChunk; // harmless in-range index for idle lanes
     float sh = (float)(p[r] - (double)ind[r]);
     s[r] = (sh == 0.0f) ? 1e-20f : sh;                      // np.sinc's own 0 -> 1e-20 substitution
     const bool one = !(dp[r] > 1.0);                        // fc == 1 (also catches the 1e-12 floor)
@@ -316,9 +292,14 @@ __global__ __launch_bounds__(kSincBlock) void k_sinc(const double* __restrict__ 
   }
 #pragma unroll
   for (int r = 0; r < kSincR; ++r) {
-    if (!valid[r]) continue;
     const int64_t j = j0 + t + (int64_t)r * kSincBlock;
-    float v = fastlane[r] ? res[r] : sinc_one_f64(p[r], dp[r], sig, sig_stride, len_in, NT);
+    if (j >= len_out) continue;
+    float v = res[r];
+    if (!fastlane[r]) {
+      const double pj = pos[j];
+      const double dpj = (j + 1 < len_out) ? pos[j + 1] - pj : pj - pos[j - 1];
+      v = sinc_one_f64(pj, dpj, sig, sig_stride, len_in, NT);
+    }
     out[j * out_stride] = v;
   }
 }
@@ -363,8 +344,12 @@ static int get_sinc_table(int device, int NT, SincTable* out) {
   // a2[n] = pi*n^2/win, b[n] = -pi/win with win = float32(np.hanning(2NT+1)[NT+n]), n = 0..NT-1
   std::vector<float4> ab(NT + kChunk);
   for (int n = 0; n < NT + kChunk; ++n) {
-    float win = n < NT ? (float)(0.5 + 0.5 * cos(M_PI * (double)n / (double)NT)) : 1.0f;
-    ab[n] = make_float4((float)(M_PI * (double)n * (double)n / (double)win), (float)(-M_PI / (double)win), (float)n, 0.0f);
+    if (n < NT) {
+      float win = (float)(0.5 + 0.5 * cos(M_PI * (double)n / (double)NT));
+      ab[n] = make_float4((float)(M_PI * (double)n * (double)n / (double)win), (float)(-M_PI / (double)win), (float)n, 0.0f);
+    } else {
+      ab[n] = make_float4(INFINITY, (float)(-M_PI), (float)n, 0.0f);   // padded taps: rcp(q*b + inf) == 0
+    }
   }
   SincTable t;
   PAR_HIP_CHECK(hipMalloc(&t.ab, ab.size() * sizeof(float4)));

@@ -1,0 +1,83 @@
+"""Multi-GPU sharding of the varispeed path: independent (file, channel) work items, one process
+per GPU, NO data-path collective.
+
+The reference processes files and channels independently (`for filename ...` util/resampling.py:168,
+`for out_channel, in_channel ...` :225), so the work shards embarrassingly: every rank owns a
+disjoint slice of the work-item list, keeps its results (the host gathers them by writing files),
+and the only communication is the benchmark's barrier plus a MAX (time) / SUM (sample count)
+reduction -- over RCCL when the ranks hold GPUs ("nccl" backend), over gloo in the CPU tests.
+"""
+import os
+import time
+
+import torch
+
+
+def shard_items(n_items, world, rank):
+    """Static longest-first style assignment for equally sized items: rank r takes items
+    r, r+world, r+2*world, ...  (every rank gets ceil or floor of n_items/world)."""
+    return list(range(rank, n_items, world))
+
+
+def work_items(n_files, n_channels):
+    """(file, channel) pairs in the order the reference would visit them."""
+    return [(f, c) for f in range(n_files) for c in range(n_channels)]
+
+
+class RankContext:
+    """Process-group plumbing shared by bench.py and the CPU tests."""
+
+    def __init__(self, backend=None):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.device = "cpu"
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend == "nccl":
+                torch.cuda.set_device(self.local)
+                self.device = f"cuda:{self.local}"
+                dist.init_process_group("nccl", device_id=torch.device(self.device))
+            else:
+                dist.init_process_group(backend)
+            self.dist = dist
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(self.local)
+            self.device = f"cuda:{self.local}"
+
+    def barrier(self):
+        if self.device != "cpu":
+            torch.cuda.synchronize()
+        if self.dist:
+            self.dist.barrier()
+
+    def timed(self, fn, steps):
+        """barrier + sync, run fn() `steps` times, sync + barrier; returns MAX-over-ranks seconds."""
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.barrier()
+        return self.reduce_max(time.perf_counter() - t0)
+
+    def _reduce(self, value, op):
+        if not self.dist:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def reduce_max(self, value):
+        return self._reduce(value, self.dist.ReduceOp.MAX if self.dist else None)
+
+    def reduce_sum(self, value):
+        return self._reduce(value, self.dist.ReduceOp.SUM if self.dist else None)
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
