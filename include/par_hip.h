@@ -108,6 +108,19 @@ int par_speed_to_pos_fill(int device, const double* speeds, int64_t m, const voi
 int par_sinc_resample_f32(int device, const double* pos, int64_t len_out, const float* sig, int64_t sig_stride,
                           int64_t len_in, int NT, float* out, int64_t out_stride, void* stream);
 
+/* Higher-level slot of resampling.run (util/resampling.py:184, :225-227): positions + sinc interpolation of
+ * one channel from a finished plan.  n_chunks > 1 pipelines the work in pieces (position fill of chunk c+1
+ * on a library-owned side stream while chunk c is interpolated); 0 = auto (= 1 on MI355X, where the overlap
+ * measured no gain).  Bit-identical to par_speed_to_pos_fill + par_sinc_resample_f32.  pos is caller-owned f64[len_out]
+ * scratch (it holds the reference's sample_at array afterwards). */
+int par_varispeed_resample_f32(int device, const double* speeds, int64_t m, const void* work, int64_t len_out,
+                               double* pos, const float* sig, int64_t sig_stride, int64_t len_in, int NT, float* out,
+                               int64_t out_stride, int n_chunks, void* stream);
+/* Profiling hook (bench.py roofline leg): HIP-event timing, on the caller's stream, of the K_sinc launches
+ * issued by the last par_varispeed_resample_f32 call on `device`. */
+int par_profile_enable(int device, int on);
+int par_profile_read(int device, float* total_ms, int* launches, int64_t* samples);
+
 /* "Linear" mode of resampling.run (util/resampling.py:229): np.interp(pos, arange(len), sig, 0, 0). */
 int par_linear_resample_f32(int device, const double* pos, int64_t len_out, const float* sig, int64_t sig_stride,
                             int64_t len_in, float* out, int64_t out_stride, void* stream);

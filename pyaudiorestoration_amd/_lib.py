@@ -37,6 +37,10 @@ SIGNATURES = {
                                          ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int), c_vp]),
     "par_speed_to_pos_fill": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "par_sinc_resample_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp]),
+    "par_varispeed_resample_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_i64,
+                                           c_int, c_vp]),
+    "par_profile_enable": (c_int, [c_int, c_int]),
+    "par_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(c_int), ctypes.POINTER(c_i64)]),
     "par_linear_resample_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "par_synth_signal_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_dbl, c_u64, c_vp]),
     "par_synth_speed_curve_f64": (c_int, [c_int, c_vp, c_vp, c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_vp]),

@@ -53,4 +53,11 @@ __device__ inline long long wave_max_ll(long long v) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// cross-file launch helpers (pos.hip, sinc.hip) used by the pipelined resampler in varispeed.hip
+int launch_pos_fill(const double* speeds, int64_t m, const void* work, double* pos, int64_t len_out, int64_t j_lo,
+                    int64_t j_hi, hipStream_t s);
+int launch_sinc(int device, const double* pos, int64_t len_out, int64_t j_begin, int64_t count, const float* sig,
+                int64_t sig_stride, int64_t len_in, int NT, float* out, int64_t out_stride, hipStream_t s);
+constexpr int64_t kSincTileOutputs = 1024;   // outputs per K_sinc workgroup (chunk boundaries align to it)
+
 }  // namespace par

@@ -533,7 +533,8 @@ constexpr int kFillWaves = 4;
 __global__ __launch_bounds__(kWave * kFillWaves) void k_pos_fill(const double* __restrict__ sp,
                                                                   const int64_t* __restrict__ seg_start,
                                                                   const double* __restrict__ seg_off, int64_t nseg,
-                                                                  int64_t len_out, double* __restrict__ pos) {
+                                                                  int64_t len_out, int64_t j_lo, int64_t j_hi,
+                                                                  double* __restrict__ pos) {
   __shared__ double buf[kFillWaves][kWave][kFillChunk + 1];
   __shared__ long long s_start[kFillWaves][kWave];
   __shared__ int s_n[kFillWaves][kWave];
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(kWave * kFillWaves) void k_pos_fill(const double* _
     start = seg_start[i];
     n = seg_start[i + 1] - start;
     if (n >= 2) r = make_ramp(sp[i], sp[i + 1], n);
-    if (start >= (long long)len_out) n = 0;
+    if (start >= (long long)len_out || start < (long long)j_lo || start >= (long long)j_hi) n = 0;   // not this chunk's
     else if (start + n > (long long)len_out) n = len_out - start;     // trimmed tail: fewer samples, same ramp
     off = seg_off[i];
   }
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(kWave * kFillWaves) void k_pos_fill(const double* _
     nmax = t > nmax ? t : nmax;
   }
   double c = 0.0;
-  for (long long k0 = 0; k0 < nmax; k0 += kFillChunk) {
+  for (long long k0 = 0; k0 < nmax; k0 += kFillChunk) {   // nmax == 0: the whole wave belongs to other chunks
     for (int kk = 0; kk < kFillChunk; kk += 4) {
       // four independent IEEE divisions in flight; only the running sum is serial
       const double r0 = ramp_recip(k0 + kk, r), r1 = ramp_recip(k0 + kk + 1, r);
@@ -669,6 +670,19 @@ static int host_plan(const PlanView& pv, const double* d_st, const double* d_sp,
   return PAR_OK;
 }
 
+
+
+// positions of the segments whose first output index lies in [j_lo, j_hi)  (used whole or chunked)
+int launch_pos_fill(const double* speeds, int64_t m, const void* work, double* pos, int64_t len_out, int64_t j_lo,
+                    int64_t j_hi, hipStream_t s) {
+  PlanView pv = plan_view(const_cast<void*>(work), m);
+  const int64_t nseg = m - 1;
+  hipLaunchKernelGGL(k_pos_fill, dim3((unsigned)ceil_div(nseg, kWave * kFillWaves)), dim3(kWave * kFillWaves), 0, s, speeds,
+                     pv.seg_start, pv.seg_off, nseg, len_out, j_lo, j_hi, pos);
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
 }  // namespace par
 
 extern "C" {
@@ -750,12 +764,7 @@ int par_speed_to_pos_fill(int device, const double* speeds, int64_t m, const voi
   PAR_REQUIRE(speeds && work && (pos || len_out == 0) && m >= 2, PAR_ERR_ARG, "par_speed_to_pos_fill: bad args");
   if (len_out == 0) return PAR_OK;
   PAR_HIP_CHECK(hipSetDevice(device));
-  PlanView pv = plan_view(const_cast<void*>(work), m);
-  const int64_t nseg = m - 1;
-  hipLaunchKernelGGL(k_pos_fill, dim3((unsigned)ceil_div(nseg, kWave * kFillWaves)), dim3(kWave * kFillWaves), 0,
-                     as_stream(stream), speeds, pv.seg_start, pv.seg_off, nseg, len_out, pos);
-  PAR_HIP_CHECK(hipGetLastError());
-  return PAR_OK;
+  return launch_pos_fill(speeds, m, work, pos, len_out, 0, INT64_MAX, as_stream(stream));
 }
 
 }  // extern "C"

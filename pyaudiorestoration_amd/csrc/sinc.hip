@@ -212,11 +212,12 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
 __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict__ pos, int64_t len_out,
                                                       const float* __restrict__ sig, int64_t sig_stride,
                                                       int64_t len_in, int NT, const float4* __restrict__ tab,
-                                                      float* __restrict__ out, int64_t out_stride) {
+                                                      float* __restrict__ out, int64_t out_stride, int64_t j_begin,
+                                                      int64_t j_end) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   __shared__ long long red[2 * (kSincBlock / kWave)];
   const int t = threadIdx.x;
-  const int64_t j0 = (int64_t)blockIdx.x * kSincTile;
+  const int64_t j0 = j_begin + (int64_t)blockIdx.x * kSincTile;     // this launch covers outputs [j_begin, j_end)
 
   double p[kSincR], dp[kSincR];
   long long ind[kSincR];
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
 #pragma unroll
   for (int r = 0; r < kSincR; ++r) {
     const int64_t j = j0 + t + (int64_t)r * kSincBlock;
-    valid[r] = j < len_out;
+    valid[r] = j < j_end;
     p[r] = 0.0;
     dp[r] = 1.0;
     ind[r] = 0;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
 #pragma unroll
   for (int r = 0; r < kSincR; ++r) {
     const int64_t j = j0 + t + (int64_t)r * kSincBlock;
-    if (j >= len_out) continue;
+    if (j >= j_end) continue;
     float v = res[r];
     if (!fastlane[r]) {
       const double pj = pos[j];
@@ -359,6 +360,22 @@ static int get_sinc_table(int device, int NT, SincTable* out) {
   return PAR_OK;
 }
 
+static_assert(kSincTile == kSincTileOutputs, "chunk alignment constant out of sync");
+
+// outputs [j_begin, j_begin+count) of a len_out-long position array (j_begin must be tile aligned)
+int launch_sinc(int device, const double* pos, int64_t len_out, int64_t j_begin, int64_t count, const float* sig,
+                int64_t sig_stride, int64_t len_in, int NT, float* out, int64_t out_stride, hipStream_t s) {
+  if (count <= 0) return PAR_OK;
+  SincTable tab;
+  int rc = get_sinc_table(device, NT, &tab);
+  if (rc != PAR_OK) return rc;
+  const int64_t blocks = ceil_div(count, kSincTile);
+  hipLaunchKernelGGL(k_sinc, dim3((unsigned)blocks), dim3(kSincBlock), kSincCap * sizeof(float), s, pos, len_out, sig,
+                     sig_stride, len_in, NT, tab.ab, out, out_stride, j_begin, j_begin + count);
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
 }  // namespace par
 
 extern "C" {
@@ -372,14 +389,7 @@ int par_sinc_resample_f32(int device, const double* pos, int64_t len_out, const 
   PAR_REQUIRE(NT >= 1 && NT <= 512, PAR_ERR_ARG, "par_sinc_resample_f32: NT=%d outside [1,512]", NT);
   PAR_REQUIRE(len_in >= 1 && sig_stride >= 1 && out_stride >= 1, PAR_ERR_ARG, "par_sinc_resample_f32: bad sizes");
   PAR_HIP_CHECK(hipSetDevice(device));
-  SincTable tab;
-  int rc = get_sinc_table(device, NT, &tab);
-  if (rc != PAR_OK) return rc;
-  const int64_t blocks = ceil_div(len_out, kSincTile);
-hipLaunchKernelGGL(k_sinc, dim3((unsigned)blocks), dim3(kSincBlock), kSincCap * sizeof(float), as_stream(stream), pos,
-                     len_out, sig, sig_stride, len_in, NT, tab.ab, out, out_stride);
-  PAR_HIP_CHECK(hipGetLastError());
-  return PAR_OK;
+  return launch_sinc(device, pos, len_out, 0, len_out, sig, sig_stride, len_in, NT, out, out_stride, as_stream(stream));
 }
 
 int par_linear_resample_f32(int device, const double* pos, int64_t len_out, const float* sig, int64_t sig_stride,

@@ -1,0 +1,131 @@
+// Varispeed resample of one channel from a finished plan: positions (K_pos fill) then interpolation
+// (K_sinc), optionally chunked so that the fill of chunk c+1 runs on a side stream while K_sinc works on
+// chunk c (measured: no gain on MI355X, see below; default is one chunk).  Same results as par_speed_to_pos_fill + par_sinc_resample_f32 (same kernels, the
+// chunk boundaries are K_sinc tile boundaries); this is the "higher-level slot" of resampling.run
+// (reference util/resampling.py:184, :225-227).
+#include "par_common.h"
+#include <map>
+#include <vector>
+
+namespace par {
+
+constexpr int kMaxChunks = 32;
+
+struct Pipe {
+  hipStream_t side = nullptr;
+  hipEvent_t start = nullptr;
+  hipEvent_t filled[kMaxChunks] = {};
+  // optional profiling of the K_sinc launches (bench.py's roofline leg)
+  bool profile = false;
+  hipEvent_t t0[kMaxChunks] = {}, t1[kMaxChunks] = {};
+  int timed_launches = 0;
+  int64_t timed_samples = 0;
+  std::vector<float> ms;          // per-launch durations collected by par_profile_read
+};
+static std::mutex g_pipe_mu;
+static std::map<int, Pipe> g_pipes;
+
+static int get_pipe(int device, Pipe** out) {
+  std::lock_guard<std::mutex> lk(g_pipe_mu);
+  Pipe& p = g_pipes[device];
+  if (!p.side) {
+    PAR_HIP_CHECK(hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking));
+    PAR_HIP_CHECK(hipEventCreateWithFlags(&p.start, hipEventDisableTiming));
+    for (int i = 0; i < kMaxChunks; ++i) {
+      PAR_HIP_CHECK(hipEventCreateWithFlags(&p.filled[i], hipEventDisableTiming));
+      PAR_HIP_CHECK(hipEventCreate(&p.t0[i]));
+      PAR_HIP_CHECK(hipEventCreate(&p.t1[i]));
+    }
+  }
+  *out = &p;
+  return PAR_OK;
+}
+
+}  // namespace par
+
+extern "C" {
+
+int par_varispeed_resample_f32(int device, const double* speeds, int64_t m, const void* work, int64_t len_out,
+                               double* pos, const float* sig, int64_t sig_stride, int64_t len_in, int NT, float* out,
+                               int64_t out_stride, int n_chunks, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(speeds && work && pos && sig && out && m >= 2, PAR_ERR_ARG, "par_varispeed_resample_f32: null pointer");
+  PAR_REQUIRE(len_out >= 2, PAR_ERR_ARG, "par_varispeed_resample_f32: len_out=%lld < 2", (long long)len_out);
+  PAR_REQUIRE(NT >= 1 && NT <= 512 && len_in >= 1 && sig_stride >= 1 && out_stride >= 1, PAR_ERR_ARG,
+              "par_varispeed_resample_f32: bad sizes");
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipStream_t main = as_stream(stream);
+  // auto = 1: on MI355X the two kernels do not overlap usefully (measured, 115 M and 691 M outputs:
+  // 1 chunk 1.91 / 10.42 ms per step, 4-32 chunks 1.96-2.15 / 10.67 ms) -- each launch already fills
+  // all 256 CUs, so the side-stream fill only steals slots from K_sinc.  The chunked form is kept for
+  // callers that want the first output samples early.
+  if (n_chunks <= 0) n_chunks = 1;
+  if (n_chunks > kMaxChunks) n_chunks = kMaxChunks;
+  int64_t per = ceil_div(ceil_div(len_out, n_chunks), kSincTileOutputs) * kSincTileOutputs;
+  n_chunks = (int)ceil_div(len_out, per);
+  Pipe* p = nullptr;
+  int rc = get_pipe(device, &p);
+  if (rc != PAR_OK) return rc;
+  std::lock_guard<std::mutex> lk(g_pipe_mu);      // one pipelined call per process at a time (shared side stream)
+  // side stream starts after everything already queued on the caller's stream (the plan kernels)
+  PAR_HIP_CHECK(hipEventRecord(p->start, main));
+  PAR_HIP_CHECK(hipStreamWaitEvent(p->side, p->start, 0));
+  for (int c = 0; c < n_chunks; ++c) {
+    const int64_t j_lo = (int64_t)c * per;
+    const int64_t j_hi = (c == n_chunks - 1) ? INT64_MAX : j_lo + per;
+    rc = launch_pos_fill(speeds, m, work, pos, len_out, j_lo, j_hi, p->side);
+    if (rc != PAR_OK) return rc;
+    PAR_HIP_CHECK(hipEventRecord(p->filled[c], p->side));
+  }
+  for (int c = 0; c < n_chunks; ++c) {
+    // outputs [j_lo, j_hi) read pos[j_hi] too: the first position of the next chunk's first segment
+    const int need = c + 1 < n_chunks ? c + 1 : c;
+    PAR_HIP_CHECK(hipStreamWaitEvent(main, p->filled[need], 0));
+    const int64_t j_lo = (int64_t)c * per;
+    const int64_t cnt = (j_lo + per <= len_out) ? per : len_out - j_lo;
+    if (p->profile) PAR_HIP_CHECK(hipEventRecord(p->t0[c], main));
+    rc = launch_sinc(device, pos, len_out, j_lo, cnt, sig, sig_stride, len_in, NT, out, out_stride, main);
+    if (rc != PAR_OK) return rc;
+    if (p->profile) PAR_HIP_CHECK(hipEventRecord(p->t1[c], main));
+  }
+  if (p->profile) {
+    p->timed_launches = n_chunks;
+    p->timed_samples = len_out;
+  }
+  return PAR_OK;
+}
+
+// profiling hook for bench.py: HIP-event timing of the K_sinc launches issued by the last pipelined call
+int par_profile_enable(int device, int on) {
+  using namespace par;
+  PAR_HIP_CHECK(hipSetDevice(device));
+  Pipe* p = nullptr;
+  int rc = get_pipe(device, &p);
+  if (rc != PAR_OK) return rc;
+  p->profile = on != 0;
+  p->timed_launches = 0;
+  return PAR_OK;
+}
+
+// sums the K_sinc launch durations of the last pipelined call (synchronises on them)
+int par_profile_read(int device, float* total_ms, int* launches, int64_t* samples) {
+  using namespace par;
+  PAR_REQUIRE(total_ms && launches && samples, PAR_ERR_ARG, "par_profile_read: null");
+  PAR_HIP_CHECK(hipSetDevice(device));
+  Pipe* p = nullptr;
+  int rc = get_pipe(device, &p);
+  if (rc != PAR_OK) return rc;
+  float tot = 0.0f;
+  for (int c = 0; c < p->timed_launches; ++c) {
+    float ms = 0.0f;
+    PAR_HIP_CHECK(hipEventSynchronize(p->t1[c]));
+    PAR_HIP_CHECK(hipEventElapsedTime(&ms, p->t0[c], p->t1[c]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = p->timed_launches;
+  *samples = p->timed_samples;
+  return PAR_OK;
+}
+
+}  // extern "C"

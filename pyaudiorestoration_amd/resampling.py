@@ -24,10 +24,15 @@ def find_cutoff(array, cutoff):
 
 # ----------------------------------------------------------------------------- positions
 
-def speed_to_pos_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_host_chain=False, info=None):
-    """Device speed curve (float64 tensors) -> float64 position tensor (the written prefix).
-    force_host_chain runs the serial host evaluation of the two order-dependent chains (the exact
-    fallback of the device scans); `info`, if a dict, receives {"path": 0 device | 1 host, "trimmed"}."""
+class SpeedPlan:
+    """Device-resident result of the planning stage of speed_to_pos (segment lengths, offsets, trim)."""
+
+    def __init__(self, speeds_t, m, work, len_out, trimmed, path, dev):
+        self.speeds_t, self.m, self.work, self.len_out, self.trimmed, self.path, self.dev = \
+            speeds_t, m, work, len_out, trimmed, path, dev
+
+
+def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_host_chain=False):
     dev = _dev.device_index(dev if dev is not None else sampletimes_t.device)
     L = _lib.lib()
     m = sampletimes_t.numel()
@@ -37,16 +42,41 @@ def speed_to_pos_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force
     work = _dev.empty(nbytes, torch.uint8, dev)
     len_out = ctypes.c_int64(0)
     trimmed = ctypes.c_int(0)
-    sp = _dev.stream_ptr(dev)
     path = ctypes.c_int(0)
     _lib.check(L.par_speed_to_pos_plan_ex(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m, int(num_imput_samples),
                                           _dev.ptr(work), nbytes, ctypes.byref(len_out), ctypes.byref(trimmed),
-                                          1 if force_host_chain else 0, ctypes.byref(path), sp))
+                                          1 if force_host_chain else 0, ctypes.byref(path), _dev.stream_ptr(dev)))
+    return SpeedPlan(speeds_t, m, work, len_out.value, bool(trimmed.value), path.value, dev)
+
+
+def speed_to_pos_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_host_chain=False, info=None):
+    """Device speed curve (float64 tensors) -> float64 position tensor (the written prefix).
+    force_host_chain runs the serial host evaluation of the two order-dependent chains (the exact
+    fallback of the device scans); `info`, if a dict, receives {"path": 0 device | 1 host, "trimmed"}."""
+    plan = speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev, force_host_chain)
     if info is not None:
-        info.update(path=path.value, trimmed=bool(trimmed.value))
-    pos = _dev.empty(len_out.value, torch.float64, dev)
-    _lib.check(L.par_speed_to_pos_fill(dev, _dev.ptr(speeds_t), m, _dev.ptr(work), _dev.ptr(pos), len_out.value, sp))
+        info.update(path=plan.path, trimmed=plan.trimmed)
+    pos = _dev.empty(plan.len_out, torch.float64, plan.dev)
+    _lib.check(_lib.lib().par_speed_to_pos_fill(plan.dev, _dev.ptr(speeds_t), plan.m, _dev.ptr(plan.work), _dev.ptr(pos),
+                                                plan.len_out, _dev.stream_ptr(plan.dev)))
     return pos
+
+
+def varispeed_resample_dev(plan, sig_t, NT, out_t=None, pos_t=None, sig_stride=1, len_in=None, out_stride=1, n_chunks=0):
+    """Positions + sinc interpolation of one channel from a SpeedPlan, pipelined on two streams
+    (position fill of chunk c+1 under the interpolation of chunk c).  Returns (out, pos)."""
+    dev = plan.dev
+    L = _lib.lib()
+    if len_in is None:
+        len_in = sig_t.numel() // sig_stride
+    if pos_t is None:
+        pos_t = _dev.empty(plan.len_out, torch.float64, dev)
+    if out_t is None:
+        out_t = _dev.empty(plan.len_out * out_stride, torch.float32, dev)
+    _lib.check(L.par_varispeed_resample_f32(dev, _dev.ptr(plan.speeds_t), plan.m, _dev.ptr(plan.work), plan.len_out,
+                                            _dev.ptr(pos_t), _dev.ptr(sig_t), sig_stride, len_in, int(NT), _dev.ptr(out_t),
+                                            out_stride, n_chunks, _dev.stream_ptr(dev)))
+    return out_t, pos_t
 
 
 def speed_to_pos(sampletimes, speeds, num_imput_samples):

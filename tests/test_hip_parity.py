@@ -358,3 +358,21 @@ def test_speed_plan_device_scans_vs_serial_host_chain(par, golden):
     a = par.resampling.speed_to_pos_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), 10**9, info=info)
     ref, _ = C.speed_to_pos(st, sp, 10**9)
     assert info["path"] == 1 and np.array_equal(a.cpu().numpy(), ref)
+
+
+def test_pipelined_varispeed_equals_two_step_path(par):
+    """par_varispeed_resample_f32 (fill of chunk c+1 under the sinc of chunk c, two streams) must be
+    bit-identical to par_speed_to_pos_fill + par_sinc_resample_f32, for any chunk count."""
+    t = par.torch
+    sr, dur = 96000, 30.0
+    n = int(sr * dur)
+    sc = inputs.bench_speed_curve(dur, sr)
+    sig_t = t.from_numpy(inputs.bench_signal(0, n, sr)).cuda()
+    st_t, sp_t = t.from_numpy(sc[:, 0] * sr).cuda(), t.from_numpy(np.ascontiguousarray(sc[:, 1])).cuda()
+    pos_ref = par.resampling.speed_to_pos_dev(st_t, sp_t, n)
+    out_ref = par.resampling.sinc_resample_dev(pos_ref, sig_t, 32)
+    for chunks in (0, 1, 3, 8, 32):
+        plan = par.resampling.speed_plan_dev(st_t, sp_t, n)
+        out, pos = par.resampling.varispeed_resample_dev(plan, sig_t, 32, n_chunks=chunks)
+        t.cuda.synchronize()
+        assert t.equal(pos, pos_ref) and t.equal(out, out_ref), chunks
