@@ -24,7 +24,6 @@
 //    sub-sample shift in [-0.5, 0.5] and fc drop to float32.
 #include "par_common.h"
 #include <math.h>
-#include <stdlib.h>
 #include <map>
 #include <vector>
 
@@ -209,6 +208,8 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
   for (int r = 0; r < R; ++r) res[r] = centre[r] + fmaf(s[r], accM[r], accP[r]);
 }
 
+// 6 waves/SIMD (80 VGPRs) measured best: 4 -> 1.39 ms, 5 -> 1.29, 6 -> 1.25, 7 -> 1.32, 8 -> 1.59 (spills) per
+// 115 M outputs.  Fully unrolling the tap loop (compile-time NT) was tried twice and spills badly.
 __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict__ pos, int64_t len_out,
                                                       const float* __restrict__ sig, int64_t sig_stride,
                                                       int64_t len_in, int NT, const float4* __restrict__ tab,
