@@ -123,6 +123,13 @@ def main():
         k_ms = sum(sinc_ms) / n_launch                      # average K_sinc launch duration (HIP events)
         samples_per_launch = len_out.value * len(sinc_ms) / n_launch
         achieved = ALGO_BYTES_PER_SAMPLE * samples_per_launch / (k_ms * 1e-3) / 1e9
+        # HBM traffic from the committed PMC passes (tools/profile_round.sh): bytes/sample x this run's rate
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = round(tr["hbm_bytes_per_sample"] * samples_per_launch / (k_ms * 1e-3) / 1e9, 2)
+        except Exception:
+            pass
         res = {
             "metric": "Msamples/sec resampled (192 kHz varispeed)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
@@ -132,11 +139,12 @@ def main():
                        "samples_in_per_gpu": n_in, "samples_out_per_gpu": int(len_out.value), "NT": a.nt,
                        "step": "plan (device scans) + positions (K_pos fill, f64) pipelined under K_sinc; inputs resident in HBM"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "k_sinc",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": "k_sinc",
                          "kernel_ms": round(k_ms, 4), "launches_per_step": n_launch // len(sinc_ms),
                          "samples_per_launch": int(samples_per_launch),
-                         "note": "8 algorithmic B/output sample (4 B in + 4 B out); the kernel is VALU-bound "
-                                 "(64 taps/sample), see DESIGN.md"},
+                         "note": "achieved = 8 algorithmic B/output sample (4 B in + 4 B out) / HIP-event K_sinc time; "
+                                 "traffic = PMC HBM bytes (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json) "
+                                 "incl. the 8 B float64 position read; the kernel is v_rcp/VALU-bound, see DESIGN.md"},
         }
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(a.sr, a.nt)

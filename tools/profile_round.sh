@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun):
+#   tools/profile_round.sh r01         -> gpurun_out/r01/*  (copy the summaries into profiles/ afterwards
+#                                         with tools/summarise_profiles.py)
+# Counters are collected in separate passes with --kernel-trace only (never with sys/hip/hsa traces).
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+rocprofv3 --kernel-trace --stats -d "$OUT" -o trace -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT" -o fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT" -o write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/write.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d "$OUT" -o sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/sq.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM -d "$OUT" -o lds -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/lds.log" 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d "$OUT" -o grbm -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/grbm.log" 2>&1
+cat "$OUT/bench_default.json"
