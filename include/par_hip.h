@@ -72,6 +72,10 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
 int par_istft_f32(int device, const float* spec, int64_t n_frames, int n_fft, int hop, const float* window,
                   float* frames, float* y, int64_t y_len, int64_t skip, void* stream);
 
+/* Spectral gain mask of the dropout healer (dropout_healer_gui.py:161-162, util/units.py:28-29 to_fac):
+ * spec[i] *= 10^(gain_db[i]/20) for a frame-major complex64 spectrogram and a float32 mask of `count` bins. */
+int par_spec_apply_gain_db_c64(int device, float* spec, const float* gain_db, int64_t count, void* stream);
+
 /* ---- R1: speed curve -> fractional read positions ----------------------------------
  * Replaces resampling.speed_to_pos (util/resampling.py:93-137).  Two calls because the
  * caller must allocate the position array:

@@ -246,6 +246,22 @@ def main():
     save("pipeline", track_times=tr.times, track_freqs=tr.freqs, curve=curve, pos=pos, y=y,
          cfg=np.array([sr, n, n_fft, hop]))
 
+    # ------------------------------------- config 4: dropout healer on L2 calls
+    # the glue (dropout_healer_gui.py:111-166) lives in oracle_np.heal_dropouts; here it runs on the
+    # REFERENCE's stft/istft so the fixture pins both the glue's use of them and the spectral numerics.
+    sys.path.insert(0, ROOT)
+    from oracle import oracle_np
+    sr_h = 44100
+    xh = (inputs.sine(30000, 1500.0, sr_h, 0.4) + 0.05 * inputs.noise(30000, 60)).astype(np.float32)
+    xh[9000:9300] *= 0.05                                   # two synthetic dropouts
+    xh[20000:20500] *= 0.1
+    marks = [(0.2000, 500.0, 0.2110, 6000.0, 0.5), (0.4500, 800.0, 0.4680, 9000.0, 0.5),
+             (0.2050, 1000.0, 0.2150, 3000.0, 1.0)]      # the third overlaps the first (gain clip path)
+    healed = oracle_np.heal_dropouts(xh, sr_h, marks, 512, 32,
+                                     stft_fn=lambda x, n_fft, step: fourier.stft(x, n_fft=n_fft, step=step),
+                                     istft_fn=lambda S, length, hop_length: fourier.istft(S, length=length, hop_length=hop_length))
+    save("heal", y=healed[:, 0].astype(np.float64), marks=np.array(marks), sr=np.array(sr_h))
+
     # ----------------------------------------------- Linear mode + lag curve
     sig = inputs.noise(5000, 50)
     lag = np.array([[0.0, 0.0], [0.02, 0.0005], [0.06, -0.001], [0.1, 0.002]])

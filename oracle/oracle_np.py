@@ -444,3 +444,48 @@ def master_speed_curve(lines, duration, sr, hop, bands=(0, 20)):
     out = np.array(data)
     np.power(2, out[:, 1], out[:, 1])
     return out
+
+
+# ------------------------------------------------------------- config 4: dropout healer
+
+def heal_dropouts(signal, sr, markers, fft_size=512, hop=32, stft_fn=None, istft_fn=None):
+    """dropout_healer_gui.Canvas.resample_files (dropout_healer_gui.py:111-166), one pass per channel.
+    markers: (a0, a1, b0, b1, surrounding) as DropoutSample.to_cfg() (util/markers.py:368-426).
+    stft_fn/istft_fn default to this module's restatements (gen_golden passes the reference's own)."""
+    from scipy.interpolate import RegularGridInterpolator
+    stft_fn = stft_fn or stft
+    istft_fn = istft_fn or istft
+    sig2d = signal[:, None] if signal.ndim == 1 else signal
+    n, ch = sig2d.shape
+    out = np.empty(sig2d.shape, dtype=sig2d.dtype)
+    y_pad = fix_length(sig2d, n + fft_size // 2)
+
+    def t2f(t):
+        return int(t * sr / hop)
+
+    def f2b(f):
+        return max(1, min(fft_size // 2, int(round(f * fft_size / sr))))
+
+    for c in range(ch):
+        S = np.array(stft_fn(y_pad[:, c], n_fft=fft_size, step=hop))
+        db = 20 * np.log10(np.abs(S) + .0000001)
+        gain_whole = np.zeros(S.shape, dtype=float)
+        for (a0, a1, b0, b1, surrounding) in markers:
+            width, t = abs(a0 - b0), (a0 + b0) / 2
+            f, height = (a1 + b1) / 2, abs(a1 - b1)
+            frame_b, frame_a = t2f(t - width / 2), t2f(t + width / 2)
+            fs = max(1, t2f(width * surrounding))
+            bin_l, bin_u = f2b(f - height / 2), f2b(f + height / 2)
+            before = np.mean(db[bin_l:bin_u, frame_b - fs:frame_b], axis=1)
+            after = np.mean(db[bin_l:bin_u, frame_a:frame_a + fs], axis=1)
+            fp_frames = np.linspace(frame_b, frame_a, num=frame_a - frame_b)
+            fp_bins = np.linspace(bin_l, bin_u, num=bin_u - bin_l)
+            interp = RegularGridInterpolator(((frame_b, frame_a), fp_bins), (before, after))
+            mp_bins, mp_frames = np.meshgrid(fp_bins, fp_frames)
+            fp_db = np.swapaxes(interp((mp_frames, mp_bins)), 0, 1)
+            g = fp_db - db[bin_l:bin_u, frame_b:frame_a]
+            np.clip(g, gain_whole[bin_l:bin_u, frame_b:frame_a], 255, out=g)
+            gain_whole[bin_l:bin_u, frame_b:frame_a] = g
+        S = S * np.power(10, gain_whole / 20)
+        out[:, c] = istft_fn(S, length=n, hop_length=hop)
+    return out

@@ -328,3 +328,29 @@ int par_istft_f32(int device, const float* spec, int64_t n_frames, int n_fft, in
 }
 
 }  // extern "C"
+
+// ---- spectral gain mask (config 4, dropout_healer_gui.py:161-162): S *= 10^(gain_db/20) ----------------
+namespace par {
+__global__ void k_apply_gain_db(float2* __restrict__ spec, const float* __restrict__ gain_db, int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float g = gain_db[i];
+  if (g == 0.0f) return;                               // np.power(10, 0/20) == 1 exactly
+  const float f = exp2f(g * 0.16609640474436813f);     // 10^(g/20) = 2^(g*log2(10)/20)
+  float2 v = spec[i];
+  v.x *= f;
+  v.y *= f;
+  spec[i] = v;
+}
+}  // namespace par
+
+extern "C" int par_spec_apply_gain_db_c64(int device, float* spec, const float* gain_db, int64_t count, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(spec && gain_db && count >= 0, PAR_ERR_ARG, "par_spec_apply_gain_db_c64: bad args");
+  if (count == 0) return PAR_OK;
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipLaunchKernelGGL(k_apply_gain_db, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<float2*>(spec), gain_db, count);
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}

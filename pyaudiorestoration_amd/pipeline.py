@@ -70,3 +70,67 @@ def respeed(signal, sr, trail, fft_size=1024, hop=256, zeropad=1, mode="Peak", t
                                            out_stride=ch, dev=dev)
     return {"spectrum": spec, "times": track.times, "freqs": track.freqs, "speed_curve": curve, "positions": pos_t,
             "output": out_t}
+
+
+# ---------------------------------------------------------------------- config 4: dropout healer
+def to_dB(a):
+    """util/units.py:24-25."""
+    return 20 * np.log10(a)
+
+
+def heal_dropouts(signal, sr, markers, fft_size=512, hop=32, channels=None, device=None):
+    """Spectral inpainting of marked dropouts -- headless restatement of
+    dropout_healer_gui.Canvas.resample_files (dropout_healer_gui.py:111-166).
+
+    signal: float32 (n, ch).  markers: iterable of (a0, a1, b0, b1, surrounding) = the reference's
+    DropoutSample.to_cfg() (util/markers.py:368-388, 424-426): corner (t, f) pairs and the
+    surrounding factor.  STFT, gain application and ISTFT run on the device; the per-marker target
+    (mean dB of the frames before/after, bilinear fill, clip against earlier markers) is O(box) host
+    math on slices copied back from HBM, like the GUI does it on its cached spectrogram."""
+    import ctypes
+    from scipy.interpolate import RegularGridInterpolator
+    from . import _lib
+    dev = _dev.device_index(device)
+    L = _lib.lib()
+    sig2d = signal[:, None] if signal.ndim == 1 else signal
+    n, ch = sig2d.shape
+    if channels is None:
+        channels = range(ch)
+    out = np.empty(sig2d.shape, dtype=sig2d.dtype)
+    y_pad = fourier.fix_length(sig2d, n + fft_size // 2, axis=0)
+    pad_t = _dev.to_dev(y_pad, torch.float32, dev)                      # (n + fft/2, ch) in HBM
+
+    def t2f(t):
+        return int(t * sr / hop)
+
+    def f2b(f):
+        return max(1, min(fft_size // 2, int(round(f * fft_size / sr))))
+
+    for c in channels:
+        S = fourier.stft(pad_t.reshape(-1)[c::ch] if ch > 1 else pad_t.reshape(-1), n_fft=fft_size, step=hop)  # (bins, frames) device
+        fm = S.T                                                           # frame-major [frames][bins] view, contiguous
+        gain = torch.zeros(fm.shape, dtype=torch.float32, device=fm.device)
+        for (a0, a1, b0, b1, surrounding) in markers:
+            width, t = abs(a0 - b0), (a0 + b0) / 2
+            f, height = (a1 + b1) / 2, abs(a1 - b1)
+            frame_b, frame_a = t2f(t - width / 2), t2f(t + width / 2)
+            fs = max(1, t2f(width * surrounding))
+            bin_l, bin_u = f2b(f - height / 2), f2b(f + height / 2)
+            box = fm[frame_b - fs:frame_a + fs, bin_l:bin_u].cpu().numpy()      # small D2H
+            db = to_dB(np.abs(box.astype(np.complex128)) + .0000001).T           # (bins, frames) like the reference
+            mag_before = np.mean(db[:, 0:fs], axis=1)
+            mag_after = np.mean(db[:, fs + (frame_a - frame_b):fs + (frame_a - frame_b) + fs], axis=1)
+            fp_frames = np.linspace(frame_b, frame_a, num=frame_a - frame_b)
+            fp_bins = np.linspace(bin_l, bin_u, num=bin_u - bin_l)
+            interp = RegularGridInterpolator(((frame_b, frame_a), fp_bins), (mag_before, mag_after))
+            mp_bins, mp_frames = np.meshgrid(fp_bins, fp_frames)
+            fp_db = np.swapaxes(interp((mp_frames, mp_bins)), 0, 1)
+            gain_db = fp_db - db[:, fs:fs + (frame_a - frame_b)]
+            prev = gain[frame_b:frame_a, bin_l:bin_u].cpu().numpy().T.astype(np.float64)
+            np.clip(gain_db, prev, 255, out=gain_db)
+            gain[frame_b:frame_a, bin_l:bin_u] = torch.from_numpy(np.ascontiguousarray(gain_db.T, dtype=np.float32)).to(gain.device)
+        healed = fm.contiguous()
+        _lib.check(L.par_spec_apply_gain_db_c64(dev, _dev.ptr(healed), _dev.ptr(gain), healed.numel(), _dev.stream_ptr(dev)))
+        y = fourier.istft(healed.T, length=n, hop_length=hop)
+        out[:, c] = y.cpu().numpy()
+    return out

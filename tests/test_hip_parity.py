@@ -376,3 +376,16 @@ def test_pipelined_varispeed_equals_two_step_path(par):
         out, pos = par.resampling.varispeed_resample_dev(plan, sig_t, 32, n_chunks=chunks)
         t.cuda.synchronize()
         assert t.equal(pos, pos_ref) and t.equal(out, out_ref), chunks
+
+
+def test_heal_dropouts_config4(par, golden):
+    """dropout_healer data flow: device STFT -> host per-marker targets -> device gain mask -> device ISTFT."""
+    from test_oracle_golden import heal_input
+    g = golden["heal"]
+    sr = int(g["sr"])
+    x = heal_input(sr)
+    y = par.pipeline.heal_dropouts(x, sr, [tuple(m) for m in g["marks"]], 512, 32)
+    assert y.shape == (30000, 1) and relerr(y[:, 0], g["y"]) < TOL
+    st = np.stack((x, x[::-1].copy()), axis=-1)                     # stereo, channel views stay strided on the device
+    y2 = par.pipeline.heal_dropouts(st, sr, [tuple(m) for m in g["marks"]], 512, 32, channels=(0,))
+    assert relerr(y2[:, 0], g["y"]) < TOL

@@ -241,3 +241,20 @@ def test_c_oracle_synth_matches_numpy_generators():
     sc = inputs.bench_speed_curve(3.0, 48000)
     st, sp = C.synth_curve(len(sc), 3.0, 48000.0)
     assert np.allclose(st, sc[:, 0] * 48000, rtol=0, atol=1e-7) and np.allclose(sp, sc[:, 1], rtol=0, atol=1e-15)
+
+
+def heal_input(sr):
+    x = (inputs.sine(30000, 1500.0, sr, 0.4) + 0.05 * inputs.noise(30000, 60)).astype(np.float32)
+    x[9000:9300] *= 0.05
+    x[20000:20500] *= 0.1
+    return x
+
+
+def test_heal_dropouts_config4(golden):
+    g = golden["heal"]
+    sr = int(g["sr"])
+    x = heal_input(sr)
+    y = O.heal_dropouts(x, sr, [tuple(m) for m in g["marks"]], 512, 32)
+    assert relerr(y[:, 0], g["y"]) < 2e-6
+    assert np.abs(y[9000:9300, 0]).mean() > 4 * np.abs(x[9000:9300]).mean()      # the dropout was lifted
+    assert relerr(y[:8000, 0], x[:8000]) < 1e-4                                   # untouched region survives the round trip
