@@ -6,12 +6,13 @@
 // rfft, / sqrt(n_fft) (:157); to_mag :23-24 (|X| + 1e-7) fused as mode 1.
 // istft :314-437 with window_sumsquare :492-546 and __overlap_add :677-687.
 //
-// CDNA4 mapping: no frame matrix is ever materialised.  A 256-thread workgroup owns FR consecutive
-// frames: it gathers them straight from the (possibly channel-strided) signal with the reflect
-// boundary folded into the index, multiplies by the window, packs the real frame as an M/2-point
-// complex sequence in LDS, runs a Stockham autosort FFT (radix-4 stages + one radix-2 when needed,
-// ping-pong LDS buffers, no bit reversal), untangles the half-size spectrum into the M/2+1 real-FFT
-// bins and writes them FRAME-MAJOR (bins contiguous -> coalesced stores).  HBM traffic is the
+// CDNA4 mapping: no frame matrix is ever materialised.  A workgroup owns a few consecutive frames,
+// H/8 lanes each (one wave per frame at n_fft = 1024): a lane gathers 8 complex points straight from
+// the (possibly channel-strided) signal with the reflect boundary folded into the index, multiplies
+// by the window (the real frame is packed as an M/2-point complex sequence), runs a Stockham autosort
+// FFT with radix-8 butterflies in registers (one LDS exchange per radix-8 stage, no bit reversal),
+// untangles the half-size spectrum into the M/2+1 real-FFT bins and writes them FRAME-MAJOR (bins
+// contiguous -> coalesced stores).  HBM traffic is the
 // algorithmic minimum: each input sample is fetched from HBM once (neighbouring frames hit L2) and
 // each output bin is written once; magnitude never round-trips a complex spectrogram.
 #include "par_common.h"
@@ -74,129 +75,196 @@ __device__ __forceinline__ long long reflect_index(long long q, long long n) {
   return q < n ? q : P - q;
 }
 
-// In-LDS Stockham autosort FFT of FR independent H-point complex sequences.
-// buf holds 2*FR*H float2: [ping | pong]; returns which half holds the result.
-__device__ int lds_fft(float2* buf, int FR, int H, int logH, const float2* __restrict__ tw, int tid, int nthreads) {
-  int cur = 0;
-  int Ns = 1;
-  int remaining = logH;
-  while (remaining > 0) {
-    const float2* in = buf + cur * FR * H;
-    float2* out = buf + (cur ^ 1) * FR * H;
-    if (remaining >= 2) {
-      const int Q = H >> 2;                           // butterflies per frame
-      const int twstep = H / (Ns * 4);
-      for (int b = tid; b < FR * Q; b += nthreads) {
-        const int f = b / Q, j = b - f * Q;
-        const int k = j & (Ns - 1);
-        const float2* x = in + f * H;
-        float2 v0 = x[j], v1 = x[j + Q], v2 = x[j + 2 * Q], v3 = x[j + 3 * Q];
-        if (Ns > 1) {
-          const float2 w1 = tw[k * twstep], w2 = tw[2 * k * twstep], w3 = tw[3 * k * twstep];
-          v1 = cmul(v1, w1);
-          v2 = cmul(v2, w2);
-          v3 = cmul(v3, w3);
-        }
-        const float2 a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3), a3 = mul_mi(csub(v1, v3));
-        float2* y = out + f * H + ((j - k) << 2) + k;   // (j/Ns)*Ns*4 + k
-        y[0] = cadd(a0, a2);
-        y[Ns] = cadd(a1, a3);
-        y[2 * Ns] = csub(a0, a2);
-        y[3 * Ns] = csub(a1, a3);
-      }
-      Ns <<= 2;
-      remaining -= 2;
-    } else {
-      const int Q = H >> 1;
-      const int twstep = H / (Ns * 2);
-      for (int b = tid; b < FR * Q; b += nthreads) {
-        const int f = b / Q, j = b - f * Q;
-        const int k = j & (Ns - 1);
-        const float2* x = in + f * H;
-        float2 v0 = x[j], v1 = x[j + Q];
-        if (Ns > 1) v1 = cmul(v1, tw[k * twstep]);
-        float2* y = out + f * H + ((j - k) << 1) + k;
-        y[0] = cadd(v0, v1);
-        y[Ns] = csub(v0, v1);
-      }
-      Ns <<= 1;
-      remaining -= 1;
-    }
-    cur ^= 1;
-    __syncthreads();
-  }
-  return cur;
+// ---- FFT core ------------------------------------------------------------------------------------------
+// H-point complex Stockham autosort FFT with 8 points per lane held in REGISTERS: T = H/8 lanes per frame
+// (H = 512 -> exactly one wave per frame).  Every stage consumes x[j + q*T], q = 0..7 (conflict-free
+// LDS reads, and for the first stage coalesced global reads), does radix-8 butterflies in registers and
+// scatters to the autosort positions; a final radix-2/4 stage covers log2(H) not divisible by 3.  LDS is
+// touched log8(H) times instead of log2..log4(H) times, and indices are padded e -> e + e/8 so the
+// scattered 64-bit writes are bank-conflict free.
+__device__ __forceinline__ int lpad(int e) { return e + (e >> 3); }
+
+__device__ __forceinline__ void radix2(float2& a, float2& b) {
+  const float2 t = a;
+  a = cadd(t, b);
+  b = csub(t, b);
+}
+// forward 4-point DFT in place: (v0,v1,v2,v3) -> (X0,X1,X2,X3)
+__device__ __forceinline__ void radix4(float2& v0, float2& v1, float2& v2, float2& v3) {
+  const float2 a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3), a3 = mul_mi(csub(v1, v3));
+  v0 = cadd(a0, a2);
+  v1 = cadd(a1, a3);
+  v2 = csub(a0, a2);
+  v3 = csub(a1, a3);
+}
+// forward 8-point DFT in place, natural order in and out
+__device__ __forceinline__ void radix8(float2 (&v)[8]) {
+  // split into even (0,2,4,6) and odd (1,3,5,7) 4-point DFTs
+  float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+  float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  radix4(e0, e1, e2, e3);
+  radix4(o0, o1, o2, o3);
+  const float h = 0.70710678118654752f;
+  // odd outputs times W8^k: W8^1 = (1-i)/sqrt2, W8^2 = -i, W8^3 = (-1-i)/sqrt2
+  o1 = make_float2((o1.x + o1.y) * h, (o1.y - o1.x) * h);
+  o2 = mul_mi(o2);
+  o3 = make_float2((o3.y - o3.x) * h, -(o3.x + o3.y) * h);
+  v[0] = cadd(e0, o0);
+  v[4] = csub(e0, o0);
+  v[1] = cadd(e1, o1);
+  v[5] = csub(e1, o1);
+  v[2] = cadd(e2, o2);
+  v[6] = csub(e2, o2);
+  v[3] = cadd(e3, o3);
+  v[7] = csub(e3, o3);
 }
 
-constexpr int kStftThreads = 256;
-
-__global__ __launch_bounds__(kStftThreads) void k_stft(const float* __restrict__ x, int64_t n, int64_t x_stride,
-                                                        int n_fft, int hop, int M, int logH, int FR,
-                                                        const float* __restrict__ window, const float2* __restrict__ tw,
-                                                        const float2* __restrict__ post, float* __restrict__ out,
-                                                        int64_t n_frames, int mode, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  const int H = M >> 1;
-  const int tid = threadIdx.x;
-  const int64_t f0 = (int64_t)blockIdx.x * FR;
-  const int half = n_fft >> 1;
-  // gather + window + pack: z[j] = (xw[2j], xw[2j+1])
-  for (int e = tid; e < FR * H; e += kStftThreads) {
-    const int f = e / H, j = e - f * H;
-    float2 z = make_float2(0.0f, 0.0f);
-    const int64_t fr = f0 + f;
-    if (fr < n_frames) {
-      const int t0 = 2 * j;
-      const long long base = (long long)fr * hop - half;
-      if (t0 < n_fft) z.x = window[t0] * x[reflect_index(base + t0, n) * x_stride];
-      if (t0 + 1 < n_fft) z.y = window[t0 + 1] * x[reflect_index(base + t0 + 1, n) * x_stride];
+// v[q] = x[j + q*T] on entry (natural order); on exit X (padded LDS frame) holds the transform in natural order.
+// All lanes of the BLOCK must call this together (it synchronises with __syncthreads).
+template <int LOGH>
+__device__ __forceinline__ void fft_core(float2 (&v)[8], float2* __restrict__ X, int j, const float2* __restrict__ tw) {
+  constexpr int H = 1 << LOGH, T = H / 8;
+  constexpr int N8 = LOGH / 3, REM = LOGH % 3;
+  int Ns = 1;
+#pragma unroll
+  for (int st = 0; st < N8; ++st) {
+    if (st > 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = X[lpad(j + q * T)];
     }
-    lds[e] = z;
+    const int k = j & (Ns - 1);
+    if (st > 0) {
+      const int step = H / (Ns * 8);
+#pragma unroll
+      for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw[r * k * step]);
+    }
+    radix8(v);
+    __syncthreads();                       // everybody has finished reading X
+    const int base = ((j - k) << 3) + k;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) X[lpad(base + r * Ns)] = v[r];
+    __syncthreads();
+    Ns <<= 3;
   }
-  __syncthreads();
-  const int cur = lds_fft(lds, FR, H, logH, tw, tid, kStftThreads);
-  const float2* Z = lds + cur * FR * H;
-  const int bins = H + 1;
-  for (int e = tid; e < FR * bins; e += kStftThreads) {
-    const int f = e / bins, k = e - f * bins;
-    const int64_t fr = f0 + f;
-    if (fr >= n_frames) continue;
-    const float2 zk = Z[f * H + (k & (H - 1))];
-    const float2 zc = cconj(Z[f * H + ((H - k) & (H - 1))]);
-    const float2 ev = cadd(zk, zc);            // 2*E[k]
-    const float2 od = csub(zk, zc);            // 2*i*O[k]... untangled below
-    const float2 t = cmul(post[k], od);        // W^k * (Z[k] - conj(Z[H-k]))
-    // X[k] = 0.5*(ev) - 0.5*i*t
-    const float re = 0.5f * (ev.x + t.y) * scale;
-    const float im = 0.5f * (ev.y - t.x) * scale;
-    if (mode == 0) {
-      reinterpret_cast<float2*>(out)[fr * bins + k] = make_float2(re, im);
-    } else {
-      out[fr * bins + k] = sqrtf(re * re + im * im) + 1e-7f;
+  if (REM) {
+    constexpr int Rl = 1 << REM, U = 8 / Rl;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = X[lpad(j + q * T)];
+    const int step = H / (Ns * Rl);
+    int bk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = j + u * T;
+      const int k = b & (Ns - 1);
+      bk[u] = ((b - k) * Rl) + k;
+#pragma unroll
+      for (int r = 1; r < Rl; ++r) v[u + r * U] = cmul(v[u + r * U], tw[r * k * step]);
+      if (Rl == 2) radix2(v[u], v[u + U]);
+      else radix4(v[u], v[u + U], v[u + 2 * U], v[u + 3 * U]);
     }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < Rl; ++r) X[lpad(bk[u] + r * Ns)] = v[u + r * U];
+    __syncthreads();
+  }
+}
+
+template <int LOGH>
+struct FftGeom {
+  static constexpr int H = 1 << LOGH;
+  static constexpr int T = H / 8;                               // lanes per frame
+  static constexpr int Threads = T > 256 ? T : 256;
+  static constexpr int Frames = Threads / T;                    // frames per workgroup
+  static constexpr int FrameLds = H + H / 8 + 8;                // padded float2 slots per frame
+};
+
+template <int LOGH>
+__global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __restrict__ x, int64_t n, int64_t x_stride,
+                                                                  int n_fft, int hop, const float* __restrict__ window,
+                                                                  const float2* __restrict__ tw,
+                                                                  const float2* __restrict__ post, float* __restrict__ out,
+                                                                  int64_t n_frames, int mode, float scale) {
+  using G = FftGeom<LOGH>;
+  constexpr int H = G::H, T = G::T;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const int f = threadIdx.x / T, j = threadIdx.x - f * T;
+  float2* X = lds + f * G::FrameLds;
+  const int64_t fr = (int64_t)blockIdx.x * G::Frames + f;
+  const bool live = fr < n_frames;
+  // gather + window + pack: z[i] = (xw[2i], xw[2i+1]); lanes read consecutive float pairs (coalesced)
+  float2 v[8];
+  const long long base = (long long)fr * hop - (n_fft >> 1);
+  // interior frames (the vast majority) index the signal directly; only frames that overhang an end of
+  // the signal pay for the reflect fold (a 64-bit modulo per sample)
+  const bool interior = live && base >= 0 && base + n_fft <= (long long)n;
+  if (interior) {
+    const float* xs = x + base * x_stride;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int t0 = 2 * (j + q * T);
+      float2 z = make_float2(0.0f, 0.0f);
+      if (t0 + 1 < n_fft) {
+        const float2 w = *reinterpret_cast<const float2*>(window + t0);
+        z.x = w.x * xs[(int64_t)t0 * x_stride];
+        z.y = w.y * xs[(int64_t)(t0 + 1) * x_stride];
+      } else if (t0 < n_fft) {
+        z.x = window[t0] * xs[(int64_t)t0 * x_stride];
+      }
+      v[q] = z;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int t0 = 2 * (j + q * T);
+      float2 z = make_float2(0.0f, 0.0f);
+      if (live) {
+        if (t0 < n_fft) z.x = window[t0] * x[reflect_index(base + t0, n) * x_stride];
+        if (t0 + 1 < n_fft) z.y = window[t0 + 1] * x[reflect_index(base + t0 + 1, n) * x_stride];
+      }
+      v[q] = z;
+    }
+  }
+  fft_core<LOGH>(v, X, j, tw);
+  if (!live) return;
+  // untangle the half-size transform into the H+1 real-FFT bins; lanes write consecutive bins
+  constexpr int bins = H + 1;
+  for (int k = j; k < bins; k += T) {
+    const float2 zk = X[lpad(k & (H - 1))];
+    const float2 zc = cconj(X[lpad((H - k) & (H - 1))]);
+    const float2 ev = cadd(zk, zc);
+    const float2 t = cmul(post[k], csub(zk, zc));      // W^k * (Z[k] - conj(Z[H-k]))
+    const float re = 0.5f * (ev.x + t.y) * scale;       // X[k] = (ev - i*t)/2
+    const float im = 0.5f * (ev.y - t.x) * scale;
+    if (mode == 0) reinterpret_cast<float2*>(out)[fr * bins + k] = make_float2(re, im);
+    else out[fr * bins + k] = sqrtf(re * re + im * im) + 1e-7f;
   }
 }
 
 // ISTFT stage 1: frame f -> window * irfft(spec[f] * sqrt(n_fft))   (util/fourier.py:359, :401)
 // irfft of H+1 bins via an H-point complex inverse FFT (conjugate trick on the forward core).
-__global__ __launch_bounds__(kStftThreads) void k_istft_frames(const float2* __restrict__ spec, int64_t n_frames,
-                                                                int n_fft, int logH, int FR,
-                                                                const float* __restrict__ window,
-                                                                const float2* __restrict__ tw,
-                                                                const float2* __restrict__ post,
-                                                                float* __restrict__ frames, float scale) {
+template <int LOGH>
+__global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_istft_frames(const float2* __restrict__ spec, int64_t n_frames,
+                                                                          const float* __restrict__ window,
+                                                                          const float2* __restrict__ tw,
+                                                                          const float2* __restrict__ post,
+                                                                          float* __restrict__ frames, float scale) {
+  using G = FftGeom<LOGH>;
+  constexpr int H = G::H, T = G::T, bins = H + 1;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  const int H = n_fft >> 1;
-  const int bins = H + 1;
-  const int tid = threadIdx.x;
-  const int64_t f0 = (int64_t)blockIdx.x * FR;
-  // Build conj(Z[k]) with Z[k] = E[k] + i*O[k],  E = (X[k]+conj(X[H-k]))/2,  O = conj(W^k)*(X[k]-conj(X[H-k]))/2
+  const int f = threadIdx.x / T, j = threadIdx.x - f * T;
+  float2* X = lds + f * G::FrameLds;
+  const int64_t fr = (int64_t)blockIdx.x * G::Frames + f;
+  const bool live = fr < n_frames;
+  // conj(Z[k]) with Z[k] = E[k] + i*O[k],  E = (X[k]+conj(X[H-k]))/2,  O = conj(W^k)*(X[k]-conj(X[H-k]))/2
   // (numpy's irfft ignores the imaginary parts of the DC and Nyquist bins.)
-  for (int e = tid; e < FR * H; e += kStftThreads) {
-    const int f = e / H, k = e - f * H;
-    const int64_t fr = f0 + f;
+  float2 v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int k = j + q * T;
     float2 z = make_float2(0.0f, 0.0f);
-    if (fr < n_frames) {
+    if (live) {
       float2 a = spec[fr * bins + k];
       float2 b = spec[fr * bins + (H - k)];
       if (k == 0) {
@@ -206,25 +274,19 @@ __global__ __launch_bounds__(kStftThreads) void k_istft_frames(const float2* __r
       b = cconj(b);
       const float2 ev = cadd(a, b);
       const float2 od = cmul(cconj(post[k]), csub(a, b));
-      // Z = 0.5*(ev + i*od)
-      z = make_float2(0.5f * (ev.x - od.y), 0.5f * (ev.y + od.x));
-      z = cconj(z);
+      z = make_float2(0.5f * (ev.x - od.y), -0.5f * (ev.y + od.x));     // conj(0.5*(ev + i*od))
     }
-    lds[e] = z;
+    v[q] = z;
   }
-  __syncthreads();
-  const int cur = lds_fft(lds, FR, H, logH, tw, tid, kStftThreads);
-  const float2* Z = lds + cur * FR * H;
-  // z_time[j] = conj(FFT(conj(Z)))[j] / H ; y[2j] = re, y[2j+1] = im
-  for (int e = tid; e < FR * H; e += kStftThreads) {
-    const int f = e / H, j = e - f * H;
-    const int64_t fr = f0 + f;
-    if (fr >= n_frames) continue;
-    const float2 v = Z[f * H + j];
+  fft_core<LOGH>(v, X, j, tw);
+  if (!live) return;
+  // z_time[i] = conj(FFT(conj(Z)))[i] / H ; y[2i] = re, y[2i+1] = im
+  for (int i = j; i < H; i += T) {
+    const float2 r = X[lpad(i)];
     float2 o;
-    o.x = v.x * scale * window[2 * j];
-    o.y = -v.y * scale * window[2 * j + 1];
-    reinterpret_cast<float2*>(frames)[fr * H + j] = o;
+    o.x = r.x * scale * window[2 * i];
+    o.y = -r.y * scale * window[2 * i + 1];
+    reinterpret_cast<float2*>(frames)[fr * H + i] = o;
   }
 }
 
@@ -285,13 +347,25 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
   int rc = get_twiddles(device, M, &tw);
   if (rc != PAR_OK) return rc;
   const int64_t n_frames = par_stft_frames(n, n_fft, hop);
-  int FR = 2048 / H;
-  if (FR < 1) FR = 1;
-  if (FR > 8) FR = 8;
-  const size_t lds = (size_t)2 * FR * H * sizeof(float2);
   const float scale = (float)(1.0 / sqrt((double)n_fft));
-  hipLaunchKernelGGL(k_stft, dim3((unsigned)ceil_div(n_frames, FR)), dim3(kStftThreads), lds, as_stream(stream), x, n,
-                     x_stride, n_fft, hop, M, ilog2(H), FR, window, tw.w, tw.post, out, n_frames, mode, scale);
+#define PAR_STFT_LAUNCH(LH)                                                                                          \
+  hipLaunchKernelGGL(k_stft<LH>, dim3((unsigned)ceil_div(n_frames, FftGeom<LH>::Frames)), dim3(FftGeom<LH>::Threads),  \
+                     (size_t)FftGeom<LH>::Frames * FftGeom<LH>::FrameLds * sizeof(float2), as_stream(stream), x, n,      \
+                     x_stride, n_fft, hop, window, tw.w, tw.post, out, n_frames, mode, scale)
+  switch (ilog2(H)) {
+    case 3: PAR_STFT_LAUNCH(3); break;
+    case 4: PAR_STFT_LAUNCH(4); break;
+    case 5: PAR_STFT_LAUNCH(5); break;
+    case 6: PAR_STFT_LAUNCH(6); break;
+    case 7: PAR_STFT_LAUNCH(7); break;
+    case 8: PAR_STFT_LAUNCH(8); break;
+    case 9: PAR_STFT_LAUNCH(9); break;
+    case 10: PAR_STFT_LAUNCH(10); break;
+    case 11: PAR_STFT_LAUNCH(11); break;
+    case 12: PAR_STFT_LAUNCH(12); break;
+    default: PAR_REQUIRE(false, PAR_ERR_UNSUPPORTED, "par_stft_f32: unsupported size");
+  }
+#undef PAR_STFT_LAUNCH
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }
@@ -308,16 +382,27 @@ int par_istft_f32(int device, const float* spec, int64_t n_frames, int n_fft, in
   int rc = get_twiddles(device, n_fft, &tw);
   if (rc != PAR_OK) return rc;
   const int H = n_fft / 2;
-  int FR = 2048 / H;
-  if (FR < 1) FR = 1;
-  if (FR > 8) FR = 8;
-  const size_t lds = (size_t)2 * FR * H * sizeof(float2);
-  // spec * sqrt(n_fft) (:359), irfft's 1/n_fft, and the conj-trick's 1/H fold into one factor:
-  // irfft(X)[t] = (1/n_fft) * sum ...; the H-point complex inverse carries 1/H with a factor 2 from packing.
+  // spec * sqrt(n_fft) (:359) and the 1/H of the H-point complex inverse fold into one factor
   const float scale = (float)(sqrt((double)n_fft) / (double)H);
-  hipLaunchKernelGGL(k_istft_frames, dim3((unsigned)ceil_div(n_frames, FR)), dim3(kStftThreads), lds, as_stream(stream),
-                     reinterpret_cast<const float2*>(spec), n_frames, n_fft, ilog2(H), FR, window, tw.w, tw.post, frames,
-                     scale);
+  const float2* sp2 = reinterpret_cast<const float2*>(spec);
+#define PAR_ISTFT_LAUNCH(LH)                                                                                            \
+  hipLaunchKernelGGL(k_istft_frames<LH>, dim3((unsigned)ceil_div(n_frames, FftGeom<LH>::Frames)),                         \
+                     dim3(FftGeom<LH>::Threads), (size_t)FftGeom<LH>::Frames * FftGeom<LH>::FrameLds * sizeof(float2),      \
+                     as_stream(stream), sp2, n_frames, window, tw.w, tw.post, frames, scale)
+  switch (ilog2(H)) {
+    case 3: PAR_ISTFT_LAUNCH(3); break;
+    case 4: PAR_ISTFT_LAUNCH(4); break;
+    case 5: PAR_ISTFT_LAUNCH(5); break;
+    case 6: PAR_ISTFT_LAUNCH(6); break;
+    case 7: PAR_ISTFT_LAUNCH(7); break;
+    case 8: PAR_ISTFT_LAUNCH(8); break;
+    case 9: PAR_ISTFT_LAUNCH(9); break;
+    case 10: PAR_ISTFT_LAUNCH(10); break;
+    case 11: PAR_ISTFT_LAUNCH(11); break;
+    case 12: PAR_ISTFT_LAUNCH(12); break;
+    default: PAR_REQUIRE(false, PAR_ERR_UNSUPPORTED, "par_istft_f32: unsupported size");
+  }
+#undef PAR_ISTFT_LAUNCH
   PAR_HIP_CHECK(hipGetLastError());
   if (y_len > 0) {
     hipLaunchKernelGGL(k_istft_ola, dim3((unsigned)ceil_div(y_len, 256)), dim3(256), 0, as_stream(stream), frames,
