@@ -23,6 +23,7 @@
 //  * positions stay float64 end to end (a 345.6 M-sample index does not fit float32); only the
 //    sub-sample shift in [-0.5, 0.5] and fc drop to float32.
 #include "par_common.h"
+#include <limits.h>
 #include <math.h>
 #include <map>
 #include <vector>
@@ -91,6 +92,10 @@ __device__ __noinline__ float sinc_one_f64(double p, double dp, const float* __r
 // The n loop runs in chunks of kChunk taps so that LDS offsets inside a chunk are instruction immediates,
 // the chunk's table entries arrive in one scalar load, and the (-1)^n sign is a free operand modifier.
 constexpr int kChunk = 4;
+// LDS pointers carry their address space in the type so that, kept live across the chunk loop, they stay
+// ds_read base registers with immediate offsets (generic pointers degrade to flat loads, indices to a
+// shift+add per access).
+typedef __attribute__((address_space(3))) const float lds_cfloat;
 
 // fc == 1 for every lane of the wave: U_n = -(-1)^n sin(pi s), V_n = +(-1)^n sin(pi s) -> factored out.
 // Accumulates e = sum (-1)^n (sig[+n]+sig[-n]) R_n  and  d = sum (-1)^n n (sig[+n]-sig[-n]) R_n.
@@ -98,13 +103,15 @@ template <int R>
 __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const int (&c)[R], const float (&s)[R],
                                            int NT, const float4* __restrict__ tab, float (&res)[R]) {
   float q[R], e[R], d[R];
-  int tp[R], tm[R];                          // LDS word indices (kept as indices so the loads stay ds_read)
+  lds_cfloat* tp[R];
+  lds_cfloat* tm[R];
+  lds_cfloat* tl = (lds_cfloat*)tile;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     q[r] = s[r] * s[r];
     e[r] = d[r] = 0.0f;
-    tp[r] = c[r] + 1;                        // -> t[+n0]
-    tm[r] = c[r] - kChunk;                   // -> t[-(n0 + kChunk - 1)]
+    tp[r] = tl + c[r] + 1;                   // -> t[+n0]
+    tm[r] = tl + c[r] - kChunk;              // -> t[-(n0 + kChunk - 1)]
   }
   int n0 = 1;
 #pragma unroll 1
@@ -117,7 +124,7 @@ __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const
       const float fn = ab[k].z;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float sp = tile[tp[r] + k], sm = tile[tm[r] + (kChunk - 1 - k)];
+        const float sp = tp[r][k], sm = tm[r][kChunk - 1 - k];
         const float D = sp - sm, E = sp + sm;
         const float Rn = fast_rcp(fmaf(q[r], ab[k].y, ab[k].x));
         const float DR = D * Rn;
@@ -150,7 +157,9 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
                                              const float (&fc)[R], const float (&dd)[R], int NT,
                                              const float4* __restrict__ tab, float (&res)[R]) {
   float q[R], accP[R], accM[R], U[R], Up[R], V[R], Vp[R], c2[R], centre[R];
-  int tp[R], tm[R];
+  lds_cfloat* tp[R];
+  lds_cfloat* tm[R];
+  lds_cfloat* tl = (lds_cfloat*)tile;
   const float b0 = tab[0].y;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -172,8 +181,8 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
     q[r] = s[r] * s[r];
     centre[r] = tile[c[r]] * (Up[r] * fast_rcp(s[r] * b0));
     accP[r] = accM[r] = 0.0f;
-    tp[r] = c[r] + 1;
-    tm[r] = c[r] - kChunk;
+    tp[r] = tl + c[r] + 1;
+    tm[r] = tl + c[r] - kChunk;
   }
   int n0 = 1;
 #pragma unroll 1
@@ -186,7 +195,7 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
       const float fn = ab[k].z;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float G = tile[tp[r] + k] * U[r], H = tile[tm[r] + (kChunk - 1 - k)] * V[r];
+        const float G = tp[r][k] * U[r], H = tm[r][kChunk - 1 - k] * V[r];
         const float Rn = fast_rcp(fmaf(q[r], ab[k].y, ab[k].x));
         accM[r] = fmaf(G - H, Rn, accM[r]);
         accP[r] = fmaf((G + H) * Rn, fn, accP[r]);
@@ -216,32 +225,54 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
                                                       float* __restrict__ out, int64_t out_stride, int64_t j_begin,
                                                       int64_t j_end) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
-  __shared__ long long red[2 * (kSincBlock / kWave)];
+  __shared__ int red[2 * (kSincBlock / kWave)];
   const int t = threadIdx.x;
   const int64_t j0 = j_begin + (int64_t)blockIdx.x * kSincTile;     // this launch covers outputs [j_begin, j_end)
 
-  double p[kSincR], dp[kSincR];
-  long long ind[kSincR];
-  bool valid[kSincR];
-  long long mn = INT64_MAX, mx = INT64_MIN;
+  // Block-uniform EVEN integer anchor: indices are handled as int32 offsets from it (no 64-bit integer
+  // math per output); an even anchor keeps round-half-even ties identical to rint(p).
+  const double p0 = pos[j0];
+  const long long anchor = (fabs(p0) < 4.0e18) ? (llrint(p0) & ~1ll) : 0ll;
+  const double anchor_d = (double)anchor;
+  float res[kSincR];
+  int c[kSincR];                                   // first: index relative to the anchor, later: LDS index
+  float s[kSincR], fc[kSincR], dd[kSincR];
+  bool valid[kSincR], fastlane[kSincR];
+  bool unity = true, wild = false;
+  int mn = INT_MAX, mx = INT_MIN;
 #pragma unroll
   for (int r = 0; r < kSincR; ++r) {
     const int64_t j = j0 + t + (int64_t)r * kSincBlock;
     valid[r] = j < j_end;
-    p[r] = 0.0;
-    dp[r] = 1.0;
-    ind[r] = 0;
+    c[r] = 0;
+    s[r] = 0.25f;
+    fc[r] = 1.0f;
+    dd[r] = 0.0f;
     if (valid[r]) {
-      p[r] = pos[j];
+      const double p = pos[j];
       // last output reuses the previous period (util/resampling.py:76-77)
-      dp[r] = (j + 1 < len_out) ? pos[j + 1] - p[r] : p[r] - pos[j - 1];
-      ind[r] = llrint(p[r]);
-      mn = ind[r] < mn ? ind[r] : mn;
-      mx = ind[r] > mx ? ind[r] : mx;
+      const double dp = (j + 1 < len_out) ? pos[j + 1] - p : p - pos[j - 1];
+      const double rel = p - anchor_d;             // exact to ~1e-13: anchor is within a tile's span of p
+      const double rf = rint(rel);
+      if (fabs(rel) < 1.0e9) c[r] = (int)rf; else wild = true;
+      const float sh = (float)(rel - rf);          // = p - rint(p)
+      s[r] = (sh == 0.0f) ? 1e-20f : sh;           // np.sinc's own 0 -> 1e-20 substitution
+      const bool one = !(dp > 1.0);                // fc == 1 (also catches the 1e-12 floor)
+      const float inv = fast_rcp((float)(dp > 1e-12 ? dp : 1e-12));
+      fc[r] = one ? 1.0f : inv;
+      dd[r] = one ? 0.0f : (float)(dp - 1.0) * inv;   // 1 - fc without cancellation
+      unity = unity && one;
+      mn = c[r] < mn ? c[r] : mn;
+      mx = c[r] > mx ? c[r] : mx;
     }
   }
-  mn = wave_min_ll(mn);
-  mx = wave_max_ll(mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int a = __shfl_xor(mn, o, kWave), b = __shfl_xor(mx, o, kWave);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if (__any(wild)) mn = INT_MIN;                    // poisons the span test below for the whole block
   if ((t & (kWave - 1)) == 0) {
     red[t / kWave] = mn;
     red[kSincBlock / kWave + t / kWave] = mx;
@@ -254,37 +285,25 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
   }
   // the tap loops run in chunks of kChunk and may touch up to kChunk-1 taps beyond +-(NT-1); those
   // carry an exactly-zero weight (R_n = rcp(inf)) but must read finite data: stage a kChunk margin.
-  const long long lo = mn - NT - kChunk;
-  const long long span = mx + NT + kChunk - lo;    // <= kSincCap for the LDS path
-  const bool staged = span <= kSincCap;
+  const int margin = NT + kChunk;
+  const long long span = (long long)mx - (long long)mn + 2ll * margin;     // <= kSincCap for the LDS path
+  const bool staged = mn != INT_MIN && span <= kSincCap;
+  const long long lo = anchor + mn - margin;        // signal index of tile[0]
   if (staged) {
-    for (long long q = t; q < span; q += kSincBlock) {
+    for (int q = t; q < (int)span; q += kSincBlock) {
       const long long g = lo + q;
       tile[q] = (g >= 0 && g < (long long)len_in) ? sig[g * sig_stride] : 0.0f;
     }
   }
   __syncthreads();
 
-  // From here on only (c, s, fc, dd) stay live through the tap loops; the float64 position, its period
-  // and the 64-bit index are dropped (the rare float64 slow path re-reads them) to keep VGPRs low.
-  float res[kSincR];
-  int c[kSincR];
-  float s[kSincR], fc[kSincR], dd[kSincR];
-  bool fastlane[kSincR];
-  bool unity = true, anyfast = false;
+  // leading-edge outputs (ind < NT) keep the reference's mis-aligned taps: float64 slow path.
+  bool anyfast = false;
+  const long long edge = (long long)NT - anchor;    // ind >= NT  <=>  rel index >= edge
 #pragma unroll
   for (int r = 0; r < kSincR; ++r) {
-    // leading-edge outputs (ind < NT) keep the reference's mis-aligned taps: float64 path.
-    fastlane[r] = valid[r] && staged && ind[r] >= NT;
-    c[r] = fastlane[r] ? (int)(ind[r] - lo) : NT + kChunk; // harmless in-range index for idle lanes
-    float sh = (float)(p[r] - (double)ind[r]);
-    s[r] = (sh == 0.0f) ? 1e-20f : sh;                      // np.sinc's own 0 -> 1e-20 substitution
-    const bool one = !(dp[r] > 1.0);                        // fc == 1 (also catches the 1e-12 floor)
-    const float dpf = (float)(dp[r] > 1e-12 ? dp[r] : 1e-12);
-    const float inv = fast_rcp(dpf);
-    fc[r] = one ? 1.0f : inv;
-    dd[r] = one ? 0.0f : (float)(dp[r] - 1.0) * inv;        // 1 - fc without cancellation
-    unity = unity && (one || !fastlane[r]);
+    fastlane[r] = valid[r] && staged && (long long)c[r] >= edge;
+    c[r] = fastlane[r] ? c[r] - mn + margin : margin;      // LDS index of the window centre (idle lanes: harmless)
     anyfast = anyfast || fastlane[r];
     res[r] = 0.0f;
   }
