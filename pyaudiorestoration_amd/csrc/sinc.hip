@@ -97,8 +97,53 @@ constexpr int kChunk = 4;
 // shift+add per access).
 typedef __attribute__((address_space(3))) const float lds_cfloat;
 
+// How R_n(q) = (win_n/pi)/(n^2 - q), q = shift^2 <= 1/4, is evaluated for the taps of one chunk.  Only the
+// four innermost pairs pay for a v_rcp_f32 (quarter rate); from n = 5 on q/n^2 <= 0.01 and the geometric
+// series A_n*(1 + q/n^2 + q^2/n^4) is exact to 1e-6 relative (weight <= 0.06: 6e-8 absolute), from
+// n = 13 on one term suffices (2e-6 * weight 0.017).  The table rows change meaning accordingly.
+enum { kRcp = 0, kPoly2 = 1, kPoly1 = 2 };
+constexpr int kPoly2From = 5;     // rows n >= 5 : (A_n, B_n, n, C_n) with A = win/(pi n^2), B = A/n^2, C = B/n^2
+constexpr int kPoly1From = 13;    // rows n >= 13: only (A_n, B_n) are used
+template <int MODE>
+__device__ __forceinline__ float tap_R(float q, const float4& t) {
+  if (MODE == kRcp) return fast_rcp(fmaf(q, t.y, t.x));            // row = (pi n^2/win, -pi/win, n, -)
+  if (MODE == kPoly2) return fmaf(fmaf(t.w, q, t.y), q, t.x);
+  return fmaf(t.y, q, t.x);
+}
+
 // fc == 1 for every lane of the wave: U_n = -(-1)^n sin(pi s), V_n = +(-1)^n sin(pi s) -> factored out.
 // Accumulates e = sum (-1)^n (sig[+n]+sig[-n]) R_n  and  d = sum (-1)^n n (sig[+n]-sig[-n]) R_n.
+template <int MODE, int R>
+__device__ __forceinline__ void unity_chunk(lds_cfloat* (&tp)[R], lds_cfloat* (&tm)[R], const float (&q)[R],
+                                            float (&e)[R], float (&d)[R], const float4* __restrict__ tab, int n0) {
+  float4 ab[kChunk];                         // wave-uniform: one s_load_dwordx16, operands stay in SGPRs
+#pragma unroll
+  for (int k = 0; k < kChunk; ++k) ab[k] = tab[n0 + k];
+#pragma unroll
+  for (int k = 0; k < kChunk; ++k) {
+    const float fn = ab[k].z;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float sp = tp[r][k], sm = tm[r][kChunk - 1 - k];
+      const float D = sp - sm, E = sp + sm;
+      const float Rn = tap_R<MODE>(q[r], ab[k]);
+      const float DR = D * Rn;
+      if (k & 1) {                           // n0 is odd, so odd k is an even n: +
+        e[r] = fmaf(E, Rn, e[r]);
+        d[r] = fmaf(DR, fn, d[r]);
+      } else {                               // odd n: -
+        e[r] = fmaf(-E, Rn, e[r]);
+        d[r] = fmaf(-DR, fn, d[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    tp[r] += kChunk;
+    tm[r] -= kChunk;
+  }
+}
+
 template <int R>
 __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const int (&c)[R], const float (&s)[R],
                                            int NT, const float4* __restrict__ tab, float (&res)[R]) {
@@ -113,36 +158,15 @@ __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const
     tp[r] = tl + c[r] + 1;                   // -> t[+n0]
     tm[r] = tl + c[r] - kChunk;              // -> t[-(n0 + kChunk - 1)]
   }
-  int n0 = 1;
-#pragma unroll 1
-  for (; n0 < NT; n0 += kChunk) {            // n0 is odd: n0+k is odd for even k; taps >= NT have R_n == 0
-    float4 ab[kChunk];                       // wave-uniform: one s_load_dwordx16, operands stay in SGPRs
-#pragma unroll
-    for (int k = 0; k < kChunk; ++k) ab[k] = tab[n0 + k];
-#pragma unroll
-    for (int k = 0; k < kChunk; ++k) {
-      const float fn = ab[k].z;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float sp = tp[r][k], sm = tm[r][kChunk - 1 - k];
-        const float D = sp - sm, E = sp + sm;
-        const float Rn = fast_rcp(fmaf(q[r], ab[k].y, ab[k].x));
-        const float DR = D * Rn;
-        if (k & 1) {                         // even n: +
-          e[r] = fmaf(E, Rn, e[r]);
-          d[r] = fmaf(DR, fn, d[r]);
-        } else {                             // odd n: -
-          e[r] = fmaf(-E, Rn, e[r]);
-          d[r] = fmaf(-DR, fn, d[r]);
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      tp[r] += kChunk;
-      tm[r] -= kChunk;
-    }
+  int n0 = 1;                                // taps >= NT have R_n == 0 (padded table rows)
+  if (n0 < NT) {
+    unity_chunk<kRcp, R>(tp, tm, q, e, d, tab, n0);
+    n0 += kChunk;
   }
+#pragma unroll 1
+  for (; n0 < NT && n0 < kPoly1From; n0 += kChunk) unity_chunk<kPoly2, R>(tp, tm, q, e, d, tab, n0);
+#pragma unroll 1
+  for (; n0 < NT; n0 += kChunk) unity_chunk<kPoly1, R>(tp, tm, q, e, d, tab, n0);
   const float b0 = tab[0].y;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -153,10 +177,45 @@ __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const
 
 // general fc in (0, 1]: numerators by 3-term recurrences seeded at the centre and run outwards.
 template <int R>
+struct GenState {
+  float q[R], accP[R], accM[R], U[R], Up[R], V[R], Vp[R], c2[R];
+};
+template <int MODE, int R>
+__device__ __forceinline__ void general_chunk(lds_cfloat* (&tp)[R], lds_cfloat* (&tm)[R], GenState<R>& g,
+                                              const float4* __restrict__ tab, int n0) {
+  float4 ab[kChunk];
+#pragma unroll
+  for (int k = 0; k < kChunk; ++k) ab[k] = tab[n0 + k];
+#pragma unroll
+  for (int k = 0; k < kChunk; ++k) {
+    const float fn = ab[k].z;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float G = tp[r][k] * g.U[r], H = tm[r][kChunk - 1 - k] * g.V[r];
+      const float Rn = tap_R<MODE>(g.q[r], ab[k]);
+      g.accM[r] = fmaf(G - H, Rn, g.accM[r]);
+      g.accP[r] = fmaf((G + H) * Rn, fn, g.accP[r]);
+      const float un = fmaf(g.c2[r], g.U[r], -g.Up[r]);
+      g.Up[r] = g.U[r];
+      g.U[r] = un;
+      const float vn = fmaf(g.c2[r], g.V[r], -g.Vp[r]);
+      g.Vp[r] = g.V[r];
+      g.V[r] = vn;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    tp[r] += kChunk;
+    tm[r] -= kChunk;
+  }
+}
+
+template <int R>
 __device__ __forceinline__ void taps_general(const float* __restrict__ tile, const int (&c)[R], const float (&s)[R],
                                              const float (&fc)[R], const float (&dd)[R], int NT,
                                              const float4* __restrict__ tab, float (&res)[R]) {
-  float q[R], accP[R], accM[R], U[R], Up[R], V[R], Vp[R], c2[R], centre[R];
+  GenState<R> g;
+  float centre[R];
   lds_cfloat* tp[R];
   lds_cfloat* tm[R];
   lds_cfloat* tl = (lds_cfloat*)tile;
@@ -173,48 +232,28 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
       sth = sinpi_half(fc[r]);
       cth = cospi_half(fc[r]);
     }
-    Up[r] = -sphi;                                    // U_0 = sin(-phi)
-    Vp[r] = sphi;                                     // V_0 = sin(+phi)
-    U[r] = fmaf(sth, cphi, -cth * sphi);              // U_1 = sin(theta - phi)
-    V[r] = fmaf(sth, cphi, cth * sphi);               // V_1 = sin(theta + phi)
-    c2[r] = 2.0f * cth;
-    q[r] = s[r] * s[r];
-    centre[r] = tile[c[r]] * (Up[r] * fast_rcp(s[r] * b0));
-    accP[r] = accM[r] = 0.0f;
+    g.Up[r] = -sphi;                                  // U_0 = sin(-phi)
+    g.Vp[r] = sphi;                                   // V_0 = sin(+phi)
+    g.U[r] = fmaf(sth, cphi, -cth * sphi);            // U_1 = sin(theta - phi)
+    g.V[r] = fmaf(sth, cphi, cth * sphi);             // V_1 = sin(theta + phi)
+    g.c2[r] = 2.0f * cth;
+    g.q[r] = s[r] * s[r];
+    centre[r] = tile[c[r]] * (g.Up[r] * fast_rcp(s[r] * b0));
+    g.accP[r] = g.accM[r] = 0.0f;
     tp[r] = tl + c[r] + 1;
     tm[r] = tl + c[r] - kChunk;
   }
   int n0 = 1;
-#pragma unroll 1
-  for (; n0 < NT; n0 += kChunk) {
-    float4 ab[kChunk];                       // wave-uniform: one s_load_dwordx16, operands stay in SGPRs
-#pragma unroll
-    for (int k = 0; k < kChunk; ++k) ab[k] = tab[n0 + k];
-#pragma unroll
-    for (int k = 0; k < kChunk; ++k) {
-      const float fn = ab[k].z;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float G = tp[r][k] * U[r], H = tm[r][kChunk - 1 - k] * V[r];
-        const float Rn = fast_rcp(fmaf(q[r], ab[k].y, ab[k].x));
-        accM[r] = fmaf(G - H, Rn, accM[r]);
-        accP[r] = fmaf((G + H) * Rn, fn, accP[r]);
-        const float un = fmaf(c2[r], U[r], -Up[r]);
-        Up[r] = U[r];
-        U[r] = un;
-        const float vn = fmaf(c2[r], V[r], -Vp[r]);
-        Vp[r] = V[r];
-        V[r] = vn;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      tp[r] += kChunk;
-      tm[r] -= kChunk;
-    }
+  if (n0 < NT) {
+    general_chunk<kRcp, R>(tp, tm, g, tab, n0);
+    n0 += kChunk;
   }
+#pragma unroll 1
+  for (; n0 < NT && n0 < kPoly1From; n0 += kChunk) general_chunk<kPoly2, R>(tp, tm, g, tab, n0);
+#pragma unroll 1
+  for (; n0 < NT; n0 += kChunk) general_chunk<kPoly1, R>(tp, tm, g, tab, n0);
 #pragma unroll
-  for (int r = 0; r < R; ++r) res[r] = centre[r] + fmaf(s[r], accM[r], accP[r]);
+  for (int r = 0; r < R; ++r) res[r] = centre[r] + fmaf(s[r], g.accM[r], g.accP[r]);
 }
 
 // 6 waves/SIMD (80 VGPRs) measured best: 4 -> 1.39 ms, 5 -> 1.29, 6 -> 1.25, 7 -> 1.32, 8 -> 1.59 (spills) per
@@ -349,7 +388,7 @@ __global__ __launch_bounds__(256) void k_lerp(const double* __restrict__ pos, in
 
 // ---- host side: per-(device, NT) tap tables -------------------------------------------------------
 struct SincTable {
-  float4* ab = nullptr;      // ab[n] = (pi*n^2/win_n, -pi/win_n, n, 0)
+  float4* ab = nullptr;      // per-tap rows, see tap_R
 };
 static std::mutex g_tab_mu;
 static std::map<std::pair<int, int>, SincTable> g_tabs;
@@ -365,11 +404,14 @@ static int get_sinc_table(int device, int NT, SincTable* out) {
   // a2[n] = pi*n^2/win, b[n] = -pi/win with win = float32(np.hanning(2NT+1)[NT+n]), n = 0..NT-1
   std::vector<float4> ab(NT + kChunk);
   for (int n = 0; n < NT + kChunk; ++n) {
-    if (n < NT) {
-      float win = (float)(0.5 + 0.5 * cos(M_PI * (double)n / (double)NT));
-      ab[n] = make_float4((float)(M_PI * (double)n * (double)n / (double)win), (float)(-M_PI / (double)win), (float)n, 0.0f);
-    } else {
-      ab[n] = make_float4(INFINITY, (float)(-M_PI), (float)n, 0.0f);   // padded taps: rcp(q*b + inf) == 0
+    const double win = n < NT ? (double)(float)(0.5 + 0.5 * cos(M_PI * (double)n / (double)NT)) : 0.0;
+    const double n2 = (double)n * (double)n;
+    if (n < kPoly2From) {            // reciprocal rows; padded taps: rcp(q*b + inf) == 0
+      ab[n] = n < NT ? make_float4((float)(M_PI * n2 / win), (float)(-M_PI / win), (float)n, 0.0f)
+                     : make_float4(INFINITY, (float)(-M_PI), (float)n, 0.0f);
+    } else {                         // series rows; padded taps: all-zero coefficients
+      const double A = win / (M_PI * n2);
+      ab[n] = make_float4((float)A, (float)(A / n2), (float)n, (float)(A / (n2 * n2)));
     }
   }
   SincTable t;
