@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--sr", type=int, default=192000)
     ap.add_argument("--nt", type=int, default=32)
     ap.add_argument("--chunks", type=int, default=0, help="pipeline chunks per file (0 = auto, 1 = no overlap)")
+    ap.add_argument("--no-fused", action="store_true", help="materialise the float64 position array (reference-shaped path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -89,8 +90,13 @@ def main():
     nbytes = int(L.par_speed_plan_bytes(m))
     work = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{dev}")
     cap = int(n_in * 1.02) + 1024
-    pos = torch.empty(cap, dtype=torch.float64, device=f"cuda:{dev}")
     out = torch.empty(cap, dtype=torch.float32, device=f"cuda:{dev}")
+    fused = not a.no_fused
+    if fused:       # cumsum checkpoints + tile map: positions are regenerated inside K_sinc, never stored
+        aux_bytes = int(L.par_fused_aux_bytes(cap, m))
+        aux = torch.empty(aux_bytes, dtype=torch.uint8, device=f"cuda:{dev}")
+    else:           # reference-shaped path: float64 sample_at array in HBM
+        pos = torch.empty(cap, dtype=torch.float64, device=f"cuda:{dev}")
     torch.cuda.synchronize()
 
     _lib.check(L.par_profile_enable(dev, 1))         # HIP events around every K_sinc launch, on its own stream
@@ -98,13 +104,22 @@ def main():
     len_out = ctypes.c_int64(0)
     trimmed = ctypes.c_int(0)
 
+    ok = ctypes.c_int(0)
+
     def step(timed):
-        _lib.check(L.par_speed_to_pos_plan(dev, _dev.ptr(st), _dev.ptr(spd), m, n_in, _dev.ptr(work), nbytes,
-                                           ctypes.byref(len_out), ctypes.byref(trimmed), sp_))
-        assert 2 <= len_out.value <= cap
-        # fill (side stream) pipelined under K_sinc (this stream), chunked on K_sinc tile boundaries
-        _lib.check(L.par_varispeed_resample_f32(dev, _dev.ptr(spd), m, _dev.ptr(work), len_out.value, _dev.ptr(pos),
-                                                _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, a.chunks, sp_))
+        if fused:
+            _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(st), _dev.ptr(spd), m, n_in, _dev.ptr(work), nbytes,
+                                                     _dev.ptr(aux), aux_bytes, cap, ctypes.byref(len_out),
+                                                     ctypes.byref(trimmed), 0, None, ctypes.byref(ok), sp_))
+            assert ok.value == 1 and 2 <= len_out.value <= cap
+            _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(spd), m, _dev.ptr(work), _dev.ptr(aux), len_out.value,
+                                                 _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, sp_))
+        else:
+            _lib.check(L.par_speed_to_pos_plan(dev, _dev.ptr(st), _dev.ptr(spd), m, n_in, _dev.ptr(work), nbytes,
+                                               ctypes.byref(len_out), ctypes.byref(trimmed), sp_))
+            assert 2 <= len_out.value <= cap
+            _lib.check(L.par_varispeed_resample_f32(dev, _dev.ptr(spd), m, _dev.ptr(work), len_out.value, _dev.ptr(pos),
+                                                    _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, a.chunks, sp_))
         if timed:
             ms, nl, ns = ctypes.c_float(0), ctypes.c_int(0), ctypes.c_int64(0)
             _lib.check(L.par_profile_read(dev, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(ns)))   # waits for them
@@ -137,7 +152,7 @@ def main():
             "config": {"workload": f"{a.seconds:g}-s {a.sr} Hz mono float32 varispeed resample, +-1% sinusoidal speed "
                                    f"curve (0.55 Hz, hop 256), {2 * a.nt}-tap Hann sinc; one file per GPU",
                        "samples_in_per_gpu": n_in, "samples_out_per_gpu": int(len_out.value), "NT": a.nt,
-                       "step": "plan (device scans) + positions (K_pos fill, f64) pipelined under K_sinc; inputs resident in HBM"},
+                       "step": ("plan (device scans, cumsum checkpoints) + fused K_sinc (float64 positions regenerated per tile in LDS)" if fused else "plan (device scans) + K_pos fill (float64 position array) + K_sinc") + "; inputs resident in HBM"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": "k_sinc",
                          "kernel_ms": round(k_ms, 4), "launches_per_step": n_launch // len(sinc_ms),

@@ -28,86 +28,13 @@
 // The O(len_out) work (one IEEE division per output sample, twice: reciprocal sums, then the fill) is
 // one lane per segment; k/(n-1) uses Markstein's correctly-rounded quotient from y = RN(1/(n-1)).
 #include "par_common.h"
+#include "pos_plan.h"
 #include <math.h>
 #include <vector>
 
 #pragma clang fp contract(off)
 
 namespace par {
-
-// ---------------------------------------------------------------------------------- plan layout
-struct PlanHeader {
-  int64_t m;
-  int64_t len_out;        // trimmed length or total written
-  int64_t total_written;  // sum n_i
-  unsigned long long trim_seg;   // first segment whose [first,last] straddles n_in, or ~0
-  int64_t cap;            // the reference's end_guess buffer size
-  int32_t trimmed;
-  int32_t flags;          // kFlag*
-  int32_t n_direct;
-  int32_t n_runs;
-  double speed_sum;
-};
-constexpr int kFlagAmbiguous = 1;   // a cumulative length is too close to a rounding tie
-constexpr int kFlagBadLength = 2;   // some n_i < 2 (reference divides by zero / indexes an empty array)
-constexpr int kFlagRange = 4;       // a_i outside the exactly-representable fixed-point range
-constexpr int kFlagVerify = 8;      // offset-chain binade prediction failed verification
-constexpr int kFlagDirectOverflow = 16;
-constexpr int kMaxDirect = 2048;
-constexpr unsigned long long kNoTrim = ~0ull;
-
-struct U128 {
-  unsigned long long hi, lo;       // value = hi + lo * 2^-64
-};
-struct PElem {                      // parity-dependent translation (+ segmented-scan head flag)
-  long long c0, c1;                 // increment when the incoming integer is even / odd
-  long long head;                   // 1: a run starts at this element (scan restarts here)
-  long long pad;
-};
-struct RunEntry {
-  long long start;                  // first segment of the run
-  double x;                         // offset at that segment (bit-exact)
-};
-
-constexpr size_t kHdrBytes = 256;
-struct PlanView {
-  PlanHeader* hdr;
-  int64_t* seg_start;   // [m]   seg_start[i] = outputs before segment i; [m-1] = total
-  double* seg_off;      // [m]   offset chain; seg_off[i] = position offset of segment i; [m-1] = final
-  double* S;            // [m]   per-segment reciprocal sums
-  double* xs;           // [m]   approx offsets (plain f64 scan)
-  char* scan;           // [m * 32] scan elements (U128 then PElem)
-  char* bsum;           // block sums for the scans
-  long long* direct;    // [kMaxDirect] indices of direct (binade-crossing) steps
-  RunEntry* runs;       // [kMaxDirect + 2]
-};
-inline size_t scan_blocks(int64_t n) { return (size_t)((n + 1023) / 1024); }
-inline size_t plan_bytes(int64_t m) {
-  return kHdrBytes + (size_t)m * (8 + 8 + 8 + 8 + 32) + (scan_blocks(m) + 8) * 32 + kMaxDirect * 8 +
-         (kMaxDirect + 2) * sizeof(RunEntry) + 256;
-}
-inline PlanView plan_view(void* work, int64_t m) {
-  char* b = static_cast<char*>(work);
-  PlanView v;
-  v.hdr = reinterpret_cast<PlanHeader*>(b);
-  b += kHdrBytes;
-  v.seg_start = reinterpret_cast<int64_t*>(b);
-  b += (size_t)m * 8;
-  v.seg_off = reinterpret_cast<double*>(b);
-  b += (size_t)m * 8;
-  v.S = reinterpret_cast<double*>(b);
-  b += (size_t)m * 8;
-  v.xs = reinterpret_cast<double*>(b);
-  b += (size_t)m * 8;
-  v.scan = b;
-  b += (size_t)m * 32;
-  v.bsum = b;
-  b += (scan_blocks(m) + 8) * 32;
-  v.direct = reinterpret_cast<long long*>(b);
-  b += kMaxDirect * 8;
-  v.runs = reinterpret_cast<RunEntry*>(b);
-  return v;
-}
 
 // ------------------------------------------------------------------------------ generic scans
 struct AddU128 {
@@ -270,6 +197,10 @@ __global__ void k_init_header(PlanHeader* h, int64_t m) {
   h->n_direct = 0;
   h->n_runs = 0;
   h->speed_sum = 0.0;
+  h->ck_len = 0;
+  h->ck_valid = 0;
+  h->pad2 = 0;
+  h->written = 0;
 }
 
 // a_i (util/resampling.py:103,:111) in numpy's order, converted EXACTLY to 64.64 fixed point.
@@ -325,47 +256,55 @@ __global__ void k_speed_sum(const double* __restrict__ sp, int64_t m, PlanHeader
   if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&h->speed_sum, acc);
 }
 
-struct Ramp {
-  double s0, ds, nm1, y;     // y = RN(1/(n-1))
-};
-__device__ __forceinline__ Ramp make_ramp(double s0, double s1, long long n) {
-  Ramp r;
-  r.s0 = s0;
-  r.ds = s1 - s0;
-  r.nm1 = (double)(n - 1);
-  r.y = 1.0 / r.nm1;
-  return r;
-}
-// 1 / (k/(n-1) * ds + s0), every operation individually rounded like numpy (:120, :125).
-// k/(n-1) by Markstein's theorem: with y = RN(1/b), q0 = RN(a*y), r = a - b*q0 (exact, fma),
-// q = RN(q0 + r*y) is the correctly rounded a/b  (checked exhaustively for n <= 6000 on the host).
-__device__ __forceinline__ double ramp_recip(long long k, const Ramp& r) {
-  const double a = (double)k;
-  const double q0 = a * r.y;
-  const double rem = __builtin_fma(-q0, r.nm1, a);
-  const double q = __builtin_fma(rem, r.y, q0);
-  const double bs = q * r.ds + r.s0;          // not fused (-ffp-contract=off)
-  return 1.0 / bs;
-}
-
 // S_i = last element of np.cumsum(1/block_speeds): strictly sequential float64 adds, one lane per segment.
+// With ck != nullptr the running sum is also checkpointed every kCk steps (slot layout: pos_plan.h) for the
+// fused resampler, which then regenerates the positions of a tile from the nearest checkpoint.
 __global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
-                                                 int64_t nseg, double* __restrict__ S) {
+                                                 int64_t nseg, double* __restrict__ S, double* __restrict__ ck,
+                                                 int64_t ck_len, PlanHeader* __restrict__ h) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nseg) return;
-  const long long n = seg_start[i + 1] - seg_start[i];
+  const long long start = seg_start[i];
+  const long long n = seg_start[i + 1] - start;
   double c = 0.0;
   if (n >= 2) {
     const Ramp r = make_ramp(sp[i], sp[i + 1], n);
+    const long long slot0 = ck_slot0(start, i);
+    // segments whose slots do not fit are skipped here; whether any of them is actually needed (starts
+    // before len_out) is decided by k_tile_seg once the trim is known
+    const bool ck_ok = ck != nullptr && slot0 + (n + kCk - 1) / kCk <= ck_len;
     long long k = 0;
-    for (; k + 1 < n; k += 2) {               // two independent divisions in flight
-      const double r0 = ramp_recip(k, r), r1 = ramp_recip(k + 1, r);
-      c = c + r0;
-      c = c + r1;
+    for (; k + kCk <= n; k += kCk) {          // kCk independent divisions in flight per block
+      double rr[kCk];
+#pragma unroll
+      for (int u = 0; u < kCk; ++u) rr[u] = ramp_recip(k + u, r);
+#pragma unroll
+      for (int u = 0; u < kCk; ++u) c = c + rr[u];
+      if (ck_ok && k + kCk < n) ck[slot0 + k / kCk + 1] = c;      // cumsum after step k + kCk - 1
     }
-    if (k < n) c = c + ramp_recip(k, r);
+    for (; k < n; ++k) c = c + ramp_recip(k, r);
   }
   S[i] = c;
+}
+
+// tile_seg[t] = segment that contains output t * kSincTileOutputs (tiles of the fused resampler)
+__global__ void k_tile_seg(const int64_t* __restrict__ seg_start, int64_t nseg, int64_t ck_len, int64_t max_tiles,
+                           int64_t* __restrict__ tile_seg, PlanHeader* __restrict__ h) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg) return;
+  const int64_t len_out = h->len_out;                  // written by k_trim / the host path earlier on this stream
+  const long long a = seg_start[i], b = seg_start[i + 1];
+  if (b <= a || a >= (long long)len_out) return;
+  if (ck_slot0(a, i) + (b - a + kCk - 1) / kCk > ck_len ||
+      (len_out + kSincTileOutputs - 1) / kSincTileOutputs + 1 > max_tiles) {
+    atomicOr(&h->flags, kFlagCkOverflow);               // a needed segment has no checkpoints: fused path refused
+    return;
+  }
+  for (long long t = (a + kSincTileOutputs - 1) / kSincTileOutputs; t * kSincTileOutputs < b; ++t)
+    if (t * kSincTileOutputs < (long long)len_out) tile_seg[t] = i;
+  // extra entry [n_tiles]: the segment that holds the LAST output
+  if (a <= (long long)len_out - 1 && (long long)len_out - 1 < b)
+    tile_seg[(len_out + kSincTileOutputs - 1) / kSincTileOutputs] = i;
 }
 
 __device__ __forceinline__ int f64_exponent(double x) { return (int)((__double_as_longlong(x) >> 52) & 0x7ff); }
@@ -522,6 +461,9 @@ __global__ void k_trim(const double* __restrict__ st, const double* __restrict__
     }
     len = seg_start[i] + arg;
     h->trimmed = 1;
+    h->written = seg_start[i + 1];        // the whole trim segment is written before the test (:127-129)
+  } else {
+    h->written = h->total_written;
   }
   h->len_out = len;
 }
@@ -663,6 +605,10 @@ static int host_plan(const PlanView& pv, const double* d_st, const double* d_sp,
   out->n_direct = 0;
   out->n_runs = 0;
   out->speed_sum = sum;
+  out->ck_len = 0;
+  out->ck_valid = 0;
+  out->pad2 = 0;
+  out->written = acc;
   PAR_HIP_CHECK(hipMemcpyAsync(pv.seg_start, start.data(), m * sizeof(int64_t), hipMemcpyHostToDevice, s));
   PAR_HIP_CHECK(hipMemcpyAsync(pv.seg_off, off.data(), m * sizeof(double), hipMemcpyHostToDevice, s));
   PAR_HIP_CHECK(hipMemcpyAsync(pv.hdr, out, sizeof(PlanHeader), hipMemcpyHostToDevice, s));
@@ -689,20 +635,24 @@ extern "C" {
 
 size_t par_speed_plan_bytes(int64_t m) { return par::plan_bytes(m < 2 ? 2 : m); }
 
-// force_host != 0 exercises the serial host path (tests use it to cross-check the device scans);
-// *path_used = 0 device scans, 1 serial host path.
-int par_speed_to_pos_plan_ex(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
-                             void* work, size_t work_bytes, int64_t* len_out, int* trimmed, int force_host,
-                             int* path_used, void* stream) {
+// Shared implementation.  aux (optional, device): cumsum checkpoints for the fused resampler.
+static int plan_impl(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in, void* work,
+                     size_t work_bytes, void* aux, size_t aux_bytes, int64_t max_out, int64_t* len_out, int* trimmed,
+                     int force_host, int* path_used, void* stream) {
   using namespace par;
   PAR_REQUIRE(sampletimes && speeds && work && len_out && trimmed, PAR_ERR_ARG, "par_speed_to_pos_plan: null pointer");
   PAR_REQUIRE(m >= 2, PAR_ERR_ARG, "par_speed_to_pos_plan: need at least 2 speed samples (m=%lld)", (long long)m);
   PAR_REQUIRE(work_bytes >= plan_bytes(m), PAR_ERR_WORKSPACE, "par_speed_to_pos_plan: workspace %zu < %zu", work_bytes,
               plan_bytes(m));
+  PAR_REQUIRE(!aux || aux_bytes >= fused_aux_bytes(max_out, m), PAR_ERR_WORKSPACE,
+              "par_speed_to_pos_plan: aux buffer %zu < %zu", aux_bytes, aux ? fused_aux_bytes(max_out, m) : (size_t)0);
   PAR_HIP_CHECK(hipSetDevice(device));
   hipStream_t s = as_stream(stream);
   const int64_t nseg = m - 1;
   PlanView pv = plan_view(work, m);
+  double* ck = static_cast<double*>(aux);
+  const int64_t ck_len = aux ? max_out / kCk + m + 16 : 0;
+  const int64_t max_tiles = aux ? max_out / kSincTileOutputs + 4 : 0;
   PlanHeader h;
   memset(&h, 0, sizeof(h));
   bool need_host = force_host != 0;
@@ -715,7 +665,8 @@ int par_speed_to_pos_plan_ex(int device, const double* sampletimes, const double
     if (rc != PAR_OK) return rc;
     hipLaunchKernelGGL(k_seg_lengths, dim3(g256), dim3(256), 0, s, fix, nseg, pv.seg_start, pv.hdr);
     hipLaunchKernelGGL(k_speed_sum, dim3(64), dim3(256), 0, s, speeds, m, pv.hdr);
-    hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.S);
+    hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.S, ck,
+                       ck_len, pv.hdr);
     PAR_HIP_CHECK(hipMemcpyAsync(pv.xs, pv.S, nseg * sizeof(double), hipMemcpyDeviceToDevice, s));
     rc = inclusive_scan<AddF64>(pv.xs, nseg, reinterpret_cast<double*>(pv.bsum), s);
     if (rc != PAR_OK) return rc;
@@ -729,27 +680,89 @@ int par_speed_to_pos_plan_ex(int device, const double* sampletimes, const double
                        pv.hdr);
     hipLaunchKernelGGL(k_trim, dim3(1), dim3(1), 0, s, sampletimes, speeds, pv.seg_start, pv.seg_off, m, (double)n_in,
                        pv.hdr);
+    if (aux)
+      hipLaunchKernelGGL(k_tile_seg, dim3(g256), dim3(256), 0, s, pv.seg_start, nseg, ck_len, max_tiles,
+                         reinterpret_cast<int64_t*>(ck + ck_len), pv.hdr);
     PAR_HIP_CHECK(hipGetLastError());
     PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
     PAR_HIP_CHECK(hipStreamSynchronize(s));
-    // any flag (near-tie length, n_i < 2, range, verification, too many crossings): the serial path
-    // decides -- it also produces the reference's own diagnosis for genuinely bad curves.
-    if (h.flags) need_host = true;
+    // any flag but the checkpoint one (near-tie length, n_i < 2, range, verification, too many crossings):
+    // the serial path decides -- it also produces the reference's own diagnosis for genuinely bad curves.
+    if (h.flags & ~kFlagCkOverflow) need_host = true;
   }
+  int ck_valid = aux && !(h.flags & kFlagCkOverflow);
   if (need_host) {
     int rc = host_plan(pv, sampletimes, speeds, m, n_in, &h, s);
     if (rc != PAR_OK) return rc;
+    ck_valid = 0;
+    if (aux) {     // checkpoints + tile map for the serial path's segmentation: same exact device arithmetic
+      hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.S, ck,
+                         ck_len, pv.hdr);
+      hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, s, pv.seg_start, nseg, ck_len,
+                         max_tiles, reinterpret_cast<int64_t*>(ck + ck_len), pv.hdr);
+      PAR_HIP_CHECK(hipGetLastError());
+      PlanHeader h2;
+      PAR_HIP_CHECK(hipMemcpyAsync(&h2, pv.hdr, sizeof(h2), hipMemcpyDeviceToHost, s));
+      PAR_HIP_CHECK(hipStreamSynchronize(s));
+      ck_valid = !(h2.flags & kFlagCkOverflow);
+    }
   } else {
     // the reference writes each segment into its end_guess-sized buffer BEFORE testing the trim (:127-129)
-    const int64_t written = h.trimmed ? h.len_out : h.total_written;
-    PAR_REQUIRE(written <= h.cap, PAR_ERR_ARG,
+    PAR_REQUIRE(h.written <= h.cap, PAR_ERR_ARG,
                 "par_speed_to_pos_plan: positions overflow the reference's end_guess buffer (%lld > %lld); it raises here",
-                (long long)written, (long long)h.cap);
+                (long long)h.written, (long long)h.cap);
+  }
+  if (aux) {
+    // publish checkpoint validity with the plan
+    h.ck_len = ck_len;
+    h.ck_valid = ck_valid;
+    h.flags &= ~kFlagCkOverflow;
+    PAR_HIP_CHECK(hipMemcpyAsync(pv.hdr, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    PAR_HIP_CHECK(hipStreamSynchronize(s));     // h lives on this stack frame
   }
   if (path_used) *path_used = need_host ? 1 : 0;
   *len_out = h.len_out;
   *trimmed = h.trimmed;
   return PAR_OK;
+}
+
+}  // extern "C"
+
+namespace par {
+// used by varispeed.hip
+int plan_fused_ok(const void* work, int64_t m, int* ok, hipStream_t s) {
+  PlanHeader h;
+  PAR_HIP_CHECK(hipMemcpyAsync(&h, plan_view(const_cast<void*>(work), m).hdr, sizeof(h), hipMemcpyDeviceToHost, s));
+  PAR_HIP_CHECK(hipStreamSynchronize(s));
+  *ok = h.ck_valid;
+  return PAR_OK;
+}
+}  // namespace par
+
+extern "C" {
+
+// force_host != 0 exercises the serial host path (tests use it to cross-check the device scans);
+// *path_used = 0 device scans, 1 serial host path.
+int par_speed_to_pos_plan_ex(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
+                             void* work, size_t work_bytes, int64_t* len_out, int* trimmed, int force_host,
+                             int* path_used, void* stream) {
+  return plan_impl(device, sampletimes, speeds, m, n_in, work, work_bytes, nullptr, 0, 0, len_out, trimmed, force_host,
+                   path_used, stream);
+}
+
+size_t par_fused_aux_bytes(int64_t max_out, int64_t m) { return par::fused_aux_bytes(max_out, m < 2 ? 2 : m); }
+
+// Plan + cumsum checkpoints (every 8th step of each segment) + tile map in `aux`, for par_varispeed_fused_f32.
+// max_out bounds len_out (e.g. 1.02 * n_in); a larger result leaves the plan valid but the fused path refused.
+int par_speed_to_pos_plan_fused(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
+                                void* work, size_t work_bytes, void* aux, size_t aux_bytes, int64_t max_out,
+                                int64_t* len_out, int* trimmed, int force_host, int* path_used, int* fused_ok,
+                                void* stream) {
+  PAR_REQUIRE(aux && max_out > 0, PAR_ERR_ARG, "par_speed_to_pos_plan_fused: aux buffer required");
+  int rc = plan_impl(device, sampletimes, speeds, m, n_in, work, work_bytes, aux, aux_bytes, max_out, len_out, trimmed,
+                     force_host, path_used, stream);
+  if (rc == PAR_OK && fused_ok) rc = par::plan_fused_ok(work, m, fused_ok, par::as_stream(stream));
+  return rc;
 }
 
 int par_speed_to_pos_plan(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,

@@ -1,0 +1,127 @@
+// Plan layout and exact ramp arithmetic shared by K_pos (pos.hip) and the fused K_sinc (sinc.hip).
+#pragma once
+#include "par_common.h"
+
+namespace par {
+
+// ---------------------------------------------------------------------------------- plan layout
+struct PlanHeader {
+  int64_t m;
+  int64_t len_out;        // trimmed length or total written
+  int64_t total_written;  // sum n_i
+  unsigned long long trim_seg;   // first segment whose [first,last] straddles n_in, or ~0
+  int64_t cap;            // the reference's end_guess buffer size
+  int32_t trimmed;
+  int32_t flags;          // kFlag*
+  int32_t n_direct;
+  int32_t n_runs;
+  double speed_sum;
+  int64_t ck_len;         // checkpoint slots available in the caller's aux buffer (0: none)
+  int32_t ck_valid;       // 1: the aux buffer holds this plan's cumsum checkpoints (fused resampler may run)
+  int32_t pad2;
+  int64_t written;        // outputs the reference has written into its buffer when it stops (end of the trim segment)
+};
+constexpr int kFlagAmbiguous = 1;   // a cumulative length is too close to a rounding tie
+constexpr int kFlagBadLength = 2;   // some n_i < 2 (reference divides by zero / indexes an empty array)
+constexpr int kFlagRange = 4;       // a_i outside the exactly-representable fixed-point range
+constexpr int kFlagVerify = 8;      // offset-chain binade prediction failed verification
+constexpr int kFlagDirectOverflow = 16;
+constexpr int kFlagCkOverflow = 32;  // checkpoint buffer too small (plan stays valid; the fused path is refused)
+constexpr int kMaxDirect = 2048;
+constexpr unsigned long long kNoTrim = ~0ull;
+
+struct U128 {
+  unsigned long long hi, lo;       // value = hi + lo * 2^-64
+};
+struct PElem {                      // parity-dependent translation (+ segmented-scan head flag)
+  long long c0, c1;                 // increment when the incoming integer is even / odd
+  long long head;                   // 1: a run starts at this element (scan restarts here)
+  long long pad;
+};
+struct RunEntry {
+  long long start;                  // first segment of the run
+  double x;                         // offset at that segment (bit-exact)
+};
+
+constexpr size_t kHdrBytes = 256;
+struct PlanView {
+  PlanHeader* hdr;
+  int64_t* seg_start;   // [m]   seg_start[i] = outputs before segment i; [m-1] = total
+  double* seg_off;      // [m]   offset chain; seg_off[i] = position offset of segment i; [m-1] = final
+  double* S;            // [m]   per-segment reciprocal sums
+  double* xs;           // [m]   approx offsets (plain f64 scan)
+  char* scan;           // [m * 32] scan elements (U128 then PElem)
+  char* bsum;           // block sums for the scans
+  long long* direct;    // [kMaxDirect] indices of direct (binade-crossing) steps
+  RunEntry* runs;       // [kMaxDirect + 2]
+};
+inline size_t scan_blocks(int64_t n) { return (size_t)((n + 1023) / 1024); }
+inline size_t plan_bytes(int64_t m) {
+  return kHdrBytes + (size_t)m * (8 + 8 + 8 + 8 + 32) + (scan_blocks(m) + 8) * 32 + kMaxDirect * 8 +
+         (kMaxDirect + 2) * sizeof(RunEntry) + 256;
+}
+inline PlanView plan_view(void* work, int64_t m) {
+  char* b = static_cast<char*>(work);
+  PlanView v;
+  v.hdr = reinterpret_cast<PlanHeader*>(b);
+  b += kHdrBytes;
+  v.seg_start = reinterpret_cast<int64_t*>(b);
+  b += (size_t)m * 8;
+  v.seg_off = reinterpret_cast<double*>(b);
+  b += (size_t)m * 8;
+  v.S = reinterpret_cast<double*>(b);
+  b += (size_t)m * 8;
+  v.xs = reinterpret_cast<double*>(b);
+  b += (size_t)m * 8;
+  v.scan = b;
+  b += (size_t)m * 32;
+  v.bsum = b;
+  b += (scan_blocks(m) + 8) * 32;
+  v.direct = reinterpret_cast<long long*>(b);
+  b += kMaxDirect * 8;
+  v.runs = reinterpret_cast<RunEntry*>(b);
+  return v;
+}
+
+
+// ---------------------------------------------------------------------------------- ramp arithmetic
+struct Ramp {
+  double s0, ds, nm1, y;     // y = RN(1/(n-1))
+};
+__device__ __forceinline__ Ramp make_ramp(double s0, double s1, long long n) {
+#pragma clang fp contract(off)
+  Ramp r;
+  r.s0 = s0;
+  r.ds = s1 - s0;
+  r.nm1 = (double)(n - 1);
+  r.y = 1.0 / r.nm1;
+  return r;
+}
+// 1 / (k/(n-1) * ds + s0), every operation individually rounded like numpy (:120, :125).
+// k/(n-1) by Markstein's theorem: with y = RN(1/b), q0 = RN(a*y), r = a - b*q0 (exact, fma),
+// q = RN(q0 + r*y) is the correctly rounded a/b  (checked exhaustively for n <= 6000 on the host).
+__device__ __forceinline__ double ramp_recip(long long k, const Ramp& r) {
+#pragma clang fp contract(off)   // block scope: also holds when included from files built with contraction on
+  const double a = (double)k;
+  const double q0 = a * r.y;
+  const double rem = __builtin_fma(-q0, r.nm1, a);
+  const double q = __builtin_fma(rem, r.y, q0);
+  const double bs = q * r.ds + r.s0;          // not fused (-ffp-contract=off)
+  return 1.0 / bs;
+}
+
+
+// ---------------------------------------------------------------------------- cumsum checkpoints
+// The fused resampler regenerates positions inside K_sinc from per-segment checkpoints of the running
+// reciprocal sum: slot(i, b) holds cumsum after step kCk*b - 1 of segment i (b >= 1; b = 0 is 0.0).
+// slot(i, b) = start_i/kCk + i + b is unique and monotone without any prefix sum, because a segment of n
+// samples owns ceil(n/kCk) <= n/kCk + 1 slots.
+constexpr int kCk = 8;
+__host__ __device__ inline long long ck_slot0(long long seg_start, long long i) { return seg_start / kCk + i; }
+inline size_t fused_aux_bytes(int64_t max_out, int64_t m) {
+  const size_t ck = (size_t)(max_out / kCk + m + 16);
+  const size_t tiles = (size_t)(max_out / kSincTileOutputs + 4);
+  return (ck + tiles) * 8;
+}
+
+}  // namespace par

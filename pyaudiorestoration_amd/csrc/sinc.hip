@@ -23,6 +23,7 @@
 //  * positions stay float64 end to end (a 345.6 M-sample index does not fit float32); only the
 //    sub-sample shift in [-0.5, 0.5] and fc drop to float32.
 #include "par_common.h"
+#include "pos_plan.h"
 #include <limits.h>
 #include <math.h>
 #include <map>
@@ -258,19 +259,91 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
 
 // 6 waves/SIMD (80 VGPRs) measured best: 4 -> 1.39 ms, 5 -> 1.29, 6 -> 1.25, 7 -> 1.32, 8 -> 1.59 (spills) per
 // 115 M outputs.  Fully unrolling the tap loop (compile-time NT) was tried twice and spills badly.
+//
+// FUSED = true: there is no position array in HBM.  The workgroup regenerates the float64 positions of its
+// tile into LDS from the plan (segment starts / offsets / speeds) and the per-segment cumsum checkpoints:
+// one lane per checkpoint block advances kCk sequential float64 adds (bit-identical to numpy's cumsum) and
+// scatters pos = cumsum + offset into P[]; everything downstream is the same code as the position-array path.
+struct FusedArgs {
+  const double* speeds;
+  const int64_t* seg_start;
+  const double* seg_off;
+  const double* ck;
+  const int64_t* tile_seg;
+  int64_t nseg;
+};
+constexpr int kPosLds = kSincTile + 2;                 // positions jlo .. jhi of a tile (fused mode)
+constexpr int kPosLdsFloats = 2 * kPosLds + 2;         // float slots they occupy (keeps the tile 16-B aligned)
+constexpr int kSincCapFused = 4096;                    // signal floats staged in fused mode (speeds up to ~3.7)
+
+__device__ __forceinline__ void generate_tile_positions(const FusedArgs& fa, int64_t j0, int64_t len_out, int64_t jlo,
+                                                        int64_t jhi, double* __restrict__ P, int t) {
+  const int64_t T = j0 / kSincTile;
+  long long i0 = fa.tile_seg[T];
+  if (jlo < fa.seg_start[i0]) i0 -= 1;                                    // j0 opens a segment: j0-1 is in the previous one
+  const int64_t n_tiles = (len_out + kSincTile - 1) / kSincTile;
+  const long long i1 = (jhi == (T + 1) * kSincTile) ? fa.tile_seg[T + 1] : fa.tile_seg[n_tiles];   // segment holding jhi
+  const long long s0 = fa.seg_start[i0], s1 = fa.seg_start[i1];
+  const long long g_lo = ck_slot0(s0, i0) + (jlo - s0) / kCk;
+  const long long g_hi = ck_slot0(s1, i1) + (jhi - s1) / kCk;
+  for (long long g = g_lo + t; g <= g_hi; g += kSincBlock) {
+    // slot -> (segment, block): slot0 is monotone in the segment index
+    long long lo = i0, hi = i1;
+    if (hi - lo <= 16) {
+      while (lo < hi && ck_slot0(fa.seg_start[lo + 1], lo + 1) <= g) ++lo;
+    } else {
+      while (lo < hi) {
+        const long long mid = (lo + hi + 1) >> 1;
+        if (ck_slot0(fa.seg_start[mid], mid) <= g) lo = mid; else hi = mid - 1;
+      }
+    }
+    const long long i = lo;
+    const long long start = fa.seg_start[i];
+    const long long n = fa.seg_start[i + 1] - start;
+    const long long b = g - ck_slot0(start, i);
+    const long long k0 = b * kCk;
+    if (k0 >= n) continue;                                                // unused gap slot
+    const Ramp r = make_ramp(fa.speeds[i], fa.speeds[i + 1], n);
+    const double off = fa.seg_off[i];
+    double c = b ? fa.ck[g] : 0.0;
+    double rr[kCk];
+#pragma unroll
+    for (int u = 0; u < kCk; ++u) rr[u] = ramp_recip(k0 + u, r);
+#pragma unroll
+    for (int u = 0; u < kCk; ++u) {
+#pragma clang fp contract(off)
+      c = c + rr[u];
+      const long long jj = start + k0 + u;
+      if (k0 + u < n && jj >= jlo && jj <= jhi) P[jj - jlo] = c + off;
+    }
+  }
+}
+
+template <bool FUSED>
 __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict__ pos, int64_t len_out,
                                                       const float* __restrict__ sig, int64_t sig_stride,
                                                       int64_t len_in, int NT, const float4* __restrict__ tab,
                                                       float* __restrict__ out, int64_t out_stride, int64_t j_begin,
-                                                      int64_t j_end) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];
+                                                      int64_t j_end, FusedArgs fa) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   __shared__ int red[2 * (kSincBlock / kWave)];
   const int t = threadIdx.x;
   const int64_t j0 = j_begin + (int64_t)blockIdx.x * kSincTile;     // this launch covers outputs [j_begin, j_end)
+  float* tile = FUSED ? lds_raw + kPosLdsFloats : lds_raw;
+  const int cap = FUSED ? kSincCapFused : kSincCap;
+  // position source: the caller's array, or the tile's positions regenerated into LDS
+  double* P = reinterpret_cast<double*>(lds_raw);
+  const int64_t jlo = j0 > 0 ? j0 - 1 : 0;
+  if (FUSED) {
+    const int64_t jhi = (j0 + kSincTile < len_out) ? j0 + kSincTile : len_out - 1;
+    generate_tile_positions(fa, j0, len_out, jlo, jhi, P, t);
+    __syncthreads();
+  }
+  const double* psrc = FUSED ? P - jlo : pos;     // psrc[j] is the position of output j in both modes
 
   // Block-uniform EVEN integer anchor: indices are handled as int32 offsets from it (no 64-bit integer
   // math per output); an even anchor keeps round-half-even ties identical to rint(p).
-  const double p0 = pos[j0];
+  const double p0 = psrc[j0];
   const long long anchor = (fabs(p0) < 4.0e18) ? (llrint(p0) & ~1ll) : 0ll;
   const double anchor_d = (double)anchor;
   float res[kSincR];
@@ -288,9 +361,9 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
     fc[r] = 1.0f;
     dd[r] = 0.0f;
     if (valid[r]) {
-      const double p = pos[j];
+      const double p = psrc[j];
       // last output reuses the previous period (util/resampling.py:76-77)
-      const double dp = (j + 1 < len_out) ? pos[j + 1] - p : p - pos[j - 1];
+      const double dp = (j + 1 < len_out) ? psrc[j + 1] - p : p - psrc[j - 1];
       const double rel = p - anchor_d;             // exact to ~1e-13: anchor is within a tile's span of p
       const double rf = rint(rel);
       if (fabs(rel) < 1.0e9) c[r] = (int)rf; else wild = true;
@@ -326,7 +399,7 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
   // carry an exactly-zero weight (R_n = rcp(inf)) but must read finite data: stage a kChunk margin.
   const int margin = NT + kChunk;
   const long long span = (long long)mx - (long long)mn + 2ll * margin;     // <= kSincCap for the LDS path
-  const bool staged = mn != INT_MIN && span <= kSincCap;
+  const bool staged = mn != INT_MIN && span <= cap;
   const long long lo = anchor + mn - margin;        // signal index of tile[0]
   if (staged) {
     for (int q = t; q < (int)span; q += kSincBlock) {
@@ -356,8 +429,8 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
     if (j >= j_end) continue;
     float v = res[r];
     if (!fastlane[r]) {
-      const double pj = pos[j];
-      const double dpj = (j + 1 < len_out) ? pos[j + 1] - pj : pj - pos[j - 1];
+      const double pj = psrc[j];
+      const double dpj = (j + 1 < len_out) ? psrc[j + 1] - pj : pj - psrc[j - 1];
       v = sinc_one_f64(pj, dpj, sig, sig_stride, len_in, NT);
     }
     out[j * out_stride] = v;
@@ -432,8 +505,36 @@ int launch_sinc(int device, const double* pos, int64_t len_out, int64_t j_begin,
   int rc = get_sinc_table(device, NT, &tab);
   if (rc != PAR_OK) return rc;
   const int64_t blocks = ceil_div(count, kSincTile);
-  hipLaunchKernelGGL(k_sinc, dim3((unsigned)blocks), dim3(kSincBlock), kSincCap * sizeof(float), s, pos, len_out, sig,
-                     sig_stride, len_in, NT, tab.ab, out, out_stride, j_begin, j_begin + count);
+  hipLaunchKernelGGL(k_sinc<false>, dim3((unsigned)blocks), dim3(kSincBlock), kSincCap * sizeof(float), s, pos, len_out,
+                     sig, sig_stride, len_in, NT, tab.ab, out, out_stride, j_begin, j_begin + count, FusedArgs{});
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
+// whole output range, positions regenerated in-kernel from the plan + checkpoints (no position array)
+int launch_sinc_fused(int device, const double* speeds, int64_t m, const void* work, const void* aux, int64_t len_out,
+                      const float* sig, int64_t sig_stride, int64_t len_in, int NT, float* out, int64_t out_stride,
+                      hipStream_t s) {
+  SincTable tab;
+  int rc = get_sinc_table(device, NT, &tab);
+  if (rc != PAR_OK) return rc;
+  PlanView pv = plan_view(const_cast<void*>(work), m);
+  PlanHeader h;
+  PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
+  PAR_HIP_CHECK(hipStreamSynchronize(s));
+  PAR_REQUIRE(h.ck_valid && h.len_out == len_out && h.m == m, PAR_ERR_ARG,
+              "par_varispeed_fused_f32: the plan holds no valid checkpoints for this call (use par_speed_to_pos_plan_fused)");
+  FusedArgs fa;
+  fa.speeds = speeds;
+  fa.seg_start = pv.seg_start;
+  fa.seg_off = pv.seg_off;
+  fa.ck = static_cast<const double*>(aux);
+  fa.tile_seg = reinterpret_cast<const int64_t*>(fa.ck + h.ck_len);
+  fa.nseg = m - 1;
+  const int64_t blocks = ceil_div(len_out, kSincTile);
+  hipLaunchKernelGGL(k_sinc<true>, dim3((unsigned)blocks), dim3(kSincBlock),
+                     (kPosLdsFloats + kSincCapFused) * sizeof(float), s, nullptr, len_out, sig, sig_stride, len_in, NT,
+                     tab.ab, out, out_stride, (int64_t)0, len_out, fa);
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }

@@ -27,12 +27,17 @@ def find_cutoff(array, cutoff):
 class SpeedPlan:
     """Device-resident result of the planning stage of speed_to_pos (segment lengths, offsets, trim)."""
 
-    def __init__(self, speeds_t, m, work, len_out, trimmed, path, dev):
+    def __init__(self, speeds_t, m, work, len_out, trimmed, path, dev, aux=None, fused_ok=False):
         self.speeds_t, self.m, self.work, self.len_out, self.trimmed, self.path, self.dev = \
             speeds_t, m, work, len_out, trimmed, path, dev
+        # fused_ok: the plan carries cumsum checkpoints for every needed segment (fused K_sinc can run)
+        self.aux, self.fused_ok = aux, fused_ok
 
 
-def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_host_chain=False):
+def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_host_chain=False, fused=False,
+                   max_out=None):
+    """Planning stage.  fused=True also stores per-segment cumsum checkpoints (every 8th step) so that
+    varispeed_resample_dev can regenerate positions inside K_sinc instead of reading a position array."""
     dev = _dev.device_index(dev if dev is not None else sampletimes_t.device)
     L = _lib.lib()
     m = sampletimes_t.numel()
@@ -43,6 +48,22 @@ def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_h
     len_out = ctypes.c_int64(0)
     trimmed = ctypes.c_int(0)
     path = ctypes.c_int(0)
+    if fused:
+        if max_out is None:
+            # the reference's own output bound (util/resampling.py:108): int(mean(speeds) * span * 1.01);
+            # buffer sizing only, so a torch reduction is fine here
+            span = float(sampletimes_t[-1] - sampletimes_t[0])
+            longest = float((sampletimes_t[1:] - sampletimes_t[:-1]).max()) * float(speeds_t.max())
+            max_out = int(float(speeds_t.mean()) * span * 1.01) + int(longest) + 1024
+        aux_bytes = int(L.par_fused_aux_bytes(max_out, m))
+        aux = _dev.empty(aux_bytes, torch.uint8, dev)
+        ok = ctypes.c_int(0)
+        _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m,
+                                                 int(num_imput_samples), _dev.ptr(work), nbytes, _dev.ptr(aux), aux_bytes,
+                                                 max_out, ctypes.byref(len_out), ctypes.byref(trimmed),
+                                                 1 if force_host_chain else 0, ctypes.byref(path), ctypes.byref(ok),
+                                                 _dev.stream_ptr(dev)))
+        return SpeedPlan(speeds_t, m, work, len_out.value, bool(trimmed.value), path.value, dev, aux, bool(ok.value))
     _lib.check(L.par_speed_to_pos_plan_ex(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m, int(num_imput_samples),
                                           _dev.ptr(work), nbytes, ctypes.byref(len_out), ctypes.byref(trimmed),
                                           1 if force_host_chain else 0, ctypes.byref(path), _dev.stream_ptr(dev)))
@@ -62,9 +83,26 @@ def speed_to_pos_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force
     return pos
 
 
+def varispeed_fused_dev(plan, sig_t, NT, out_t=None, sig_stride=1, len_in=None, out_stride=1):
+    """Sinc interpolation of one channel straight from a fused SpeedPlan: K_sinc regenerates each tile's
+    float64 positions in LDS (no position array in HBM).  Same output as the two-step path."""
+    if not plan.fused_ok:
+        raise ValueError("plan has no valid checkpoints: build it with speed_plan_dev(..., fused=True)")
+    dev = plan.dev
+    L = _lib.lib()
+    if len_in is None:
+        len_in = sig_t.numel() // sig_stride
+    if out_t is None:
+        out_t = _dev.empty(plan.len_out * out_stride, torch.float32, dev)
+    _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(plan.speeds_t), plan.m, _dev.ptr(plan.work), _dev.ptr(plan.aux),
+                                         plan.len_out, _dev.ptr(sig_t), sig_stride, len_in, int(NT), _dev.ptr(out_t),
+                                         out_stride, _dev.stream_ptr(dev)))
+    return out_t
+
+
 def varispeed_resample_dev(plan, sig_t, NT, out_t=None, pos_t=None, sig_stride=1, len_in=None, out_stride=1, n_chunks=0):
-    """Positions + sinc interpolation of one channel from a SpeedPlan, pipelined on two streams
-    (position fill of chunk c+1 under the interpolation of chunk c).  Returns (out, pos)."""
+    """Positions + sinc interpolation of one channel from a SpeedPlan (position array materialised in
+    `pos_t`, optionally pipelined in chunks).  Returns (out, pos)."""
     dev = plan.dev
     L = _lib.lib()
     if len_in is None:

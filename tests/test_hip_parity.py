@@ -389,3 +389,40 @@ def test_heal_dropouts_config4(par, golden):
     st = np.stack((x, x[::-1].copy()), axis=-1)                     # stereo, channel views stay strided on the device
     y2 = par.pipeline.heal_dropouts(st, sr, [tuple(m) for m in g["marks"]], 512, 32, channels=(0,))
     assert relerr(y2[:, 0], g["y"]) < TOL
+
+
+def test_fused_varispeed_equals_position_array_path(par):
+    """Fused K_sinc (positions regenerated per tile in LDS from cumsum checkpoints) must give exactly the
+    output of speed_to_pos + sinc on the materialised float64 positions, for smooth, jittery, coarse and
+    short-segment curves, with and without the end trim, and on the serial-host plan path."""
+    t = par.torch
+    rng = np.random.default_rng(3)
+    cases = []
+    sr, dur = 96000, 20.0
+    n = int(sr * dur)
+    sc = inputs.bench_speed_curve(dur, sr)
+    cases.append(("bench", sc[:, 0] * sr, np.ascontiguousarray(sc[:, 1]), n, n))
+    st = np.linspace(0, 600000, 600000 // 64)                                     # hop 64, noisy, untrimmed (n_in huge)
+    cases.append(("hop64", st, 1 + 0.04 * np.sin(np.arange(len(st)) * 0.01) + 0.003 * rng.standard_normal(len(st)), 700000, 10**8))
+    st = np.cumsum(rng.uniform(3.0, 40.0, 30000))                                 # very short, uneven segments
+    cases.append(("short", st, rng.uniform(0.8, 1.25, 30000), int(st[-1]) + 100, int(st[-1] * 0.7)))
+    st = np.array([0.0, 50000.0, 120000.0])                                       # two huge segments (coarse curve)
+    cases.append(("coarse", st, np.array([1.1, 0.9, 1.05]), 130000, 110000))
+    for name, st, sp, n_sig, n_in in cases:
+        sig_t = t.from_numpy(inputs.noise(n_sig, 5)).cuda()
+        st_t, sp_t = t.from_numpy(st).cuda(), t.from_numpy(sp).cuda()
+        pos_ref = par.resampling.speed_to_pos_dev(st_t, sp_t, n_in)
+        out_ref = par.resampling.sinc_resample_dev(pos_ref, sig_t, 32)
+        for force_host in (False, True):
+            plan = par.resampling.speed_plan_dev(st_t, sp_t, n_in, fused=True, force_host_chain=force_host)
+            assert plan.fused_ok and plan.len_out == pos_ref.numel(), (name, force_host)
+            out = par.resampling.varispeed_fused_dev(plan, sig_t, 32)
+            t.cuda.synchronize()
+            assert t.equal(out, out_ref), (name, force_host, float((out - out_ref).abs().max()))
+    # other qualities through the same fused path
+    sig_t = t.from_numpy(inputs.noise(n, 6)).cuda()
+    st_t, sp_t = t.from_numpy(sc[:, 0] * sr).cuda(), t.from_numpy(np.ascontiguousarray(sc[:, 1])).cuda()
+    pos_ref = par.resampling.speed_to_pos_dev(st_t, sp_t, n)
+    for NT in (5, 50):
+        plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
+        assert t.equal(par.resampling.varispeed_fused_dev(plan, sig_t, NT), par.resampling.sinc_resample_dev(pos_ref, sig_t, NT))
