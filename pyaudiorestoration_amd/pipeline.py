@@ -58,13 +58,16 @@ def respeed(signal, sr, trail, fft_size=1024, hop=256, zeropad=1, mode="Peak", t
     curve = master_speed_curve([(track.times, trace_to_speed(track.freqs))], n / sr, sr, hop, bands)
     st_t = _dev.to_dev(curve[:, 0] * sr, torch.float64, dev)
     sp_t = _dev.to_dev(np.ascontiguousarray(curve[:, 1]), torch.float64, dev)
-    pos_t = resampling.speed_to_pos_dev(st_t, sp_t, n, dev)
+    pos_t = resampling.speed_to_pos_dev(st_t, sp_t, n, dev)      # kept: the GUI shows / reuses sample_at
+    plan = resampling.speed_plan_dev(st_t, sp_t, n, dev, fused=True) if resampling_mode == "Sinc" else None
     out_t = _dev.empty((pos_t.numel(), ch), torch.float32, dev)
     for c in range(ch):
-        fn = resampling.sinc_resample_dev if resampling_mode == "Sinc" else None
-        if fn is not None:
-            fn(pos_t, sig_t.reshape(-1)[c:], sinc_quality, out_t.reshape(-1)[c:], sig_stride=ch, len_in=n,
-               out_stride=ch, dev=dev)
+        if resampling_mode == "Sinc" and plan.fused_ok:
+            resampling.varispeed_fused_dev(plan, sig_t.reshape(-1)[c:], sinc_quality, out_t.reshape(-1)[c:], sig_stride=ch,
+                                           len_in=n, out_stride=ch)
+        elif resampling_mode == "Sinc":
+            resampling.sinc_resample_dev(pos_t, sig_t.reshape(-1)[c:], sinc_quality, out_t.reshape(-1)[c:], sig_stride=ch,
+                                         len_in=n, out_stride=ch, dev=dev)
         else:
             resampling.linear_resample_dev(pos_t, sig_t.reshape(-1)[c:], out_t.reshape(-1)[c:], sig_stride=ch, len_in=n,
                                            out_stride=ch, dev=dev)

@@ -206,11 +206,19 @@ def run(filenames, signal_data=None, speed_curve=None, resampling_mode="Linear",
                 signal, sr, num_channels = io_ops.read_file(filename)
             sig_t = _dev.to_dev(signal, torch.float32, dev)          # (n, ch) C-order in HBM
             n_in, n_ch_in = signal.shape
+            plan = None
+            pos_t = None
             if speed_curve is not None:
                 sampletimes = speed_curve[:, 0] * sr
                 speeds = speed_curve[:, 1]
-                pos_t = speed_to_pos_dev(_dev.to_dev(np.asarray(sampletimes, dtype=np.float64), torch.float64, dev),
-                                         _dev.to_dev(np.asarray(speeds, dtype=np.float64), torch.float64, dev), n_in, dev)
+                st_t = _dev.to_dev(np.asarray(sampletimes, dtype=np.float64), torch.float64, dev)
+                sp_t = _dev.to_dev(np.asarray(speeds, dtype=np.float64), torch.float64, dev)
+                # Sinc mode: fused plan (positions are regenerated inside K_sinc, no sample_at array in HBM)
+                plan = speed_plan_dev(st_t, sp_t, n_in, dev, fused=(resampling_mode == "Sinc"))
+                if not plan.fused_ok:
+                    pos_t = _dev.empty(plan.len_out, torch.float64, dev)
+                    _lib.check(_lib.lib().par_speed_to_pos_fill(dev, _dev.ptr(sp_t), plan.m, _dev.ptr(plan.work),
+                                                                _dev.ptr(pos_t), plan.len_out, _dev.stream_ptr(dev)))
             elif lag_curve is not None:
                 sampletimes = lag_curve[:, 0] * sr
                 lags = lag_curve[:, 1] * sr
@@ -229,13 +237,16 @@ def run(filenames, signal_data=None, speed_curve=None, resampling_mode="Linear",
         else:
             use_channels = tuple(range(num_channels))
         with log_duration("Resampling"):
-            length = pos_t.numel()
+            length = plan.len_out if plan is not None else pos_t.numel()
             num_channels = len(use_channels)
             out_t = _dev.empty((length, num_channels), torch.float32, dev)
             for out_channel, in_channel in enumerate(use_channels):
                 sig_view = sig_t.reshape(-1)[in_channel:]
                 out_view = out_t.reshape(-1)[out_channel:]
-                if resampling_mode == "Sinc":
+                if resampling_mode == "Sinc" and plan is not None and plan.fused_ok:
+                    varispeed_fused_dev(plan, sig_view, sinc_quality, out_view, sig_stride=n_ch_in, len_in=n_in,
+                                        out_stride=num_channels)
+                elif resampling_mode == "Sinc":
                     sinc_resample_dev(pos_t, sig_view, sinc_quality, out_view, sig_stride=n_ch_in, len_in=n_in,
                                       out_stride=num_channels, dev=dev)
                 elif resampling_mode == "Linear":
