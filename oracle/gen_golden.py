@@ -262,6 +262,41 @@ def main():
                                      istft_fn=lambda S, length, hop_length: fourier.istft(S, length=length, hop_length=hop_length))
     save("heal", y=healed[:, 0].astype(np.float64), marks=np.array(marks), sr=np.array(sr_h))
 
+    # ------------------------------ configs 1 and 3 on the reference's own sample files
+    # The FLAC files are DATA copied into tests/golden/ (the reference has no tests; these are its demo
+    # inputs, named by BASELINE.json configs 1 and 3).  soundfile is absent, so they are decoded with the
+    # build's own decoder, which verifies the STREAMINFO MD5 of the decoded PCM.
+    from pyaudiorestoration_amd import io_ops as my_io
+    def grid(a, k=97):
+        return np.asarray(a).ravel()[::k].copy()
+    x1, sr1, _ = my_io.read_flac(os.path.join(a.ref, "samples", "flutter.flac"))
+    m1 = fourier.get_mag(x1[:, 0], 1024, 256, "hann", 1)
+    x3, sr3, _ = my_io.read_flac(os.path.join(a.ref, "samples", "flutter_192.flac"))
+    spec3 = fourier.get_mag(x3[:, 0], 1024, 256, "blackmanharris", 1)
+    tr3 = wow.wow_detectors["Peak"](spec3, x3, [(0.2, 4000.0), (4.0, 4000.0)], 1024, 256, sr3, 0.5, "Linear")
+    l2s = np.log2(tr3.freqs)
+    l2s -= np.mean(l2s)
+    dur3 = len(x3) / sr3
+    msr = sr3 / 256
+    times3 = np.linspace(0, dur3, num=int(dur3 * msr))
+    col = np.zeros((len(times3), 1), dtype=np.float32)
+    col[:, 0] = np.interp(times3, tr3.times, l2s, left=np.nan, right=np.nan)
+    mean3 = np.nanmean(col, axis=1)
+    wow.interp_nans(mean3)
+    filt3 = filters.butter_bandpass_filter(mean3, 0, 20, msr, order=3)
+    curve3 = np.stack((times3, filt3), axis=-1)
+    np.power(2, curve3[:, 1], curve3[:, 1])
+    pos3 = resampling.speed_to_pos(curve3[:, 0] * sr3, curve3[:, 1], len(x3))
+    pos3 = pos3[:written_len(curve3[:, 0] * sr3, curve3[:, 1], len(pos3))]
+    sel = np.concatenate((np.arange(0, 3000), np.arange(400000, 403000), np.arange(len(pos3) - 3000, len(pos3))))
+    y3_sel = np.concatenate([resampling.sinc_wrapper(pos3[a0:a0 + 3001], x3[:, 0], 0, 32)[:3000]
+                             for a0 in (0, 400000)] +
+                            [resampling.sinc_wrapper(pos3[len(pos3) - 3000:], x3[:, 0], 0, 32)])
+    save("samples", c1_shape=np.array(m1.shape), c1_sum=np.array(m1.sum()), c1_grid=grid(m1), c1_sr=np.array(sr1),
+         c1_n=np.array(len(x1)), c3_shape=np.array(spec3.shape), c3_sum=np.array(spec3.sum()), c3_grid=grid(spec3),
+         c3_sr=np.array(sr3), c3_n=np.array(len(x3)), c3_track_times=tr3.times, c3_track_freqs=tr3.freqs, c3_curve=curve3,
+         c3_len_pos=np.array(len(pos3)), c3_pos_grid=grid(pos3, 1009), c3_sel=sel, c3_y_sel=y3_sel)
+
     # ----------------------------------------------- Linear mode + lag curve
     sig = inputs.noise(5000, 50)
     lag = np.array([[0.0, 0.0], [0.02, 0.0005], [0.06, -0.001], [0.1, 0.002]])

@@ -426,3 +426,31 @@ def test_fused_varispeed_equals_position_array_path(par):
     for NT in (5, 50):
         plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
         assert t.equal(par.resampling.varispeed_fused_dev(plan, sig_t, NT), par.resampling.sinc_resample_dev(pos_ref, sig_t, NT))
+
+
+def test_config1_and_config3_on_reference_samples(par, golden):
+    """BASELINE configs 1 and 3 on the reference's own demo files (data fixtures under tests/golden/):
+    FLAC decode -> get_mag -> PeakTracker -> master speed curve -> positions -> fused sinc resample."""
+    import os
+    from pyaudiorestoration_amd import io_ops
+    from test_oracle_golden import GOLD, grid
+    g = golden["samples"]
+    x1, sr1, _ = io_ops.read_file(os.path.join(GOLD, "flutter.flac"))
+    m = par.fourier.get_mag(x1[:, 0], 1024, 256, "hann", 1)
+    assert m.shape == (513, 728) and relerr(grid(m), g["c1_grid"]) < TOL
+    x3, sr3, _ = io_ops.read_file(os.path.join(GOLD, "flutter_192.flac"))
+    r = par.pipeline.respeed(x3, sr3, [(0.2, 4000.0), (4.0, 4000.0)], 1024, 256, 1, "Peak", 0.5, (0, 20), 32)
+    assert r["spectrum"].shape == (513, 3169) and relerr(grid(r["spectrum"].cpu().numpy()), g["c3_grid"]) < TOL
+    assert np.array_equal(r["times"], g["c3_track_times"]) and relerr(r["freqs"], g["c3_track_freqs"]) < 1e-6
+    assert relerr(r["speed_curve"][:, 1], g["c3_curve"][:, 1]) < 1e-7
+    assert r["positions"].numel() == int(g["c3_len_pos"])
+    assert np.max(np.abs(r["positions"].cpu().numpy()[::1009] - g["c3_pos_grid"])) < 1e-3     # 1e-10 curve difference x 8e5 samples
+    y = r["output"].cpu().numpy()[:, 0]
+    assert relerr(y[g["c3_sel"]], g["c3_y_sel"]) < 5e-5       # curve differs ~1e-7 -> positions ~1e-5
+    # with the reference's exact curve the positions are bit-identical and the output within tolerance
+    t = par.torch
+    curve = g["c3_curve"]
+    plan = par.resampling.speed_plan_dev(t.from_numpy(curve[:, 0] * sr3).cuda(), t.from_numpy(np.ascontiguousarray(curve[:, 1])).cuda(),
+                                         len(x3), fused=True)
+    y2 = par.resampling.varispeed_fused_dev(plan, t.from_numpy(np.ascontiguousarray(x3[:, 0])).cuda(), 32).cpu().numpy()
+    assert len(y2) == int(g["c3_len_pos"]) and relerr(y2[g["c3_sel"]], g["c3_y_sel"]) < TOL

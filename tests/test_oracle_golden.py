@@ -3,8 +3,12 @@ real reference by oracle/gen_golden.py.  CPU-only."""
 import numpy as np
 import pytest
 
+import os
+
 import inputs
 from oracle import oracle_np as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def relerr(a, b):
@@ -258,3 +262,44 @@ def test_heal_dropouts_config4(golden):
     assert relerr(y[:, 0], g["y"]) < 2e-6
     assert np.abs(y[9000:9300, 0]).mean() > 4 * np.abs(x[9000:9300]).mean()      # the dropout was lifted
     assert relerr(y[:8000, 0], x[:8000]) < 1e-4                                   # untouched region survives the round trip
+
+
+# ------------------------------------------------- BASELINE configs 1 and 3 on the reference's sample files
+def grid(a, k=97):
+    return np.asarray(a).ravel()[::k]
+
+
+def test_flac_decoder_reads_the_reference_samples():
+    """tests/golden/flutter*.flac are DATA files of the reference (its demo inputs).  The decoder verifies the
+    STREAMINFO MD5 of the decoded PCM itself; sizes/rates are the ones SURVEY 8c recorded."""
+    from pyaudiorestoration_amd import io_ops
+    x, sr, ch = io_ops.read_file(os.path.join(GOLD, "flutter.flac"))
+    assert x.shape == (186291, 1) and x.dtype == np.float32 and sr == 44100 and ch == 1
+    x, sr, ch = io_ops.read_file(os.path.join(GOLD, "flutter_192.flac"))
+    assert x.shape == (811063, 1) and sr == 192000 and ch == 1
+
+
+def test_config1_flutter_stft_plumbing(golden):
+    from pyaudiorestoration_amd import io_ops
+    g = golden["samples"]
+    x, sr, _ = io_ops.read_file(os.path.join(GOLD, "flutter.flac"))
+    m = O.get_mag(x[:, 0], 1024, 256, "hann", 1)
+    assert m.shape == tuple(g["c1_shape"]) == (513, 728)
+    assert relerr(grid(m), g["c1_grid"]) < 2e-6 and abs(m.sum() - float(g["c1_sum"])) < 1e-5 * float(g["c1_sum"])
+
+
+def test_config3_flutter192_pipeline(golden):
+    from pyaudiorestoration_amd import io_ops
+    from oracle import oracle_c as C
+    g = golden["samples"]
+    x, sr, _ = io_ops.read_file(os.path.join(GOLD, "flutter_192.flac"))
+    spec = O.get_mag(x[:, 0], 1024, 256, "blackmanharris", 1)
+    assert spec.shape == tuple(g["c3_shape"]) == (513, 3169) and relerr(grid(spec), g["c3_grid"]) < 2e-6
+    t, f = O.track_peak(spec, [(0.2, 4000.0), (4.0, 4000.0)], 1024, 256, sr, 0.5)
+    assert np.array_equal(t, g["c3_track_times"]) and relerr(f, g["c3_track_freqs"]) < 1e-6
+    curve = O.master_speed_curve([(t, O.trace_to_speed(f))], len(x) / sr, sr, 256, bands=(0, 20))
+    assert relerr(curve[:, 1], g["c3_curve"][:, 1]) < 1e-7
+    pos, _ = C.speed_to_pos(g["c3_curve"][:, 0] * sr, g["c3_curve"][:, 1], len(x))
+    assert len(pos) == int(g["c3_len_pos"]) and np.array_equal(pos[::1009], g["c3_pos_grid"])
+    y = C.sinc(pos, x[:, 0], 32, threads=8)
+    assert relerr(y[g["c3_sel"]], g["c3_y_sel"]) < 3e-7
