@@ -420,8 +420,24 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
     res[r] = 0.0f;
   }
   if (__any(anyfast)) {
-    if (__all(unity)) taps_unity<kSincR>(tile, c, s, NT, tab, res);
-    else taps_general<kSincR>(tile, c, s, fc, dd, NT, tab, res);
+    if (__all(unity)) {
+      taps_unity<kSincR>(tile, c, s, NT, tab, res);
+    } else {
+      // the general path carries 10 live values per output: two passes over half of the lane's outputs keep
+      // it inside the 80-VGPR budget (one pass spilled 48 B/lane = as much HBM write traffic as the output)
+      static_assert(kSincR == 4, "split assumes 4 outputs per lane");
+      const int ca[2] = {c[0], c[1]}, cb[2] = {c[2], c[3]};
+      const float sa[2] = {s[0], s[1]}, sb[2] = {s[2], s[3]};
+      const float fa_[2] = {fc[0], fc[1]}, fb_[2] = {fc[2], fc[3]};
+      const float da[2] = {dd[0], dd[1]}, db[2] = {dd[2], dd[3]};
+      float ra[2], rb[2];
+      taps_general<2>(tile, ca, sa, fa_, da, NT, tab, ra);
+      taps_general<2>(tile, cb, sb, fb_, db, NT, tab, rb);
+      res[0] = ra[0];
+      res[1] = ra[1];
+      res[2] = rb[0];
+      res[3] = rb[1];
+    }
   }
 #pragma unroll
   for (int r = 0; r < kSincR; ++r) {

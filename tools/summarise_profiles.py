@@ -35,15 +35,17 @@ for db in ("fetch", "write", "sq", "lds", "grbm"):
     for (k, n), (cnt, a) in sorted(counters(db + "_results.db", "par::").items()):
         if any(s in k for s in ("k_sinc", "k_pos_fill", "k_seg_sum", "k_stft")):
             lines.append(f"{k[:60]:60s} {n:24s} n={cnt:3d} avg={a:18.1f}")
-            vals[(k.split('(')[0], n)] = a
+            short = "k_sinc" if "k_sinc" in k else ("k_pos_fill" if "k_pos_fill" in k else ("k_seg_sum" if "k_seg_sum" in k else "k_stft"))
+            vals[(short, n)] = a
 open(os.path.join(prof, f"{tag}_pmc.txt"), "w").write("\n".join(lines) + "\n")
 bench = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(prof, f"{tag}_bench_default.json"), "w"), indent=1)
-fetch = vals.get(("par::k_sinc", "FETCH_SIZE"))
-write = vals.get(("par::k_sinc", "WRITE_SIZE"))
+fetch = vals.get(("k_sinc", "FETCH_SIZE"))
+write = vals.get(("k_sinc", "WRITE_SIZE"))
 if fetch and write:
     n = bench["roofline"]["samples_per_launch"]
-    t = {"kernel": "k_sinc", "samples_per_launch": n, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+    t = {"kernel": bench["roofline"].get("kernel", "k_sinc") + (" (fused: positions regenerated in LDS)" if "fused" in bench["config"]["step"].split(";")[0] else ""),
+         "samples_per_launch": n, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
          "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "hbm_bytes_per_sample": (2 * fetch + write) * 1024 / n,
          "correction": "FETCH_SIZE x2 (gfx950 coalesced-read under-count, MI355X_MICROARCH.md HBM section), KiB units",
          "source": f"profiles/{tag}_pmc.txt"}
