@@ -454,3 +454,36 @@ def test_config1_and_config3_on_reference_samples(par, golden):
                                          len(x3), fused=True)
     y2 = par.resampling.varispeed_fused_dev(plan, t.from_numpy(np.ascontiguousarray(x3[:, 0])).cuda(), 32).cpu().numpy()
     assert len(y2) == int(g["c3_len_pos"]) and relerr(y2[g["c3_sel"]], g["c3_y_sel"]) < TOL
+
+
+def test_fused_extreme_curves_and_channels(par):
+    """Fused path under stress: fast curves whose tiles overflow the LDS stage (float64 slow path),
+    slow curves (many outputs per input), stereo strided views, tiny NT and NT = 100."""
+    t = par.torch
+    from oracle import oracle_c as C
+    rng = np.random.default_rng(8)
+    sig = np.stack((inputs.noise(400000, 1), inputs.noise(400000, 2)), axis=-1)
+    sig_t = t.from_numpy(sig).cuda()
+    for name, lo, hi, hop, NT in (("fast", 2.5, 6.0, 128, 16), ("slow", 0.3, 0.6, 256, 32), ("wide", 0.5, 2.0, 32, 100),
+                                  ("nt1", 0.9, 1.1, 256, 1)):
+        m = 300000 // hop
+        st = np.linspace(0, 300000, m)
+        sp = np.clip(0.5 * (lo + hi) + 0.5 * (hi - lo) * np.sin(np.arange(m) * 0.05) + 0.01 * rng.standard_normal(m), lo, hi)
+        st_t, sp_t = t.from_numpy(st).cuda(), t.from_numpy(sp).cuda()
+        n_in = 300000
+        pos_ref = par.resampling.speed_to_pos_dev(st_t, sp_t, n_in)
+        plan = par.resampling.speed_plan_dev(st_t, sp_t, n_in, fused=True)
+        assert plan.fused_ok and plan.len_out == pos_ref.numel(), name
+        out = t.zeros((plan.len_out, 2), dtype=t.float32, device="cuda")
+        ref = t.zeros_like(out)
+        for c in range(2):
+            par.resampling.varispeed_fused_dev(plan, sig_t.reshape(-1)[c:], NT, out.reshape(-1)[c:], sig_stride=2,
+                                               len_in=400000, out_stride=2)
+            par.resampling.sinc_resample_dev(pos_ref, sig_t.reshape(-1)[c:], NT, ref.reshape(-1)[c:], sig_stride=2,
+                                             len_in=400000, out_stride=2)
+        t.cuda.synchronize()
+        assert t.equal(out, ref), name
+        # and the position-array path itself against the C oracle on a slice
+        pos = pos_ref.cpu().numpy()
+        k = min(len(pos) - 1, 60000)
+        assert relerr(ref[:k, 1].cpu().numpy(), C.sinc(pos[:k + 1], sig[:, 1].copy(), NT, threads=8)[:k]) < TOL, name
