@@ -112,7 +112,7 @@ def main():
                                                      _dev.ptr(aux), aux_bytes, cap, ctypes.byref(len_out),
                                                      ctypes.byref(trimmed), 0, None, ctypes.byref(ok), sp_))
             assert ok.value == 1 and 2 <= len_out.value <= cap
-            _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(spd), m, _dev.ptr(work), _dev.ptr(aux), len_out.value,
+            _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(spd), m, _dev.ptr(work), _dev.ptr(aux), cap, len_out.value,
                                                  _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, sp_))
         else:
             _lib.check(L.par_speed_to_pos_plan(dev, _dev.ptr(st), _dev.ptr(spd), m, n_in, _dev.ptr(work), nbytes,

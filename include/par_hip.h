@@ -126,16 +126,17 @@ int par_varispeed_resample_f32(int device, const double* speeds, int64_t m, cons
  * par_varispeed_fused_f32 then runs K_sinc with each workgroup regenerating its tile's float64 positions in LDS
  * from those checkpoints (sequential float64 adds, bit-identical to numpy's cumsum) -- same output as
  * par_speed_to_pos_fill + par_sinc_resample_f32, 16 B/sample less HBM traffic.  *fused_ok (optional) reports
- * whether the checkpoints of every needed segment fit in aux; if not, par_varispeed_fused_f32 fails with
- * PAR_ERR_ARG and callers use the position-array path (the plan itself stays valid). */
+ * whether the checkpoints of every needed segment fit in aux; only then may par_varispeed_fused_f32 be called
+ * (with the same work/aux/max_out and the returned len_out -- it does not read the plan back, so that it never
+ * synchronises); otherwise callers use the position-array path (the plan itself stays valid). */
 size_t par_fused_aux_bytes(int64_t max_out, int64_t m);
 int par_speed_to_pos_plan_fused(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
                                 void* work, size_t work_bytes, void* aux, size_t aux_bytes, int64_t max_out,
                                 int64_t* len_out, int* trimmed, int force_host, int* path_used, int* fused_ok,
                                 void* stream);
 int par_varispeed_fused_f32(int device, const double* speeds, int64_t m, const void* work, const void* aux,
-                            int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in, int NT, float* out,
-                            int64_t out_stride, void* stream);
+                            int64_t max_out, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in,
+                            int NT, float* out, int64_t out_stride, void* stream);
 
 /* Profiling hook (bench.py roofline leg): HIP-event timing, on the caller's stream, of the K_sinc launches
  * issued by the last par_varispeed_resample_f32 call on `device`. */

@@ -44,7 +44,8 @@ SIGNATURES = {
     "par_speed_to_pos_plan_fused": (c_int, [c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_sz, c_vp, c_sz, c_i64,
                                             ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int),
                                             ctypes.POINTER(c_int), c_vp]),
-    "par_varispeed_fused_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp]),
+    "par_varispeed_fused_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64,
+                                        c_vp]),
     "par_profile_enable": (c_int, [c_int, c_int]),
     "par_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(c_int), ctypes.POINTER(c_i64)]),
     "par_linear_resample_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),

@@ -287,6 +287,13 @@ __global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, c
   S[i] = c;
 }
 
+// after k_tile_seg: publish checkpoint validity in the header (device side, so the host needs one read-back)
+__global__ void k_publish_ck(PlanHeader* __restrict__ h, int64_t ck_len) {
+  h->ck_len = ck_len;
+  h->ck_valid = (h->flags & kFlagCkOverflow) ? 0 : 1;
+  h->flags &= ~kFlagCkOverflow;
+}
+
 // tile_seg[t] = segment that contains output t * kSincTileOutputs (tiles of the fused resampler)
 __global__ void k_tile_seg(const int64_t* __restrict__ seg_start, int64_t nseg, int64_t ck_len, int64_t max_tiles,
                            int64_t* __restrict__ tile_seg, PlanHeader* __restrict__ h) {
@@ -638,7 +645,7 @@ size_t par_speed_plan_bytes(int64_t m) { return par::plan_bytes(m < 2 ? 2 : m); 
 // Shared implementation.  aux (optional, device): cumsum checkpoints for the fused resampler.
 static int plan_impl(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in, void* work,
                      size_t work_bytes, void* aux, size_t aux_bytes, int64_t max_out, int64_t* len_out, int* trimmed,
-                     int force_host, int* path_used, void* stream) {
+                     int force_host, int* path_used, int* fused_ok, void* stream) {
   using namespace par;
   PAR_REQUIRE(sampletimes && speeds && work && len_out && trimmed, PAR_ERR_ARG, "par_speed_to_pos_plan: null pointer");
   PAR_REQUIRE(m >= 2, PAR_ERR_ARG, "par_speed_to_pos_plan: need at least 2 speed samples (m=%lld)", (long long)m);
@@ -664,7 +671,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
     int rc = inclusive_scan<AddU128>(fix, nseg, reinterpret_cast<U128*>(pv.bsum), s);
     if (rc != PAR_OK) return rc;
     hipLaunchKernelGGL(k_seg_lengths, dim3(g256), dim3(256), 0, s, fix, nseg, pv.seg_start, pv.hdr);
-    hipLaunchKernelGGL(k_speed_sum, dim3(64), dim3(256), 0, s, speeds, m, pv.hdr);
+    hipLaunchKernelGGL(k_speed_sum, dim3((unsigned)(m / 4096 + 1)), dim3(256), 0, s, speeds, m, pv.hdr);
     hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.S, ck,
                        ck_len, pv.hdr);
     PAR_HIP_CHECK(hipMemcpyAsync(pv.xs, pv.S, nseg * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -680,31 +687,30 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
                        pv.hdr);
     hipLaunchKernelGGL(k_trim, dim3(1), dim3(1), 0, s, sampletimes, speeds, pv.seg_start, pv.seg_off, m, (double)n_in,
                        pv.hdr);
-    if (aux)
+    if (aux) {
       hipLaunchKernelGGL(k_tile_seg, dim3(g256), dim3(256), 0, s, pv.seg_start, nseg, ck_len, max_tiles,
                          reinterpret_cast<int64_t*>(ck + ck_len), pv.hdr);
+      hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
+    }
     PAR_HIP_CHECK(hipGetLastError());
     PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
     PAR_HIP_CHECK(hipStreamSynchronize(s));
     // any flag but the checkpoint one (near-tie length, n_i < 2, range, verification, too many crossings):
     // the serial path decides -- it also produces the reference's own diagnosis for genuinely bad curves.
-    if (h.flags & ~kFlagCkOverflow) need_host = true;
+    if (h.flags) need_host = true;     // (the checkpoint flag has already been folded into ck_valid)
   }
-  int ck_valid = aux && !(h.flags & kFlagCkOverflow);
   if (need_host) {
     int rc = host_plan(pv, sampletimes, speeds, m, n_in, &h, s);
     if (rc != PAR_OK) return rc;
-    ck_valid = 0;
     if (aux) {     // checkpoints + tile map for the serial path's segmentation: same exact device arithmetic
       hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.S, ck,
                          ck_len, pv.hdr);
       hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, s, pv.seg_start, nseg, ck_len,
                          max_tiles, reinterpret_cast<int64_t*>(ck + ck_len), pv.hdr);
+      hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
       PAR_HIP_CHECK(hipGetLastError());
-      PlanHeader h2;
-      PAR_HIP_CHECK(hipMemcpyAsync(&h2, pv.hdr, sizeof(h2), hipMemcpyDeviceToHost, s));
+      PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
       PAR_HIP_CHECK(hipStreamSynchronize(s));
-      ck_valid = !(h2.flags & kFlagCkOverflow);
     }
   } else {
     // the reference writes each segment into its end_guess-sized buffer BEFORE testing the trim (:127-129)
@@ -712,34 +718,12 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
                 "par_speed_to_pos_plan: positions overflow the reference's end_guess buffer (%lld > %lld); it raises here",
                 (long long)h.written, (long long)h.cap);
   }
-  if (aux) {
-    // publish checkpoint validity with the plan
-    h.ck_len = ck_len;
-    h.ck_valid = ck_valid;
-    h.flags &= ~kFlagCkOverflow;
-    PAR_HIP_CHECK(hipMemcpyAsync(pv.hdr, &h, sizeof(h), hipMemcpyHostToDevice, s));
-    PAR_HIP_CHECK(hipStreamSynchronize(s));     // h lives on this stack frame
-  }
   if (path_used) *path_used = need_host ? 1 : 0;
+  if (fused_ok) *fused_ok = aux ? h.ck_valid : 0;
   *len_out = h.len_out;
   *trimmed = h.trimmed;
   return PAR_OK;
 }
-
-}  // extern "C"
-
-namespace par {
-// used by varispeed.hip
-int plan_fused_ok(const void* work, int64_t m, int* ok, hipStream_t s) {
-  PlanHeader h;
-  PAR_HIP_CHECK(hipMemcpyAsync(&h, plan_view(const_cast<void*>(work), m).hdr, sizeof(h), hipMemcpyDeviceToHost, s));
-  PAR_HIP_CHECK(hipStreamSynchronize(s));
-  *ok = h.ck_valid;
-  return PAR_OK;
-}
-}  // namespace par
-
-extern "C" {
 
 // force_host != 0 exercises the serial host path (tests use it to cross-check the device scans);
 // *path_used = 0 device scans, 1 serial host path.
@@ -747,7 +731,7 @@ int par_speed_to_pos_plan_ex(int device, const double* sampletimes, const double
                              void* work, size_t work_bytes, int64_t* len_out, int* trimmed, int force_host,
                              int* path_used, void* stream) {
   return plan_impl(device, sampletimes, speeds, m, n_in, work, work_bytes, nullptr, 0, 0, len_out, trimmed, force_host,
-                   path_used, stream);
+                   path_used, nullptr, stream);
 }
 
 size_t par_fused_aux_bytes(int64_t max_out, int64_t m) { return par::fused_aux_bytes(max_out, m < 2 ? 2 : m); }
@@ -759,10 +743,8 @@ int par_speed_to_pos_plan_fused(int device, const double* sampletimes, const dou
                                 int64_t* len_out, int* trimmed, int force_host, int* path_used, int* fused_ok,
                                 void* stream) {
   PAR_REQUIRE(aux && max_out > 0, PAR_ERR_ARG, "par_speed_to_pos_plan_fused: aux buffer required");
-  int rc = plan_impl(device, sampletimes, speeds, m, n_in, work, work_bytes, aux, aux_bytes, max_out, len_out, trimmed,
-                     force_host, path_used, stream);
-  if (rc == PAR_OK && fused_ok) rc = par::plan_fused_ok(work, m, fused_ok, par::as_stream(stream));
-  return rc;
+  return plan_impl(device, sampletimes, speeds, m, n_in, work, work_bytes, aux, aux_bytes, max_out, len_out, trimmed,
+                   force_host, path_used, fused_ok, stream);
 }
 
 int par_speed_to_pos_plan(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,

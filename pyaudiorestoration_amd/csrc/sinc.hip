@@ -528,24 +528,22 @@ int launch_sinc(int device, const double* pos, int64_t len_out, int64_t j_begin,
 }
 
 // whole output range, positions regenerated in-kernel from the plan + checkpoints (no position array)
-int launch_sinc_fused(int device, const double* speeds, int64_t m, const void* work, const void* aux, int64_t len_out,
-                      const float* sig, int64_t sig_stride, int64_t len_in, int NT, float* out, int64_t out_stride,
-                      hipStream_t s) {
+int launch_sinc_fused(int device, const double* speeds, int64_t m, const void* work, const void* aux, int64_t max_out,
+                      int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in, int NT, float* out,
+                      int64_t out_stride, hipStream_t s) {
   SincTable tab;
   int rc = get_sinc_table(device, NT, &tab);
   if (rc != PAR_OK) return rc;
   PlanView pv = plan_view(const_cast<void*>(work), m);
-  PlanHeader h;
-  PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
-  PAR_HIP_CHECK(hipStreamSynchronize(s));
-  PAR_REQUIRE(h.ck_valid && h.len_out == len_out && h.m == m, PAR_ERR_ARG,
-              "par_varispeed_fused_f32: the plan holds no valid checkpoints for this call (use par_speed_to_pos_plan_fused)");
+  // No header read-back here (it would cost a stream sync per channel): the caller vouches, through the
+  // fused_ok flag of par_speed_to_pos_plan_fused, that aux holds this plan's checkpoints for max_out.
+  const int64_t ck_len = max_out / kCk + m + 16;
   FusedArgs fa;
   fa.speeds = speeds;
   fa.seg_start = pv.seg_start;
   fa.seg_off = pv.seg_off;
   fa.ck = static_cast<const double*>(aux);
-  fa.tile_seg = reinterpret_cast<const int64_t*>(fa.ck + h.ck_len);
+  fa.tile_seg = reinterpret_cast<const int64_t*>(fa.ck + ck_len);
   fa.nseg = m - 1;
   const int64_t blocks = ceil_div(len_out, kSincTile);
   hipLaunchKernelGGL(k_sinc<true>, dim3((unsigned)blocks), dim3(kSincBlock),

@@ -98,11 +98,12 @@ int par_varispeed_resample_f32(int device, const double* speeds, int64_t m, cons
 // Fused form: no position array at all.  Needs a plan made by par_speed_to_pos_plan_fused (checkpoints + tile map
 // in `aux`); K_sinc regenerates each tile's float64 positions in LDS, bit-identical to the materialised path.
 int par_varispeed_fused_f32(int device, const double* speeds, int64_t m, const void* work, const void* aux,
-                            int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in, int NT, float* out,
-                            int64_t out_stride, void* stream) {
+                            int64_t max_out, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in,
+                            int NT, float* out, int64_t out_stride, void* stream) {
   using namespace par;
   PAR_REQUIRE(speeds && work && aux && sig && out && m >= 2, PAR_ERR_ARG, "par_varispeed_fused_f32: null pointer");
-  PAR_REQUIRE(len_out >= 2, PAR_ERR_ARG, "par_varispeed_fused_f32: len_out=%lld < 2", (long long)len_out);
+  PAR_REQUIRE(len_out >= 2 && len_out <= max_out, PAR_ERR_ARG,
+              "par_varispeed_fused_f32: len_out=%lld outside [2, max_out=%lld]", (long long)len_out, (long long)max_out);
   PAR_REQUIRE(NT >= 1 && NT <= 512 && len_in >= 1 && sig_stride >= 1 && out_stride >= 1, PAR_ERR_ARG,
               "par_varispeed_fused_f32: bad sizes");
   PAR_HIP_CHECK(hipSetDevice(device));
@@ -111,7 +112,8 @@ int par_varispeed_fused_f32(int device, const double* speeds, int64_t m, const v
   if (rc != PAR_OK) return rc;
   hipStream_t main = as_stream(stream);
   if (p->profile) PAR_HIP_CHECK(hipEventRecord(p->t0[0], main));
-  rc = launch_sinc_fused(device, speeds, m, work, aux, len_out, sig, sig_stride, len_in, NT, out, out_stride, main);
+  rc = launch_sinc_fused(device, speeds, m, work, aux, max_out, len_out, sig, sig_stride, len_in, NT, out, out_stride,
+                         main);
   if (rc != PAR_OK) return rc;
   if (p->profile) {
     PAR_HIP_CHECK(hipEventRecord(p->t1[0], main));

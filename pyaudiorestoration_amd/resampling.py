@@ -27,11 +27,11 @@ def find_cutoff(array, cutoff):
 class SpeedPlan:
     """Device-resident result of the planning stage of speed_to_pos (segment lengths, offsets, trim)."""
 
-    def __init__(self, speeds_t, m, work, len_out, trimmed, path, dev, aux=None, fused_ok=False):
+    def __init__(self, speeds_t, m, work, len_out, trimmed, path, dev, aux=None, fused_ok=False, max_out=0):
         self.speeds_t, self.m, self.work, self.len_out, self.trimmed, self.path, self.dev = \
             speeds_t, m, work, len_out, trimmed, path, dev
         # fused_ok: the plan carries cumsum checkpoints for every needed segment (fused K_sinc can run)
-        self.aux, self.fused_ok = aux, fused_ok
+        self.aux, self.fused_ok, self.max_out = aux, fused_ok, max_out
 
 
 def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_host_chain=False, fused=False,
@@ -63,7 +63,8 @@ def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_h
                                                  max_out, ctypes.byref(len_out), ctypes.byref(trimmed),
                                                  1 if force_host_chain else 0, ctypes.byref(path), ctypes.byref(ok),
                                                  _dev.stream_ptr(dev)))
-        return SpeedPlan(speeds_t, m, work, len_out.value, bool(trimmed.value), path.value, dev, aux, bool(ok.value))
+        return SpeedPlan(speeds_t, m, work, len_out.value, bool(trimmed.value), path.value, dev, aux, bool(ok.value),
+                         max_out)
     _lib.check(L.par_speed_to_pos_plan_ex(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m, int(num_imput_samples),
                                           _dev.ptr(work), nbytes, ctypes.byref(len_out), ctypes.byref(trimmed),
                                           1 if force_host_chain else 0, ctypes.byref(path), _dev.stream_ptr(dev)))
@@ -95,8 +96,8 @@ def varispeed_fused_dev(plan, sig_t, NT, out_t=None, sig_stride=1, len_in=None, 
     if out_t is None:
         out_t = _dev.empty(plan.len_out * out_stride, torch.float32, dev)
     _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(plan.speeds_t), plan.m, _dev.ptr(plan.work), _dev.ptr(plan.aux),
-                                         plan.len_out, _dev.ptr(sig_t), sig_stride, len_in, int(NT), _dev.ptr(out_t),
-                                         out_stride, _dev.stream_ptr(dev)))
+                                         plan.max_out, plan.len_out, _dev.ptr(sig_t), sig_stride, len_in, int(NT),
+                                         _dev.ptr(out_t), out_stride, _dev.stream_ptr(dev)))
     return out_t
 
 

@@ -487,3 +487,27 @@ def test_fused_extreme_curves_and_channels(par):
         pos = pos_ref.cpu().numpy()
         k = min(len(pos) - 1, 60000)
         assert relerr(ref[:k, 1].cpu().numpy(), C.sinc(pos[:k + 1], sig[:, 1].copy(), NT, threads=8)[:k]) < TOL, name
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the contract's keys, a roofline and a cpu_baseline object."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--seconds", "20", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["scaling"] == "weak" and r["vs_baseline"] is None
+    assert r["value"] > 1000 and "workload" in r["config"] and "model" not in r["config"]
+    rl = r["roofline"]
+    assert rl["bound"] == "hbm" and rl["peak"] == 8000.0 and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-4
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
