@@ -1,0 +1,88 @@
+"""Headless pyrespeeder: a fresh replacement for the reference's stale
+experiments/pyrespeeder_cmd.py.  Files are independent work items: one host thread per GPU pulls
+(file) items from a queue, every file goes STFT -> tracker -> master speed curve -> fused sinc
+resample on that GPU, results are written as <stem>_res<suffix>.wav like resampling.run does
+(util/resampling.py:235-237).  No Qt, no collective communication.
+
+    python -m pyaudiorestoration_amd.cli respeed --trail 0.2,4000,4.0,4000 tape1.flac tape2.wav
+    python -m pyaudiorestoration_amd.cli resample --curve curve.json tape.wav      # [[t_seconds, speed], ...]
+"""
+import argparse
+import json
+import logging
+import os
+import queue
+import sys
+import threading
+
+import numpy as np
+
+
+def _worker(dev, jobs, args, results):
+    import torch
+    from . import io_ops, pipeline, resampling
+    torch.cuda.set_device(dev)
+    while True:
+        try:
+            path = jobs.get_nowait()
+        except queue.Empty:
+            return
+        try:
+            signal, sr, ch = io_ops.read_file(path)
+            if args.cmd == "respeed":
+                t0, f0, t1, f1 = args.trail
+                r = pipeline.respeed(signal, sr, [(t0, f0), (t1, f1)], args.fft_size, args.hop, 1, args.mode,
+                                     args.tolerance, (0, args.lowpass), args.quality, device=dev)
+                out = r["output"].cpu().numpy()
+                io_ops.write_wav_float(f"{os.path.splitext(path)[0]}_res{args.suffix}.wav", out, sr)
+                np.save(f"{os.path.splitext(path)[0]}_speed{args.suffix}.npy", r["speed_curve"])
+            else:
+                curve = np.asarray(json.load(open(args.curve)), dtype=np.float64)
+                resampling.run((path,), signal_data=((signal, sr),), speed_curve=curve, resampling_mode=args.resampling,
+                               sinc_quality=args.quality, suffix=args.suffix)
+            results.append((path, None))
+        except Exception as e:                      # keep the other files going; report at the end
+            logging.exception(f"{path} failed")
+            results.append((path, e))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="pyaudiorestoration_amd.cli")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    a = sub.add_parser("respeed", help="trace a pilot tone / hum and remove wow & flutter")
+    a.add_argument("--trail", type=lambda s: [float(v) for v in s.split(",")], required=True, help="t0,f0,t1,f1 (s, Hz)")
+    a.add_argument("--mode", default="Peak", help="tracker name as in wow_detection.wow_detectors")
+    a.add_argument("--tolerance", type=float, default=0.5, help="semitones")
+    a.add_argument("--fft-size", type=int, default=1024)
+    a.add_argument("--hop", type=int, default=256)
+    a.add_argument("--lowpass", type=float, default=20.0, help="speed-curve low-pass (Hz)")
+    b = sub.add_parser("resample", help="apply a given speed curve")
+    b.add_argument("--curve", required=True, help="JSON [[t_seconds, speed], ...]")
+    b.add_argument("--resampling", default="Sinc", choices=("Sinc", "Linear"))
+    for p in (a, b):
+        p.add_argument("--quality", type=int, default=50, help="sinc_quality (NT); GUI default 50")
+        p.add_argument("--suffix", default="")
+        p.add_argument("--gpus", type=int, default=0, help="GPUs to use (0 = all visible)")
+        p.add_argument("files", nargs="+")
+    args = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format="%(levelname)s %(message)s")
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("no ROCm GPU visible; this tool has no CPU fallback")
+    n_gpu = torch.cuda.device_count() if args.gpus <= 0 else min(args.gpus, torch.cuda.device_count())
+    jobs = queue.Queue()
+    for f in sorted(args.files, key=lambda p: -os.path.getsize(p)):     # longest first
+        jobs.put(f)
+    results = []
+    threads = [threading.Thread(target=_worker, args=(d, jobs, args, results)) for d in range(n_gpu)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    failed = [p for p, e in results if e is not None]
+    logging.info(f"{len(results) - len(failed)} file(s) done on {n_gpu} GPU(s), {len(failed)} failed")
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

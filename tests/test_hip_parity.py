@@ -511,3 +511,25 @@ def test_bench_contract_line():
     assert rl["bound"] == "hbm" and rl["peak"] == 8000.0 and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-4
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_headless_cli_respeed_and_resample(par, golden, tmp_path):
+    """The headless pyrespeeder CLI on the reference's flutter_192.flac: same result as the golden config-3 flow."""
+    import json
+    import os
+    import shutil
+    from pyaudiorestoration_amd import cli, io_ops
+    from test_oracle_golden import GOLD
+    g = golden["samples"]
+    f = str(tmp_path / "tape.flac")
+    shutil.copy(os.path.join(GOLD, "flutter_192.flac"), f)
+    assert cli.main(["respeed", "--trail", "0.2,4000,4.0,4000", "--quality", "32", f]) == 0
+    y, sr, ch = io_ops.read_file(str(tmp_path / "tape_res.wav"))
+    assert sr == 192000 and ch == 1 and len(y) == int(g["c3_len_pos"])
+    assert relerr(y[g["c3_sel"], 0], g["c3_y_sel"]) < 5e-5
+    curve = np.load(str(tmp_path / "tape_speed.npy"))
+    assert relerr(curve[:, 1], g["c3_curve"][:, 1]) < 1e-7
+    json.dump(g["c3_curve"].tolist(), open(str(tmp_path / "c.json"), "w"))
+    assert cli.main(["resample", "--curve", str(tmp_path / "c.json"), "--quality", "32", "--suffix", "_b", f]) == 0
+    y2, _, _ = io_ops.read_file(str(tmp_path / "tape_res_b.wav"))
+    assert relerr(y2[g["c3_sel"], 0], g["c3_y_sel"]) < TOL
