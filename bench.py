@@ -57,6 +57,42 @@ def cpu_baseline(sr, nt, budget_s=15.0):
                       f"C speed_to_pos on 1 thread + C sinc on {cores} threads (contiguous chunks like sinc_wrapper_mt)"}
 
 
+def stft_secondary(sig, dev, n_fft=1024, hop=256):
+    """Secondary line (not the metric): K_stft magnitude throughput on the same resident signal, against
+    its 12.02 B/sample HBM roofline and the reference's own GPU route torch.stft + abs
+    (util/fourier.py:101-107, rocFFT) -- a reported baseline, not the optimisation target."""
+    import math
+    import numpy as np
+    import scipy.signal
+    import torch
+    from pyaudiorestoration_amd import fourier
+    x = sig[:min(sig.numel(), 57_600_000)]
+    n = x.numel()
+    win = torch.from_numpy(scipy.signal.get_window("blackmanharris", n_fft).astype(np.float32)).to(x.device)
+
+    def t_of(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    t_mag = t_of(lambda: fourier.stft_dev(x, n_fft, hop, win, 1, 1, dev=dev))
+
+    def ref():
+        r = torch.stft(x, n_fft, hop_length=hop, window=win, win_length=n_fft, center=True, pad_mode="reflect",
+                       normalized=False, onesided=True, return_complex=True)
+        r /= math.sqrt(n_fft)
+        return r.abs() + 1e-7
+    t_ref = t_of(ref, 3)
+    bps = 4 + 4 * (n_fft / 2 + 1) / hop
+    return {"kernel": "k_stft get_mag 1024/256", "samples": n, "Msamples/s": round(n / t_mag / 1e6, 1),
+            "algorithmic_GB/s": round(n * bps / t_mag / 1e9, 1), "frac_of_hbm_peak": round(n * bps / t_mag / 8e12, 4),
+            "torch_stft_abs_Msamples/s": round(n / t_ref / 1e6, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +197,8 @@ def main():
                                  "traffic = PMC HBM bytes (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json) "
                                  "incl. the 8 B float64 position read; the kernel is v_rcp/VALU-bound, see DESIGN.md"},
         }
+        if world == 1:
+            res["secondary"] = stft_secondary(sig, dev)
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(a.sr, a.nt)
         print(json.dumps(res), flush=True)
