@@ -135,8 +135,17 @@ __device__ __forceinline__ void fft_core(float2 (&v)[8], float2* __restrict__ X,
     const int k = j & (Ns - 1);
     if (st > 0) {
       const int step = H / (Ns * 8);
-#pragma unroll
-      for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw[r * k * step]);
+      // one gathered twiddle load per stage; the other six are its powers (3 multiply levels, ~2 ulp)
+      const float2 w1 = tw[k * step];
+      const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+      const float2 w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+      v[1] = cmul(v[1], w1);
+      v[2] = cmul(v[2], w2);
+      v[3] = cmul(v[3], w3);
+      v[4] = cmul(v[4], w4);
+      v[5] = cmul(v[5], w5);
+      v[6] = cmul(v[6], w6);
+      v[7] = cmul(v[7], w7);
     }
     radix8(v);
     __syncthreads();                       // everybody has finished reading X
