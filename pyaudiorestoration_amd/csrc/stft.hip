@@ -119,12 +119,33 @@ __device__ __forceinline__ void radix8(float2 (&v)[8]) {
   v[7] = csub(e3, o3);
 }
 
+// The lanes of one frame exchange data through LDS.  Up to 64 lanes per frame they all sit in ONE wave, whose
+// LDS operations execute in order: a compiler-level fence is enough and the waves of a workgroup never wait
+// for each other; larger frames need the workgroup barrier.
+template <int T>
+__device__ __forceinline__ void frame_sync() {
+  if constexpr (T <= kWave) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
+}
+
 // v[q] = x[j + q*T] on entry (natural order); on exit X (padded LDS frame) holds the transform in natural order.
-// All lanes of the BLOCK must call this together (it synchronises with __syncthreads).
+// All lanes of the frame (for T > 64: of the workgroup) must call this together.
 template <int LOGH>
 __device__ __forceinline__ void fft_core(float2 (&v)[8], float2* __restrict__ X, int j, const float2* __restrict__ tw) {
   constexpr int H = 1 << LOGH, T = H / 8;
   constexpr int N8 = LOGH / 3, REM = LOGH % 3;
+  // the gathered twiddle of every later stage depends only on the lane: fetch them all up front so their
+  // latency hides under the first butterflies instead of sitting between the LDS exchanges
+  float2 w1s[N8 > 1 ? N8 : 1];
+#pragma unroll
+  for (int st = 1; st < N8; ++st) {
+    const int Nst = 1 << (3 * st);
+    w1s[st] = tw[(j & (Nst - 1)) * (H / (Nst * 8))];
+  }
   int Ns = 1;
 #pragma unroll
   for (int st = 0; st < N8; ++st) {
@@ -134,9 +155,8 @@ __device__ __forceinline__ void fft_core(float2 (&v)[8], float2* __restrict__ X,
     }
     const int k = j & (Ns - 1);
     if (st > 0) {
-      const int step = H / (Ns * 8);
       // one gathered twiddle load per stage; the other six are its powers (3 multiply levels, ~2 ulp)
-      const float2 w1 = tw[k * step];
+      const float2 w1 = w1s[st];
       const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
       const float2 w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
       v[1] = cmul(v[1], w1);
@@ -148,11 +168,11 @@ __device__ __forceinline__ void fft_core(float2 (&v)[8], float2* __restrict__ X,
       v[7] = cmul(v[7], w7);
     }
     radix8(v);
-    __syncthreads();                       // everybody has finished reading X
+    frame_sync<T>();                       // everybody has finished reading X
     const int base = ((j - k) << 3) + k;
 #pragma unroll
     for (int r = 0; r < 8; ++r) X[lpad(base + r * Ns)] = v[r];
-    __syncthreads();
+    frame_sync<T>();
     Ns <<= 3;
   }
   if (REM) {
@@ -171,12 +191,12 @@ __device__ __forceinline__ void fft_core(float2 (&v)[8], float2* __restrict__ X,
       if (Rl == 2) radix2(v[u], v[u + U]);
       else radix4(v[u], v[u + U], v[u + 2 * U], v[u + 3 * U]);
     }
-    __syncthreads();
+    frame_sync<T>();
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int r = 0; r < Rl; ++r) X[lpad(bk[u] + r * Ns)] = v[u + r * U];
-    __syncthreads();
+    frame_sync<T>();
   }
 }
 
@@ -235,15 +255,23 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
       v[q] = z;
     }
   }
+  // untangling twiddles W^k of this lane's bins (k = j, j+T, ..): fetched before the FFT so they are in
+  // registers when the last exchange completes
+  constexpr int bins = H + 1;
+  float2 pw[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) pw[i] = (j + i * T < bins) ? post[j + i * T] : make_float2(0.0f, 0.0f);
   fft_core<LOGH>(v, X, j, tw);
   if (!live) return;
   // untangle the half-size transform into the H+1 real-FFT bins; lanes write consecutive bins
-  constexpr int bins = H + 1;
-  for (int k = j; k < bins; k += T) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int k = j + i * T;
+    if (k >= bins) break;
     const float2 zk = X[lpad(k & (H - 1))];
     const float2 zc = cconj(X[lpad((H - k) & (H - 1))]);
     const float2 ev = cadd(zk, zc);
-    const float2 t = cmul(post[k], csub(zk, zc));      // W^k * (Z[k] - conj(Z[H-k]))
+    const float2 t = cmul(pw[i], csub(zk, zc));        // W^k * (Z[k] - conj(Z[H-k]))
     const float re = 0.5f * (ev.x + t.y) * scale;       // X[k] = (ev - i*t)/2
     const float im = 0.5f * (ev.y - t.x) * scale;
     if (mode == 0) reinterpret_cast<float2*>(out)[fr * bins + k] = make_float2(re, im);
