@@ -76,6 +76,23 @@ int par_istft_f32(int device, const float* spec, int64_t n_frames, int n_fft, in
  * spec[i] *= 10^(gain_db[i]/20) for a frame-major complex64 spectrogram and a float32 mask of `count` bins. */
 int par_spec_apply_gain_db_c64(int device, float* spec, const float* gain_db, int64_t count, void* stream);
 
+/* Gain mask of the dropout healer for a BATCH of markers (dropout_healer_gui.py:135-159): for each marker
+ * (frame_b, frame_a, fs, bin_l, bin_u -- int32[n_markers][5] in device memory, the integers the reference
+ * derives at :136-142) the mean dB of the fs frames before/after the box per bin, the linear fill across the
+ * box (:149-153), gain = target - dB (:155) and np.clip(gain, previous, 255) (:157) folded into the mask.
+ *   spec     device complex64 [n_frames][bins], frame-major (par_stft_f32 output); read only
+ *   gain_db  device f32 [n_frames][bins], zero-initialised by the caller; updated with an atomic max, which
+ *            equals the reference's marker-by-marker clip because the mask is non-negative (heal.hip header)
+ * A marker whose box or surrounding frames leave the spectrogram contributes nothing. */
+int par_inpaint_gain_db_c64(int device, const float* spec, int64_t n_frames, int64_t bins, const int32_t* markers,
+                            int64_t n_markers, float* gain_db, void* stream);
+
+/* Band volume curve of the dropout detector (dropout_healer_gui.py:195-203):
+ * out[i] = mean_b 20*log10(mag[frame_b+i][b]), b in [bin_l, bin_u), i in [0, frame_a-frame_b); f64 out.
+ *   mag  device f32 [n_frames][bins] frame-major magnitude (get_mag output, already + 1e-7). */
+int par_band_mean_db_f32(int device, const float* mag, int64_t n_frames, int64_t bins, int bin_l, int bin_u,
+                         int64_t frame_b, int64_t frame_a, double* out, void* stream);
+
 /* ---- R1: speed curve -> fractional read positions ----------------------------------
  * Replaces resampling.speed_to_pos (util/resampling.py:93-137).  Two calls because the
  * caller must allocate the position array:
@@ -146,6 +163,16 @@ int par_profile_read(int device, float* total_ms, int* launches, int64_t* sample
 /* "Linear" mode of resampling.run (util/resampling.py:229): np.interp(pos, arange(len), sig, 0, 0). */
 int par_linear_resample_f32(int device, const double* pos, int64_t len_out, const float* sig, int64_t sig_stride,
                             int64_t len_in, float* out, int64_t out_stride, void* stream);
+
+/* Lag-curve branch of resampling.run (util/resampling.py:189-206): pos = clip(np.interp(arange(num_out), xp, fp), 0),
+ * cut at the first value >= len_signal (find_cutoff :265-270).  np.interp's operation order is kept (no FMA),
+ * so positions are bit-identical.
+ *   xp, fp   device f64[m], m >= 2: sampletimes and sampletimes - lags (samples)
+ *   pos      device f64[num_out] (caller-allocated; only the first *len_out entries are meaningful)
+ *   work     device scratch, >= 8 bytes
+ *   len_out  host: num_out, or the cut-off index; *trimmed = 1 when the cut-off fired.  Synchronises the stream. */
+int par_lag_to_pos_f64(int device, const double* xp, const double* fp, int64_t m, int64_t num_out, int64_t len_signal,
+                       double* pos, void* work, int64_t* len_out, int* trimmed, void* stream);
 
 /* ---- synthetic workload generators, so bench inputs are born in HBM ---------- */
 int par_synth_signal_f32(int device, float* out, int64_t start, int64_t count, double sr, uint64_t seed, void* stream);

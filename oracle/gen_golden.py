@@ -262,6 +262,15 @@ def main():
                                      istft_fn=lambda S, length, hop_length: fourier.istft(S, length=length, hop_length=hop_length))
     save("heal", y=healed[:, 0].astype(np.float64), marks=np.array(marks), sr=np.array(sr_h))
 
+    # dropout detector (dropout_healer_gui.py:185-242) on the reference's get_mag
+    xd = inputs.detect_input(sr_h)
+    md = fourier.get_mag(xd, 512, 32, "blackmanharris", 1)
+    det_args = (sr_h, 512, 32, 0.1, 2.6, 3000, 12000)
+    vol_d, fb_d = oracle_np.band_volume_db(md, *det_args)
+    found = oracle_np.detect_dropouts(md, *det_args, width_ms=20, sensitivity=5)
+    save("detect", vol=vol_d, frame_b=np.array(fb_d), args=np.array(det_args, dtype=np.float64),
+         found=np.array([(a[0], a[1], b[0], b[1]) for a, b in found]))
+
     # ------------------------------ configs 1 and 3 on the reference's own sample files
     # The FLAC files are DATA copied into tests/golden/ (the reference has no tests; these are its demo
     # inputs, named by BASELINE.json configs 1 and 3).  soundfile is absent, so they are decoded with the

@@ -489,3 +489,46 @@ def heal_dropouts(signal, sr, markers, fft_size=512, hop=32, stft_fn=None, istft
         S = S * np.power(10, gain_whole / 20)
         out[:, c] = istft_fn(S, length=n, hop_length=hop)
     return out
+
+
+def band_volume_db(imdata, sr, fft_size, hop, t_0, t_1, f_lower, f_upper):
+    """dropout_healer_gui.py:195-203: mean over the band of to_dB(magnitude), per frame."""
+    db = 20 * np.log10(np.array(imdata))
+    frame_b, frame_a = int(t_0 * sr / hop), int(t_1 * sr / hop)
+    f2b = lambda f: max(1, min(fft_size // 2, int(round(f * fft_size / sr))))
+    return np.mean(db[f2b(f_lower):f2b(f_upper), frame_b:frame_a], axis=0), frame_b
+
+
+def detect_dropouts(imdata, sr, fft_size, hop, t_0, t_1, f_lower, f_upper, width_ms=20, sensitivity=5):
+    """Batch detection branch of dropout_healer_gui.Canvas.on_mouse_release (dropout_healer_gui.py:185-242).
+    imdata = the cached magnitude spectrogram (bins, frames).  -> list of corner pairs (:240)."""
+    import scipy.signal
+    from scipy.signal import savgol_filter
+    vol, frame_b = band_volume_db(imdata, sr, fft_size, hop, t_0, t_1, f_lower, f_upper)
+    t2f = lambda t: int(t * sr / hop)
+    f2t = lambda f: f / sr * hop
+    half_width = width_ms / 1000 / 2
+    fhw = t2f(half_width)
+    vol_lt = savgol_filter(vol, fhw * 12, 5)
+    vol_st = savgol_filter(vol, fhw, 5)
+    peaks, _ = scipy.signal.find_peaks(-vol, height=None, threshold=None, distance=None, prominence=10.0 - sensitivity,
+                                       wlen=None, rel_height=0.5, plateau_size=None)
+    found = []
+    for f_peak in peaks:
+        t_center = f2t(frame_b + f_peak)
+        try:
+            f_qw = t2f(half_width / 4)
+            f_before, f_after = f_peak - f_qw, f_peak + f_qw
+            xp = np.arange(f_before, f_after)
+            parabola = np.poly1d(np.polyfit(xp, vol_st[f_before:f_after], 2), r=False, variable=None)
+            f_hw = t2f(half_width)
+            f_before, f_after = f_peak - f_hw, f_peak + f_hw
+            xp = np.arange(f_before, f_after)
+            fp = parabola(xp)
+            f_intersection = scipy.signal.argrelmin(np.abs(fp - vol_lt[f_before:f_after]))[0]
+            assert len(f_intersection) == 2
+            half_width = f2t(f_intersection[1] - f_intersection[0])
+        except Exception:
+            pass
+        found.append(((t_center - half_width, f_lower), (t_center + half_width, f_upper)))
+    return found

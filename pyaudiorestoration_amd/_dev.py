@@ -27,7 +27,8 @@ def to_dev(a, dtype, dev):
     """numpy (any stride) / torch -> contiguous device tensor of `dtype`."""
     if isinstance(a, torch.Tensor):
         return a.to(device=f"cuda:{dev}", dtype=dtype).contiguous()
-    np_dtype = {torch.float32: np.float32, torch.float64: np.float64, torch.complex64: np.complex64}[dtype]
+    np_dtype = {torch.float32: np.float32, torch.float64: np.float64, torch.complex64: np.complex64,
+                torch.int32: np.int32, torch.int64: np.int64}[dtype]
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np_dtype)).to(f"cuda:{dev}")
 
 

@@ -10,6 +10,8 @@ positions (K_pos) -> sinc resample (K_sinc), with the signal and spectrogram res
 """
 import warnings
 
+import logging
+
 import numpy as np
 import torch
 
@@ -81,17 +83,54 @@ def to_dB(a):
     return 20 * np.log10(a)
 
 
+def marker_geometry(marker, sr, hop, fft_size):
+    """(frame_b, frame_a, frame_surrounding, bin_l, bin_u) of one DropoutSample.to_cfg() tuple
+    (a0, a1, b0, b1, surrounding): the integer arithmetic of dropout_healer_gui.py:99-109,136-142 on
+    width/t/f/height as util/markers.py:368-388 derives them from the two corners."""
+    a0, a1, b0, b1, surrounding = marker
+
+    def t2f(t):
+        return int(t * sr / hop)
+
+    def f2b(f):
+        return max(1, min(fft_size // 2, int(round(f * fft_size / sr))))
+
+    width, t = abs(a0 - b0), (a0 + b0) / 2
+    f, height = (a1 + b1) / 2, abs(a1 - b1)
+    return (t2f(t - width / 2), t2f(t + width / 2), max(1, t2f(width * surrounding)),
+            f2b(f - height / 2), f2b(f + height / 2))
+
+
+def inpaint_gain_dev(spec_fm, geometry, dev=None):
+    """Gain mask (dB, float32 [frames][bins]) for a batch of marker geometries on a frame-major complex64
+    device spectrogram: ONE launch of K_heal for all markers (dropout_healer_gui.py:135-159)."""
+    from . import _lib
+    dev = _dev.device_index(dev)
+    frames, bins = spec_fm.shape
+    geo = np.asarray(geometry, dtype=np.int64).reshape(-1, 5)
+    for (fb, fa, fs, bl, bu) in geo:
+        # the reference would slice with a negative start / past the end and average an empty slice (NaN
+        # gain -> NaN audio), or hand RegularGridInterpolator an empty axis; refuse both
+        if fb - fs < 0 or fa + fs > frames or fa - fb < 1:
+            raise ValueError(f"dropout marker frames [{fb}-{fs}, {fa}+{fs}) leave the {frames}-frame spectrogram or are empty")
+        if bu - bl < 1:
+            raise ValueError("dropout marker spans no frequency bin")
+    gain = torch.zeros((frames, bins), dtype=torch.float32, device=spec_fm.device)
+    if len(geo):
+        geo_t = _dev.to_dev(np.ascontiguousarray(geo, dtype=np.int32), torch.int32, dev)
+        _lib.check(_lib.lib().par_inpaint_gain_db_c64(dev, _dev.ptr(spec_fm), frames, bins, _dev.ptr(geo_t), len(geo),
+                                                      _dev.ptr(gain), _dev.stream_ptr(dev)))
+    return gain
+
+
 def heal_dropouts(signal, sr, markers, fft_size=512, hop=32, channels=None, device=None):
     """Spectral inpainting of marked dropouts -- headless restatement of
     dropout_healer_gui.Canvas.resample_files (dropout_healer_gui.py:111-166).
 
     signal: float32 (n, ch).  markers: iterable of (a0, a1, b0, b1, surrounding) = the reference's
     DropoutSample.to_cfg() (util/markers.py:368-388, 424-426): corner (t, f) pairs and the
-    surrounding factor.  STFT, gain application and ISTFT run on the device; the per-marker target
-    (mean dB of the frames before/after, bilinear fill, clip against earlier markers) is O(box) host
-    math on slices copied back from HBM, like the GUI does it on its cached spectrogram."""
-    import ctypes
-    from scipy.interpolate import RegularGridInterpolator
+    surrounding factor.  STFT, the per-marker targets and gain mask (all markers in one launch), gain
+    application and ISTFT run on the device; only the healed channel returns to the host."""
     from . import _lib
     dev = _dev.device_index(device)
     L = _lib.lib()
@@ -102,38 +141,68 @@ def heal_dropouts(signal, sr, markers, fft_size=512, hop=32, channels=None, devi
     out = np.empty(sig2d.shape, dtype=sig2d.dtype)
     y_pad = fourier.fix_length(sig2d, n + fft_size // 2, axis=0)
     pad_t = _dev.to_dev(y_pad, torch.float32, dev)                      # (n + fft/2, ch) in HBM
-
-    def t2f(t):
-        return int(t * sr / hop)
-
-    def f2b(f):
-        return max(1, min(fft_size // 2, int(round(f * fft_size / sr))))
-
+    geometry = [marker_geometry(m, sr, hop, fft_size) for m in markers]
     for c in channels:
         S = fourier.stft(pad_t.reshape(-1)[c::ch] if ch > 1 else pad_t.reshape(-1), n_fft=fft_size, step=hop)  # (bins, frames) device
-        fm = S.T                                                           # frame-major [frames][bins] view, contiguous
-        gain = torch.zeros(fm.shape, dtype=torch.float32, device=fm.device)
-        for (a0, a1, b0, b1, surrounding) in markers:
-            width, t = abs(a0 - b0), (a0 + b0) / 2
-            f, height = (a1 + b1) / 2, abs(a1 - b1)
-            frame_b, frame_a = t2f(t - width / 2), t2f(t + width / 2)
-            fs = max(1, t2f(width * surrounding))
-            bin_l, bin_u = f2b(f - height / 2), f2b(f + height / 2)
-            box = fm[frame_b - fs:frame_a + fs, bin_l:bin_u].cpu().numpy()      # small D2H
-            db = to_dB(np.abs(box.astype(np.complex128)) + .0000001).T           # (bins, frames) like the reference
-            mag_before = np.mean(db[:, 0:fs], axis=1)
-            mag_after = np.mean(db[:, fs + (frame_a - frame_b):fs + (frame_a - frame_b) + fs], axis=1)
-            fp_frames = np.linspace(frame_b, frame_a, num=frame_a - frame_b)
-            fp_bins = np.linspace(bin_l, bin_u, num=bin_u - bin_l)
-            interp = RegularGridInterpolator(((frame_b, frame_a), fp_bins), (mag_before, mag_after))
-            mp_bins, mp_frames = np.meshgrid(fp_bins, fp_frames)
-            fp_db = np.swapaxes(interp((mp_frames, mp_bins)), 0, 1)
-            gain_db = fp_db - db[:, fs:fs + (frame_a - frame_b)]
-            prev = gain[frame_b:frame_a, bin_l:bin_u].cpu().numpy().T.astype(np.float64)
-            np.clip(gain_db, prev, 255, out=gain_db)
-            gain[frame_b:frame_a, bin_l:bin_u] = torch.from_numpy(np.ascontiguousarray(gain_db.T, dtype=np.float32)).to(gain.device)
-        healed = fm.contiguous()
+        healed = S.T.contiguous()                                          # frame-major [frames][bins]
+        gain = inpaint_gain_dev(healed, geometry, dev)
         _lib.check(L.par_spec_apply_gain_db_c64(dev, _dev.ptr(healed), _dev.ptr(gain), healed.numel(), _dev.stream_ptr(dev)))
         y = fourier.istft(healed.T, length=n, hop_length=hop)
         out[:, c] = y.cpu().numpy()
     return out
+
+
+def band_volume_db(mag, sr, fft_size, hop, t_0, t_1, f_lower, f_upper, device=None):
+    """Volume curve of the dropout detector (dropout_healer_gui.py:195-203): mean over bins
+    [bin_l, bin_u) of to_dB(magnitude) for frames [frame_b, frame_a).  mag: (bins, frames) magnitude as
+    fourier.get_mag returns it (device tensor, or numpy which is uploaded).  -> (vol f64 numpy, frame_b)."""
+    from . import _lib
+    dev = _dev.device_index(device)
+    if not torch.is_tensor(mag):
+        mag = _dev.to_dev(np.ascontiguousarray(np.asarray(mag, dtype=np.float32).T), torch.float32, dev).T
+    fm = mag.T if mag.T.is_contiguous() else mag.T.contiguous()
+    frames, bins = fm.shape
+    frame_b, frame_a = int(t_0 * sr / hop), int(t_1 * sr / hop)
+    f2b = lambda f: max(1, min(fft_size // 2, int(round(f * fft_size / sr))))
+    bin_l, bin_u = f2b(f_lower), f2b(f_upper)
+    frame_a = min(frame_a, frames)                                        # numpy slicing clamps the end
+    vol = _dev.empty(max(0, frame_a - frame_b), torch.float64, dev)
+    _lib.check(_lib.lib().par_band_mean_db_f32(dev, _dev.ptr(fm), frames, bins, bin_l, bin_u, frame_b, frame_a,
+                                               _dev.ptr(vol), _dev.stream_ptr(dev)))
+    return vol.cpu().numpy(), frame_b
+
+
+def detect_dropouts(mag, sr, fft_size, hop, t_0, t_1, f_lower, f_upper, width_ms=20, sensitivity=5, device=None):
+    """Batch dropout detection -- headless restatement of the Alt-drag branch of
+    dropout_healer_gui.Canvas.on_mouse_release (dropout_healer_gui.py:185-242).  The band volume curve
+    (the only pass over the spectrogram) runs on the device; the valley search on that short curve uses the
+    same scipy calls as the reference (savgol_filter, find_peaks prominence, polyfit refinement).
+    Returns [((t_before, f_lower), (t_after, f_upper)), ...] = the corner pairs the reference hands to
+    DropoutSample (:240).  width_ms / sensitivity are DropoutWidget.width / .sensitivity (util/widgets.py:715-727)."""
+    import scipy.signal
+    from scipy.signal import savgol_filter
+    vol, frame_b = band_volume_db(mag, sr, fft_size, hop, t_0, t_1, f_lower, f_upper, device)
+    t2f = lambda t: int(t * sr / hop)
+    f2t = lambda f: f / sr * hop
+    half_width = width_ms / 1000 / 2
+    frames_half_width = t2f(half_width)
+    vol_lt = savgol_filter(vol, frames_half_width * 12, 5)
+    vol_st = savgol_filter(vol, frames_half_width, 5)
+    peaks, _ = scipy.signal.find_peaks(-vol, prominence=10.0 - sensitivity, rel_height=0.5)
+    found = []
+    for f_peak in peaks:
+        t_center = f2t(frame_b + f_peak)
+        try:
+            f_qw = t2f(half_width / 4)
+            xp = np.arange(f_peak - f_qw, f_peak + f_qw)
+            parabola = np.poly1d(np.polyfit(xp, vol_st[f_peak - f_qw:f_peak + f_qw], 2))
+            f_hw = t2f(half_width)
+            f_before, f_after = f_peak - f_hw, f_peak + f_hw
+            fp = parabola(np.arange(f_before, f_after))
+            f_intersection = scipy.signal.argrelmin(np.abs(fp - vol_lt[f_before:f_after]))[0]
+            assert len(f_intersection) == 2
+            half_width = f2t(f_intersection[1] - f_intersection[0])       # (sic) carried over to later peaks, :232
+        except Exception:
+            logging.exception(f"Could not refine width at peak {f_peak}")
+        found.append(((t_center - half_width, f_lower), (t_center + half_width, f_upper)))
+    return found

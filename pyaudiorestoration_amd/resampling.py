@@ -134,6 +134,29 @@ def speed_to_pos(sampletimes, speeds, num_imput_samples):
 
 # ----------------------------------------------------------------------------- interpolation
 
+def lag_to_pos_dev(lag_curve, sr, num_input_samples, dev=None):
+    """Lag-curve branch of resampling.run (util/resampling.py:189-206) on the device: np.interp over
+    arange(num_output_samples), find_cutoff trim and clip(0) in one kernel; the float64 position array is
+    born in HBM.  lag_curve: (m, 2) array of (time s, lag s).  -> device f64 positions (trimmed view)."""
+    dev = _dev.device_index(dev)
+    lag_curve = np.asarray(lag_curve, dtype=np.float64)
+    sampletimes = lag_curve[:, 0] * sr
+    lags = lag_curve[:, 1] * sr
+    num_output_samples = num_input_samples + abs(lags[-1])
+    num_out = int(np.ceil(num_output_samples))                        # len(np.arange(float stop))
+    xp_t = _dev.to_dev(sampletimes, torch.float64, dev)
+    fp_t = _dev.to_dev(sampletimes - lags, torch.float64, dev)
+    pos_t = _dev.empty(num_out, torch.float64, dev)
+    work = _dev.empty(1, torch.int64, dev)
+    len_out, trimmed = ctypes.c_int64(0), ctypes.c_int(0)
+    _lib.check(_lib.lib().par_lag_to_pos_f64(dev, _dev.ptr(xp_t), _dev.ptr(fp_t), len(sampletimes), num_out,
+                                             int(num_input_samples), _dev.ptr(pos_t), _dev.ptr(work),
+                                             ctypes.byref(len_out), ctypes.byref(trimmed), _dev.stream_ptr(dev)))
+    if trimmed.value:
+        logging.debug(f"Trimmed to sample {len_out.value}")
+    return pos_t[:len_out.value]
+
+
 def sinc_resample_dev(pos_t, sig_t, NT, out_t=None, sig_stride=1, len_in=None, out_stride=1, dev=None):
     """pos_t float64[len_out], sig_t float32 (stride sig_stride) -> float32 out (stride out_stride)."""
     dev = _dev.device_index(dev if dev is not None else pos_t.device)
@@ -221,16 +244,7 @@ def run(filenames, signal_data=None, speed_curve=None, resampling_mode="Linear",
                     _lib.check(_lib.lib().par_speed_to_pos_fill(dev, _dev.ptr(sp_t), plan.m, _dev.ptr(plan.work),
                                                                 _dev.ptr(pos_t), plan.len_out, _dev.stream_ptr(dev)))
             elif lag_curve is not None:
-                sampletimes = lag_curve[:, 0] * sr
-                lags = lag_curve[:, 1] * sr
-                num_output_samples = n_in + abs(lags[-1])
-                sample_at = np.interp(np.arange(num_output_samples), sampletimes, sampletimes - lags)
-                trim_end = find_cutoff(sample_at, n_in)
-                if trim_end is not None:
-                    logging.debug(f"Trimmed to sample {trim_end[0]}")
-                    sample_at = sample_at[:trim_end[0]]
-                np.clip(sample_at, 0, None, out=sample_at)
-                pos_t = _dev.to_dev(sample_at, torch.float64, dev)
+                pos_t = lag_to_pos_dev(lag_curve, sr, n_in, dev)
             else:
                 raise UnboundLocalError("local variable 'sample_at' referenced before assignment")  # reference behaviour
         if use_channels:

@@ -54,3 +54,13 @@ def pilot(n, sr, f0=4000.0, fm_hz=8.0, fm_depth=0.005, noise_db=-60.0, seed=3):
 def checksum(a):
     a = np.ascontiguousarray(a)
     return float(np.sum(a.astype(np.float64) * (1 + (np.arange(a.size) % 7))))
+
+
+def detect_input(sr=44100, n=120000):
+    """Broadband noise + tone with four smooth-edged dropouts (-20..-26 dB, 8..20 ms) for the detector tests."""
+    x = 0.2 * noise(n, 77) + sine(n, 5000.0, sr, 0.2)
+    env = np.ones(n)
+    for (c, w, depth) in ((20000, 500, 0.05), (47000, 700, 0.08), (80500, 880, 0.05), (101000, 360, 0.1)):
+        k = np.arange(c - w, c + w)
+        env[k] = np.minimum(env[k], 1 - (1 - depth) * np.hanning(2 * w) ** 0.25)
+    return (x * env).astype(np.float32)

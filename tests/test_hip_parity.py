@@ -217,6 +217,29 @@ def test_linear_and_lag_golden(par, golden):
     assert relerr(got, g["lin"]) < 1e-6
 
 
+def test_lag_curve_positions_bit_exact(par, golden, tmp_path):
+    """K_lag: np.interp over arange + find_cutoff + clip restated on the device, bit for bit; and the lag branch
+    of resampling.run end to end."""
+    from oracle import oracle_np as O
+    from pyaudiorestoration_amd import io_ops
+    g = golden["linear_lag"]
+    sig = inputs.noise(5000, 50)
+    pos = par.resampling.lag_to_pos_dev(g["lag"], int(g["sr"]), len(sig)).cpu().numpy()
+    assert pos.shape == g["pos"].shape and np.array_equal(pos, g["pos"])
+    rng = np.random.default_rng(11)
+    for n, m in ((100000, 40), (7777, 2), (300000, 500)):
+        t = np.sort(rng.uniform(0, n / 48000, m))
+        t[0] = 0.0
+        lag = np.stack((t, np.cumsum(rng.normal(0, 2e-4, m))), axis=-1)
+        want = O.lag_to_positions(lag, 48000, n)
+        got = par.resampling.lag_to_pos_dev(lag, 48000, n).cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (n, m)
+    fn = str(tmp_path / "sync.wav")
+    par.resampling.run((fn,), signal_data=((sig[:, None], int(g["sr"])),), lag_curve=g["lag"], resampling_mode="Linear")
+    y, _, _ = io_ops.read_file(str(tmp_path / "sync_res.wav"))
+    assert relerr(y[:, 0], g["lin"]) < 1e-6
+
+
 def test_run_writes_res_wav_like_reference(par, golden, tmp_path):
     """resampling.run drop-in: progress callbacks, channel filtering, output naming, FLOAT wav."""
     from pyaudiorestoration_amd import io_ops
@@ -389,6 +412,41 @@ def test_heal_dropouts_config4(par, golden):
     st = np.stack((x, x[::-1].copy()), axis=-1)                     # stereo, channel views stay strided on the device
     y2 = par.pipeline.heal_dropouts(st, sr, [tuple(m) for m in g["marks"]], 512, 32, channels=(0,))
     assert relerr(y2[:, 0], g["y"]) < TOL
+
+
+def test_heal_batched_markers_one_launch(par):
+    """Config 4 shape: the signal tiled x8 with the markers repeated per tile -- all 24 gain boxes come from ONE
+    K_heal launch (atomic max == the reference's marker-by-marker clip) and must match the oracle's serial loop."""
+    from oracle import oracle_np as O
+    from test_oracle_golden import heal_input
+    sr, tiles = 44100, 8
+    x1 = heal_input(sr)
+    x = np.tile(x1, tiles)
+    base = [(0.2000, 500.0, 0.2110, 6000.0, 0.5), (0.4500, 800.0, 0.4680, 9000.0, 0.5), (0.2050, 1000.0, 0.2150, 3000.0, 1.0)]
+    marks = [(a0 + k * len(x1) / sr, a1, b0 + k * len(x1) / sr, b1, s) for k in range(tiles) for (a0, a1, b0, b1, s) in base]
+    want = O.heal_dropouts(x, sr, marks, 512, 32)
+    got = par.pipeline.heal_dropouts(x, sr, marks, 512, 32)
+    assert relerr(got[:, 0], want[:, 0]) < TOL
+    with pytest.raises(ValueError):
+        par.pipeline.heal_dropouts(x1, sr, [(0.0, 500.0, 0.01, 6000.0, 0.5)], 512, 32)      # surrounding frames < 0
+
+
+def test_dropout_detector_matches_golden(par, golden):
+    """Detector: device get_mag -> K_heal band volume -> scipy valley search == fixture from the reference's get_mag."""
+    g = golden["detect"]
+    sr, fft, hop, t0, t1, fl, fu = g["args"]
+    x = par.torch.from_numpy(inputs.detect_input(int(sr))).cuda()
+    m = par.fourier.get_mag(x, int(fft), int(hop), "blackmanharris", 1)
+    vol, fb = par.pipeline.band_volume_db(m, int(sr), int(fft), int(hop), t0, t1, fl, fu)
+    assert fb == int(g["frame_b"]) and np.abs(vol - g["vol"]).max() < 1e-4           # dB
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        found = par.pipeline.detect_dropouts(m, int(sr), int(fft), int(hop), t0, t1, fl, fu, 20, 5)
+    got = np.array([(a[0], a[1], b[0], b[1]) for a, b in found])
+    assert got.shape == g["found"].shape and np.abs(got - g["found"]).max() < 1e-9
+    m_np = par.pipeline.band_volume_db(m.cpu().numpy(), int(sr), int(fft), int(hop), t0, t1, fl, fu)[0]   # numpy spectrogram in
+    assert np.array_equal(m_np, vol)
 
 
 def test_fused_varispeed_equals_position_array_path(par):

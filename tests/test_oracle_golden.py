@@ -1,5 +1,7 @@
 """Pins oracle/oracle_np.py (the CPU restatement) to golden vectors captured from the
 real reference by oracle/gen_golden.py.  CPU-only."""
+import warnings
+
 import numpy as np
 import pytest
 
@@ -262,6 +264,23 @@ def test_heal_dropouts_config4(golden):
     assert relerr(y[:, 0], g["y"]) < 2e-6
     assert np.abs(y[9000:9300, 0]).mean() > 4 * np.abs(x[9000:9300]).mean()      # the dropout was lifted
     assert relerr(y[:8000, 0], x[:8000]) < 1e-4                                   # untouched region survives the round trip
+
+
+def test_dropout_detector(golden):
+    """dropout_healer_gui.py:185-242 restated on the oracle's get_mag vs the fixture made on the reference's."""
+    g = golden["detect"]
+    sr, fft, hop, t0, t1, fl, fu = g["args"]
+    m = O.get_mag(inputs.detect_input(int(sr)), int(fft), int(hop), "blackmanharris", 1)
+    vol, fb = O.band_volume_db(m, int(sr), int(fft), int(hop), t0, t1, fl, fu)
+    assert fb == int(g["frame_b"]) and np.abs(vol - g["vol"]).max() < 1e-4           # dB
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        found = O.detect_dropouts(m, int(sr), int(fft), int(hop), t0, t1, fl, fu, 20, 5)
+    got = np.array([(a[0], a[1], b[0], b[1]) for a, b in found])
+    assert got.shape == g["found"].shape and np.abs(got - g["found"]).max() < 1e-9
+    centres = (got[:, 0] + got[:, 2]) / 2
+    for c in (20000, 47000, 80500, 101000):                                          # every planted dropout is found
+        assert np.abs(centres - c / sr).min() < 0.004
 
 
 # ------------------------------------------------- BASELINE configs 1 and 3 on the reference's sample files
