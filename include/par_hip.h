@@ -65,10 +65,13 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
  * window_sumsquare (:492-546) and __overlap_add (:677-687).  Does NOT mutate `spec`.
  *   spec     device complex64 [n_frames][bins] frame-major (bins = n_fft/2+1)
  *   window   device f32[n_fft]  (get_window(name, n_fft, fftbins=True))
- *   frames   device f32 scratch [n_frames][n_fft]
+ *   frames   device f32 scratch of par_istft_scratch_floats(n_frames, n_fft, hop) floats; that is 0 (pass NULL)
+ *            when the frames are overlap-added in LDS and never stored (the overlap-add span of one workgroup
+ *            fits 64 KB: every shipped size), else [n_frames][n_fft]
  *   y        device f32[y_len]; y[t] = ola[t + skip] / sumsq[t + skip] (0 beyond the ola length),
  *            skip = n_fft/2 and y_len = `length` reproduce fix_length(y[n_fft//2:], length) (:430-435).
  */
+int64_t par_istft_scratch_floats(int64_t n_frames, int n_fft, int hop);
 int par_istft_f32(int device, const float* spec, int64_t n_frames, int n_fft, int hop, const float* window,
                   float* frames, float* y, int64_t y_len, int64_t skip, void* stream);
 

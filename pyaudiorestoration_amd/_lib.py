@@ -29,6 +29,7 @@ SIGNATURES = {
     "par_stream_sync": (c_int, [c_int, c_vp]),
     "par_stft_frames": (c_i64, [c_i64, c_int, c_int]),
     "par_stft_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
+    "par_istft_scratch_floats": (c_i64, [c_i64, c_int, c_int]),
     "par_istft_f32": (c_int, [c_int, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "par_spec_apply_gain_db_c64": (c_int, [c_int, c_vp, c_vp, c_i64, c_vp]),
     "par_inpaint_gain_db_c64": (c_int, [c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),

@@ -354,9 +354,141 @@ __global__ __launch_bounds__(256) void k_istft_ola(const float* __restrict__ fra
   y[t] = acc;
 }
 
+// Fused ISTFT: the [n_frames][n_fft] time-frame array never exists in HBM (at hop = n_fft/16 it is 16x the signal,
+// written once and read once by the two-kernel path).  A workgroup owns NF = Frames*s consecutive frames,
+// s = ceil(n_fft/hop) being the spacing at which frames stop overlapping.  Round r = 0..s-1 inverse-transforms the
+// Frames frames F0 + r + u*s: they are pairwise disjoint in time, so each frame's own lanes add it straight into
+// the LDS overlap-add accumulator with plain read-modify-writes; one workgroup barrier per round orders the
+// rounds.  The summation order per sample is fixed (by round), so results are reproducible run to run.
+// The workgroup writes the (NF - s + 1)*hop samples that only its own frames cover; the s-1 frames on either side
+// are transformed by the neighbour as well ((s-1)/NF extra work: 12 % at 512/32).
+template <int LOGH>
+__global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_istft_fused(const float2* __restrict__ spec, int64_t n_frames,
+                                                                         int hop, int s, const float* __restrict__ window,
+                                                                         const float2* __restrict__ tw,
+                                                                         const float2* __restrict__ post,
+                                                                         float* __restrict__ y, int64_t y_len, int64_t skip,
+                                                                         float scale) {
+  using G = FftGeom<LOGH>;
+  constexpr int H = G::H, T = G::T, bins = H + 1, n_fft = 2 * H;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  float* acc = reinterpret_cast<float*>(lds + G::Frames * G::FrameLds);
+  const int tid = threadIdx.x;
+  const int u = tid / T, j = tid - u * T;
+  float2* X = lds + u * G::FrameLds;
+  const int NF = G::Frames * s;
+  const int out_frames = NF - s + 1;
+  const int acc_len = (NF - 1) * hop + n_fft;
+  const int64_t F0 = (int64_t)blockIdx.x * out_frames - (s - 1);      // first frame of the workgroup (may be < 0)
+  for (int i = tid; i < acc_len; i += G::Threads) acc[i] = 0.0f;
+  // this lane's window taps are the same for every frame: keep them in registers
+  float2 wq[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) wq[q] = *reinterpret_cast<const float2*>(window + 2 * (j + q * T));
+  for (int r = 0; r < s; ++r) {
+    const int lf = r + u * s;                                         // frame index inside the workgroup
+    const int64_t fr = F0 + lf;
+    const bool live = fr >= 0 && fr < n_frames;
+    float2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = j + q * T;
+      float2 z = make_float2(0.0f, 0.0f);
+      if (live) {
+        float2 a = spec[fr * bins + k];
+        float2 b = spec[fr * bins + (H - k)];
+        if (k == 0) {
+          a.y = 0.0f;
+          b.y = 0.0f;
+        }
+        b = cconj(b);
+        const float2 ev = cadd(a, b);
+        const float2 od = cmul(cconj(post[k]), csub(a, b));
+        z = make_float2(0.5f * (ev.x - od.y), -0.5f * (ev.y + od.x));
+      }
+      v[q] = z;
+    }
+    fft_core<LOGH>(v, X, j, tw);
+    __syncthreads();                                                  // the previous round's adds (and the zeroing) are done
+    if (live) {
+      float* dst = acc + lf * hop;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = j + q * T;
+        const float2 z = X[lpad(i)];                                  // conj(FFT(conj Z)): y[2i] = re, y[2i+1] = -im
+        const float a0 = z.x * scale * wq[q].x, a1 = -z.y * scale * wq[q].y;
+        if ((hop & 1) == 0) {
+          float2 t = *reinterpret_cast<float2*>(dst + 2 * i);
+          t.x += a0;
+          t.y += a1;
+          *reinterpret_cast<float2*>(dst + 2 * i) = t;
+        } else {
+          dst[2 * i] += a0;
+          dst[2 * i + 1] += a1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* wl = reinterpret_cast<float*>(lds);                           // frame slots are free now: stage the window there
+  for (int i = tid; i < n_fft; i += G::Threads) wl[i] = window[i];
+  __syncthreads();
+  const int64_t ola_len = (int64_t)n_fft + (int64_t)hop * (n_frames - 1);
+  const int out_len = out_frames * hop;
+  const int64_t TT0 = (int64_t)blockIdx.x * out_len;                  // overlap-add coordinate of the first owned sample
+  for (int p = tid; p < out_len; p += G::Threads) {
+    const int64_t TT = TT0 + p, t = TT - skip;
+    if (t < 0) continue;
+    if (t >= y_len) break;
+    float a = 0.0f;
+    if (TT < ola_len) {
+      int64_t e_hi = TT / hop;
+      if (e_hi > n_frames - 1) e_hi = n_frames - 1;
+      const int64_t e_lo = (TT - n_fft + 1 <= 0) ? 0 : (TT - n_fft + hop) / hop;
+      float env = 0.0f;
+      for (int64_t e = e_lo; e <= e_hi; ++e) {
+        const float w = wl[TT - e * hop];
+        env += w * w;
+      }
+      a = acc[p + (s - 1) * hop];
+      if (env > 1.17549435e-38f) a /= env;                           // > tiny(float32)  (:414-415)
+    }
+    y[t] = a;
+  }
+}
+
+// bytes of LDS the fused ISTFT needs for (n_fft, hop); it is used when they fit 64 KB
+template <int LOGH>
+static inline size_t istft_fused_lds(int hop) {
+  using G = FftGeom<LOGH>;
+  const int64_t n_fft = 2 * G::H, s = (n_fft + hop - 1) / hop;
+  return (size_t)G::Frames * G::FrameLds * sizeof(float2) + (size_t)((G::Frames * s - 1) * hop + n_fft) * sizeof(float);
+}
+static inline size_t istft_fused_lds_any(int n_fft, int hop) {
+  switch (n_fft) {
+    case 16: return istft_fused_lds<3>(hop);
+    case 32: return istft_fused_lds<4>(hop);
+    case 64: return istft_fused_lds<5>(hop);
+    case 128: return istft_fused_lds<6>(hop);
+    case 256: return istft_fused_lds<7>(hop);
+    case 512: return istft_fused_lds<8>(hop);
+    case 1024: return istft_fused_lds<9>(hop);
+    case 2048: return istft_fused_lds<10>(hop);
+    case 4096: return istft_fused_lds<11>(hop);
+    case 8192: return istft_fused_lds<12>(hop);
+  }
+  return (size_t)-1;
+}
+static inline bool istft_is_fused(int n_fft, int hop) { return hop >= 1 && istft_fused_lds_any(n_fft, hop) <= 64 * 1024; }
+
 }  // namespace par
 
 extern "C" {
+
+int64_t par_istft_scratch_floats(int64_t n_frames, int n_fft, int hop) {
+  if (n_frames < 1 || n_fft < 1 || hop < 1) return 0;
+  return par::istft_is_fused(n_fft, hop) ? 0 : n_frames * (int64_t)n_fft;
+}
 
 int64_t par_stft_frames(int64_t n, int n_fft, int hop) {
   if (n < 1 || n_fft < 1 || hop < 1) return 0;
@@ -410,7 +542,7 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
 int par_istft_f32(int device, const float* spec, int64_t n_frames, int n_fft, int hop, const float* window,
                   float* frames, float* y, int64_t y_len, int64_t skip, void* stream) {
   using namespace par;
-  PAR_REQUIRE(spec && window && frames && y, PAR_ERR_ARG, "par_istft_f32: null pointer");
+  PAR_REQUIRE(spec && window && y, PAR_ERR_ARG, "par_istft_f32: null pointer");
   PAR_REQUIRE(n_frames >= 1 && hop >= 1 && y_len >= 0 && skip >= 0, PAR_ERR_ARG, "par_istft_f32: bad sizes");
   PAR_REQUIRE(n_fft >= 16 && n_fft <= 8192 && (n_fft & (n_fft - 1)) == 0, PAR_ERR_UNSUPPORTED,
               "par_istft_f32: n_fft=%d is not a power of two in [16, 8192]", n_fft);
@@ -422,6 +554,34 @@ int par_istft_f32(int device, const float* spec, int64_t n_frames, int n_fft, in
   // spec * sqrt(n_fft) (:359) and the 1/H of the H-point complex inverse fold into one factor
   const float scale = (float)(sqrt((double)n_fft) / (double)H);
   const float2* sp2 = reinterpret_cast<const float2*>(spec);
+  if (istft_is_fused(n_fft, hop)) {
+    if (y_len == 0) return PAR_OK;
+    const int s = (n_fft + hop - 1) / hop;
+#define PAR_ISTFT_FUSED(LH)                                                                                             \
+  {                                                                                                                     \
+    const int64_t out_len = (int64_t)(FftGeom<LH>::Frames * s - s + 1) * hop;                                             \
+    hipLaunchKernelGGL(k_istft_fused<LH>, dim3((unsigned)ceil_div(y_len + skip, out_len)), dim3(FftGeom<LH>::Threads),    \
+                       istft_fused_lds<LH>(hop), as_stream(stream), sp2, n_frames, hop, s, window, tw.w, tw.post, y,     \
+                       y_len, skip, scale);                                                                              \
+  }
+    switch (ilog2(H)) {
+      case 3: PAR_ISTFT_FUSED(3); break;
+      case 4: PAR_ISTFT_FUSED(4); break;
+      case 5: PAR_ISTFT_FUSED(5); break;
+      case 6: PAR_ISTFT_FUSED(6); break;
+      case 7: PAR_ISTFT_FUSED(7); break;
+      case 8: PAR_ISTFT_FUSED(8); break;
+      case 9: PAR_ISTFT_FUSED(9); break;
+      case 10: PAR_ISTFT_FUSED(10); break;
+      case 11: PAR_ISTFT_FUSED(11); break;
+      case 12: PAR_ISTFT_FUSED(12); break;
+      default: PAR_REQUIRE(false, PAR_ERR_UNSUPPORTED, "par_istft_f32: unsupported size");
+    }
+#undef PAR_ISTFT_FUSED
+    PAR_HIP_CHECK(hipGetLastError());
+    return PAR_OK;
+  }
+  PAR_REQUIRE(frames, PAR_ERR_ARG, "par_istft_f32: n_fft=%d hop=%d needs the frames scratch (par_istft_scratch_floats)", n_fft, hop);
 #define PAR_ISTFT_LAUNCH(LH)                                                                                            \
   hipLaunchKernelGGL(k_istft_frames<LH>, dim3((unsigned)ceil_div(n_frames, FftGeom<LH>::Frames)),                         \
                      dim3(FftGeom<LH>::Threads), (size_t)FftGeom<LH>::Frames * FftGeom<LH>::FrameLds * sizeof(float2),      \

@@ -97,13 +97,14 @@ def istft_dev(spec_t, hop_length, window_t, length=None, dev=None):
         n_frames = min(total_frames, int(np.ceil((length + n_fft) / hop_length)))
     else:
         n_frames = total_frames
-    frames = _dev.empty((n_frames, n_fft), torch.float32, dev)
+    scratch = int(L.par_istft_scratch_floats(n_frames, n_fft, hop_length))        # 0: frames are overlap-added in LDS
+    frames = _dev.empty(scratch, torch.float32, dev) if scratch else None
     if length is None:
         y_len = hop_length * (n_frames - 1)         # y[n_fft//2 : -(n_fft//2)]
     else:
         y_len = int(length)
     y = _dev.empty(max(y_len, 0), torch.float32, dev)
-    _lib.check(L.par_istft_f32(dev, _dev.ptr(fm), n_frames, n_fft, hop_length, _dev.ptr(window_t), _dev.ptr(frames),
+    _lib.check(L.par_istft_f32(dev, _dev.ptr(fm), n_frames, n_fft, hop_length, _dev.ptr(window_t), _dev.ptr(frames) if scratch else None,
                                _dev.ptr(y), y.numel(), n_fft // 2, _dev.stream_ptr(dev)))
     return y
 

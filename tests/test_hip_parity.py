@@ -116,6 +116,27 @@ def test_istft_heal_framing_and_device_roundtrip(par, golden):
     assert relerr(yt.cpu().numpy(), xt.cpu().numpy()) < TOL
 
 
+@pytest.mark.parametrize("n_fft,hop", [(16, 4), (64, 7), (256, 64), (512, 1), (512, 33), (1024, 256), (2048, 512),
+                                       (4096, 1024), (8192, 2048), (256, 300), (128, 5000)])
+def test_istft_size_matrix_vs_oracle(par, n_fft, hop):
+    """Every transform size, even/odd/tiny/oversized hops: the fused LDS overlap-add (and, for (128, 5000) and 8192/2048, the
+    two-kernel path whose overlap-add span does not fit LDS) against the oracle on a modified spectrogram."""
+    from oracle import oracle_np as O
+    n = max(6 * n_fft, 3000) + 37
+    if hop == 5000:
+        n = 60000
+    x = inputs.noise(n, n_fft + hop)
+    S = O.stft(x, n_fft, hop, "blackmanharris").astype(np.complex64)
+    S[1:n_fft // 4, ::2] *= 0.5
+    for length in (n, None, n // 2 + 3):
+        want = O.istft(S, hop, "blackmanharris", length)
+        got = par.fourier.istft(S, hop_length=hop, length=length)
+        assert got.shape == want.shape and relerr(got, want) < TOL, (n_fft, hop, length)
+    from pyaudiorestoration_amd import _lib
+    L = _lib.lib()
+    assert (L.par_istft_scratch_floats(10, n_fft, hop) != 0) == (hop == 5000 or n_fft == 8192)   # only these spans exceed 64 KB of LDS
+
+
 # ------------------------------------------------------------------------------- positions
 def test_speed_to_pos_golden_bit_exact(par, golden):
     g = golden["speed_to_pos"]
