@@ -90,6 +90,13 @@ int par_spec_apply_gain_db_c64(int device, float* spec, const float* gain_db, in
 int par_inpaint_gain_db_c64(int device, const float* spec, int64_t n_frames, int64_t bins, const int32_t* markers,
                             int64_t n_markers, float* gain_db, void* stream);
 
+/* Apply the mask over the marker boxes only and clear it (dropout_healer_gui.py:161-162 restricted to where the
+ * mask can be non-zero): spec[i] *= 10^(gain_db[i]/20), gain_db[i] = 0 for every bin of every box; a bin inside
+ * several boxes is scaled once.  `markers` as for par_inpaint_gain_db_c64.  Leaves gain_db all zeros, ready for
+ * the next file, so a batch driver zero-fills the mask once per allocation, not once per file. */
+int par_spec_apply_gain_boxes_c64(int device, float* spec, int64_t n_frames, int64_t bins, const int32_t* markers,
+                                  int64_t n_markers, float* gain_db, void* stream);
+
 /* Band volume curve of the dropout detector (dropout_healer_gui.py:195-203):
  * out[i] = mean_b 20*log10(mag[frame_b+i][b]), b in [bin_l, bin_u), i in [0, frame_a-frame_b); f64 out.
  *   mag  device f32 [n_frames][bins] frame-major magnitude (get_mag output, already + 1e-7). */

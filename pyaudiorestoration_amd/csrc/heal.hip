@@ -52,6 +52,30 @@ __global__ void __launch_bounds__(256) k_inpaint_gain(const float2* __restrict__
   }
 }
 
+// Apply-and-clear over the marker boxes only: spec *= 10^(gain/20) (util/units.py:28-29 to_fac) for every masked
+// bin, taking the mask value with an atomic exchange so that a bin inside several overlapping boxes is scaled
+// exactly once; the mask is all zeros again afterwards (no dense zero-fill / dense apply pass per file).
+__global__ void __launch_bounds__(256) k_apply_gain_boxes(float2* __restrict__ spec, int64_t n_frames, int64_t bins,
+                                                          const int32_t* __restrict__ markers, float* __restrict__ gain) {
+  const int32_t* mk = markers + (int64_t)blockIdx.x * 5;
+  const int64_t frame_b = mk[0], frame_a = mk[1], fs = mk[2];
+  const int bin_l = mk[3], bin_u = mk[4];
+  if (fs < 1 || frame_a - frame_b < 1 || frame_b - fs < 0 || frame_a + fs > n_frames || bin_l < 0 || bin_u > bins) return;
+  const int nb = bin_u - bin_l;
+  if (nb < 1) return;
+  const int64_t total = (frame_a - frame_b) * nb;
+  for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
+    const int64_t idx = (frame_b + e / nb) * bins + bin_l + (e % nb);
+    const float g = __int_as_float(atomicExch(reinterpret_cast<int*>(gain + idx), 0));
+    if (g == 0.0f) continue;
+    const float f = exp2f(g * 0.16609640474436813f);     // 10^(g/20) = 2^(g*log2(10)/20)
+    float2 v = spec[idx];
+    v.x *= f;
+    v.y *= f;
+    spec[idx] = v;
+  }
+}
+
 // one wave per frame, lanes stride over the band; mag is the float32 magnitude (already + 1e-7)
 __global__ void __launch_bounds__(256) k_band_mean_db(const float* __restrict__ mag, int64_t bins, int bin_l, int bin_u,
                                                       int64_t frame_b, int64_t count, double* __restrict__ out) {
@@ -78,6 +102,20 @@ extern "C" int par_inpaint_gain_db_c64(int device, const float* spec, int64_t n_
   PAR_HIP_CHECK(hipSetDevice(device));
   hipLaunchKernelGGL(k_inpaint_gain, dim3((unsigned)n_markers), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float2*>(spec), n_frames, bins, markers, gain_db);
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
+extern "C" int par_spec_apply_gain_boxes_c64(int device, float* spec, int64_t n_frames, int64_t bins, const int32_t* markers,
+                                             int64_t n_markers, float* gain_db, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(spec && markers && gain_db && n_frames > 0 && bins > 0 && n_markers >= 0, PAR_ERR_ARG,
+              "par_spec_apply_gain_boxes_c64: bad args");
+  if (n_markers == 0) return PAR_OK;
+  PAR_REQUIRE(n_markers <= 0x7fffffff, PAR_ERR_ARG, "par_spec_apply_gain_boxes_c64: too many markers");
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipLaunchKernelGGL(k_apply_gain_boxes, dim3((unsigned)n_markers), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<float2*>(spec), n_frames, bins, markers, gain_db);
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }

@@ -101,13 +101,7 @@ def marker_geometry(marker, sr, hop, fft_size):
             f2b(f - height / 2), f2b(f + height / 2))
 
 
-def inpaint_gain_dev(spec_fm, geometry, dev=None):
-    """Gain mask (dB, float32 [frames][bins]) for a batch of marker geometries on a frame-major complex64
-    device spectrogram: ONE launch of K_heal for all markers (dropout_healer_gui.py:135-159)."""
-    from . import _lib
-    dev = _dev.device_index(dev)
-    frames, bins = spec_fm.shape
-    geo = np.asarray(geometry, dtype=np.int64).reshape(-1, 5)
+def _check_geometry(geo, frames):
     for (fb, fa, fs, bl, bu) in geo:
         # the reference would slice with a negative start / past the end and average an empty slice (NaN
         # gain -> NaN audio), or hand RegularGridInterpolator an empty axis; refuse both
@@ -115,11 +109,42 @@ def inpaint_gain_dev(spec_fm, geometry, dev=None):
             raise ValueError(f"dropout marker frames [{fb}-{fs}, {fa}+{fs}) leave the {frames}-frame spectrogram or are empty")
         if bu - bl < 1:
             raise ValueError("dropout marker spans no frequency bin")
-    gain = torch.zeros((frames, bins), dtype=torch.float32, device=spec_fm.device)
+
+
+def inpaint_gain_dev(spec_fm, geometry, dev=None, gain=None):
+    """Gain mask (dB, float32 [frames][bins]) for a batch of marker geometries on a frame-major complex64
+    device spectrogram: ONE launch of K_heal for all markers (dropout_healer_gui.py:135-159).
+    `gain`: an all-zero mask to reuse (heal_spectrum_dev leaves it all-zero again)."""
+    from . import _lib
+    dev = _dev.device_index(dev)
+    frames, bins = spec_fm.shape
+    geo = np.asarray(geometry, dtype=np.int64).reshape(-1, 5)
+    _check_geometry(geo, frames)
+    if gain is None:
+        gain = torch.zeros((frames, bins), dtype=torch.float32, device=spec_fm.device)
     if len(geo):
         geo_t = _dev.to_dev(np.ascontiguousarray(geo, dtype=np.int32), torch.int32, dev)
         _lib.check(_lib.lib().par_inpaint_gain_db_c64(dev, _dev.ptr(spec_fm), frames, bins, _dev.ptr(geo_t), len(geo),
                                                       _dev.ptr(gain), _dev.stream_ptr(dev)))
+    return gain
+
+
+def heal_spectrum_dev(spec_fm, geometry, dev=None, gain=None):
+    """In-place inpaint of a frame-major complex64 device spectrogram: mask for all markers (one launch), then
+    apply-and-clear over the boxes only (one launch).  Returns the (all-zero again) mask for reuse."""
+    from . import _lib
+    dev = _dev.device_index(dev)
+    frames, bins = spec_fm.shape
+    geo = np.asarray(geometry, dtype=np.int64).reshape(-1, 5)
+    _check_geometry(geo, frames)
+    if gain is None:
+        gain = torch.zeros((frames, bins), dtype=torch.float32, device=spec_fm.device)
+    if len(geo):
+        L = _lib.lib()
+        geo_t = _dev.to_dev(np.ascontiguousarray(geo, dtype=np.int32), torch.int32, dev)
+        args = (dev, _dev.ptr(spec_fm), frames, bins, _dev.ptr(geo_t), len(geo), _dev.ptr(gain), _dev.stream_ptr(dev))
+        _lib.check(L.par_inpaint_gain_db_c64(*args))
+        _lib.check(L.par_spec_apply_gain_boxes_c64(*args))
     return gain
 
 
@@ -131,9 +156,7 @@ def heal_dropouts(signal, sr, markers, fft_size=512, hop=32, channels=None, devi
     DropoutSample.to_cfg() (util/markers.py:368-388, 424-426): corner (t, f) pairs and the
     surrounding factor.  STFT, the per-marker targets and gain mask (all markers in one launch), gain
     application and ISTFT run on the device; only the healed channel returns to the host."""
-    from . import _lib
     dev = _dev.device_index(device)
-    L = _lib.lib()
     sig2d = signal[:, None] if signal.ndim == 1 else signal
     n, ch = sig2d.shape
     if channels is None:
@@ -142,11 +165,11 @@ def heal_dropouts(signal, sr, markers, fft_size=512, hop=32, channels=None, devi
     y_pad = fourier.fix_length(sig2d, n + fft_size // 2, axis=0)
     pad_t = _dev.to_dev(y_pad, torch.float32, dev)                      # (n + fft/2, ch) in HBM
     geometry = [marker_geometry(m, sr, hop, fft_size) for m in markers]
+    gain = None
     for c in channels:
         S = fourier.stft(pad_t.reshape(-1)[c::ch] if ch > 1 else pad_t.reshape(-1), n_fft=fft_size, step=hop)  # (bins, frames) device
         healed = S.T.contiguous()                                          # frame-major [frames][bins]
-        gain = inpaint_gain_dev(healed, geometry, dev)
-        _lib.check(L.par_spec_apply_gain_db_c64(dev, _dev.ptr(healed), _dev.ptr(gain), healed.numel(), _dev.stream_ptr(dev)))
+        gain = heal_spectrum_dev(healed, geometry, dev, gain)              # mask is zero again: reused by the next channel
         y = fourier.istft(healed.T, length=n, hop_length=hop)
         out[:, c] = y.cpu().numpy()
     return out
