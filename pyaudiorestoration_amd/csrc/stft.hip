@@ -385,6 +385,22 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_istft_fused(const fl
   float2 wq[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) wq[q] = *reinterpret_cast<const float2*>(window + 2 * (j + q * T));
+  // the spectrum rows of round r+1 are fetched before round r is transformed (software double buffering: the
+  // global-load latency hides under the butterflies instead of stalling every round)
+  float2 pa[8], pb[8], pk[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) pk[q] = cconj(post[j + q * T]);
+  auto fetch = [&](int r) {
+    const int64_t fr = F0 + r + u * s;
+    const bool live = r < s && fr >= 0 && fr < n_frames;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = j + q * T;
+      pa[q] = live ? spec[fr * bins + k] : make_float2(0.0f, 0.0f);
+      pb[q] = live ? spec[fr * bins + (H - k)] : make_float2(0.0f, 0.0f);
+    }
+  };
+  fetch(0);
   for (int r = 0; r < s; ++r) {
     const int lf = r + u * s;                                         // frame index inside the workgroup
     const int64_t fr = F0 + lf;
@@ -393,21 +409,17 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_istft_fused(const fl
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int k = j + q * T;
-      float2 z = make_float2(0.0f, 0.0f);
-      if (live) {
-        float2 a = spec[fr * bins + k];
-        float2 b = spec[fr * bins + (H - k)];
-        if (k == 0) {
-          a.y = 0.0f;
-          b.y = 0.0f;
-        }
-        b = cconj(b);
-        const float2 ev = cadd(a, b);
-        const float2 od = cmul(cconj(post[k]), csub(a, b));
-        z = make_float2(0.5f * (ev.x - od.y), -0.5f * (ev.y + od.x));
+      float2 a = pa[q], b = pb[q];
+      if (k == 0) {
+        a.y = 0.0f;
+        b.y = 0.0f;
       }
-      v[q] = z;
+      b = cconj(b);
+      const float2 ev = cadd(a, b);
+      const float2 od = cmul(pk[q], csub(a, b));
+      v[q] = make_float2(0.5f * (ev.x - od.y), -0.5f * (ev.y + od.x));   // zeros stay zeros for a dead frame
     }
+    fetch(r + 1);
     fft_core<LOGH>(v, X, j, tw);
     __syncthreads();                                                  // the previous round's adds (and the zeroing) are done
     if (live) {
