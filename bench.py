@@ -93,6 +93,50 @@ def stft_secondary(sig, dev, n_fft=1024, hop=256):
             "torch_stft_abs_Msamples/s": round(n / t_ref / 1e6, 1)}
 
 
+def heal_secondary(dev, tiles=256):
+    """Secondary line: BASELINE config 4 shape -- 322 531-sample signal tiled x256, STFT 512/32 -> 32 inpaint boxes
+    per tile (one K_heal launch) -> apply-and-clear -> fused ISTFT, resident in HBM; 136.5 algorithmic B/sample
+    (SURVEY 8d).  Synthetic stand-in with dropouts_sample.flac's length and rate."""
+    import numpy as np
+    import scipy.signal
+    import torch
+    from pyaudiorestoration_amd import _dev, _lib, pipeline
+    L = _lib.lib()
+    n1, sr, n_fft, hop = 322531, 44100, 512, 32
+    n = n1 * tiles
+    s = _dev.stream_ptr(dev)
+    x = torch.zeros(n + n_fft // 2, dtype=torch.float32, device=f"cuda:{dev}")
+    _lib.check(L.par_synth_signal_f32(dev, _dev.ptr(x), 0, n, float(sr), 0x5EED, s))
+    rng = np.random.default_rng(4)
+    marks = []
+    for k in range(tiles):
+        for t in np.sort(rng.uniform(0.2, n1 / sr - 0.2, 32)):
+            w = rng.uniform(0.004, 0.02)
+            marks.append((k * n1 / sr + t - w / 2, 500.0, k * n1 / sr + t + w / 2, 9000.0, 0.5))
+    geo = torch.from_numpy(np.array([pipeline.marker_geometry(m, sr, hop, n_fft) for m in marks], dtype=np.int32)).to(x.device)
+    win = torch.from_numpy(scipy.signal.get_window("blackmanharris", n_fft).astype(np.float32)).to(x.device)
+    frames, bins = int(L.par_stft_frames(n + n_fft // 2, n_fft, hop)), n_fft // 2 + 1
+    spec = torch.empty((frames, bins), dtype=torch.complex64, device=x.device)
+    gain = torch.zeros((frames, bins), dtype=torch.float32, device=x.device)
+    y = torch.empty(n, dtype=torch.float32, device=x.device)
+
+    def step():
+        _lib.check(L.par_stft_f32(dev, _dev.ptr(x), n + n_fft // 2, 1, n_fft, hop, 1, _dev.ptr(win), _dev.ptr(spec), 0, s))
+        _lib.check(L.par_inpaint_gain_db_c64(dev, _dev.ptr(spec), frames, bins, _dev.ptr(geo), len(marks), _dev.ptr(gain), s))
+        _lib.check(L.par_spec_apply_gain_boxes_c64(dev, _dev.ptr(spec), frames, bins, _dev.ptr(geo), len(marks), _dev.ptr(gain), s))
+        _lib.check(L.par_istft_f32(dev, _dev.ptr(spec), frames, n_fft, hop, _dev.ptr(win), None, _dev.ptr(y), n, n_fft // 2, s))
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    return {"workload": f"config 4: dropout inpaint, {n1} samples x{tiles} tiles, stft 512/32, {len(marks)} boxes", "samples": n,
+            "ms": round(dt * 1e3, 3), "Msamples/s": round(n / dt / 1e6, 1), "algorithmic_GB/s": round(n * 136.5 / dt / 1e9, 1),
+            "frac_of_hbm_peak": round(n * 136.5 / dt / 8e12, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,7 +222,8 @@ def main():
         traffic = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            traffic = round(tr["hbm_bytes_per_sample"] * samples_per_launch / (k_ms * 1e-3) / 1e9, 2)
+            if ("fused" in tr.get("kernel", "")) == bool(fused):          # the committed PMC pass measured this form
+                traffic = round(tr["hbm_bytes_per_sample"] * samples_per_launch / (k_ms * 1e-3) / 1e9, 2)
         except Exception:
             pass
         res = {
@@ -194,11 +239,14 @@ def main():
                          "kernel_ms": round(k_ms, 4), "launches_per_step": n_launch // len(sinc_ms),
                          "samples_per_launch": int(samples_per_launch),
                          "note": "achieved = 8 algorithmic B/output sample (4 B in + 4 B out) / HIP-event K_sinc time; "
-                                 "traffic = PMC HBM bytes (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json) "
-                                 "incl. the 8 B float64 position read; the kernel is v_rcp/VALU-bound, see DESIGN.md"},
+                                 "traffic = PMC HBM bytes/sample (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json) at this "
+                                 "run's rate" + (": signal + output + 1 B/sample cumsum checkpoints + tile halos"
+                                                 if fused else " incl. the 8 B float64 position read") +
+                                 "; the kernel is VALU-bound (~80 % VALU issue utilisation), see DESIGN.md"},
         }
         if world == 1:
             res["secondary"] = stft_secondary(sig, dev)
+            res["secondary_config4"] = heal_secondary(dev)
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(a.sr, a.nt)
         print(json.dumps(res), flush=True)

@@ -38,13 +38,19 @@ class RankContext:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # PAR_DIST_BACKEND=gloo lets the N>1 flow be exercised on a box with fewer GPUs than ranks
+                backend = os.environ.get("PAR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(self.local)
                 self.device = f"cuda:{self.local}"
                 dist.init_process_group("nccl", device_id=torch.device(self.device))
             else:
                 dist.init_process_group(backend)
+                if torch.cuda.is_available():
+                    self.local %= torch.cuda.device_count()
+                    torch.cuda.set_device(self.local)
+                    self.device = f"cuda:{self.local}"
+            self.reduce_device = self.device if backend == "nccl" else "cpu"
             self.dist = dist
         elif torch.cuda.is_available():
             torch.cuda.set_device(self.local)
@@ -68,7 +74,7 @@ class RankContext:
     def _reduce(self, value, op):
         if not self.dist:
             return float(value)
-        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.reduce_device)
         self.dist.all_reduce(t, op=op)
         return float(t.item())
 
