@@ -259,32 +259,70 @@ __global__ void k_speed_sum(const double* __restrict__ sp, int64_t m, PlanHeader
 // S_i = last element of np.cumsum(1/block_speeds): strictly sequential float64 adds, one lane per segment.
 // With ck != nullptr the running sum is also checkpointed every kCk steps (slot layout: pos_plan.h) for the
 // fused resampler, which then regenerates the positions of a tile from the nearest checkpoint.
+//
+// Checkpoint stores go through a 64 x 16 LDS transpose: written lane-by-lane they would be 64 scattered 8-byte
+// stores per instruction (one segment ~ 33 slots apart per lane: a 64-byte DRAM sector per 8 useful bytes);
+// transposed, a quarter wave writes 16 consecutive slots of ONE segment (128-byte runs).
+constexpr int kCkRound = 16;       // checkpoints per lane per transpose round (= 128 cumsum steps; 8.7 KB LDS per wave)
 __global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
                                                  int64_t nseg, double* __restrict__ S, double* __restrict__ ck,
                                                  int64_t ck_len, PlanHeader* __restrict__ h) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nseg) return;
-  const long long start = seg_start[i];
-  const long long n = seg_start[i + 1] - start;
+  __shared__ double T[kWave][kCkRound + 1];
+  __shared__ long long slot_of[kWave];
+  __shared__ int n_ck[kWave];
+  const int lane = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + lane;
+  long long n = 0, slot0 = 0;
+  Ramp r = make_ramp(1.0, 1.0, 2);
+  bool ck_ok = false;
+  if (i < nseg) {
+    const long long start = seg_start[i];
+    n = seg_start[i + 1] - start;
+    if (n >= 2) {
+      r = make_ramp(sp[i], sp[i + 1], n);
+      slot0 = ck_slot0(start, i);
+      // segments whose slots do not fit are skipped here; whether any of them is actually needed (starts
+      // before len_out) is decided by k_tile_seg once the trim is known
+      ck_ok = ck != nullptr && slot0 + (n + kCk - 1) / kCk <= ck_len;
+    } else {
+      n = 0;
+    }
+  }
+  // checkpoints b = 1 .. (n-1)/kCk hold the cumsum after step kCk*b - 1 (written only when steps follow)
+  const long long my_ck = ck_ok ? (n - 1) / kCk : 0;
+  slot_of[lane] = slot0;
+  const long long n_blocks = n / kCk;                       // full kCk-step blocks
+  const long long max_blocks = wave_max_ll(n_blocks);
   double c = 0.0;
-  if (n >= 2) {
-    const Ramp r = make_ramp(sp[i], sp[i + 1], n);
-    const long long slot0 = ck_slot0(start, i);
-    // segments whose slots do not fit are skipped here; whether any of them is actually needed (starts
-    // before len_out) is decided by k_tile_seg once the trim is known
-    const bool ck_ok = ck != nullptr && slot0 + (n + kCk - 1) / kCk <= ck_len;
-    long long k = 0;
-    for (; k + kCk <= n; k += kCk) {          // kCk independent divisions in flight per block
-      double rr[kCk];
+  for (long long b0 = 0; b0 < max_blocks; b0 += kCkRound) {
+    int filled = 0;
+    for (int w = 0; w < kCkRound; ++w) {
+      const long long b = b0 + w;
+      if (b >= n_blocks) break;
+      const long long k = b * kCk;
+      double rr[kCk];                                         // kCk independent divisions in flight per block
 #pragma unroll
       for (int u = 0; u < kCk; ++u) rr[u] = ramp_recip(k + u, r);
 #pragma unroll
       for (int u = 0; u < kCk; ++u) c = c + rr[u];
-      if (ck_ok && k + kCk < n) ck[slot0 + k / kCk + 1] = c;      // cumsum after step k + kCk - 1
+      T[lane][w] = c;                                         // checkpoint b + 1
+      filled = w + 1;
     }
-    for (; k < n; ++k) c = c + ramp_recip(k, r);
+    if (ck != nullptr) {
+      long long lim = my_ck - b0;                             // checkpoints of this round that are to be stored
+      if (lim > filled) lim = filled;
+      n_ck[lane] = lim > 0 ? (int)lim : 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int w = lane & (kCkRound - 1), half = lane / kCkRound;
+      for (int sgm = half; sgm < kWave; sgm += kWave / kCkRound)
+        if (w < n_ck[sgm]) ck[slot_of[sgm] + b0 + w + 1] = T[sgm][w];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
-  S[i] = c;
+  for (long long k = n_blocks * kCk; k < n; ++k) c = c + ramp_recip(k, r);
+  if (i < nseg) S[i] = c;
 }
 
 // after k_tile_seg: publish checkpoint validity in the header (device side, so the host needs one read-back)
