@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpar_hip.so")
+# PAR_HIP_LIB: developer override to A/B two builds of the library inside one GPU session
+LIB_PATH = os.environ.get("PAR_HIP_LIB") or os.path.join(_HERE, "libpar_hip.so")
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
