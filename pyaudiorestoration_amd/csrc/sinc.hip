@@ -114,9 +114,14 @@ __device__ __forceinline__ float tap_R(float q, const float4& t) {
 
 // fc == 1 for every lane of the wave: U_n = -(-1)^n sin(pi s), V_n = +(-1)^n sin(pi s) -> factored out.
 // Accumulates e = sum (-1)^n (sig[+n]+sig[-n]) R_n  and  d = sum (-1)^n n (sig[+n]-sig[-n]) R_n.
-template <int MODE, int R>
+// LAST: the chunk that reaches n = NT.  The reference's window is offsets -NT .. NT-1: tap -NT is in it (with the
+// Hann endpoint weight 0, so a NaN/Inf sample there still poisons the sum as 0*NaN), tap +NT and the padding
+// taps beyond are not -- their samples are replaced by 0 so that non-finite input spreads exactly as far as it
+// does in the reference.
+template <int MODE, bool LAST, int R>
 __device__ __forceinline__ void unity_chunk(lds_cfloat* (&tp)[R], lds_cfloat* (&tm)[R], const float (&q)[R],
-                                            float (&e)[R], float (&d)[R], const float4* __restrict__ tab, int n0) {
+                                            float (&e)[R], float (&d)[R], const float4* __restrict__ tab, int n0,
+                                            int NT) {
   float4 ab[kChunk];                         // wave-uniform: one s_load_dwordx16, operands stay in SGPRs
 #pragma unroll
   for (int k = 0; k < kChunk; ++k) ab[k] = tab[n0 + k];
@@ -125,7 +130,11 @@ __device__ __forceinline__ void unity_chunk(lds_cfloat* (&tp)[R], lds_cfloat* (&
     const float fn = ab[k].z;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float sp = tp[r][k], sm = tm[r][kChunk - 1 - k];
+      float sp = tp[r][k], sm = tm[r][kChunk - 1 - k];
+      if (LAST) {
+        if (n0 + k >= NT) sp = 0.0f;
+        if (n0 + k > NT) sm = 0.0f;
+      }
       const float D = sp - sm, E = sp + sm;
       const float Rn = tap_R<MODE>(q[r], ab[k]);
       const float DR = D * Rn;
@@ -159,15 +168,20 @@ __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const
     tp[r] = tl + c[r] + 1;                   // -> t[+n0]
     tm[r] = tl + c[r] - kChunk;              // -> t[-(n0 + kChunk - 1)]
   }
-  int n0 = 1;                                // taps >= NT have R_n == 0 (padded table rows)
-  if (n0 < NT) {
-    unity_chunk<kRcp, R>(tp, tm, q, e, d, tab, n0);
+  // chunks n0 = 1, 5, .. while n0 <= NT; the one containing n = NT is the LAST instance (padded table rows
+  // n >= NT have R_n == 0)
+  int n0 = 1;
+  if (n0 + kChunk <= NT) {
+    unity_chunk<kRcp, false, R>(tp, tm, q, e, d, tab, n0, NT);
     n0 += kChunk;
+#pragma unroll 1
+    for (; n0 + kChunk <= NT && n0 < kPoly1From; n0 += kChunk) unity_chunk<kPoly2, false, R>(tp, tm, q, e, d, tab, n0, NT);
+#pragma unroll 1
+    for (; n0 + kChunk <= NT; n0 += kChunk) unity_chunk<kPoly1, false, R>(tp, tm, q, e, d, tab, n0, NT);
   }
-#pragma unroll 1
-  for (; n0 < NT && n0 < kPoly1From; n0 += kChunk) unity_chunk<kPoly2, R>(tp, tm, q, e, d, tab, n0);
-#pragma unroll 1
-  for (; n0 < NT; n0 += kChunk) unity_chunk<kPoly1, R>(tp, tm, q, e, d, tab, n0);
+  if (n0 == 1) unity_chunk<kRcp, true, R>(tp, tm, q, e, d, tab, n0, NT);
+  else if (n0 < kPoly1From) unity_chunk<kPoly2, true, R>(tp, tm, q, e, d, tab, n0, NT);
+  else unity_chunk<kPoly1, true, R>(tp, tm, q, e, d, tab, n0, NT);
   const float b0 = tab[0].y;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -181,9 +195,9 @@ template <int R>
 struct GenState {
   float q[R], accP[R], accM[R], U[R], Up[R], V[R], Vp[R], c2[R];
 };
-template <int MODE, int R>
+template <int MODE, bool LAST, int R>
 __device__ __forceinline__ void general_chunk(lds_cfloat* (&tp)[R], lds_cfloat* (&tm)[R], GenState<R>& g,
-                                              const float4* __restrict__ tab, int n0) {
+                                              const float4* __restrict__ tab, int n0, int NT) {
   float4 ab[kChunk];
 #pragma unroll
   for (int k = 0; k < kChunk; ++k) ab[k] = tab[n0 + k];
@@ -192,7 +206,12 @@ __device__ __forceinline__ void general_chunk(lds_cfloat* (&tp)[R], lds_cfloat* 
     const float fn = ab[k].z;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float G = tp[r][k] * g.U[r], H = tm[r][kChunk - 1 - k] * g.V[r];
+      float sp = tp[r][k], sm = tm[r][kChunk - 1 - k];
+      if (LAST) {
+        if (n0 + k >= NT) sp = 0.0f;
+        if (n0 + k > NT) sm = 0.0f;
+      }
+      const float G = sp * g.U[r], H = sm * g.V[r];
       const float Rn = tap_R<MODE>(g.q[r], ab[k]);
       g.accM[r] = fmaf(G - H, Rn, g.accM[r]);
       g.accP[r] = fmaf((G + H) * Rn, fn, g.accP[r]);
@@ -245,14 +264,17 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
     tm[r] = tl + c[r] - kChunk;
   }
   int n0 = 1;
-  if (n0 < NT) {
-    general_chunk<kRcp, R>(tp, tm, g, tab, n0);
+  if (n0 + kChunk <= NT) {
+    general_chunk<kRcp, false, R>(tp, tm, g, tab, n0, NT);
     n0 += kChunk;
+#pragma unroll 1
+    for (; n0 + kChunk <= NT && n0 < kPoly1From; n0 += kChunk) general_chunk<kPoly2, false, R>(tp, tm, g, tab, n0, NT);
+#pragma unroll 1
+    for (; n0 + kChunk <= NT; n0 += kChunk) general_chunk<kPoly1, false, R>(tp, tm, g, tab, n0, NT);
   }
-#pragma unroll 1
-  for (; n0 < NT && n0 < kPoly1From; n0 += kChunk) general_chunk<kPoly2, R>(tp, tm, g, tab, n0);
-#pragma unroll 1
-  for (; n0 < NT; n0 += kChunk) general_chunk<kPoly1, R>(tp, tm, g, tab, n0);
+  if (n0 == 1) general_chunk<kRcp, true, R>(tp, tm, g, tab, n0, NT);
+  else if (n0 < kPoly1From) general_chunk<kPoly2, true, R>(tp, tm, g, tab, n0, NT);
+  else general_chunk<kPoly1, true, R>(tp, tm, g, tab, n0, NT);
 #pragma unroll
   for (int r = 0; r < R; ++r) res[r] = centre[r] + fmaf(s[r], g.accM[r], g.accP[r]);
 }

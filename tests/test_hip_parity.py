@@ -371,6 +371,75 @@ def test_large_properties(par):
     assert relerr(part[:-1], out[123457:323456]) < 2e-6     # chunk invariance (tile phase changes which waves take the fc==1 path)
 
 
+def test_full_size_config2_properties(par):
+    """BASELINE config 2 at FULL size (60 min @96 kHz mono = 345.6 M samples, +-1 % curve, NT = 32) through
+    size-independent properties: unit speed reproduces the input (shifted by the reference's one-sample lead),
+    positions bit-equal to the C oracle's over the whole file, 24 oracle windows spread over the hour,
+    linearity of the resampler, NaN containment to +-NT samples."""
+    from oracle import oracle_c as C
+    from pyaudiorestoration_amd import _lib, _dev
+    t = par.torch
+    sr, dur = 96000, 3600.0
+    n = int(sr * dur)
+    L = _lib.lib()
+    sig_t = t.empty(n, dtype=t.float32, device="cuda")
+    _lib.check(L.par_synth_signal_f32(0, _dev.ptr(sig_t), 0, n, float(sr), 0x5EED, _dev.stream_ptr(0)))
+    m = int(dur * sr / 256)
+    st_t = t.empty(m, dtype=t.float64, device="cuda")
+    sp_t = t.empty(m, dtype=t.float64, device="cuda")
+    _lib.check(L.par_synth_speed_curve_f64(0, _dev.ptr(st_t), _dev.ptr(sp_t), m, dur, float(sr), 0.01, 0.55, 0.7,
+                                           _dev.stream_ptr(0)))
+    # 1. unit speed: positions are 1, 2, 3, ... exactly; an integer position with fc == 1 picks one sample
+    one_t = t.ones(m, dtype=t.float64, device="cuda")
+    plan1 = par.resampling.speed_plan_dev(st_t, one_t, n, fused=True)
+    assert plan1.fused_ok
+    y1 = par.resampling.varispeed_fused_dev(plan1, sig_t, 32)
+    k = plan1.len_out
+    assert abs(k - n) <= 2
+    d = (y1[64:k - 64] - sig_t[65:k - 63]).abs().max().item()         # away from the leading-edge quirk
+    assert d < 2e-6, d
+    del y1, plan1, one_t
+    # 2. the +-1 % curve: whole-file positions against the C oracle, bit for bit
+    plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
+    assert plan.fused_ok and plan.path == 0
+    pos_t = par.resampling.speed_to_pos_dev(st_t, sp_t, n)
+    ref_pos, _ = C.speed_to_pos(st_t.cpu().numpy(), sp_t.cpu().numpy(), n)
+    assert plan.len_out == len(ref_pos) == pos_t.numel()
+    assert t.equal(pos_t.cpu(), t.from_numpy(ref_pos))
+    # 3. fused output == position-array output everywhere, == oracle on 24 windows across the hour
+    out = par.resampling.varispeed_fused_dev(plan, sig_t, 32)
+    out2 = par.resampling.sinc_resample_dev(pos_t, sig_t, 32)
+    assert t.equal(out, out2)
+    del out2
+    for i in np.linspace(0, len(ref_pos) - 3000, 24).astype(np.int64):
+        lo = max(0, int(ref_pos[i]) - 200)
+        hi = min(n, int(ref_pos[i + 2000]) + 200)
+        sig_win = sig_t[lo:hi].cpu().numpy()
+        if lo == 0:
+            ref = C.sinc(ref_pos[i:i + 2001], sig_win, 32)[:2000]
+        else:                                                            # window-local coordinates: same arithmetic
+            ref = C.sinc(ref_pos[i:i + 2001] - lo, sig_win, 32)[:2000]
+        assert relerr(out[i:i + 2000].cpu().numpy(), ref) < TOL, i
+    # 4. linearity at full size: R(a x + b y) == a R(x) + b R(y)
+    y_t = t.empty(n, dtype=t.float32, device="cuda")
+    _lib.check(L.par_synth_signal_f32(0, _dev.ptr(y_t), 0, n, float(sr), 0xBEEF, _dev.stream_ptr(0)))
+    mix = 0.75 * sig_t - 0.5 * y_t
+    r_mix = par.resampling.varispeed_fused_dev(plan, mix, 32)
+    r_y = par.resampling.varispeed_fused_dev(plan, y_t, 32)
+    err = (r_mix - (0.75 * out - 0.5 * r_y)).abs().max().item()
+    assert err < 5e-6, err
+    del mix, r_mix, r_y, y_t
+    # 5. a NaN in the input poisons exactly the outputs whose reference window signal[ind-NT : ind+NT] holds it
+    bad = 200_000_000
+    sig_t[bad] = float("nan")
+    out_n = par.resampling.varispeed_fused_dev(plan, sig_t, 32)
+    ind = t.round(pos_t).to(t.int64)                          # round-half-even like Python's round()
+    expect = (ind - 32 <= bad) & (bad < ind + 32)
+    assert 60 <= int(expect.sum()) <= 68
+    assert t.equal(t.isnan(out_n), expect)
+    assert t.equal(out_n[~expect], out[~expect])
+
+
 def test_speed_plan_device_scans_vs_serial_host_chain(par, golden):
     """The device plan (128-bit fixed-point length scan + parity-translation offset scan) must agree
     bit-for-bit with the serial host evaluation, take the device path on ordinary curves, and defer
