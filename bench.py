@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--nt", type=int, default=32)
     ap.add_argument("--chunks", type=int, default=0, help="pipeline chunks per file (0 = auto, 1 = no overlap)")
     ap.add_argument("--no-fused", action="store_true", help="materialise the float64 position array (reference-shaped path)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="serial steps (plan, then K_sinc); default: the plan of file k+1 runs on a side stream under K_sinc of file k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -168,48 +170,106 @@ def main():
     _lib.check(L.par_synth_speed_curve_f64(dev, _dev.ptr(st), _dev.ptr(spd), m, a.seconds, float(a.sr), 0.01, 0.55,
                                            0.7 + rank, sp_))
     nbytes = int(L.par_speed_plan_bytes(m))
-    work = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{dev}")
     cap = int(n_in * 1.02) + 1024
     out = torch.empty(cap, dtype=torch.float32, device=f"cuda:{dev}")
     fused = not a.no_fused
+    overlap = fused and not a.no_overlap
+    n_slots = 2 if overlap else 1                      # plan buffers are double-buffered when steps are pipelined
+    work = [torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{dev}") for _ in range(n_slots)]
     if fused:       # cumsum checkpoints + tile map: positions are regenerated inside K_sinc, never stored
         aux_bytes = int(L.par_fused_aux_bytes(cap, m))
-        aux = torch.empty(aux_bytes, dtype=torch.uint8, device=f"cuda:{dev}")
+        aux = [torch.empty(aux_bytes, dtype=torch.uint8, device=f"cuda:{dev}") for _ in range(n_slots)]
     else:           # reference-shaped path: float64 sample_at array in HBM
         pos = torch.empty(cap, dtype=torch.float64, device=f"cuda:{dev}")
     torch.cuda.synchronize()
 
-    _lib.check(L.par_profile_enable(dev, 1))         # HIP events around every K_sinc launch, on its own stream
     sinc_ms, sinc_launches = [], []
     len_out = ctypes.c_int64(0)
     trimmed = ctypes.c_int(0)
-
     ok = ctypes.c_int(0)
 
-    def step(timed):
-        if fused:
-            _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(st), _dev.ptr(spd), m, n_in, _dev.ptr(work), nbytes,
-                                                     _dev.ptr(aux), aux_bytes, cap, ctypes.byref(len_out),
-                                                     ctypes.byref(trimmed), 0, None, ctypes.byref(ok), sp_))
-            assert ok.value == 1 and 2 <= len_out.value <= cap
-            _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(spd), m, _dev.ptr(work), _dev.ptr(aux), cap, len_out.value,
-                                                 _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, sp_))
-        else:
-            _lib.check(L.par_speed_to_pos_plan(dev, _dev.ptr(st), _dev.ptr(spd), m, n_in, _dev.ptr(work), nbytes,
-                                               ctypes.byref(len_out), ctypes.byref(trimmed), sp_))
-            assert 2 <= len_out.value <= cap
-            _lib.check(L.par_varispeed_resample_f32(dev, _dev.ptr(spd), m, _dev.ptr(work), len_out.value, _dev.ptr(pos),
-                                                    _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, a.chunks, sp_))
-        if timed:
-            ms, nl, ns = ctypes.c_float(0), ctypes.c_int(0), ctypes.c_int64(0)
-            _lib.check(L.par_profile_read(dev, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(ns)))   # waits for them
-            sinc_ms.append(ms.value)
-            sinc_launches.append(nl.value)
+    def plan_fused(slot, stream_ptr):
+        _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(st), _dev.ptr(spd), m, n_in, _dev.ptr(work[slot]), nbytes,
+                                                 _dev.ptr(aux[slot]), aux_bytes, cap, ctypes.byref(len_out),
+                                                 ctypes.byref(trimmed), 0, None, ctypes.byref(ok), stream_ptr))
+        assert ok.value == 1 and 2 <= len_out.value <= cap
+        return len_out.value
+
+    if overlap:
+        # Software pipeline over the files of a batch (one file per step): K_sinc of file k on the main stream,
+        # the whole plan of file k+1 (25 small latency-bound kernels + one header read-back) on a side stream
+        # underneath it.  Every step still executes one full plan and one full K_sinc; nothing is cached.
+        side = torch.cuda.Stream(device=dev)
+        side_ptr = ctypes.c_void_p(side.cuda_stream)
+        slot_free = [None, None]                        # main-stream event: K_sinc that read this slot is done
+        state = {"k": 0, "len": plan_fused(0, sp_)}    # pipeline prologue: plan of the first file
+        ev_pairs = []
+        # reference point outside the timed region: K_sinc with the GPU to itself (no plan underneath)
+        alone = []
+        for _ in range(3):
+            e0, e1, ms = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_float(0)
+            _lib.check(L.par_event_create(ctypes.byref(e0)))
+            _lib.check(L.par_event_create(ctypes.byref(e1)))
+            _lib.check(L.par_event_record(e0, sp_))
+            _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(spd), m, _dev.ptr(work[0]), _dev.ptr(aux[0]), cap,
+                                                 state["len"], _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, sp_))
+            _lib.check(L.par_event_record(e1, sp_))
+            _lib.check(L.par_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+            alone.append(ms.value)
+            L.par_event_destroy(e0)
+            L.par_event_destroy(e1)
+
+        def step(timed):
+            k = state["k"]
+            cur, nxt = k % 2, (k + 1) % 2
+            e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+            if timed:
+                _lib.check(L.par_event_create(ctypes.byref(e0)))
+                _lib.check(L.par_event_create(ctypes.byref(e1)))
+                _lib.check(L.par_event_record(e0, sp_))
+            _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(spd), m, _dev.ptr(work[cur]), _dev.ptr(aux[cur]), cap,
+                                                 state["len"], _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, sp_))
+            if timed:
+                _lib.check(L.par_event_record(e1, sp_))
+                ev_pairs.append((e0, e1))
+            slot_free[cur] = torch.cuda.Event()
+            slot_free[cur].record(torch.cuda.current_stream(dev))
+            if slot_free[nxt] is not None:
+                side.wait_event(slot_free[nxt])          # the K_sinc that last read slot `nxt` must be finished
+            state["len"] = plan_fused(nxt, side_ptr)    # returns after the side stream drained (header read-back)
+            state["k"] = k + 1
+    else:
+        _lib.check(L.par_profile_enable(dev, 1))         # HIP events around every K_sinc launch, on its own stream
+
+        def step(timed):
+            if fused:
+                n_out = plan_fused(0, sp_)
+                _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(spd), m, _dev.ptr(work[0]), _dev.ptr(aux[0]), cap, n_out,
+                                                     _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, sp_))
+            else:
+                _lib.check(L.par_speed_to_pos_plan(dev, _dev.ptr(st), _dev.ptr(spd), m, n_in, _dev.ptr(work[0]), nbytes,
+                                                   ctypes.byref(len_out), ctypes.byref(trimmed), sp_))
+                assert 2 <= len_out.value <= cap
+                _lib.check(L.par_varispeed_resample_f32(dev, _dev.ptr(spd), m, _dev.ptr(work[0]), len_out.value, _dev.ptr(pos),
+                                                        _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, a.chunks, sp_))
+            if timed:
+                ms, nl, ns = ctypes.c_float(0), ctypes.c_int(0), ctypes.c_int64(0)
+                _lib.check(L.par_profile_read(dev, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(ns)))   # waits for them
+                sinc_ms.append(ms.value)
+                sinc_launches.append(nl.value)
 
     for _ in range(a.warmup):
         step(False)
     dt = ctx.timed(lambda: step(True), a.steps)        # barrier+sync | K steps | sync+barrier, MAX over ranks
     total_per_step = ctx.reduce_sum(len_out.value)     # whole-job output samples per step
+    if overlap:                                        # K_sinc durations of the timed steps (events on its own stream)
+        for e0, e1 in ev_pairs:
+            ms = ctypes.c_float(0)
+            _lib.check(L.par_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+            sinc_ms.append(ms.value)
+            sinc_launches.append(1)
+            L.par_event_destroy(e0)
+            L.par_event_destroy(e1)
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -233,7 +293,8 @@ def main():
             "config": {"workload": f"{a.seconds:g}-s {a.sr} Hz mono float32 varispeed resample, +-1% sinusoidal speed "
                                    f"curve (0.55 Hz, hop 256), {2 * a.nt}-tap Hann sinc; one file per GPU",
                        "samples_in_per_gpu": n_in, "samples_out_per_gpu": int(len_out.value), "NT": a.nt,
-                       "step": ("plan (device scans, cumsum checkpoints) + fused K_sinc (float64 positions regenerated per tile in LDS)" if fused else "plan (device scans) + K_pos fill (float64 position array) + K_sinc") + "; inputs resident in HBM"},
+                       "step": ("plan (device scans, cumsum checkpoints) + fused K_sinc (float64 positions regenerated per tile in LDS)" if fused else "plan (device scans) + K_pos fill (float64 position array) + K_sinc") + "; inputs resident in HBM"
+                               + ("; batch pipelining: the plan of file k+1 runs on a side stream under K_sinc of file k (every step = one full plan + one full K_sinc)" if overlap else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": "k_sinc",
                          "kernel_ms": round(k_ms, 4), "launches_per_step": n_launch // len(sinc_ms),
@@ -244,6 +305,13 @@ def main():
                                                  if fused else " incl. the 8 B float64 position read") +
                                  "; the kernel is VALU-bound (~80 % VALU issue utilisation), see DESIGN.md"},
         }
+        if overlap:
+            k_alone = min(alone)
+            res["roofline"]["kernel_ms_alone"] = round(k_alone, 4)
+            res["roofline"]["frac_alone"] = round(ALGO_BYTES_PER_SAMPLE * samples_per_launch / (k_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            res["roofline"]["note"] += ("; kernel_ms is measured in the timed region, where the next file's plan kernels "
+                                        "share the GPU with K_sinc; kernel_ms_alone / frac_alone = the same launch with the "
+                                        "GPU to itself, measured before the timed region")
         if world == 1:
             res["secondary"] = stft_secondary(sig, dev)
             res["secondary_config4"] = heal_secondary(dev)
