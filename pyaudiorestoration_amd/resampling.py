@@ -34,40 +34,49 @@ class SpeedPlan:
         self.aux, self.fused_ok, self.max_out = aux, fused_ok, max_out
 
 
+def fused_max_out(sampletimes_t, speeds_t):
+    """Output bound used to size the fused plan's checkpoint buffer: the reference's own end_guess
+    (util/resampling.py:108, int(mean(speeds) * span * 1.01)) plus the longest segment.  Buffer sizing only,
+    so torch reductions are fine here."""
+    span = float(sampletimes_t[-1] - sampletimes_t[0])
+    longest = float((sampletimes_t[1:] - sampletimes_t[:-1]).max()) * float(speeds_t.max())
+    return int(float(speeds_t.mean()) * span * 1.01) + int(longest) + 1024
+
+
 def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_host_chain=False, fused=False,
-                   max_out=None):
+                   max_out=None, work=None, aux=None, stream=None):
     """Planning stage.  fused=True also stores per-segment cumsum checkpoints (every 8th step) so that
-    varispeed_resample_dev can regenerate positions inside K_sinc instead of reading a position array."""
+    varispeed_resample_dev can regenerate positions inside K_sinc instead of reading a position array.
+    work / aux: caller-owned uint8 device buffers to (re)use; stream: torch stream to plan on (default: current)."""
     dev = _dev.device_index(dev if dev is not None else sampletimes_t.device)
     L = _lib.lib()
     m = sampletimes_t.numel()
     if speeds_t.numel() != m:
         raise ValueError("sampletimes and speeds must have the same length")
     nbytes = int(L.par_speed_plan_bytes(m))
-    work = _dev.empty(nbytes, torch.uint8, dev)
+    if work is None or work.numel() < nbytes:
+        work = _dev.empty(nbytes, torch.uint8, dev)
+    s_ptr = _dev.stream_ptr(dev) if stream is None else ctypes.c_void_p(stream.cuda_stream)
     len_out = ctypes.c_int64(0)
     trimmed = ctypes.c_int(0)
     path = ctypes.c_int(0)
     if fused:
         if max_out is None:
-            # the reference's own output bound (util/resampling.py:108): int(mean(speeds) * span * 1.01);
-            # buffer sizing only, so a torch reduction is fine here
-            span = float(sampletimes_t[-1] - sampletimes_t[0])
-            longest = float((sampletimes_t[1:] - sampletimes_t[:-1]).max()) * float(speeds_t.max())
-            max_out = int(float(speeds_t.mean()) * span * 1.01) + int(longest) + 1024
+            max_out = fused_max_out(sampletimes_t, speeds_t)
         aux_bytes = int(L.par_fused_aux_bytes(max_out, m))
-        aux = _dev.empty(aux_bytes, torch.uint8, dev)
+        if aux is None or aux.numel() < aux_bytes:
+            aux = _dev.empty(aux_bytes, torch.uint8, dev)
         ok = ctypes.c_int(0)
         _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m,
-                                                 int(num_imput_samples), _dev.ptr(work), nbytes, _dev.ptr(aux), aux_bytes,
-                                                 max_out, ctypes.byref(len_out), ctypes.byref(trimmed),
+                                                 int(num_imput_samples), _dev.ptr(work), work.numel(), _dev.ptr(aux),
+                                                 aux.numel(), max_out, ctypes.byref(len_out), ctypes.byref(trimmed),
                                                  1 if force_host_chain else 0, ctypes.byref(path), ctypes.byref(ok),
-                                                 _dev.stream_ptr(dev)))
+                                                 s_ptr))
         return SpeedPlan(speeds_t, m, work, len_out.value, bool(trimmed.value), path.value, dev, aux, bool(ok.value),
                          max_out)
     _lib.check(L.par_speed_to_pos_plan_ex(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m, int(num_imput_samples),
-                                          _dev.ptr(work), nbytes, ctypes.byref(len_out), ctypes.byref(trimmed),
-                                          1 if force_host_chain else 0, ctypes.byref(path), _dev.stream_ptr(dev)))
+                                          _dev.ptr(work), work.numel(), ctypes.byref(len_out), ctypes.byref(trimmed),
+                                          1 if force_host_chain else 0, ctypes.byref(path), s_ptr))
     return SpeedPlan(speeds_t, m, work, len_out.value, bool(trimmed.value), path.value, dev)
 
 
@@ -99,6 +108,71 @@ def varispeed_fused_dev(plan, sig_t, NT, out_t=None, sig_stride=1, len_in=None, 
                                          plan.max_out, plan.len_out, _dev.ptr(sig_t), sig_stride, len_in, int(NT),
                                          _dev.ptr(out_t), out_stride, _dev.stream_ptr(dev)))
     return out_t
+
+
+def varispeed_batch_dev(items, NT, dev=None):
+    """Software-pipelined fused resampling of a batch of device-resident work items on one GPU (the per-GPU
+    inner loop of a file batch): while K_sinc of item k runs on the current stream, the whole plan
+    of item k+1 -- ~25 small latency-bound kernels and a header read-back -- runs on a side stream underneath
+    it.  Plan buffers are double-buffered; an event keeps a slot from being re-planned before the K_sinc that
+    reads it has finished.
+
+    items: iterable of (sampletimes_t, speeds_t, sig_t) or (sampletimes_t, speeds_t, sig_t, sig_stride, len_in)
+    with float64 / float32 device tensors.  Yields (index, out_t, plan) in order; out_t is ready on the current
+    stream (synchronise or keep using that stream).  An item whose plan has no valid checkpoints is resampled
+    through the position-array path."""
+    dev = _dev.device_index(dev)
+    main = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(device=dev)
+    work, aux, free = [None, None], [None, None], [None, None]
+
+    def plan_item(item, slot, stream, ready=None):
+        st_t, sp_t, sig_t = item[0], item[1], item[2]
+        len_in = item[4] if len(item) > 4 else sig_t.numel() // (item[3] if len(item) > 3 else 1)
+        if stream is None:
+            plan = speed_plan_dev(st_t, sp_t, len_in, dev, fused=True, work=work[slot], aux=aux[slot])
+        else:
+            stream.wait_event(ready)                       # the item's tensors were produced on the main stream
+            if free[slot] is not None:
+                stream.wait_event(free[slot])              # the K_sinc that last read this slot is done
+            # sizing reductions, (re)allocation and the plan itself all live on the side stream: a .item() there
+            # does not wait for the K_sinc running on the main stream
+            with torch.cuda.stream(stream):
+                plan = speed_plan_dev(st_t, sp_t, len_in, dev, fused=True, work=work[slot], aux=aux[slot], stream=stream)
+        work[slot], aux[slot] = plan.work, plan.aux        # keep (possibly grown) buffers for reuse
+        return plan
+
+    it = iter(items)
+    try:
+        cur_item = next(it)
+    except StopIteration:
+        return
+    plan = plan_item(cur_item, 0, None)
+    k = 0
+    while True:
+        slot = k % 2
+        # fetch the next item BEFORE launching this K_sinc: whatever its producer enqueues on the main stream
+        # (uploads, generators) then precedes the long kernel instead of queueing behind it
+        try:
+            nxt_item = next(it)
+        except StopIteration:
+            nxt_item = None
+        ready = torch.cuda.Event()
+        ready.record(main)
+        sig_t = cur_item[2]
+        stride = cur_item[3] if len(cur_item) > 3 else 1
+        len_in = cur_item[4] if len(cur_item) > 4 else sig_t.numel() // stride
+        if plan.fused_ok:
+            out_t = varispeed_fused_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)
+        else:
+            out_t, _ = varispeed_resample_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)
+        free[slot] = torch.cuda.Event()
+        free[slot].record(main)
+        nxt_plan = plan_item(nxt_item, (k + 1) % 2, side, ready) if nxt_item is not None else None
+        yield k, out_t, plan
+        if nxt_item is None:
+            return
+        cur_item, plan, k = nxt_item, nxt_plan, k + 1
 
 
 def varispeed_resample_dev(plan, sig_t, NT, out_t=None, pos_t=None, sig_stride=1, len_in=None, out_stride=1, n_chunks=0):

@@ -637,6 +637,37 @@ def test_fused_extreme_curves_and_channels(par):
         assert relerr(ref[:k, 1].cpu().numpy(), C.sinc(pos[:k + 1], sig[:, 1].copy(), NT, threads=8)[:k]) < TOL, name
 
 
+def test_batch_pipeline_equals_item_by_item(par):
+    """varispeed_batch_dev (plan of item k+1 on a side stream under K_sinc of item k, double-buffered plan slots that
+    grow) gives bit-identical outputs to planning and resampling each item on its own, in order, including items
+    produced lazily on the main stream by the iterator."""
+    t = par.torch
+    R = par.resampling
+    rng = np.random.default_rng(8)
+    specs = [(300000, 0.01), (50000, 0.3), (1200000, 0.02), (1200000, 0.02), (7000, 0.0), (640000, 0.15)]
+
+    def make(i):
+        n, depth = specs[i]
+        m = max(3, n // 256)
+        st = np.linspace(0, n, m)
+        sp = 1.0 + depth * np.sin(np.arange(m) * 0.37 + i) + 0.001 * rng.standard_normal(m)
+        sig = inputs.noise(n, 100 + i)
+        return t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), t.from_numpy(sig).cuda()    # uploads on the main stream
+
+    items = [make(i) for i in range(len(specs))]
+    want = []
+    for st_t, sp_t, sig_t in items:
+        plan = R.speed_plan_dev(st_t, sp_t, sig_t.numel(), fused=True)
+        want.append(R.varispeed_fused_dev(plan, sig_t, 16).clone())
+    rng = np.random.default_rng(8)                       # same random curves for the lazy producer
+    got = [(k, out.clone(), plan.len_out) for k, out, plan in R.varispeed_batch_dev((make(i) for i in range(len(specs))), 16)]
+    t.cuda.synchronize()
+    assert [k for k, _, _ in got] == list(range(len(specs)))
+    for (k, out, n_out), w in zip(got, want):
+        assert n_out == w.numel() and t.equal(out, w), k
+    assert list(R.varispeed_batch_dev([], 16)) == []
+
+
 def test_bench_contract_line():
     """bench.py prints ONE JSON line with the contract's keys, a roofline and a cpu_baseline object."""
     import json
