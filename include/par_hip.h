@@ -204,6 +204,15 @@ int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins,
 int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
                       double* freqs, int fft_size, double sr, double tolerance_oct, void* stream);
 
+/* W3: sign-change indices of a (band-passed) float64 signal, ascending -- zero_crossings(a) =
+ * np.where(np.bitwise_xor(a[1:] > 0, a[:-1] > 0))[0] (util/wow_detection.py:448-450), the full-rate pass of
+ * ZeroCrossingTracker.trace (:340).
+ *   work   device int64[par_zero_crossings_work_len(n)]
+ *   idx    device int64[cap], or NULL to only count; *count (host) = number of crossings.  Synchronises the stream. */
+int64_t par_zero_crossings_work_len(int64_t n);
+int par_zero_crossings_f64(int device, const double* x, int64_t n, int64_t* work, int64_t* idx, int64_t cap, int64_t* count,
+                           void* stream);
+
 /* ---- F1: zero-phase SOS filtering ------------------------------------------------------
  * Replaces scipy.signal.sosfiltfilt(sos, data) as called by butter_bandpass_filter
  * (util/filters.py:24): odd extension of padlen samples, sosfilt_zi initial state scaled by the

@@ -103,9 +103,105 @@ __global__ __launch_bounds__(64) void k_track_cog(const float* __restrict__ mag,
   }
 }
 
+// ---- zero crossings (ZeroCrossingTracker, util/wow_detection.py:340, 448-450) -----------------------------
+// indices i with (x[i+1] > 0) != (x[i] > 0), ascending: count per 1024-sample tile, scan of the tile counts,
+// ordered write (ballot + popcount inside a wave, LDS prefix across the 4 waves of a tile).
+constexpr int kZcTile = 1024;
+
+__device__ __forceinline__ bool crossing_at(const double* __restrict__ x, int64_t i, int64_t n) {
+  return i + 1 < n && ((x[i + 1] > 0.0) != (x[i] > 0.0));
+}
+
+__global__ __launch_bounds__(256) void k_zc_count(const double* __restrict__ x, int64_t n, long long* __restrict__ counts) {
+  __shared__ int part[4];
+  const int64_t base = (int64_t)blockIdx.x * kZcTile;
+  int c = 0;
+#pragma unroll
+  for (int q = 0; q < kZcTile / 256; ++q) c += crossing_at(x, base + q * 256 + threadIdx.x, n) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = (long long)part[0] + part[1] + part[2] + part[3];
+}
+
+// exclusive scan of the tile counts by one workgroup (chunks of 1024 with a running carry); counts[n_tiles] = total
+__global__ __launch_bounds__(1024) void k_zc_scan(long long* __restrict__ counts, int64_t n_tiles) {
+  __shared__ long long buf[1024];
+  __shared__ long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t c0 = 0; c0 < n_tiles; c0 += 1024) {
+    const int64_t i = c0 + threadIdx.x;
+    const long long v = i < n_tiles ? counts[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                 // Hillis-Steele inclusive scan
+      const long long t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < n_tiles) counts[i] = carry + buf[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += buf[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[n_tiles] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_zc_write(const double* __restrict__ x, int64_t n, const long long* __restrict__ offs,
+                                                  long long* __restrict__ idx) {
+  __shared__ int wave_cnt[4];
+  const int64_t base = (int64_t)blockIdx.x * kZcTile;
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  long long out = offs[blockIdx.x];
+  // a wave owns 64 consecutive samples per round, 4 rounds of 256: keeps the indices ascending
+  for (int q = 0; q < kZcTile / 256; ++q) {
+    const int64_t i = base + q * 256 + threadIdx.x;
+    const bool hit = crossing_at(x, i, n);
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wave_cnt[w] = __popcll(m);
+    __syncthreads();
+    long long before = 0;
+    for (int k = 0; k < w; ++k) before += wave_cnt[k];
+    if (hit) idx[out + before + __popcll(m & ((1ull << lane) - 1ull))] = (long long)i;
+    out += (long long)wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+}
+
 }  // namespace par
 
 extern "C" {
+
+int64_t par_zero_crossings_work_len(int64_t n) { return n < 2 ? 2 : (n + par::kZcTile - 1) / par::kZcTile + 1; }
+
+int par_zero_crossings_f64(int device, const double* x, int64_t n, int64_t* work, int64_t* idx, int64_t cap, int64_t* count,
+                           void* stream) {
+  using namespace par;
+  PAR_REQUIRE(x && work && count && n >= 0, PAR_ERR_ARG, "par_zero_crossings_f64: bad args");
+  *count = 0;
+  if (n < 2) return PAR_OK;
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipStream_t s = as_stream(stream);
+  const int64_t n_tiles = ceil_div(n, kZcTile);
+  long long* offs = reinterpret_cast<long long*>(work);
+  hipLaunchKernelGGL(k_zc_count, dim3((unsigned)n_tiles), dim3(256), 0, s, x, n, offs);
+  hipLaunchKernelGGL(k_zc_scan, dim3(1), dim3(1024), 0, s, offs, n_tiles);
+  PAR_HIP_CHECK(hipGetLastError());
+  long long total = 0;
+  PAR_HIP_CHECK(hipMemcpyAsync(&total, offs + n_tiles, sizeof(total), hipMemcpyDeviceToHost, s));
+  PAR_HIP_CHECK(hipStreamSynchronize(s));
+  *count = (int64_t)total;
+  if (!idx) return PAR_OK;                                  // query form: count only
+  PAR_REQUIRE(cap >= total, PAR_ERR_WORKSPACE, "par_zero_crossings_f64: %lld crossings do not fit idx[%lld]", total,
+              (long long)cap);
+  if (total == 0) return PAR_OK;
+  hipLaunchKernelGGL(k_zc_write, dim3((unsigned)n_tiles), dim3(256), 0, s, x, n, offs, reinterpret_cast<long long*>(idx));
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
 
 int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
                        double* freqs, int fft_size, double sr, double tolerance_oct, int mode, void* stream) {

@@ -32,37 +32,43 @@ def sosfiltfilt_dev(sos, x_t, dev=None):
 
 
 def _design(lowcut, highcut, fs, order):
-    nyq = 0.5 * fs
-    low = lowcut / nyq
-    high = highcut / nyq
-    low_in_range = 0 < low < 1
-    high_in_range = 0 < high < 1
-    if low_in_range and high_in_range:
-        return scipy.signal.butter(order, [low, high], btype='band', output='sos')
-    elif low_in_range and not high_in_range:
-        return scipy.signal.butter(order, low, btype='high', output='sos')
-    elif not low_in_range and high_in_range:
-        return scipy.signal.butter(order, high, btype='low', output='sos')
+    """SOS Butterworth design for the cut-offs that lie strictly inside (0, Nyquist): both -> band-pass, only the
+    lower -> high-pass, only the upper -> low-pass, neither -> None (util/filters.py:7-23)."""
+    edges = {"low": lowcut / (0.5 * fs), "high": highcut / (0.5 * fs)}
+    usable = {k: v for k, v in edges.items() if 0 < v < 1}
+    if len(usable) == 2:
+        return scipy.signal.butter(order, [usable["low"], usable["high"]], btype='band', output='sos')
+    if "low" in usable:
+        return scipy.signal.butter(order, usable["low"], btype='high', output='sos')
+    if "high" in usable:
+        return scipy.signal.butter(order, usable["high"], btype='low', output='sos')
     return None
 
 
-def butter_bandpass_filter(data, lowcut, highcut, fs, order=5):
-    """Performs a low, high or bandpass filter if low & highcut are in range"""
+def bandpass_dev(data, lowcut, highcut, fs, order=5, dev=None):
+    """butter_bandpass_filter whose result stays in HBM (float64 device tensor) for a next device stage;
+    numpy or tensor input.  Neither cut-off inside (0, Nyquist): the input itself, uploaded if needed."""
+    dev = _dev.device_index(dev if dev is not None else (data.device if isinstance(data, torch.Tensor) else None))
+    x_t = _dev.to_dev(data if isinstance(data, torch.Tensor) else np.asarray(data), torch.float64, dev)
     sos = _design(lowcut, highcut, fs, order)
-    if sos is None:
+    return x_t if sos is None else sosfiltfilt_dev(sos, x_t, dev)
+
+
+def butter_bandpass_filter(data, lowcut, highcut, fs, order=5):
+    """Zero-phase Butterworth band / high / low-pass, or the input itself when neither cut-off lies inside
+    (0, Nyquist) -- the contract of the reference's util/filters.py:7-24.  The design is scipy's (host, a few
+    coefficients); the filtering runs in K_sosfiltfilt.  numpy in -> numpy out, device tensor in -> device tensor."""
+    if _design(lowcut, highcut, fs, order) is None:
         return data
-    if isinstance(data, torch.Tensor):
-        return sosfiltfilt_dev(sos, data.to(torch.float64))
-    dev = _dev.device_index(None)
-    x_t = _dev.to_dev(np.asarray(data), torch.float64, dev)
-    return sosfiltfilt_dev(sos, x_t, dev).cpu().numpy()
+    y = bandpass_dev(data, lowcut, highcut, fs, order)
+    return y if isinstance(data, torch.Tensor) else y.cpu().numpy()
 
 
 def moving_average(a, n=3):
-    ret = np.cumsum(a, dtype=float)
-    ret[n:] = ret[n:] - ret[:-n]
-    return ret[n - 1:] / n
+    """Box filter over n samples, len(a) - n + 1 outputs (util/filters.py:27-30)."""
+    return np.convolve(np.asarray(a, dtype=float), np.full(n, 1.0 / n), mode="valid")
 
 
 def make_odd(n):
+    """n, or the next odd number (util/filters.py:33-36)."""
     return n if n % 2 else n + 1

@@ -7,9 +7,8 @@ that tuple.  Arrays are returned with the reference's logical s
 ``(n_freqs, n_frames)``; memory is frame-major (a transposed view), which the reference's own numpy
 backend also produces for n_fft > 512 (util/fourier.py:147).
 """
-import contextlib
 import logging
-import time
+from time import perf_counter
 
 import numpy as np
 import torch
@@ -31,11 +30,17 @@ def get_mag(*args, **kwargs):
     return stft(*args, _mode=1, **kwargs)
 
 
-@contextlib.contextmanager
-def timed_log(method_name):
-    start = time.time()
-    yield
-    logging.info(f"{method_name} {time.time() - start:0.2f}s")
+class timed_log:
+    """`with timed_log("hip"):` logs "<name> <seconds>s" at INFO on exit (the reference's backends do the same)."""
+
+    def __init__(self, method_name):
+        self.method_name = method_name
+
+    def __enter__(self):
+        self.t0 = perf_counter()
+
+    def __exit__(self, *exc):
+        logging.info("%s %0.2fs", self.method_name, perf_counter() - self.t0)
 
 
 def stft_dev(x_t, n_fft, step, window_t, zeropad=1, mode=0, x_stride=1, n=None, dev=None):
@@ -137,18 +142,16 @@ def istft(stft_matrix, hop_length=None, win_length=None, window_name='blackmanha
 
 
 def fix_length(data, size, axis=-1, **kwargs):
-    """Fix the length of an array to exactly `size` along an axis (trailing zero pad / trim)."""
-    kwargs.setdefault('mode', 'constant')
-    n = data.shape[axis]
-    if n > size:
-        slices = [slice(None)] * data.ndim
-        slices[axis] = slice(0, size)
-        return data[tuple(slices)]
-    elif n < size:
-        lengths = [(0, 0)] * data.ndim
-        lengths[axis] = (0, size - n)
-        return np.pad(data, lengths, **kwargs)
-    return data
+    """Trim or trailing-pad `data` to exactly `size` along `axis` (np.pad keywords, zero padding by default);
+    a view when trimming, the array itself when the length already fits -- util/fourier.py:440-478."""
+    have = data.shape[axis]
+    if have == size:
+        return data
+    ax = axis % data.ndim
+    if have > size:
+        return data[(slice(None),) * ax + (slice(0, size),)]
+    widths = [(0, size - have) if k == ax else (0, 0) for k in range(data.ndim)]
+    return np.pad(data, widths, **{"mode": "constant", **kwargs})
 
 
 def fft_freqs(n_fft, fs):

@@ -284,69 +284,76 @@ def sinc_core(sample_at, signal, lowpass, output, win_func, N):
 
 # ----------------------------------------------------------------------------- run
 
+class _Progress:
+    """Progress reporting with the reference's signal protocol: `prog_sig.notifyProgress.emit(value)`; silent
+    when no signal object was given."""
+
+    def __init__(self, prog_sig):
+        self._emit = prog_sig.notifyProgress.emit if prog_sig else (lambda value: None)
+
+    def __call__(self, value):
+        self._emit(value)
+
+
+def _plan_positions(sig_shape, sr, speed_curve, lag_curve, want_fused, dev):
+    """(SpeedPlan or None, float64 position tensor or None) for one file.  Speed curve: the plan; its position
+    array is only materialised when the fused K_sinc cannot be used.  Lag curve: K_lag positions."""
+    n_in = sig_shape[0]
+    if speed_curve is not None:
+        curve = np.asarray(speed_curve, dtype=np.float64)
+        st_t = _dev.to_dev(curve[:, 0] * sr, torch.float64, dev)
+        sp_t = _dev.to_dev(np.ascontiguousarray(curve[:, 1]), torch.float64, dev)
+        plan = speed_plan_dev(st_t, sp_t, n_in, dev, fused=want_fused)
+        if plan.fused_ok:
+            return plan, None
+        pos_t = _dev.empty(plan.len_out, torch.float64, dev)
+        _lib.check(_lib.lib().par_speed_to_pos_fill(dev, _dev.ptr(sp_t), plan.m, _dev.ptr(plan.work), _dev.ptr(pos_t),
+                                                    plan.len_out, _dev.stream_ptr(dev)))
+        return plan, pos_t
+    if lag_curve is not None:
+        return None, lag_to_pos_dev(lag_curve, sr, n_in, dev)
+    # the reference reaches its channel loop with `sample_at` never assigned
+    raise UnboundLocalError("local variable 'sample_at' referenced before assignment")
+
+
 def run(filenames, signal_data=None, speed_curve=None, resampling_mode="Linear", sinc_quality=50, use_channels=(),
         prog_sig=None, lag_curve=None, suffix=""):
-    """Drop-in for resampling.run (util/resampling.py:162-240): same progress callbacks, channel
-    filtering and output naming; positions and all channels stay in HBM until the final D2H."""
+    """Batch resampler with the contract of the reference's resampling.run (util/resampling.py:162-240): per file,
+    positions from the speed curve (or lag curve), every selected channel resampled ("Sinc" or "Linear"), result
+    written as `<stem>_res<suffix>.wav` (32-bit float), progress emitted as 0, then (k+1)/channels*100 per
+    channel, then 100 per file.  `signal_data` optionally supplies decoded `(signal, sr)` pairs.  The file's
+    channels, its positions (or the fused plan) and the interleaved output stay in HBM; one D2H per file."""
     from . import io_ops
-    if prog_sig:
-        prog_sig.notifyProgress.emit(0)
-    if signal_data is None:
-        signal_data = [None for filename in filenames]
+    progress = _Progress(prog_sig)
+    progress(0)
     dev = _dev.device_index(None)
-    for filename, sig_data in zip(filenames, signal_data):
+    decoded = signal_data if signal_data is not None else [None] * len(filenames)
+    for filename, given in zip(filenames, decoded):
         with log_duration("Preparing"):
             logging.info(f"Resampling '{os.path.basename(filename)}'... {resampling_mode}, {sinc_quality}, {use_channels}")
-            if sig_data:
-                signal, sr = sig_data
-                num_channels = signal.shape[1]
-            else:
-                signal, sr, num_channels = io_ops.read_file(filename)
-            sig_t = _dev.to_dev(signal, torch.float32, dev)          # (n, ch) C-order in HBM
+            signal, sr = given if given else io_ops.read_file(filename)[:2]
             n_in, n_ch_in = signal.shape
-            plan = None
-            pos_t = None
-            if speed_curve is not None:
-                sampletimes = speed_curve[:, 0] * sr
-                speeds = speed_curve[:, 1]
-                st_t = _dev.to_dev(np.asarray(sampletimes, dtype=np.float64), torch.float64, dev)
-                sp_t = _dev.to_dev(np.asarray(speeds, dtype=np.float64), torch.float64, dev)
-                # Sinc mode: fused plan (positions are regenerated inside K_sinc, no sample_at array in HBM)
-                plan = speed_plan_dev(st_t, sp_t, n_in, dev, fused=(resampling_mode == "Sinc"))
-                if not plan.fused_ok:
-                    pos_t = _dev.empty(plan.len_out, torch.float64, dev)
-                    _lib.check(_lib.lib().par_speed_to_pos_fill(dev, _dev.ptr(sp_t), plan.m, _dev.ptr(plan.work),
-                                                                _dev.ptr(pos_t), plan.len_out, _dev.stream_ptr(dev)))
-            elif lag_curve is not None:
-                pos_t = lag_to_pos_dev(lag_curve, sr, n_in, dev)
-            else:
-                raise UnboundLocalError("local variable 'sample_at' referenced before assignment")  # reference behaviour
-        if use_channels:
-            use_channels = [channel for channel in use_channels if channel < signal.shape[1]]
-        else:
-            use_channels = tuple(range(num_channels))
+            sig_t = _dev.to_dev(signal, torch.float32, dev)                  # (n, ch) interleaved, like the file
+            plan, pos_t = _plan_positions(signal.shape, sr, speed_curve, lag_curve, resampling_mode == "Sinc", dev)
+        # channel selection persists across files, as the reference rebinds its argument
+        use_channels = [c for c in use_channels if c < n_ch_in] if use_channels else tuple(range(n_ch_in))
         with log_duration("Resampling"):
-            length = plan.len_out if plan is not None else pos_t.numel()
-            num_channels = len(use_channels)
-            out_t = _dev.empty((length, num_channels), torch.float32, dev)
-            for out_channel, in_channel in enumerate(use_channels):
-                sig_view = sig_t.reshape(-1)[in_channel:]
-                out_view = out_t.reshape(-1)[out_channel:]
-                if resampling_mode == "Sinc" and plan is not None and plan.fused_ok:
-                    varispeed_fused_dev(plan, sig_view, sinc_quality, out_view, sig_stride=n_ch_in, len_in=n_in,
-                                        out_stride=num_channels)
-                elif resampling_mode == "Sinc":
-                    sinc_resample_dev(pos_t, sig_view, sinc_quality, out_view, sig_stride=n_ch_in, len_in=n_in,
-                                      out_stride=num_channels, dev=dev)
+            n_out_ch = len(use_channels)
+            length = plan.len_out if pos_t is None else pos_t.numel()
+            out_t = _dev.empty((length, n_out_ch), torch.float32, dev)
+            for k, ch in enumerate(use_channels):
+                src, dst = sig_t.reshape(-1)[ch:], out_t.reshape(-1)[k:]      # strided channel views, no copies
+                layout = dict(sig_stride=n_ch_in, len_in=n_in, out_stride=n_out_ch)
+                if resampling_mode == "Sinc":
+                    if pos_t is None:
+                        varispeed_fused_dev(plan, src, sinc_quality, dst, **layout)
+                    else:
+                        sinc_resample_dev(pos_t, src, sinc_quality, dst, dev=dev, **layout)
                 elif resampling_mode == "Linear":
-                    linear_resample_dev(pos_t, sig_view, out_view, sig_stride=n_ch_in, len_in=n_in,
-                                        out_stride=num_channels, dev=dev)
-                if prog_sig:
-                    prog_sig.notifyProgress.emit((out_channel + 1) / num_channels * 100)
-            output = out_t.cpu().numpy()
+                    linear_resample_dev(pos_t, src, dst, dev=dev, **layout)
+                progress((k + 1) / n_out_ch * 100)
+            result = out_t.cpu().numpy()
         with log_duration("Writing"):
-            out_file_path = f"{os.path.splitext(filename)[0]}_res{suffix}.wav"
-            io_ops.write_wav_float(out_file_path, output, sr)
-            if prog_sig:
-                prog_sig.notifyProgress.emit(100)
+            io_ops.write_wav_float(f"{os.path.splitext(filename)[0]}_res{suffix}.wav", result, sr)
+            progress(100)
     logging.info("Done!")

@@ -1,33 +1,85 @@
-"""Mirror of reference util/wow_detection.py -- same classes, constructor signature and registry.
+"""Wow/flutter pitch trackers behind the reference's tracker API (util/wow_detection.py).
 
-Track :28-139 (trail sampling and band arithmetic on the host, O(trail)), PeakTracker :294-304,
-PeakTrackTracker :307-327, CenterOfGravity :256-291 run their per-frame trace() loops in
-K_track (csrc/track.hip) on a device-resident, frame-major float32 magnitude spectrogram.
-ZeroCrossingTracker :330-358 band-passes the signal segment with K_sosfiltfilt and finishes the
-O(#crossings) post-processing on the host.  CorrelationTracker :396-436 (W4, lowest priority in
-SURVEY 8a) is host numpy/scipy exactly like the reference; PartialsTracker needs librosa + a
-matplotlib window and is not provided.
+API kept (what pyrespeeder_gui.py:185-189 and the headless pipeline rely on): the `wow_detectors` registry
+maps the GUI names to classes constructed as `cls(spectrum, signal, trail, fft_size, hop, sr, tolerance_st,
+adaptation_mode)`; construction runs the trace and leaves `times` / `freqs` (Hz per STFT frame of the trail's
+span).  `fit_sin` / `trace_sine_reg` keep their return contracts.  Everything else is this package's design:
+
+* trail sampling (frame span, time grid, drawn frequencies) is a pure function, `sample_trail`;
+* Peak / Peak Track / Center of Gravity run in K_track (csrc/track.hip) on the device-resident, frame-major
+  float32 magnitude spectrogram K_stft wrote -- no spectrogram ever returns to the host;
+* Zero-Crossing: band-pass in K_sosfiltfilt, sign-change compaction in K_track (`par_zero_crossings_f64`); only
+  the crossing indices come back for the O(#crossings) smoothing;
+* Correlation: batched -- one quadratic-spline evaluation for all frames (the band rows are the only part of the
+  spectrogram copied to the host), one batched FFT cross-correlation, vectorised peak refinement;
+* Partials needs librosa + an interactive matplotlib window and is not provided.
+
+Reference semantics each piece reproduces are cited at the definitions.
 """
+import ctypes
 import logging
-from inspect import isclass
 
 import numpy as np
-import scipy.interpolate
 import scipy.optimize
 import torch
+from scipy.interpolate import make_interp_spline
 from scipy.signal import get_window
 
 from . import _dev, _lib, filters, fourier
-from .correlation import xcorr, parabolic
+from .correlation import xcorr_rows
+
+MIN_BAND_BINS = 4
 
 
-def nan_helper(y):
-    return np.isnan(y), lambda z: z.nonzero()[0]
-
+# ------------------------------------------------------------------------------------------ helpers
 
 def interp_nans(y):
-    nans, x = nan_helper(y)
-    y[nans] = np.interp(x(nans), x(~nans), y[~nans])
+    """Fill NaNs of a 1-D array in place by linear interpolation over the valid samples (the reference's
+    post-processing step, util/wow_detection.py:15-25, 61)."""
+    bad = np.isnan(y)
+    if bad.any():
+        pos = np.arange(len(y))
+        y[bad] = np.interp(pos[bad], pos[~bad], y[~bad])
+
+
+def sample_trail(trail, n_frames, hop, sr):
+    """Drawn trail [(t seconds, f Hz), ...] -> (frame_0, frame_1, times, freqs).
+
+    Semantics of Track.sample_trail / ensure_frames (util/wow_detection.py:63-95): the trail is sorted by time
+    IN PLACE (callers see it), the frame span is [int(t_first*sr/hop), int(t_last*sr/hop)] clipped to the
+    spectrogram -- a bound that is exactly 0 leaves the clip at the spectrogram edge -- and the time grid has one
+    point per frame but runs to the END of the span (linspace over frame_1 - frame_0 points)."""
+    trail.sort(key=lambda point: point[0])
+    t_pts = np.array([p[0] for p in trail], dtype=np.float64)
+    f_pts = np.array([p[1] for p in trail], dtype=np.float64)
+    frame_0, frame_1 = 0, int(n_frames)
+    if t_pts[0]:
+        frame_0 = max(frame_0, int(t_pts[0] * sr / hop))
+    if t_pts[-1]:
+        frame_1 = min(frame_1, int(t_pts[-1] * sr / hop))
+    if frame_0 == frame_1:
+        logging.warning("No point in tracing just one FFT")
+    times = np.linspace(frame_0 * hop / sr, frame_1 * hop / sr, frame_1 - frame_0)
+    return frame_0, frame_1, times, np.interp(times, t_pts, f_pts)
+
+
+def octave_band(freq, half_width_octaves):
+    """(f * 2^-w, f * 2^+w): the tolerance band around a frequency (util/wow_detection.py:109-117)."""
+    centre = np.log2(freq)
+    return np.power(2, centre - half_width_octaves), np.power(2, centre + half_width_octaves)
+
+
+def band_to_bins(f_lo, f_hi, fft_size, sr, n_bins, min_bins=MIN_BAND_BINS):
+    """Band edges in Hz -> (NL, NU) bin slice, at least `min_bins` wide (util/wow_detection.py:81-82, 97-107:
+    edges clamped to [1 Hz, Nyquist], bins to [1, n_bins-1], Python round-half-even, symmetric widening)."""
+    def to_bin(f):
+        return int(min(n_bins - 1, max(1, int(np.rint(f * fft_size / sr)))))
+    lo, hi = to_bin(max(1.0, f_lo)), to_bin(min(sr / 2, f_hi))
+    missing = min_bins - (hi - lo)
+    if missing > 0:
+        grow = (missing + 1) // 2
+        lo, hi = lo - grow, hi + grow
+    return lo, hi
 
 
 def spectrum_to_device(spectrum, dev=None):
@@ -39,177 +91,112 @@ def spectrum_to_device(spectrum, dev=None):
     return _dev.to_dev(np.asarray(spectrum).T, torch.float32, dev)
 
 
+def zero_crossings_dev(x_t, dev=None):
+    """Indices i with (x[i+1] > 0) != (x[i] > 0) of a float64 device tensor, ascending, as a device int64
+    tensor (zero_crossings, util/wow_detection.py:448-450)."""
+    dev = _dev.device_index(dev if dev is not None else x_t.device)
+    L = _lib.lib()
+    n = x_t.numel()
+    work = _dev.empty(int(L.par_zero_crossings_work_len(n)), torch.int64, dev)
+    count = ctypes.c_int64(0)
+    _lib.check(L.par_zero_crossings_f64(dev, _dev.ptr(x_t), n, _dev.ptr(work), None, 0, ctypes.byref(count),
+                                        _dev.stream_ptr(dev)))
+    idx = _dev.empty(count.value, torch.int64, dev)
+    if count.value:
+        _lib.check(L.par_zero_crossings_f64(dev, _dev.ptr(x_t), n, _dev.ptr(work), _dev.ptr(idx), idx.numel(),
+                                            ctypes.byref(count), _dev.stream_ptr(dev)))
+    return idx
+
+
+def zero_crossings(a):
+    """Host-array convenience form of zero_crossings_dev (same name as the reference's helper)."""
+    dev = _dev.device_index(None)
+    return zero_crossings_dev(_dev.to_dev(np.asarray(a, dtype=np.float64), torch.float64, dev), dev).cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------ trackers
+
 class Track:
+    """Base of all trackers: samples the trail, runs `trace()`, patches NaNs.  Attributes the callers read:
+    times, freqs (and frame_0 / frame_1, the spectrogram frames they refer to)."""
+    name = None
     tooltip = ""
 
     def __init__(self, spectrum, signal, trail, fft_size, hop, sr, tolerance_st=1, adaptation_mode="Linear",
                  dB_cutoff=75):
-        self.fft_size = fft_size
-        self.hop = hop
-        self.sr = sr
-        self.spectrum = spectrum
-        self.signal = signal
+        self.spectrum, self.signal = spectrum, signal
+        self.fft_size, self.hop, self.sr = fft_size, hop, sr
+        self.num_bins, n_frames = spectrum.shape
         self.fft_freqs = fourier.fft_freqs(fft_size, sr)
-        self.frame_0 = 0
-        self.num_bins, self.frame_1 = self.spectrum.shape
-        self.sample_trail(trail)
-        self.NL = 0
-        self.NU = 0
-        # tolerance in semitones; on log2 scale one semitone is 1/12
-        self.tolerance = tolerance_st / 12
-        self.min_bins = 4
+        self.frame_0, self.frame_1, self.times, self.freqs = sample_trail(trail, n_frames, hop, sr)
+        self.tolerance = tolerance_st / 12                 # semitones -> octaves
+        self.NL = self.NU = 0
         self.trace()
         interp_nans(self.freqs)
 
     def trace(self):
-        pass
+        """Overwrite self.freqs in place; the base class keeps the drawn trail."""
 
-    def sample_trail(self, trail):
-        trail.sort(key=lambda tup: tup[0])
-        times_raw = [d[0] for d in trail]
-        freqs_raw = [d[1] for d in trail]
-        self.ensure_frames(times_raw[0], times_raw[-1])
-        self.times = np.linspace(self.frame_0 * self.hop / self.sr, self.frame_1 * self.hop / self.sr,
-                                 self.frame_1 - self.frame_0)
-        self.freqs = np.interp(self.times, times_raw, freqs_raw)
+    def _device_spectrum(self):
+        dev = _dev.device_index(self.spectrum.device if isinstance(self.spectrum, torch.Tensor) else None)
+        return dev, spectrum_to_device(self.spectrum, dev)
 
-    def bin_2_freq(self, b):
-        return b / self.fft_size * self.sr
-
-    def freq_2_bin(self, f):
-        return max(1, min(self.num_bins - 1, int(round(f * self.fft_size / self.sr))))
-
-    def time_2_frame(self, t):
-        return int(t * self.sr / self.hop)
-
-    def ensure_frames(self, t0, t1):
-        if t0:
-            self.frame_0 = max(self.frame_0, self.time_2_frame(t0))
-        if t1:
-            self.frame_1 = min(self.frame_1, self.time_2_frame(t1))
-        if self.frame_0 == self.frame_1:
-            logging.warning("No point in tracing just one FFT")
-
-    def set_bin_limits(self, fL, fU):
-        fL = max(1.0, fL)
-        fU = min(self.sr / 2, fU)
-        self.NL = self.freq_2_bin(fL)
-        self.NU = self.freq_2_bin(fU)
-        while (self.NU - self.NL) < self.min_bins:
-            self.NL -= 1
-            self.NU += 1
-
-    def freq_plus_tolerance(self, freq, tolerance=None):
-        if tolerance is None:
-            tolerance = self.tolerance
-        logfreq = np.log2(freq)
-        return np.power(2, (logfreq - tolerance)), np.power(2, (logfreq + tolerance))
-
-    # -- device plumbing shared by the HIP-backed trackers
-    def _run_device(self, kind, mode=0):
+    def _trace_on_device(self, kernel, *extra):
+        """Per-frame band search in K_track: freqs go up as the drawn trail and come back traced."""
         if len(self.freqs) == 0:
             return
-        dev = _dev.device_index(self.spectrum.device if isinstance(self.spectrum, torch.Tensor) else None)
-        L = _lib.lib()
-        mag = spectrum_to_device(self.spectrum, dev)
-        n_frames, bins = mag.shape
+        dev, mag = self._device_spectrum()
         f_t = _dev.to_dev(self.freqs, torch.float64, dev)
-        if kind == "peak":
-            _lib.check(L.par_track_peak_f64(dev, _dev.ptr(mag), n_frames, bins, self.frame_0, len(self.freqs),
-                                            _dev.ptr(f_t), self.fft_size, float(self.sr), float(self.tolerance), mode,
-                                            _dev.stream_ptr(dev)))
-        else:
-            _lib.check(L.par_track_cog_f64(dev, _dev.ptr(mag), n_frames, bins, self.frame_0, len(self.freqs),
-                                           _dev.ptr(f_t), self.fft_size, float(self.sr), float(self.tolerance),
-                                           _dev.stream_ptr(dev)))
+        _lib.check(kernel(dev, _dev.ptr(mag), mag.shape[0], mag.shape[1], self.frame_0, len(self.freqs), _dev.ptr(f_t),
+                          self.fft_size, float(self.sr), float(self.tolerance), *extra, _dev.stream_ptr(dev)))
         self.freqs[:] = f_t.cpu().numpy()
-
-
-def fit_sin(tt, yy, assumed_freq=None):
-    """Fit a sine to the input sequence (reference util/wow_detection.py:190-228; host, O(len) once per gesture)."""
-    tt = np.array(tt)
-    yy = np.array(yy)
-    ff = np.fft.rfftfreq(len(tt), (tt[1] - tt[0]))
-    fft_data = np.fft.rfft(yy)[1:]
-    if assumed_freq:
-        period = tt[1] - tt[0]
-        N = len(yy) + 1
-        peak_est = int(round(assumed_freq * N * period))
-        win = np.interp(np.arange(0, len(fft_data)), (0, peak_est, len(fft_data)), (0, 1, 0))
-        fft_data *= win
-    peak_bin = np.argmax(np.abs(fft_data)) + 1
-    guess_freq = ff[peak_bin]
-    guess_amp = np.std(yy) * 2. ** 0.5
-    guess_offset = np.mean(yy)
-    guess_phase = np.angle(fft_data[peak_bin])
-    guess = np.array([guess_amp, 2. * np.pi * guess_freq, guess_phase, guess_offset])
-
-    def sinfunc(t, A, w, p, c):
-        return A * np.sin(w * t + p) + c
-
-    popt, pcov = scipy.optimize.curve_fit(sinfunc, tt, yy, p0=guess)
-    A, w, p, c = popt
-    f = w / (2. * np.pi)
-    return {"amp": A, "omega": w, "phase": p, "offset": c, "freq": f, "period": 1. / f,
-            "fitfunc": lambda t: A * np.sin(w * t + p) + c, "maxcov": np.max(pcov), "rawres": (guess, popt, pcov)}
-
-
-def trace_sine_reg(speed_curve, t0, t1, rpm=None):
-    """Regression on an area of the master speed curve (reference util/wow_detection.py:231-253)."""
-    times = speed_curve[:, 0]
-    speeds = speed_curve[:, 1]
-    period = times[1] - times[0]
-    ind_start = int(t0 / period)
-    ind_stop = int(t1 / period)
-    try:
-        assumed_freq = float(rpm) / 60
-    except Exception:
-        assumed_freq = None
-    res = fit_sin(times[ind_start:ind_stop], speeds[ind_start:ind_stop], assumed_freq=assumed_freq)
-    return res["amp"], res["omega"], res["phase"], 0
 
 
 class CenterOfGravity(Track):
     name = 'Center of Gravity'
 
-    def trace(self):
-        self._run_device("cog")
+    def trace(self):          # util/wow_detection.py:256-291 -> k_track_cog
+        self._trace_on_device(_lib.lib().par_track_cog_f64)
 
 
 class PeakTracker(Track):
     name = 'Peak'
     tooltip = "Tracks the mouse input to the loudest peak frequency"
 
-    def trace(self):
-        self._run_device("peak", 0)
+    def trace(self):          # util/wow_detection.py:294-304 -> k_track_peak
+        self._trace_on_device(_lib.lib().par_track_peak_f64, 0)
 
 
 class PeakTrackTracker(Track):
     name = 'Peak Track'
     tooltip = "Follows the first peak frequency established"
 
-    def trace(self):
-        self._run_device("peak", 1)
+    def trace(self):          # util/wow_detection.py:307-327 -> k_track_peak_fixed
+        self._trace_on_device(_lib.lib().par_track_peak_f64, 1)
+
+
+def crossing_periods_to_freqs(crossings, sr, t_first, times):
+    """Sign-change indices -> frequency per requested time (util/wow_detection.py:342-358): the spacing of
+    consecutive crossings (half periods, float32 like the reference) is smoothed with a Hann kernel of about
+    10 ms of crossings on a reflect-padded sequence, turned into Hz and interpolated onto `times`."""
+    half_periods = np.diff(crossings).astype(np.float32)
+    span = int(sr / 100 / np.mean(half_periods))
+    kernel = get_window("hann", span) / span * 2
+    smooth = np.convolve(np.pad(half_periods, span, mode='reflect'), kernel, mode="same")[span:-span]
+    return np.interp(times, crossings[:len(smooth)] / sr + t_first, sr / 2 / smooth)
 
 
 class ZeroCrossingTracker(Track):
     name = 'Zero-Crossing'
     tooltip = "Track the distance between zero-crossings of the waveform. Good for flutter detection of clean signals"
 
-    def trace(self):
-        fL, _ = self.freq_plus_tolerance(np.min(self.freqs))
-        _, fU = self.freq_plus_tolerance(np.max(self.freqs))
-        s_0 = int(self.times[0] * self.sr)
-        s_1 = int(self.times[-1] * self.sr)
-        filtered_sig = filters.butter_bandpass_filter(self.signal[s_0:s_1, 0], fL, fU, self.sr, order=3)
-        crossings = zero_crossings(filtered_sig)
-        deltas = np.diff(crossings).astype(np.float32)
-        size = int(self.sr / 100 / np.mean(deltas))
-        padded = np.pad(deltas, size, mode='reflect')
-        win_sq = get_window("hann", size)
-        deltas_conv = np.convolve(padded, win_sq / size * 2, mode="same")[size:-size]
-        self.freqs[:] = np.interp(self.times, crossings[:len(deltas_conv)] / self.sr + self.times[0],
-                                  self.sr / 2 / deltas_conv)
+    def trace(self):          # util/wow_detection.py:330-358
+        f_lo = octave_band(np.min(self.freqs), self.tolerance)[0]
+        f_hi = octave_band(np.max(self.freqs), self.tolerance)[1]
+        first, last = int(self.times[0] * self.sr), int(self.times[-1] * self.sr)
+        band = filters.bandpass_dev(self.signal[first:last, 0], f_lo, f_hi, self.sr, order=3)
+        crossings = zero_crossings_dev(band).cpu().numpy()
+        self.freqs[:] = crossing_periods_to_freqs(crossings, self.sr, self.times[0], self.times)
 
 
 class PartialsTracker(Track):
@@ -221,55 +208,91 @@ class PartialsTracker(Track):
 
 
 class FreehandTracker(Track):
-    name = 'Freehand Draw'
+    name = 'Freehand Draw'     # returns the interpolated trail itself
 
-    def trace(self):
-        pass
+
+def correlation_drift(band, log_freqs):
+    """Cumulative log2-frequency drift between consecutive spectrogram frames (util/wow_detection.py:404-431).
+
+    band: (n_band_bins, F) magnitudes of the band, log_freqs: log2 of the band's bin frequencies.  Every frame is
+    resampled onto a uniform log-frequency grid (4x oversampled) by a quadratic interpolating spline -- what
+    `interp1d(kind='quadratic')` builds -- for all frames in one call; consecutive frames (the last one against
+    an all-ones frame, as the reference's buffer is initialised) are Hann-windowed and cross-correlated in one
+    batched FFT; the parabola-refined peak offset from the centre is the per-frame change."""
+    n_grid = band.shape[0] * 4
+    grid = np.linspace(log_freqs[0], log_freqs[-1], n_grid)
+    frames = make_interp_spline(log_freqs, band, k=2, axis=0, check_finite=False)(grid)       # (n_grid, F)
+    frames = np.concatenate((frames, np.ones((n_grid, 1))), axis=1) * np.hanning(n_grid)[:, None]
+    full = xcorr_rows(frames[:, :-1].T, frames[:, 1:].T)                                      # (F, 2 n_grid - 1)
+    same = full[:, (n_grid - 1) // 2:(n_grid - 1) // 2 + n_grid]
+    peak = np.argmax(same, axis=1)
+    if np.any(peak == n_grid - 1):
+        raise IndexError(f"index {n_grid} is out of bounds for axis 0 with size {n_grid}")   # the reference's f[x + 1]
+    rows = np.arange(len(peak))
+    left, mid, right = same[rows, peak - 1], same[rows, peak], same[rows, peak + 1]           # peak 0: wraps like f[-1]
+    refined = peak + 0.5 * (left - right) / (left - 2 * mid + right)
+    return np.cumsum((n_grid // 2) - refined) / n_grid * (log_freqs[-1] - log_freqs[0])
 
 
 class CorrelationTracker(Track):
     name = 'Correlation'
     tooltip = "Compare the spectra for each segment and track the offsets between"
 
-    def trace(self):
-        spec = self.spectrum.cpu().numpy() if isinstance(self.spectrum, torch.Tensor) else self.spectrum
-        fL = min(self.freqs)
-        fU = max(self.freqs)
-        self.set_bin_limits(fL, fU)
-        num_freq_samples = (self.NU - self.NL) * 4
-        log_fft_freqs = np.log2(self.fft_freqs[self.NL:self.NU])
-        linspace_fft_freqs = np.linspace(log_fft_freqs[0], log_fft_freqs[-1], num_freq_samples)
-        resampled = np.ones((num_freq_samples, len(self.freqs) + 1), )
-        for i in range(len(self.freqs)):
-            interpolator = scipy.interpolate.interp1d(log_fft_freqs, spec[self.NL:self.NU, i], kind='quadratic')
-            resampled[:, i] = interpolator(linspace_fft_freqs)
-        wind = np.hanning(num_freq_samples)
-        changes = np.ones(len(self.freqs))
-        for i in range(len(self.freqs)):
-            res = xcorr(resampled[:, i] * wind, resampled[:, i + 1] * wind, mode="same")
-            i_peak = np.argmax(res)
-            i_interp, corr = parabolic(res, i_peak)
-            changes[i] = (num_freq_samples // 2) - i_interp
-        speed = np.cumsum(changes)
-        speed = speed / num_freq_samples * (log_fft_freqs[-1] - log_fft_freqs[0])
-        log_mean_freq = np.log2((fL + fU) / 2)
-        np.power(2, (log_mean_freq + speed), self.freqs)
+    def trace(self):          # util/wow_detection.py:396-436 (reads frames 0.. whatever frame_0 is: kept)
+        f_lo, f_hi = float(np.min(self.freqs)), float(np.max(self.freqs))
+        self.NL, self.NU = band_to_bins(f_lo, f_hi, self.fft_size, self.sr, self.num_bins)
+        n = len(self.freqs)
+        if isinstance(self.spectrum, torch.Tensor):
+            band = self.spectrum[self.NL:self.NU, :n].to(torch.float64).cpu().numpy()     # the band rows only
+        else:
+            band = np.asarray(self.spectrum[self.NL:self.NU, :n], dtype=np.float64)
+        drift = correlation_drift(band, np.log2(self.fft_freqs[self.NL:self.NU]))
+        self.freqs[:] = np.power(2, np.log2((f_lo + f_hi) / 2) + drift)
 
 
 class SineRegression(Track):
     name = 'Sine Regression'
     tooltip = "Perform a regression on an area of the master speed curve to yield a sine fit"
 
-    def trace(self):
-        pass
+
+# ---------------------------------------------------------------------------------- sine regression
+
+def fit_sin(tt, yy, assumed_freq=None):
+    """Least-squares fit of A*sin(w*t + p) + c to uniformly sampled data; returns the reference's result dict
+    (util/wow_detection.py:190-228: "amp", "omega", "phase", "offset", "freq", "period", "fitfunc", "maxcov",
+    "rawres").  The start point comes from the strongest non-DC FFT bin, optionally tapered towards an assumed
+    frequency; as in the reference the start phase is read one bin above that peak (its DC-less indexing)."""
+    t = np.array(tt)
+    y = np.array(yy)
+    step = t[1] - t[0]
+    bins = np.fft.rfft(y)[1:]                                  # DC dropped: bins[j] is frequency bin j + 1
+    if assumed_freq:
+        centre = int(round(assumed_freq * (len(y) + 1) * step))
+        bins = bins * np.interp(np.arange(len(bins)), (0, centre, len(bins)), (0, 1, 0))
+    k = int(np.argmax(np.abs(bins))) + 1
+    start = np.array([np.std(y) * 2. ** 0.5, 2. * np.pi * np.fft.rfftfreq(len(t), step)[k], np.angle(bins[k]), np.mean(y)])
+
+    def model(x, amp, omega, phase, offset):
+        return amp * np.sin(omega * x + phase) + offset
+
+    best, cov = scipy.optimize.curve_fit(model, t, y, p0=start)
+    amp, omega, phase, offset = best
+    freq = omega / (2. * np.pi)
+    return {"amp": amp, "omega": omega, "phase": phase, "offset": offset, "freq": freq, "period": 1. / freq,
+            "fitfunc": lambda x: model(x, *best), "maxcov": np.max(cov), "rawres": (start, best, cov)}
 
 
-def zero_crossings(a):
-    positive = a > 0
-    return np.where(np.bitwise_xor(positive[1:], positive[:-1]))[0]
+def trace_sine_reg(speed_curve, t0, t1, rpm=None):
+    """Sine fit over [t0, t1] of a master speed curve (N, 2) -> (amp, omega, phase, 0)
+    (util/wow_detection.py:231-253); rpm, if it parses as a number, sets the assumed wow frequency rpm/60."""
+    step = speed_curve[1, 0] - speed_curve[0, 0]
+    part = speed_curve[int(t0 / step):int(t1 / step)]
+    try:
+        wow_hz = float(rpm) / 60
+    except (TypeError, ValueError):
+        wow_hz = None
+    fit = fit_sin(part[:, 0], part[:, 1], assumed_freq=wow_hz)
+    return fit["amp"], fit["omega"], fit["phase"], 0
 
 
-wow_detectors = {}
-for symbol, value in dict(locals()).items():
-    if isclass(value) and value != Track and issubclass(value, Track):
-        wow_detectors[value.name] = value
+wow_detectors = {cls.name: cls for cls in Track.__subclasses__()}

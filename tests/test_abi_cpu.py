@@ -107,3 +107,60 @@ def test_host_filter_design_matches_reference_branches():
     assert filters._design(0, 20, 100, 5).shape == (3, 6)   # low
     assert filters.make_odd(4) == 5 and filters.make_odd(5) == 5
     assert np.allclose(filters.moving_average(x, 3), [1, 2, 3, 4, 5, 6, 7, 8])
+
+
+# ----------------------------------------------------------------- host logic of the tracker / correlation mirrors
+def test_correlation_module_matches_golden(golden):
+    """The package's own FFT cross-correlation / parabola / find_delay against the fixture made with the reference."""
+    import inputs
+    from pyaudiorestoration_amd import correlation as C
+    g = golden["correlation"]
+    assert C.parabolic([1, 3, 2], 1) == (1.1666666666666667, 3.0416666666666665) == tuple(g["parabolic"])   # KAT7
+    aa = np.sin(np.arange(521) * 1.0)
+    bb = np.sin(np.arange(521) * 1.0 + 3)
+    keep = aa.copy()
+    assert np.allclose(C.find_delay(aa, bb, window_name="hann"), g["find_delay"], rtol=1e-9, atol=1e-9)
+    assert not np.array_equal(aa, keep)                                  # windowed in place, like the reference
+    a, b = inputs.noise(200, 40).astype(np.float64), inputs.noise(200, 41).astype(np.float64)
+    assert np.allclose(C.xcorr(a, b, mode="same"), g["xcorr_same"], rtol=0, atol=1e-12)
+    import scipy.signal
+    for n, m in ((7, 7), (64, 9), (9, 64), (33, 1)):
+        u, v = inputs.noise(n, n).astype(np.float64), inputs.noise(m, m + 1).astype(np.float64)
+        un, vn = u / np.linalg.norm(u), v / np.linalg.norm(v)
+        for mode in ("full", "same") + (("valid",) if n >= m else ()):
+            assert np.allclose(C.xcorr(u, v, mode), scipy.signal.correlate(un, vn, mode=mode), rtol=0, atol=1e-12), (n, m, mode)
+
+
+def test_tracker_host_geometry_and_correlation_core(golden):
+    """sample_trail / band_to_bins / correlation_drift (batched spline + batched FFT correlation) reproduce the
+    reference's Correlation and Freehand traces; fit_sin recovers a planted sine."""
+    import inputs
+    from oracle import oracle_np as O
+    from pyaudiorestoration_amd import wow_detection as W
+    g = golden["trackers"]
+    sr, n, n_fft, hop = (int(v) for v in g["cfg"])
+    spec = O.get_mag(inputs.pilot(n, sr), n_fft, hop, "blackmanharris", 1)
+    trail = [(1.3, 4000.0), (0.2, 4000.0)]                               # unsorted on purpose
+    f0, f1, times, freqs = W.sample_trail(trail, spec.shape[1], hop, sr)
+    assert trail == [(0.2, 4000.0), (1.3, 4000.0)]                       # sorted in place, like the reference
+    assert np.array_equal(times, g["freehand_draw_times"]) and np.array_equal(freqs, g["freehand_draw_freqs"])
+    lo, hi = W.band_to_bins(freqs.min(), freqs.max(), n_fft, sr, spec.shape[0])
+    assert hi - lo >= 4
+    drift = W.correlation_drift(np.asarray(spec[lo:hi, :len(freqs)], dtype=np.float64),
+                                np.log2(O.fft_freqs(n_fft, sr)[lo:hi]))
+    got = np.power(2, np.log2((freqs.min() + freqs.max()) / 2) + drift)
+    assert relerr(got, g["correlation_freqs"]) < 1e-6
+    assert W.band_to_bins(10.0, 12.0, 1024, 44100, 513) == (-1, 3)       # widened symmetrically from (1, 1)
+    assert set(W.wow_detectors) == {"Center of Gravity", "Peak", "Peak Track", "Zero-Crossing", "Partials",
+                                    "Freehand Draw", "Correlation", "Sine Regression"}
+    t = np.arange(0, 20, 0.05)
+    fit = W.fit_sin(t, 0.3 * np.sin(2 * np.pi * 0.55 * t + 0.4) + 1.0, assumed_freq=0.55)
+    assert abs(abs(fit["amp"]) - 0.3) < 1e-6 and abs(fit["freq"] - 0.55) < 1e-6 and abs(fit["offset"] - 1.0) < 1e-6
+    curve = np.stack((t, 0.01 * np.sin(2 * np.pi * 0.55 * t) + 1.0), axis=-1)
+    amp, omega, phase, zero = W.trace_sine_reg(curve, 2.0, 18.0, rpm="33.333")
+    assert abs(abs(amp) - 0.01) < 1e-6 and abs(omega / (2 * np.pi) - 0.55) < 1e-5 and zero == 0
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
