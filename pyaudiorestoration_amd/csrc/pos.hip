@@ -299,10 +299,10 @@ __global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, c
     for (int w = 0; w < kCkRound; ++w) {
       const long long b = b0 + w;
       if (b >= n_blocks) break;
-      const long long k = b * kCk;
+      const double a0 = (double)(b * kCk);
       double rr[kCk];                                         // kCk independent divisions in flight per block
 #pragma unroll
-      for (int u = 0; u < kCk; ++u) rr[u] = ramp_recip(k + u, r);
+      for (int u = 0; u < kCk; ++u) rr[u] = ramp_recip(a0 + (double)u, r);
 #pragma unroll
       for (int u = 0; u < kCk; ++u) c = c + rr[u];
       T[lane][w] = c;                                         // checkpoint b + 1
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, c
       __builtin_amdgcn_wave_barrier();
     }
   }
-  for (long long k = n_blocks * kCk; k < n; ++k) c = c + ramp_recip(k, r);
+  for (long long k = n_blocks * kCk; k < n; ++k) c = c + ramp_recip((double)k, r);
   if (i < nseg) S[i] = c;
 }
 
@@ -497,7 +497,7 @@ __global__ void k_trim(const double* __restrict__ st, const double* __restrict__
     double c = 0.0, best = INFINITY;
     long long arg = 0;
     for (long long k = 0; k < n; ++k) {
-      c = c + ramp_recip(k, r);
+      c = c + ramp_recip((double)k, r);
       const double d = fabs((c + off) - n_in);
       if (d < best) {
         best = d;
@@ -550,8 +550,9 @@ __global__ __launch_bounds__(kWave * kFillWaves) void k_pos_fill(const double* _
   for (long long k0 = 0; k0 < nmax; k0 += kFillChunk) {   // nmax == 0: the whole wave belongs to other chunks
     for (int kk = 0; kk < kFillChunk; kk += 4) {
       // four independent IEEE divisions in flight; only the running sum is serial
-      const double r0 = ramp_recip(k0 + kk, r), r1 = ramp_recip(k0 + kk + 1, r);
-      const double r2 = ramp_recip(k0 + kk + 2, r), r3 = ramp_recip(k0 + kk + 3, r);
+      const double ak = (double)(k0 + kk);
+      const double r0 = ramp_recip(ak, r), r1 = ramp_recip(ak + 1.0, r);
+      const double r2 = ramp_recip(ak + 2.0, r), r3 = ramp_recip(ak + 3.0, r);
       const double c0 = c + r0, c1 = c0 + r1, c2 = c1 + r2, c3 = c2 + r3;
       // rows past the segment end are never read back (the store side checks k < n)
       buf[w][lane][kk] = c0 + off;

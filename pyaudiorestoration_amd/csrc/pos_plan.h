@@ -118,9 +118,10 @@ __device__ __forceinline__ Ramp make_ramp(double s0, double s1, long long n) {
 // 1 / (k/(n-1) * ds + s0), every operation individually rounded like numpy (:120, :125).
 // k/(n-1) by Markstein's theorem: with y = RN(1/b), q0 = RN(a*y), r = a - b*q0 (exact, fma),
 // q = RN(q0 + r*y) is the correctly rounded a/b  (checked exhaustively for n <= 6000 on the host).
-__device__ __forceinline__ double ramp_recip(long long k, const Ramp& r) {
+// `a` is the step index k as a double (exact below 2^53); callers that walk consecutive k pass a0 + u with a0
+// converted once, which replaces a 64-bit integer conversion per step by one exact float64 add.
+__device__ __forceinline__ double ramp_recip(double a, const Ramp& r) {
 #pragma clang fp contract(off)   // block scope: also holds when included from files built with contraction on
-  const double a = (double)k;
   const double q0 = a * r.y;
   const double rem = __builtin_fma(-q0, r.nm1, a);
   const double q = __builtin_fma(rem, r.y, q0);

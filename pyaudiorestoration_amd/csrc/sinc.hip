@@ -329,8 +329,9 @@ __device__ __forceinline__ void generate_tile_positions(const FusedArgs& fa, int
     const double off = fa.seg_off[i];
     double c = b ? fa.ck[g] : 0.0;
     double rr[kCk];
+    const double a0 = (double)k0;
 #pragma unroll
-    for (int u = 0; u < kCk; ++u) rr[u] = ramp_recip(k0 + u, r);
+    for (int u = 0; u < kCk; ++u) rr[u] = ramp_recip(a0 + (double)u, r);
 #pragma unroll
     for (int u = 0; u < kCk; ++u) {
 #pragma clang fp contract(off)
