@@ -255,27 +255,31 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
       v[q] = z;
     }
   }
-  // untangling twiddles W^k of this lane's bins (k = j, j+T, ..): fetched before the FFT so they are in
-  // registers when the last exchange completes
-  constexpr int bins = H + 1;
-  float2 pw[9];
+  // untangling twiddles W^k of this lane's bins: fetched before the FFT so they are in registers when the last
+  // exchange completes.  Bins come in pairs (k, H-k) that share everything but two signs, so a lane owns
+  // k = j, j+T, .. below H/2 and writes both members (lane 0 adds the self-paired bin H/2).
+  constexpr int bins = H + 1, P = (H / 2) / T;
+  float2 pw[P + 1];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) pw[i] = (j + i * T < bins) ? post[j + i * T] : make_float2(0.0f, 0.0f);
+  for (int i = 0; i < P; ++i) pw[i] = post[j + i * T];
+  pw[P] = post[H / 2];
   fft_core<LOGH>(v, X, j, tw);
   if (!live) return;
-  // untangle the half-size transform into the H+1 real-FFT bins; lanes write consecutive bins
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const int k = j + i * T;
-    if (k >= bins) break;
-    const float2 zk = X[lpad(k & (H - 1))];
-    const float2 zc = cconj(X[lpad((H - k) & (H - 1))]);
-    const float2 ev = cadd(zk, zc);
-    const float2 t = cmul(pw[i], csub(zk, zc));        // W^k * (Z[k] - conj(Z[H-k]))
-    const float re = 0.5f * (ev.x + t.y) * scale;       // X[k] = (ev - i*t)/2
-    const float im = 0.5f * (ev.y - t.x) * scale;
+  const float hs = 0.5f * scale;
+  auto emit = [&](int k, float re, float im) {
     if (mode == 0) reinterpret_cast<float2*>(out)[fr * bins + k] = make_float2(re, im);
     else out[fr * bins + k] = sqrtf(re * re + im * im) + 1e-7f;
+  };
+#pragma unroll
+  for (int i = 0; i <= P; ++i) {
+    const int k = (i < P) ? j + i * T : H / 2;
+    if (i == P && j != 0) break;
+    const float2 zk = X[lpad(k)];
+    const float2 zc = cconj(X[lpad((H - k) & (H - 1))]);
+    const float2 ev = cadd(zk, zc);                     // Z[k] + conj(Z[H-k])
+    const float2 t = cmul(pw[i], csub(zk, zc));         // W^k * (Z[k] - conj(Z[H-k]))
+    emit(k, (ev.x + t.y) * hs, (ev.y - t.x) * hs);      // X[k]   = (ev - i*t)/2
+    if (i < P) emit(H - k, (ev.x - t.y) * hs, (-ev.y - t.x) * hs);   // X[H-k] = (conj(ev) - i*conj(t))/2
   }
 }
 
