@@ -184,6 +184,17 @@ int par_linear_resample_f32(int device, const double* pos, int64_t len_out, cons
 int par_lag_to_pos_f64(int device, const double* xp, const double* fp, int64_t m, int64_t num_out, int64_t len_signal,
                        double* pos, void* work, int64_t* len_out, int* trimmed, void* stream);
 
+/* ---- host-side codec: FLAC decoder standing in for soundfile/libsndfile (util/io_ops.py:7-16) ----
+ * Pure host code, no GPU needed.  `data` is the whole file in host memory.
+ *   par_flac_info        STREAMINFO fields; md5 (16 bytes, optional) is the stream's PCM signature
+ *   par_flac_decode_f32  out: host float32 [total_frames][channels], scaled by 2^-(bits-1) like libsndfile's float
+ *                        read; frame-parallel over n_threads (<= 0: all cores); every frame is CRC-checked;
+ *                        verify_md5 != 0 also checks the decoded PCM against STREAMINFO's MD5. */
+int par_flac_info(const void* data, size_t nbytes, int* sample_rate, int* channels, int* bits, int64_t* total_frames,
+                  uint8_t* md5);
+int par_flac_decode_f32(const void* data, size_t nbytes, float* out, int64_t frames_cap, int n_threads, int verify_md5,
+                        int64_t* frames_decoded);
+
 /* ---- synthetic workload generators, so bench inputs are born in HBM ---------- */
 int par_synth_signal_f32(int device, float* out, int64_t start, int64_t count, double sr, uint64_t seed, void* stream);
 int par_synth_speed_curve_f64(int device, double* sampletimes, double* speeds, int64_t m, double duration_s,

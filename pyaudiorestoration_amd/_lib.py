@@ -35,6 +35,9 @@ SIGNATURES = {
     "par_spec_apply_gain_db_c64": (c_int, [c_int, c_vp, c_vp, c_i64, c_vp]),
     "par_inpaint_gain_db_c64": (c_int, [c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "par_spec_apply_gain_boxes_c64": (c_int, [c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "par_flac_info": (c_int, [c_vp, c_sz, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                              ctypes.POINTER(c_i64), c_vp]),
+    "par_flac_decode_f32": (c_int, [c_vp, c_sz, c_vp, c_i64, c_int, c_int, ctypes.POINTER(c_i64)]),
     "par_zero_crossings_work_len": (c_i64, [c_i64]),
     "par_zero_crossings_f64": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64), c_vp]),
     "par_band_mean_db_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_int, c_int, c_i64, c_i64, c_vp, c_vp]),
