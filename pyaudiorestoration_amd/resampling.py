@@ -352,7 +352,10 @@ def run(filenames, signal_data=None, speed_curve=None, resampling_mode="Linear",
                 elif resampling_mode == "Linear":
                     linear_resample_dev(pos_t, src, dst, dev=dev, **layout)
                 progress((k + 1) / n_out_ch * 100)
-            result = out_t.cpu().numpy()
+            # pinned staging for the one D2H of the file (4x the pageable rate, tools/bench_e2e.py)
+            host = torch.empty(out_t.shape, dtype=torch.float32, pin_memory=True)
+            host.copy_(out_t)
+            result = host.numpy()
         with log_duration("Writing"):
             io_ops.write_wav_float(f"{os.path.splitext(filename)[0]}_res{suffix}.wav", result, sr)
             progress(100)

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rates of the host-buffer boundaries (never bench.py's `value`): numpy in -> numpy out through
+resampling.run's device flow (signal H2D, plan + fused K_sinc, output D2H) and through the operator slot
+sinc_wrapper (which also ships a float64 sample_at array over PCIe)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+
+import inputs
+from pyaudiorestoration_amd import _dev, resampling
+
+sr, seconds = 192000, float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
+n = int(sr * seconds)
+sig = inputs.bench_signal(0, n, sr)
+curve = inputs.bench_speed_curve(seconds, sr)
+res = {"samples": n}
+
+
+def wall(fn, reps=3):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    return (time.perf_counter() - t0) / reps, out
+
+
+def flow_pageable():
+    sig_t = _dev.to_dev(sig, torch.float32, 0)
+    st_t = _dev.to_dev(curve[:, 0] * sr, torch.float64, 0)
+    sp_t = _dev.to_dev(np.ascontiguousarray(curve[:, 1]), torch.float64, 0)
+    plan = resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
+    return resampling.varispeed_fused_dev(plan, sig_t, 32).cpu().numpy()
+
+
+dt, y = wall(flow_pageable)
+res["run()-style flow, pageable numpy in/out"] = {"s": round(dt, 4), "Msamples/s": round(len(y) / dt / 1e6, 1)}
+
+pin_in = torch.from_numpy(sig).pin_memory()
+pin_out = torch.empty(int(n * 1.02) + 1024, dtype=torch.float32).pin_memory()
+
+
+def flow_pinned():
+    sig_t = pin_in.to("cuda:0", non_blocking=True)
+    st_t = _dev.to_dev(curve[:, 0] * sr, torch.float64, 0)
+    sp_t = _dev.to_dev(np.ascontiguousarray(curve[:, 1]), torch.float64, 0)
+    plan = resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
+    out = resampling.varispeed_fused_dev(plan, sig_t, 32)
+    pin_out[:out.numel()].copy_(out, non_blocking=True)
+    torch.cuda.synchronize()
+    return pin_out[:out.numel()]
+
+
+dt, y2 = wall(flow_pinned)
+res["same flow, pinned host buffers"] = {"s": round(dt, 4), "Msamples/s": round(len(y2) / dt / 1e6, 1)}
+pos = resampling.speed_to_pos(curve[:, 0] * sr, curve[:, 1], n)
+dt, y3 = wall(lambda: resampling.sinc_wrapper(pos, sig, 0, 32), 2)
+res["sinc_wrapper(sample_at f64, signal) operator slot"] = {"s": round(dt, 4), "Msamples/s": round(len(y3) / dt / 1e6, 1)}
+assert np.array_equal(y, y2.numpy())
+print(json.dumps(res, indent=1))
