@@ -200,6 +200,15 @@ __device__ __forceinline__ void fft_core(float2 (&v)[8], float2* __restrict__ X,
   }
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  Overlapping frames share most of
+// their input, so consecutive frame groups should meet in ONE L2: logical group g = (b % 8) * ceil(n/8) + b / 8
+// gives every XCD a contiguous range of frames (groups past the end exit).
+constexpr int kXcds = 8;
+__device__ __forceinline__ int64_t xcd_contiguous_block(int64_t n_blocks) {
+  const int64_t per = (n_blocks + kXcds - 1) / kXcds;
+  return (int64_t)(blockIdx.x % kXcds) * per + blockIdx.x / kXcds;
+}
+
 template <int LOGH>
 struct FftGeom {
   static constexpr int H = 1 << LOGH;
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   const int f = threadIdx.x / T, j = threadIdx.x - f * T;
   float2* X = lds + f * G::FrameLds;
-  const int64_t fr = (int64_t)blockIdx.x * G::Frames + f;
+  const int64_t fr = xcd_contiguous_block((n_frames + G::Frames - 1) / G::Frames) * G::Frames + f;
   const bool live = fr < n_frames;
   // gather + window + pack: z[i] = (xw[2i], xw[2i+1]); lanes read consecutive float pairs (coalesced)
   float2 v[8];
@@ -534,7 +543,7 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
   const int64_t n_frames = par_stft_frames(n, n_fft, hop);
   const float scale = (float)(1.0 / sqrt((double)n_fft));
 #define PAR_STFT_LAUNCH(LH)                                                                                          \
-  hipLaunchKernelGGL(k_stft<LH>, dim3((unsigned)ceil_div(n_frames, FftGeom<LH>::Frames)), dim3(FftGeom<LH>::Threads),  \
+  hipLaunchKernelGGL(k_stft<LH>, dim3((unsigned)(ceil_div(ceil_div(n_frames, FftGeom<LH>::Frames), 8) * 8)), dim3(FftGeom<LH>::Threads),  \
                      (size_t)FftGeom<LH>::Frames * FftGeom<LH>::FrameLds * sizeof(float2), as_stream(stream), x, n,      \
                      x_stride, n_fft, hop, window, tw.w, tw.post, out, n_frames, mode, scale)
   switch (ilog2(H)) {
