@@ -6,6 +6,7 @@ resample on that GPU, results are written as <stem>_res<suffix>.wav like resampl
 
     python -m pyaudiorestoration_amd.cli respeed --trail 0.2,4000,4.0,4000 tape1.flac tape2.wav
     python -m pyaudiorestoration_amd.cli resample --curve curve.json tape.wav      # [[t_seconds, speed], ...]
+    python -m pyaudiorestoration_amd.cli tapesync --project take.tapesync take2.flac
 """
 import argparse
 import json
@@ -28,6 +29,10 @@ def _worker(dev, jobs, args, results):
         except queue.Empty:
             return
         try:
+            if args.cmd == "tapesync":
+                pipeline.tapesync(args.project, source=path, out_suffix=args.suffix, device=dev)
+                results.append((path, None))
+                continue
             signal, sr, ch = io_ops.read_file(path)
             if args.cmd == "respeed":
                 t0, f0, t1, f1 = args.trail
@@ -59,7 +64,9 @@ def main(argv=None):
     b = sub.add_parser("resample", help="apply a given speed curve")
     b.add_argument("--curve", required=True, help="JSON [[t_seconds, speed], ...]")
     b.add_argument("--resampling", default="Sinc", choices=("Sinc", "Linear"))
-    for p in (a, b):
+    c = sub.add_parser("tapesync", help="apply the lag curve of a saved pytapesynch project (.tapesync) to files")
+    c.add_argument("--project", required=True, help=".tapesync JSON written by the GUI")
+    for p in (a, b, c):
         p.add_argument("--quality", type=int, default=50, help="sinc_quality (NT); GUI default 50")
         p.add_argument("--suffix", default="")
         p.add_argument("--gpus", type=int, default=0, help="GPUs to use (0 = all visible)")

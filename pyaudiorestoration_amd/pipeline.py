@@ -229,3 +229,48 @@ def detect_dropouts(mag, sr, fft_size, hop, t_0, t_1, f_lower, f_upper, width_ms
             logging.exception(f"Could not refine width at peak {f_peak}")
         found.append(((t_center - half_width, f_lower), (t_center + half_width, f_upper)))
     return found
+
+
+# ---------------------------------------------------------------------- tape synchronisation (pytapesynch)
+def lag_curve_from_markers(markers, duration, sr, hop, smoothing=3, bands=(0, 9999999)):
+    """Lag curve (N, 2) = (time s, lag s) from tape-sync markers -- headless restatement of LagLine
+    (util/markers.py:730-790) for projects without azimuth lines: markers are LagSample.to_cfg() tuples
+    (a_t, a_f, b_t, b_f, d, corr) (util/markers.py:478-479), a marker sits at t = (a_t + b_t)/2 with lag d.
+    The lag is an interpolating spline of order min(smoothing, n-1) through the markers (:737-747), sampled at
+    marker rate sr/hop on [0, |duration + lag(duration)|] (:749-758) and band-limited like every BaseLine
+    (:601-605; the default band lets everything through).  This is what pytapesynch hands to
+    resampling.run(lag_curve=...) (pytapesynch_gui.py:145-155)."""
+    from scipy.interpolate import InterpolatedUnivariateSpline
+    pts = sorted(((m[0] + m[2]) / 2, m[4]) for m in markers)
+    keys = np.array([p[0] for p in pts], dtype=np.float64)
+    lags = np.array([p[1] for p in pts], dtype=np.float64)
+
+    def lag_at(times):
+        if len(keys) == 0:
+            return np.interp(times, (0,), (0,))
+        if len(keys) == 1:
+            return np.interp(times, keys, lags)
+        return InterpolatedUnivariateSpline(keys, lags, k=min(smoothing, len(keys) - 1))(times)
+
+    end = abs(duration + float(lag_at((duration,))[0]))
+    marker_sr = sr / hop
+    times = np.linspace(0, end, num=int(end * marker_sr))
+    lo, hi = sorted(bands)
+    return np.stack((times, filters.butter_bandpass_filter(lag_at(times), lo, hi, marker_sr, order=3)), axis=-1)
+
+
+def tapesync(project, source=None, out_suffix=None, device=None):
+    """Run a saved pytapesynch project headless: `project` is the path of a .tapesync JSON (util/widgets.py:
+    1224-1233 writes it: fft_size, fft_overlap, markers, source, resampling_mode, sinc_quality, smoothing,
+    suffix) or the dict itself; `source` overrides the audio path stored in it.  Writes <source>_res<suffix>.wav
+    through resampling.run and returns the lag curve."""
+    import json
+    from . import io_ops
+    cfg = json.load(open(project)) if isinstance(project, (str, bytes)) or hasattr(project, "__fspath__") else dict(project)
+    path = source or cfg["source"]
+    signal, sr, _ = io_ops.read_file(path)
+    hop = cfg["fft_size"] // cfg.get("fft_overlap", 1)
+    curve = lag_curve_from_markers(cfg["markers"], len(signal) / sr, sr, hop, cfg.get("smoothing", 3))
+    resampling.run((path,), signal_data=((signal, sr),), lag_curve=curve, resampling_mode=cfg.get("resampling_mode", "Sinc"),
+                   sinc_quality=cfg.get("sinc_quality", 50), suffix=cfg.get("suffix", "") if out_suffix is None else out_suffix)
+    return curve

@@ -239,3 +239,28 @@ def test_native_flac_decoder_parallel_split_and_corruption(tmp_path):
         io_ops.read_flac(str(tmp_path / "short.flac"))
     x, sr, ch = io_ops.read_file(str(p))                            # the reference-named entry point uses it
     assert x.shape == want.shape and sr == 192000 and ch == 2
+
+
+def test_lag_curve_from_tapesync_markers():
+    """Headless LagLine (util/markers.py:730-790): two markers -> order-1 spline = the straight line through them,
+    extrapolated; four markers -> a cubic through all of them; sampling grid and end point follow the marker rate."""
+    import json
+    from pyaudiorestoration_amd import pipeline
+    cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "rhythm.tapesync")))
+    sr, hop = 44100, cfg["fft_size"] // cfg["fft_overlap"]
+    dur = 1344000 / sr
+    curve = pipeline.lag_curve_from_markers(cfg["markers"], dur, sr, hop, cfg["smoothing"])
+    (a0, _, b0, _, d0, _), (a1, _, b1, _, d1, _) = cfg["markers"]
+    t0, t1 = (a0 + b0) / 2, (a1 + b1) / 2
+    line = lambda t: d0 + (d1 - d0) * (t - t0) / (t1 - t0)
+    end = abs(dur + line(dur))
+    assert curve.shape == (int(end * sr / hop), 2) and curve[0, 0] == 0 and abs(curve[-1, 0] - end) < 1e-9
+    assert np.allclose(curve[:, 1], line(curve[:, 0]), rtol=0, atol=1e-9)
+    assert abs((d1 - d0) / (t1 - t0) - (1 - 1 / 1.05)) < 2e-4             # the sample really is 5 % fast
+    marks = [(t, 0, t, 0, 0.01 * t * t, 0.5) for t in (1.0, 2.0, 4.0, 7.0)]
+    cubic = pipeline.lag_curve_from_markers(marks, 10.0, 48000, 256, smoothing=3)
+    for t in (1.0, 2.0, 4.0, 7.0):
+        i = np.argmin(np.abs(cubic[:, 0] - t))
+        assert abs(cubic[i, 1] - 0.01 * cubic[i, 0] ** 2) < 1e-9       # a cubic reproduces the parabola exactly
+    one = pipeline.lag_curve_from_markers([(3.0, 0, 3.0, 0, 0.25, 1.0)], 10.0, 48000, 256)
+    assert np.all(one[:, 1] == 0.25)

@@ -668,6 +668,36 @@ def test_batch_pipeline_equals_item_by_item(par):
     assert list(R.varispeed_batch_dev([], 16)) == []
 
 
+def test_tapesync_project_on_reference_samples(par, tmp_path):
+    """pytapesynch data flow on the reference's own demo data (fixtures under tests/golden/): rhythm+5percent.flac
+    resampled with the lag curve of rhythm.tapesync must line up with rhythm.flac -- same length within a few
+    hundred samples and a normalised correlation near 1 at (almost) zero lag, where the raw +5 % file has none."""
+    import os
+    import shutil
+    from pyaudiorestoration_amd import io_ops
+    from test_oracle_golden import GOLD
+    src = str(tmp_path / "rhythm+5percent.flac")
+    shutil.copy(os.path.join(GOLD, "rhythm+5percent.flac"), src)
+    curve = par.pipeline.tapesync(os.path.join(GOLD, "rhythm.tapesync"), source=src)
+    assert curve[-1, 1] > 1.4                                              # ~1.5 s of accumulated lag after 31.5 s
+    y, sr, ch = io_ops.read_file(str(tmp_path / "rhythm+5percent_res.wav"))
+    ref, sr_ref, _ = io_ops.read_file(os.path.join(GOLD, "rhythm.flac"))
+    raw, _, _ = io_ops.read_file(src)
+    assert sr == sr_ref == 44100 and ch == 1 and abs(len(y) - len(ref)) < 2000
+
+    def best_corr(a, b, lo, hi, max_lag=400):
+        """peak normalised correlation of a[lo+max_lag : hi-max_lag] against b shifted by -max_lag..+max_lag"""
+        core = a[lo + max_lag:hi - max_lag, 0].astype(np.float64)
+        cand = b[lo:hi, 0].astype(np.float64)
+        dots = np.correlate(cand, core, mode="valid")                        # 2*max_lag + 1 lags
+        energy = np.convolve(cand * cand, np.ones(len(core)), mode="valid")
+        return float(np.max(np.abs(dots) / (np.linalg.norm(core) * np.sqrt(energy) + 1e-30)))
+    for lo in (200000, 700000, 1200000):                                    # early, middle, late: the drift is gone
+        synced = best_corr(ref, y, lo, lo + 40000)
+        unsynced = best_corr(ref, raw, lo, lo + 40000)
+        assert synced > 0.8 and synced > 3 * unsynced, (lo, synced, unsynced)
+
+
 def test_bench_contract_line():
     """bench.py prints ONE JSON line with the contract's keys, a roofline and a cpu_baseline object."""
     import json
