@@ -7,6 +7,7 @@ resample on that GPU, results are written as <stem>_res<suffix>.wav like resampl
     python -m pyaudiorestoration_amd.cli respeed --trail 0.2,4000,4.0,4000 tape1.flac tape2.wav
     python -m pyaudiorestoration_amd.cli resample --curve curve.json tape.wav      # [[t_seconds, speed], ...]
     python -m pyaudiorestoration_amd.cli tapesync --project take.tapesync take2.flac
+    python -m pyaudiorestoration_amd.cli heal --project tape.drop tape.flac
 """
 import argparse
 import json
@@ -29,8 +30,9 @@ def _worker(dev, jobs, args, results):
         except queue.Empty:
             return
         try:
-            if args.cmd == "tapesync":
-                pipeline.tapesync(args.project, source=path, out_suffix=args.suffix, device=dev)
+            if args.cmd in ("tapesync", "heal"):
+                flow = pipeline.tapesync if args.cmd == "tapesync" else pipeline.heal_project
+                flow(args.project, source=path, out_suffix=args.suffix, device=dev)
                 results.append((path, None))
                 continue
             signal, sr, ch = io_ops.read_file(path)
@@ -66,7 +68,9 @@ def main(argv=None):
     b.add_argument("--resampling", default="Sinc", choices=("Sinc", "Linear"))
     c = sub.add_parser("tapesync", help="apply the lag curve of a saved pytapesynch project (.tapesync) to files")
     c.add_argument("--project", required=True, help=".tapesync JSON written by the GUI")
-    for p in (a, b, c):
+    d = sub.add_parser("heal", help="inpaint the marked dropouts of a saved dropout-healer project (.drop)")
+    d.add_argument("--project", required=True, help=".drop JSON written by the GUI")
+    for p in (a, b, c, d):
         p.add_argument("--quality", type=int, default=50, help="sinc_quality (NT); GUI default 50")
         p.add_argument("--suffix", default="")
         p.add_argument("--gpus", type=int, default=0, help="GPUs to use (0 = all visible)")

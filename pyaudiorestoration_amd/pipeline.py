@@ -274,3 +274,22 @@ def tapesync(project, source=None, out_suffix=None, device=None):
     resampling.run((path,), signal_data=((signal, sr),), lag_curve=curve, resampling_mode=cfg.get("resampling_mode", "Sinc"),
                    sinc_quality=cfg.get("sinc_quality", 50), suffix=cfg.get("suffix", "") if out_suffix is None else out_suffix)
     return curve
+
+
+def heal_project(project, source=None, out_suffix=None, device=None):
+    """Run a saved dropout-healer project headless: `project` is a .drop JSON (fft_size, fft_overlap, dropouts,
+    surrounding, source, suffix) or the dict itself.  The saved marker tuples carry the two corners in their first
+    four fields (a_t, a_f, b_t, b_f, ...); the surrounding factor is the project-wide one.  Writes
+    <source>_drops<suffix>.wav like Canvas.resample_files (dropout_healer_gui.py:166) and returns the healed
+    (frames, channels) array."""
+    import json
+    from . import io_ops
+    cfg = json.load(open(project)) if isinstance(project, (str, bytes)) or hasattr(project, "__fspath__") else dict(project)
+    path = source or cfg["source"]
+    signal, sr, channels = io_ops.read_file(path)
+    surrounding = cfg.get("surrounding", 0.5)
+    marks = [(m[0], m[1], m[2], m[3], surrounding) for m in cfg.get("dropouts", cfg.get("markers", ()))]
+    hop = cfg["fft_size"] // cfg.get("fft_overlap", 1)
+    healed = heal_dropouts(signal, sr, marks, cfg["fft_size"], hop, device=device)
+    io_ops.write_file(path, healed, sr, channels, suffix="_drops" + (cfg.get("suffix", "") if out_suffix is None else out_suffix))
+    return healed

@@ -698,6 +698,40 @@ def test_tapesync_project_on_reference_samples(par, tmp_path):
         assert synced > 0.8 and synced > 3 * unsynced, (lo, synced, unsynced)
 
 
+def test_config4_on_the_reference_dropout_sample(par, tmp_path):
+    """BASELINE config 4 on the reference's own demo data (fixtures): dropouts_sample.flac + the 32 markers of
+    dropouts_sample.drop -> device STFT 512/32, one-launch inpaint mask, fused ISTFT; full parity against the
+    oracle's serial marker loop, dropouts lifted, everything outside the marker boxes untouched."""
+    import json
+    import os
+    import shutil
+    from oracle import oracle_np as O
+    from pyaudiorestoration_amd import io_ops
+    from test_oracle_golden import GOLD
+    src = str(tmp_path / "dropouts_sample.flac")
+    shutil.copy(os.path.join(GOLD, "dropouts_sample.flac"), src)
+    proj = os.path.join(GOLD, "dropouts_sample.drop")
+    healed = par.pipeline.heal_project(proj, source=src)
+    x, sr, ch = io_ops.read_file(src)
+    assert healed.shape == x.shape == (322531, 1) and sr == 44100
+    y, _, _ = io_ops.read_file(str(tmp_path / "dropouts_sample_drops.wav"))
+    assert np.array_equal(y, healed)
+    cfg = json.load(open(proj))
+    marks = [(m[0], m[1], m[2], m[3], cfg["surrounding"]) for m in cfg["dropouts"]]
+    assert len(marks) == 32 and cfg["fft_size"] // cfg["fft_overlap"] == 32
+    want = O.heal_dropouts(x, sr, marks, 512, 32)
+    assert relerr(healed[:, 0], want[:, 0]) < TOL
+    lifted = kept = 0
+    touched = np.zeros(len(x), dtype=bool)
+    for (t0, _, t1, _, _) in marks:
+        a, b = int(min(t0, t1) * sr), int(max(t0, t1) * sr)
+        touched[max(0, a - 600):b + 600] = True                       # box + the STFT frames that overlap it
+        lifted += np.abs(healed[a:b, 0]).mean() > 1.05 * np.abs(x[a:b, 0]).mean()
+        kept += np.abs(healed[a:b, 0]).mean() > 0.98 * np.abs(x[a:b, 0]).mean()
+    assert lifted >= 16 and kept == 32                                 # the mask only ever boosts (gain >= 0 dB)
+    assert relerr(healed[~touched, 0], x[~touched, 0]) < 1e-4         # the rest only sees the STFT round trip
+
+
 def test_bench_contract_line():
     """bench.py prints ONE JSON line with the contract's keys, a roofline and a cpu_baseline object."""
     import json
