@@ -732,6 +732,25 @@ def test_config4_on_the_reference_dropout_sample(par, tmp_path):
     assert relerr(healed[~touched, 0], x[~touched, 0]) < 1e-4         # the rest only sees the STFT round trip
 
 
+def test_zero_crossing_compaction_sizes(par):
+    """K_track's sign-change compaction (count per tile, scan of tile counts in chunks of 1024, ordered write) against
+    numpy for sizes around every boundary, incl. > 1024 tiles (multi-chunk scan), no crossings and all crossings."""
+    W = par.wow
+    t = par.torch
+    rng = np.random.default_rng(21)
+    for n in (2, 3, 255, 1023, 1024, 1025, 4096, 1024 * 1024 + 3, 3_000_001):
+        x = rng.standard_normal(n)
+        x[rng.integers(0, n, max(1, n // 50))] = 0.0                      # exact zeros count as "not positive"
+        want = np.where(np.bitwise_xor(x[1:] > 0, x[:-1] > 0))[0]
+        got = W.zero_crossings_dev(t.from_numpy(x).cuda()).cpu().numpy()
+        assert got.dtype == np.int64 and np.array_equal(got, want), n
+    assert W.zero_crossings_dev(t.ones(5000, dtype=t.float64, device="cuda")).numel() == 0
+    alt = t.tensor([1.0, -1.0] * 3000, dtype=t.float64, device="cuda")
+    assert np.array_equal(W.zero_crossings_dev(alt).cpu().numpy(), np.arange(5999))
+    assert W.zero_crossings_dev(t.ones(1, dtype=t.float64, device="cuda")).numel() == 0
+    assert np.array_equal(W.zero_crossings(np.array([0.5, -0.5, -0.1, 0.2])), [0, 2])
+
+
 def test_bench_contract_line():
     """bench.py prints ONE JSON line with the contract's keys, a roofline and a cpu_baseline object."""
     import json
