@@ -71,11 +71,34 @@ int oracle_speed_to_pos(const double* st, const double* sp, int64_t m, int64_t n
   return 0;
 }
 
-/* int(mean(speeds) * (st[-1]-st[0]) * 1.01): the reference's buffer size (:108-109), sequential mean */
+/* numpy's float64 pairwise summation (np.add.reduce on a contiguous array; numpy/_core/src/umath/loops_utils.h.src,
+ * pairwise_sum): < 8 elements sequential, <= 128 eight interleaved accumulators combined as a balanced tree plus a
+ * sequential tail, otherwise split at floor(n/2) rounded down to a multiple of 8.  np.mean = this sum / n. */
+static double np_pairwise_sum(const double* a, int64_t n) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int64_t i = 0; i < n; ++i) r += a[i];
+    return r;
+  }
+  if (n <= 128) {
+    double r[8];
+    for (int k = 0; k < 8; ++k) r[k] = a[k];
+    int64_t i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  int64_t n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+/* int(mean(speeds) * (st[-1]-st[0]) * 1.01): the reference's buffer size (:108-109), with numpy's own summation
+ * order so that the overflow test (`output[out_ind:out_ind+n] = sample_at` raising) fires on exactly the same curves */
 int64_t oracle_end_guess(const double* st, const double* sp, int64_t m) {
-  double s = 0.0;
-  for (int64_t i = 0; i < m; ++i) s += sp[i];
-  return (int64_t)((s / (double)m) * (st[m - 1] - st[0]) * 1.01) + 8;   /* +8: pairwise-vs-sequential slack */
+  return (int64_t)((np_pairwise_sum(sp, m) / (double)m) * (st[m - 1] - st[0]) * 1.01);
 }
 
 /* ------------------------------------------------------------------ sinc_core */

@@ -266,6 +266,33 @@ def test_heal_dropouts_config4(golden):
     assert relerr(y[:8000, 0], x[:8000]) < 1e-4                                   # untouched region survives the round trip
 
 
+def test_c_oracle_buffer_bound_is_numpys():
+    """The reference raises when a segment does not fit its end_guess buffer (util/resampling.py:108-109, :127); the C
+    oracle must size that buffer with numpy's own pairwise mean, or it would accept curves the reference refuses
+    (found by tools/fuzz_resampler.py)."""
+    from oracle import oracle_c as C
+    L = C.lib()
+    rng = np.random.default_rng(5)
+    for _ in range(3000):
+        m = int(rng.integers(2, 4000))
+        sp = rng.uniform(0.3, 3.0, m)
+        st = np.linspace(0, rng.uniform(10, 1e6), m)
+        assert int(L.oracle_end_guess(C._p(st), C._p(sp), m)) == int(np.mean(sp) * (st[-1] - st[0]) * 1.01)
+    # a curve whose last segment overflows the buffer before the trim test: both restatements refuse it
+    rng = np.random.default_rng(2690 + 1436)
+    n = int(rng.choice([3000, 20000, 150000, 700000]))
+    rng.choice(16)
+    seg = int(rng.choice([16, 64, 256, 1000, 5000]))
+    m = max(2, n // seg)
+    st = np.linspace(0, n, m)
+    rng.integers(0, 5)
+    sp = rng.uniform(0.5, 2.0, m)
+    with pytest.raises(ValueError):
+        O.speed_to_pos(st, sp, n)
+    with pytest.raises(ValueError):
+        C.speed_to_pos(st, sp, n)
+
+
 def test_dropout_detector(golden):
     """dropout_healer_gui.py:185-242 restated on the oracle's get_mag vs the fixture made on the reference's."""
     g = golden["detect"]

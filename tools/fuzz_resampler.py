@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end fuzz of the resampler against the C oracle (test infrastructure, run on the GPU box):
+random NT, sample counts, curve resolutions, speed ranges (incl. strong fc < 1 and fc == 1 mixes), NaN-free
+signals with silence and full-scale steps.  Positions must be bit-identical, outputs within 5e-6 of the peak (north-star tolerance 1e-5)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+from oracle import oracle_c as C
+from pyaudiorestoration_amd import _lib, resampling as R
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+t_end = time.time() + budget
+case = worst = refused = 0
+worst_cfg = None
+while time.time() < t_end:
+    rng = np.random.default_rng(seed0 + case)
+    n = int(rng.choice([3000, 20000, 150000, 700000]))
+    NT = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 13, 16, 31, 32, 33, 50, 64, 100]))
+    seg = int(rng.choice([16, 64, 256, 1000, 5000]))
+    m = max(2, n // seg)
+    st = np.linspace(0, n, m)
+    style = int(rng.integers(0, 5))
+    if style == 0:
+        sp = 1.0 + 0.01 * np.sin(np.arange(m) * 0.05 + rng.uniform(0, 6))
+    elif style == 1:
+        sp = rng.uniform(0.5, 2.0, m)
+    elif style == 2:
+        sp = np.full(m, 1.0)
+    elif style == 3:
+        sp = np.exp(np.cumsum(rng.normal(0, 0.02, m)))
+        sp = np.clip(sp, 0.3, 3.0)
+    else:
+        sp = 1.0 + 0.2 * np.sign(np.sin(np.arange(m) * 0.3))
+    sig = rng.standard_normal(n).astype(np.float32)
+    sig[n // 3:n // 3 + 500] = 0.0
+    sig[n // 2:] *= np.float32(rng.choice([1.0, 1e-3, 30.0]))
+    st_t, sp_t, sig_t = torch.from_numpy(st).cuda(), torch.from_numpy(sp).cuda(), torch.from_numpy(sig).cuda()
+    try:
+        ref_pos, _ = C.speed_to_pos(st, sp, n)
+    except ValueError:
+        # the reference raises on this curve (n_i < 2 or its end_guess buffer overflows): so must the device plan
+        try:
+            R.speed_plan_dev(st_t, sp_t, n)
+        except _lib.ParError:
+            refused += 1
+            case += 1
+            continue
+        raise SystemExit(f"case {case}: the oracle refuses this curve but the device plan accepted it")
+    if len(ref_pos) < 2:
+        case += 1
+        continue
+    try:
+        plan = R.speed_plan_dev(st_t, sp_t, n, fused=True)
+    except _lib.ParError as e:
+        raise SystemExit(f"case {case}: device plan failed where the oracle succeeded: {e}")
+    pos = R.speed_to_pos_dev(st_t, sp_t, n).cpu().numpy()
+    assert np.array_equal(pos, ref_pos), (case, "positions", n, NT, seg, style)
+    ref = C.sinc(ref_pos, sig, NT, threads=8)
+    out_a = R.sinc_resample_dev(torch.from_numpy(ref_pos).cuda(), sig_t, NT).cpu().numpy()
+    scale = max(float(np.max(np.abs(ref))), 1e-30)
+    errs = [float(np.max(np.abs(out_a - ref)) / scale)]
+    if plan.fused_ok:
+        out_f = R.varispeed_fused_dev(plan, sig_t, NT).cpu().numpy()
+        assert np.array_equal(out_f, out_a), (case, "fused != position-array", n, NT, seg, style)
+    if max(errs) > worst:
+        worst, worst_cfg = max(errs), (case, n, NT, seg, style)
+    assert max(errs) < 5e-6, (case, errs, n, NT, seg, style)       # north star: 1e-5; NT = 100 reaches ~2e-6
+    case += 1
+print(f"fuzz ok: {case} cases ({refused} refused by both the oracle and the device), worst relative error {worst:.2e} at {worst_cfg}")
