@@ -248,12 +248,48 @@ __global__ void k_seg_lengths(const U128* __restrict__ A, int64_t nseg, int64_t*
   if (f) atomicOr(&h->flags, f);
 }
 
-__global__ void k_speed_sum(const double* __restrict__ sp, int64_t m, PlanHeader* __restrict__ h) {
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) acc += sp[i];
+// sum(speeds) for the reference's buffer bound int(mean(speeds) * span * 1.01) (:108).  numpy sums pairwise; any other
+// order may differ in the last bits, so this sum is made ACCURATE instead (compensated per thread, tree across lanes,
+// compensated + tree again over the per-wave partials in the last workgroup: <= ~18 ulp-roundings, 2e-15 relative)
+// and k_trim sends the plan to the serial path -- which restates numpy's order -- in the rare case where that
+// uncertainty could move int().
+__global__ void __launch_bounds__(256) k_speed_sum(const double* __restrict__ sp, int64_t m, double* __restrict__ partial,
+                                                   PlanHeader* __restrict__ h) {
+  __shared__ double red[256];
+  __shared__ int is_last;
+  double s = 0.0, c = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    const double y = sp[i] - c;          // Kahan: pos.hip is built with -ffp-contract=off and no fast-math
+    const double t = s + y;
+    c = (t - s) - y;
+    s = t;
+  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
-  if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&h->speed_sum, acc);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
+  const int waves = blockDim.x / kWave;
+  if ((threadIdx.x & (kWave - 1)) == 0) partial[blockIdx.x * waves + threadIdx.x / kWave] = s;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(&h->pad2, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  const int64_t n_part = (int64_t)gridDim.x * waves;
+  s = 0.0;
+  c = 0.0;
+  for (int64_t i = threadIdx.x; i < n_part; i += blockDim.x) {
+    const double y = __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - c;
+    const double t = s + y;
+    c = (t - s) - y;
+    s = t;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) h->speed_sum = red[0];
 }
 
 // S_i = last element of np.cumsum(1/block_speeds): strictly sequential float64 adds, one lane per segment.
@@ -487,7 +523,12 @@ __global__ void k_trim(const double* __restrict__ st, const double* __restrict__
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int64_t nseg = m - 1;
   // int(np.mean(speeds) * (st[-1]-st[0]) * 1.01)  (:108)
-  h->cap = (int64_t)((h->speed_sum / (double)m) * (st[m - 1] - st[0]) * 1.01);
+  // speed_sum (k_speed_sum) and numpy's pairwise sum each sit within ~2.5e-15 (relative) of the true sum.  Only
+  // when the product lies that close to an integer can int() differ from numpy's: such plans (1 file in ~10^5 at
+  // hour length) go to the serial host path, which restates numpy's pairwise order.
+  const double guess = (h->speed_sum / (double)m) * (st[m - 1] - st[0]) * 1.01;
+  h->cap = (int64_t)guess;
+  if (fabs(guess - rint(guess)) <= fabs(guess) * 1e-14 + 1e-12) atomicOr(&h->flags, kFlagCapAmbiguous);
   int64_t len = h->total_written;
   if (h->trim_seg != kNoTrim && h->trim_seg < (unsigned long long)nseg) {
     const int64_t i = (int64_t)h->trim_seg;
@@ -577,6 +618,30 @@ __global__ __launch_bounds__(kWave * kFillWaves) void k_pos_fill(const double* _
 
 // ------------------------------------------------------------------ serial host path (exact, slow)
 // Used when the device plan flags an ambiguity; follows the reference loop literally.
+// numpy's float64 pairwise summation (np.add.reduce on a contiguous array): < 8 elements sequential, <= 128 eight
+// interleaved accumulators combined as a balanced tree plus a sequential tail, else split at floor(n/2) rounded
+// down to a multiple of 8.  np.mean(speeds) = this / m; the serial path sizes the reference's buffer with it.
+static double np_pairwise_sum(const double* a, int64_t n) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int64_t i = 0; i < n; ++i) r += a[i];
+    return r;
+  }
+  if (n <= 128) {
+    double r[8];
+    for (int k = 0; k < 8; ++k) r[k] = a[k];
+    int64_t i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  int64_t n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
 static int host_plan(const PlanView& pv, const double* d_st, const double* d_sp, int64_t m, int64_t n_in,
                      PlanHeader* out, hipStream_t s) {
   const int64_t nseg = m - 1;
@@ -586,8 +651,8 @@ static int host_plan(const PlanView& pv, const double* d_st, const double* d_sp,
   PAR_HIP_CHECK(hipStreamSynchronize(s));
   std::vector<int64_t> start(m);
   std::vector<double> off(m);
-  double err = 0.0, offset = st[0], sum = 0.0;
-  for (int64_t i = 0; i < m; ++i) sum += sp[i];
+  double err = 0.0, offset = st[0];
+  const double sum = np_pairwise_sum(sp.data(), m);
   const int64_t cap = (int64_t)((sum / (double)m) * (st[m - 1] - st[0]) * 1.01);
   int64_t acc = 0, out_len = -1;
   int trim = 0;
@@ -710,7 +775,8 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
     int rc = inclusive_scan<AddU128>(fix, nseg, reinterpret_cast<U128*>(pv.bsum), s);
     if (rc != PAR_OK) return rc;
     hipLaunchKernelGGL(k_seg_lengths, dim3(g256), dim3(256), 0, s, fix, nseg, pv.seg_start, pv.hdr);
-    hipLaunchKernelGGL(k_speed_sum, dim3((unsigned)(m / 4096 + 1)), dim3(256), 0, s, speeds, m, pv.hdr);
+    hipLaunchKernelGGL(k_speed_sum, dim3((unsigned)(m / 4096 + 1)), dim3(256), 0, s, speeds, m,
+                       reinterpret_cast<double*>(pv.bsum), pv.hdr);     // bsum is idle between two scans
     hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.S, ck,
                        ck_len, pv.hdr);
     PAR_HIP_CHECK(hipMemcpyAsync(pv.xs, pv.S, nseg * sizeof(double), hipMemcpyDeviceToDevice, s));

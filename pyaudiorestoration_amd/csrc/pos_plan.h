@@ -26,6 +26,7 @@ constexpr int kFlagBadLength = 2;   // some n_i < 2 (reference divides by zero /
 constexpr int kFlagRange = 4;       // a_i outside the exactly-representable fixed-point range
 constexpr int kFlagVerify = 8;      // offset-chain binade prediction failed verification
 constexpr int kFlagDirectOverflow = 16;
+constexpr int kFlagCapAmbiguous = 64; // end_guess within the device sum's error of an integer: the host path decides
 constexpr int kFlagCkOverflow = 32;  // checkpoint buffer too small (plan stays valid; the fused path is refused)
 constexpr int kMaxDirect = 2048;
 constexpr unsigned long long kNoTrim = ~0ull;

@@ -732,6 +732,31 @@ def test_config4_on_the_reference_dropout_sample(par, tmp_path):
     assert relerr(healed[~touched, 0], x[~touched, 0]) < 1e-4         # the rest only sees the STFT round trip
 
 
+def test_buffer_bound_ambiguity_goes_to_the_serial_path(par):
+    """int(mean(speeds) * span * 1.01): when the product sits within the device sum's uncertainty of an integer the
+    plan is decided by the serial path (numpy's pairwise order); everywhere else by the device scans -- and both give
+    the oracle's positions."""
+    from oracle import oracle_c as C
+    t = par.torch
+    m, n = 400, 100000
+    st = np.linspace(0, n, m)
+    k = 100500                                                          # target integer for the bound
+    sp = np.full(m, k / (n * 1.01))
+    guess = np.mean(sp) * (st[-1] - st[0]) * 1.01
+    assert abs(guess - round(guess)) < 1e-9
+    info = {}
+    pos = par.resampling.speed_to_pos_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), n, info=info).cpu().numpy()
+    assert info["path"] == 1                                            # ambiguous bound -> serial host path
+    ref, _ = C.speed_to_pos(st, sp, n)
+    assert np.array_equal(pos, ref)
+    sp2 = sp * 1.0001                                                   # a bound far from an integer: device scans
+    info = {}
+    pos2 = par.resampling.speed_to_pos_dev(t.from_numpy(st).cuda(), t.from_numpy(sp2).cuda(), n, info=info).cpu().numpy()
+    assert info["path"] == 0
+    ref2, _ = C.speed_to_pos(st, sp2, n)
+    assert np.array_equal(pos2, ref2)
+
+
 def test_zero_crossing_compaction_sizes(par):
     """K_track's sign-change compaction (count per tile, scan of tile counts in chunks of 1024, ordered write) against
     numpy for sizes around every boundary, incl. > 1024 tiles (multi-chunk scan), no crossings and all crossings."""
