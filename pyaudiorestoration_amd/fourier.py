@@ -109,6 +109,8 @@ def istft_dev(spec_t, hop_length, window_t, length=None, dev=None):
     else:
         y_len = int(length)
     y = _dev.empty(max(y_len, 0), torch.float32, dev)
+    if y.numel() == 0:                              # a single frame without an explicit length trims to nothing
+        return y
     _lib.check(L.par_istft_f32(dev, _dev.ptr(fm), n_frames, n_fft, hop_length, _dev.ptr(window_t), _dev.ptr(frames) if scratch else None,
                                _dev.ptr(y), y.numel(), n_fft // 2, _dev.stream_ptr(dev)))
     return y

@@ -137,6 +137,15 @@ def test_istft_size_matrix_vs_oracle(par, n_fft, hop):
     assert (L.par_istft_scratch_floats(10, n_fft, hop) != 0) == (hop == 5000 or n_fft == 8192)   # only these spans exceed 64 KB of LDS
 
 
+def test_istft_single_frame_without_length_is_empty(par):
+    """One frame and no explicit length: the reference trims n_fft/2 from both ends of an n_fft-long overlap-add and
+    returns an empty array (found by tools/fuzz_stft.py: the device path used to reject the empty output buffer)."""
+    S = np.ones((129, 1), dtype=np.complex64)
+    y = par.fourier.istft(S, hop_length=64)
+    assert y.shape == (0,)
+    assert par.fourier.istft(S, hop_length=64, length=100).shape == (100,)
+
+
 # ------------------------------------------------------------------------------- positions
 def test_speed_to_pos_golden_bit_exact(par, golden):
     g = golden["speed_to_pos"]
