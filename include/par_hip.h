@@ -29,6 +29,7 @@ extern "C" {
 #define PAR_ERR_HIP 2            /* a HIP runtime call failed */
 #define PAR_ERR_UNSUPPORTED 3    /* valid for the reference, not implemented here (caller falls through) */
 #define PAR_ERR_WORKSPACE 4      /* caller-provided workspace too small */
+#define PAR_ERR_EMPTY_BAND 5     /* a tracker band is empty: the reference raises ValueError (argmax of an empty slice) */
 
 /* ---- library / device ---------------------------------------------------------- */
 int par_version(void);
@@ -208,12 +209,15 @@ int par_synth_speed_curve_f64(int device, double* sampletimes, double* speeds, i
  *   freqs    device f64[count]: in = sampled trail (sample_trail :66-76), out = traced frequencies
  *   mode 0   PeakTracker: band re-centred on freqs[i] every frame
  *   mode 1   PeakTrackTracker: band fixed on freqs[0]; tolerance halves for i > 2
+ *   status   device int32 scratch (4 bytes).  A band whose widening reaches below bin 0 is an empty slice in the
+ *            reference (its argmax raises ValueError): reported as PAR_ERR_EMPTY_BAND, never clamped.  Synchronises.
  */
 int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
-                       double* freqs, int fft_size, double sr, double tolerance_oct, int mode, void* stream);
+                       double* freqs, int fft_size, double sr, double tolerance_oct, int mode, int32_t* status,
+                       void* stream);
 /* CenterOfGravity.trace (util/wow_detection.py:256-291): sequential band adaptation. */
 int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
-                      double* freqs, int fft_size, double sr, double tolerance_oct, void* stream);
+                      double* freqs, int fft_size, double sr, double tolerance_oct, int32_t* status, void* stream);
 
 /* W3: sign-change indices of a (band-passed) float64 signal, ascending -- zero_crossings(a) =
  * np.where(np.bitwise_xor(a[1:] > 0, a[:-1] > 0))[0] (util/wow_detection.py:448-450), the full-rate pass of

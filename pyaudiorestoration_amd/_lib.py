@@ -63,10 +63,10 @@ SIGNATURES = {
     "par_linear_resample_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "par_synth_signal_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_dbl, c_u64, c_vp]),
     "par_synth_speed_curve_f64": (c_int, [c_int, c_vp, c_vp, c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_vp]),
-    "par_track_peak_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_int, c_vp]),
+    "par_track_peak_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_int, c_vp, c_vp]),
     "par_sosfiltfilt_work_len": (c_i64, [c_i64, c_i64]),
     "par_sosfiltfilt_f64": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
-    "par_track_cog_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_vp]),
+    "par_track_cog_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]),
 }
 
 _lib = None
@@ -82,6 +82,11 @@ class ParError(RuntimeError):
 
 class ParUnsupported(ParError):
     """Valid for the reference but not implemented by the HIP path (status PAR_ERR_UNSUPPORTED)."""
+
+
+class ParEmptyBand(ParError, ValueError):
+    """A tracker band is empty (status PAR_ERR_EMPTY_BAND); also a ValueError, which is what the reference's
+    argmax of an empty slice raises."""
 
 
 def lib():
@@ -114,4 +119,4 @@ def last_error():
 def check(rc):
     if rc != 0:
         msg = last_error()
-        raise (ParUnsupported if rc == 3 else ParError)(rc, msg)
+        raise {3: ParUnsupported, 5: ParEmptyBand}.get(rc, ParError)(rc, msg)

@@ -33,7 +33,8 @@ __device__ __forceinline__ Band band_limits(double freq, double tol, int fft_siz
     b.NL -= 1;
     b.NU += 1;
   }
-  if (b.NL < 0) b.NL = 0;                                  // (numpy would wrap a negative slice start)
+  // A band widened below bin 0 (both edges on bin 1: a frequency below the transform's resolution) is an EMPTY
+  // numpy slice [-k:NU] in the reference, whose argmax raises; reported through `empty`, never silently clamped.
   if (b.NU > bins) b.NU = bins;
   return b;
 }
@@ -57,30 +58,44 @@ __device__ __forceinline__ double peak_freq(const float* __restrict__ col, Band 
   return x / (double)fft_size * sr;
 }
 
+__device__ __forceinline__ bool empty_band(const Band& b, int* __restrict__ empty) {
+  if (b.NL >= 0 && b.NL < b.NU) return false;
+  atomicOr(empty, 1);
+  return true;
+}
+
 __global__ void k_track_peak(const float* __restrict__ mag, int bins, int64_t frame_0, int64_t count,
-                             double* __restrict__ freqs, int fft_size, double sr, double tol) {
+                             double* __restrict__ freqs, int fft_size, double sr, double tol, int* __restrict__ empty) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const Band b = band_limits(freqs[i], tol, fft_size, sr, bins);     // PeakTracker: band follows the drawn trail
+  if (empty_band(b, empty)) return;
   freqs[i] = peak_freq(mag + (frame_0 + i) * bins, b, bins, fft_size, sr);
 }
 
 // PeakTrackTracker: band fixed on the first trail frequency (read back by the host entry point).
 __global__ void k_track_peak_fixed(const float* __restrict__ mag, int bins, int64_t frame_0, int64_t count,
-                                   double centre, double* __restrict__ freqs, int fft_size, double sr, double tol) {
+                                   double centre, double* __restrict__ freqs, int fft_size, double sr, double tol,
+                                   int* __restrict__ empty) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const Band b = band_limits(centre, i > 2 ? tol / 2 : tol, fft_size, sr, bins);
+  if (empty_band(b, empty)) return;
   freqs[i] = peak_freq(mag + (frame_0 + i) * bins, b, bins, fft_size, sr);
 }
 
 // CenterOfGravity: the band of frame i+1 depends on the result of frame i -> one wave walks the frames,
 // its 64 lanes share the bins of the current band.
 __global__ __launch_bounds__(64) void k_track_cog(const float* __restrict__ mag, int bins, int64_t frame_0, int64_t count,
-                                                   double* __restrict__ freqs, int fft_size, double sr, double tol) {
+                                                   double* __restrict__ freqs, int fft_size, double sr, double tol,
+                                                   int* __restrict__ empty) {
   const int lane = threadIdx.x;
   Band b = band_limits(freqs[0], tol, fft_size, sr, bins);
   for (int64_t i = 0; i < count; ++i) {
+    if (b.NL < 0 || b.NL >= b.NU) {                        // the reference's 0/0 centroid -> NaN -> int(round(nan)) raises
+      if (lane == 0) atomicOr(empty, 1);
+      return;
+    }
     const float* col = mag + (frame_0 + i) * bins;
     const int L = b.NU - b.NL;
     double num = 0.0, den = 0.0;
@@ -203,9 +218,22 @@ int par_zero_crossings_f64(int device, const double* x, int64_t n, int64_t* work
   return PAR_OK;
 }
 
+// Shared tail: read the "empty band" flag back (one 4-byte copy; the callers need the traced freqs on the host anyway).
+static int check_empty(int* d_flag, hipStream_t s, const char* who) {
+  int h = 0;
+  PAR_HIP_CHECK(hipMemcpyAsync(&h, d_flag, sizeof(h), hipMemcpyDeviceToHost, s));
+  PAR_HIP_CHECK(hipStreamSynchronize(s));
+  PAR_REQUIRE(h == 0, PAR_ERR_EMPTY_BAND,
+              "%s: a tracking band is empty (frequency below the transform's resolution: the reference's slice "
+              "[NL:NU] with NL < 0 is empty and its argmax raises)", who);
+  return PAR_OK;
+}
+
 int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
-                       double* freqs, int fft_size, double sr, double tolerance_oct, int mode, void* stream) {
+                       double* freqs, int fft_size, double sr, double tolerance_oct, int mode, int32_t* status,
+                       void* stream) {
   using namespace par;
+  PAR_REQUIRE(status, PAR_ERR_ARG, "par_track_peak_f64: status word missing");
   PAR_REQUIRE(mag && freqs && bins >= 3 && count >= 0 && frame_0 >= 0 && frame_0 + count <= n_frames, PAR_ERR_ARG,
               "par_track_peak_f64: bad args (frame_0=%lld count=%lld n_frames=%lld)", (long long)frame_0,
               (long long)count, (long long)n_frames);
@@ -213,31 +241,34 @@ int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins,
   if (count == 0) return PAR_OK;
   PAR_HIP_CHECK(hipSetDevice(device));
   hipStream_t s = as_stream(stream);
+  PAR_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), s));
   if (mode == 0) {
     hipLaunchKernelGGL(k_track_peak, dim3((unsigned)ceil_div(count, 64)), dim3(64), 0, s, mag, bins, frame_0, count,
-                       freqs, fft_size, sr, tolerance_oct);
+                       freqs, fft_size, sr, tolerance_oct, status);
   } else {
     double centre = 0.0;
     PAR_HIP_CHECK(hipMemcpyAsync(&centre, freqs, sizeof(double), hipMemcpyDeviceToHost, s));
     PAR_HIP_CHECK(hipStreamSynchronize(s));
     hipLaunchKernelGGL(k_track_peak_fixed, dim3((unsigned)ceil_div(count, 64)), dim3(64), 0, s, mag, bins, frame_0, count,
-                       centre, freqs, fft_size, sr, tolerance_oct);
+                       centre, freqs, fft_size, sr, tolerance_oct, status);
   }
   PAR_HIP_CHECK(hipGetLastError());
-  return PAR_OK;
+  return check_empty(status, s, "par_track_peak_f64");
 }
 
 int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
-                      double* freqs, int fft_size, double sr, double tolerance_oct, void* stream) {
+                      double* freqs, int fft_size, double sr, double tolerance_oct, int32_t* status, void* stream) {
   using namespace par;
+  PAR_REQUIRE(status, PAR_ERR_ARG, "par_track_cog_f64: status word missing");
   PAR_REQUIRE(mag && freqs && bins >= 3 && count >= 0 && frame_0 >= 0 && frame_0 + count <= n_frames, PAR_ERR_ARG,
               "par_track_cog_f64: bad args");
   if (count == 0) return PAR_OK;
   PAR_HIP_CHECK(hipSetDevice(device));
+  PAR_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), as_stream(stream)));
   hipLaunchKernelGGL(k_track_cog, dim3(1), dim3(64), 0, as_stream(stream), mag, bins, frame_0, count, freqs, fft_size, sr,
-                     tolerance_oct);
+                     tolerance_oct, status);
   PAR_HIP_CHECK(hipGetLastError());
-  return PAR_OK;
+  return check_empty(status, as_stream(stream), "par_track_cog_f64");
 }
 
 }  // extern "C"

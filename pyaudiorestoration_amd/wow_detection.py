@@ -141,14 +141,19 @@ class Track:
         dev = _dev.device_index(self.spectrum.device if isinstance(self.spectrum, torch.Tensor) else None)
         return dev, spectrum_to_device(self.spectrum, dev)
 
-    def _trace_on_device(self, kernel, *extra):
-        """Per-frame band search in K_track: freqs go up as the drawn trail and come back traced."""
+    def _trace_on_device(self, kernel, *extra, needs_first=False):
+        """Per-frame band search in K_track: freqs go up as the drawn trail and come back traced.  needs_first:
+        the tracker seeds its band from freqs[0], so an empty span is the reference's IndexError."""
         if len(self.freqs) == 0:
+            if needs_first:
+                raise IndexError("index 0 is out of bounds for axis 0 with size 0")
             return
         dev, mag = self._device_spectrum()
         f_t = _dev.to_dev(self.freqs, torch.float64, dev)
+        status = _dev.empty(1, torch.int32, dev)              # "empty band" word: ParEmptyBand (a ValueError) if set
         _lib.check(kernel(dev, _dev.ptr(mag), mag.shape[0], mag.shape[1], self.frame_0, len(self.freqs), _dev.ptr(f_t),
-                          self.fft_size, float(self.sr), float(self.tolerance), *extra, _dev.stream_ptr(dev)))
+                          self.fft_size, float(self.sr), float(self.tolerance), *extra, _dev.ptr(status),
+                          _dev.stream_ptr(dev)))
         self.freqs[:] = f_t.cpu().numpy()
 
 
@@ -156,7 +161,7 @@ class CenterOfGravity(Track):
     name = 'Center of Gravity'
 
     def trace(self):          # util/wow_detection.py:256-291 -> k_track_cog
-        self._trace_on_device(_lib.lib().par_track_cog_f64)
+        self._trace_on_device(_lib.lib().par_track_cog_f64, needs_first=True)
 
 
 class PeakTracker(Track):
@@ -172,7 +177,7 @@ class PeakTrackTracker(Track):
     tooltip = "Follows the first peak frequency established"
 
     def trace(self):          # util/wow_detection.py:307-327 -> k_track_peak_fixed
-        self._trace_on_device(_lib.lib().par_track_peak_f64, 1)
+        self._trace_on_device(_lib.lib().par_track_peak_f64, 1, needs_first=True)
 
 
 def crossing_periods_to_freqs(crossings, sr, t_first, times):

@@ -332,6 +332,31 @@ def test_trackers_golden(par, golden):
     assert relerr(tr.freqs, g["peak_freqs"]) < 1e-6
 
 
+def test_tracker_error_behaviour_matches_reference(par):
+    """Found by tools/fuzz_trackers.py: a trail below the transform's resolution makes the reference's band slice
+    [NL:NU] empty (NL < 0 after widening) and its argmax raises ValueError -- the device reports it instead of
+    clamping; a trail inside one STFT frame leaves nothing to trace: Peak returns empty, Peak Track / COG index
+    freqs[0] and raise IndexError."""
+    from oracle import oracle_np as O
+    sr, n_fft, hop = 192000, 256, 64
+    x = inputs.sine(60000, 800.0, sr, 0.5)
+    mag = par.fourier.get_mag(par.torch.from_numpy(x).cuda(), n_fft, hop, "blackmanharris", 1)
+    low = [(0.05, 800.0), (0.25, 800.0)]                                 # 800 Hz = bin 1.07 of a 750 Hz grid
+    for name in ("Peak", "Peak Track", "Center of Gravity"):
+        with pytest.raises(ValueError):
+            O.TRACKERS[name](mag.cpu().numpy(), list(low), n_fft, hop, sr, 0.5)
+        with pytest.raises(ValueError):
+            par.wow.wow_detectors[name](mag, x[:, None], list(low), n_fft, hop, sr, 0.5, "Linear")
+    one_frame = [(0.1000, 4000.0), (0.1001, 4000.0)]
+    tr = par.wow.wow_detectors["Peak"](mag, x[:, None], list(one_frame), n_fft, hop, sr, 0.5, "Linear")
+    assert len(tr.freqs) == 0 and len(tr.times) == 0
+    for name in ("Peak Track", "Center of Gravity"):
+        with pytest.raises(IndexError):
+            O.TRACKERS[name](mag.cpu().numpy(), list(one_frame), n_fft, hop, sr, 0.5)
+        with pytest.raises(IndexError):
+            par.wow.wow_detectors[name](mag, x[:, None], list(one_frame), n_fft, hop, sr, 0.5, "Linear")
+
+
 def test_pipeline_config3_flow(par, golden):
     g = golden["pipeline"]
     sr, n, n_fft, hop = (int(v) for v in g["cfg"])
