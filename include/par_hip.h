@@ -136,6 +136,10 @@ int par_speed_to_pos_fill(int device, const double* speeds, int64_t m, const voi
  * sinc_wrapper.  Bug-compatible leading edge (quirk 1).  len_out >= 2, 1 <= NT <= 512.
  *   pos   device f64[len_out];  sig device f32 (len_in, stride sig_stride);
  *   out   device f32 (len_out, stride out_stride)  -- strided column views of (n,ch) arrays.
+ * Positions may be ANY finite float64 (non-monotonic, repeated, negative, past the end, beyond the int64 range):
+ * the window is clipped like the reference's slice signal[max(0, ind-NT) : min(ind+NT, len)], an empty slice
+ * sums to 0.  Non-finite positions make the reference raise (int(round(p))); the Python mirror checks for them,
+ * this entry point leaves the corresponding outputs unspecified (0 or NaN).
  */
 int par_sinc_resample_f32(int device, const double* pos, int64_t len_out, const float* sig, int64_t sig_stride,
                           int64_t len_in, int NT, float* out, int64_t out_stride, void* stream);

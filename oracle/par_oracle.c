@@ -108,6 +108,13 @@ static void sinc_range(const double* pos, int64_t len_out, int64_t a, int64_t b,
                        int64_t len_in, int NT, const float* win, float* out, int64_t out_stride) {
   for (int64_t i = a; i < b; ++i) {
     const double p = pos[i];
+    /* Python's int(round(p)) is an arbitrary-precision integer: a position beyond the int64 range selects an empty
+     * slice of the signal (lower past the end, or upper far below 0) and the sum over it is 0.0.  Non-finite
+     * positions make the reference raise; oracle_sinc refuses them before getting here. */
+    if (!(fabs(p) < 9.0e18)) {
+      out[i * out_stride] = 0.0f;
+      continue;
+    }
     const int64_t ind = (int64_t)nearbyint(p);
     const int64_t lower = ind - NT > 0 ? ind - NT : 0;
     const int64_t upper = ind + NT < len_in ? ind + NT : len_in;
@@ -130,6 +137,8 @@ static void sinc_range(const double* pos, int64_t len_out, int64_t a, int64_t b,
 int oracle_sinc(const double* pos, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in, int NT,
                 float* out, int64_t out_stride) {
   if (len_out < 2 || NT < 1) return -1;
+  for (int64_t i = 0; i < len_out; ++i)
+    if (!isfinite(pos[i])) return -3;               /* int(round(inf / nan)) raises in the reference */
   float* win = (float*)malloc(sizeof(float) * (2 * NT + 1));
   for (int k = 0; k <= 2 * NT; ++k) win[k] = hann32(k, NT);
   sinc_range(pos, len_out, 0, len_out, sig, sig_stride, len_in, NT, win, out, out_stride);

@@ -1,4 +1,5 @@
-// K_lag -- lag curve -> fractional read positions (the pytapesynch branch of resampling.run).
+// K_lag / K_lerp -- the two np.interp call sites of resampling.run, restated with numpy's operation order: the lag
+// curve -> fractional read positions (pytapesynch branch) and the "Linear" resampling mode.
 //
 // Semantics (reference util/resampling.py:189-206): sample_at = np.interp(arange(num_out), xp, fp) with
 // xp = sampletimes, fp = sampletimes - lags; cut at the first sample_at >= len_signal (find_cutoff :265-270);
@@ -48,6 +49,29 @@ __global__ void __launch_bounds__(256) k_lag_pos(const double* __restrict__ xp, 
 
 __global__ void k_lag_init(unsigned long long* cutoff, unsigned long long v) { *cutoff = v; }
 
+// "Linear" mode: np.interp(sample_at, arange(len_in), signal, left=0, right=0)  (util/resampling.py:229)
+__global__ __launch_bounds__(256) void k_lerp(const double* __restrict__ pos, int64_t len_out,
+                                               const float* __restrict__ sig, int64_t sig_stride, int64_t len_in,
+                                               float* __restrict__ out, int64_t out_stride) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= len_out) return;
+  const double p = pos[j];
+  float v = 0.0f;
+  if (p != p) v = __builtin_nanf("");                 // np.interp passes a NaN abscissa through
+  if (p >= 0.0 && p <= (double)(len_in - 1)) {
+    long long i = (long long)p;                       // floor, p >= 0
+    if (i >= (long long)len_in - 1) {
+      v = sig[(len_in - 1) * sig_stride];
+    } else {
+      const double y0 = (double)sig[i * sig_stride], y1 = (double)sig[(i + 1) * sig_stride];
+      // numpy's interp kernel: slope*(x - x0) + y0 with slope = (y1-y0)/(x1-x0), x1-x0 == 1
+      v = (float)((y1 - y0) * (p - (double)i) + y0);   // separate roundings: this file is built with -ffp-contract=off
+    }
+  }
+  out[j * out_stride] = v;
+}
+
+
 }  // namespace par
 
 extern "C" int par_lag_to_pos_f64(int device, const double* xp, const double* fp, int64_t m, int64_t num_out,
@@ -74,5 +98,17 @@ extern "C" int par_lag_to_pos_f64(int device, const double* xp, const double* fp
     *len_out = (int64_t)h;
     if (trimmed) *trimmed = 1;
   }
+  return PAR_OK;
+}
+
+extern "C" int par_linear_resample_f32(int device, const double* pos, int64_t len_out, const float* sig, int64_t sig_stride,
+                            int64_t len_in, float* out, int64_t out_stride, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(pos && sig && out && len_out >= 0 && len_in >= 1, PAR_ERR_ARG, "par_linear_resample_f32: bad args");
+  if (len_out == 0) return PAR_OK;
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipLaunchKernelGGL(k_lerp, dim3((unsigned)ceil_div(len_out, 256)), dim3(256), 0, as_stream(stream), pos, len_out, sig,
+                     sig_stride, len_in, out, out_stride);
+  PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }

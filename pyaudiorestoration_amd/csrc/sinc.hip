@@ -66,6 +66,9 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 // in-library cross-check of the fast path.  Follows util/resampling.py:66-90 line by line.
 __device__ __noinline__ float sinc_one_f64(double p, double dp, const float* __restrict__ sig, int64_t sig_stride,
                               int64_t len_in, int NT) {
+  // Python's int(round(p)) has no range limit: a position beyond +-2^63 selects an EMPTY slice of the signal
+  // (sum 0.0).  Caught here before the 64-bit index arithmetic below could wrap (found by tools/fuzz_operator_slot.py).
+  if (!(fabs(p) < 9.0e18)) return 0.0f;
   const long long ind = llrint(p);
   const long long lower = ind - NT > 0 ? ind - NT : 0;
   const long long upper = ind + NT < (long long)len_in ? ind + NT : (long long)len_in;
@@ -476,28 +479,6 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
   }
 }
 
-#pragma clang fp contract(off)   // numpy's interp kernel is slope*(x-x0)+y0 with separate roundings
-// "Linear" mode: np.interp(sample_at, arange(len_in), signal, left=0, right=0)  (util/resampling.py:229)
-__global__ __launch_bounds__(256) void k_lerp(const double* __restrict__ pos, int64_t len_out,
-                                               const float* __restrict__ sig, int64_t sig_stride, int64_t len_in,
-                                               float* __restrict__ out, int64_t out_stride) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= len_out) return;
-  const double p = pos[j];
-  float v = 0.0f;
-  if (p >= 0.0 && p <= (double)(len_in - 1)) {
-    long long i = (long long)p;                       // floor, p >= 0
-    if (i >= (long long)len_in - 1) {
-      v = sig[(len_in - 1) * sig_stride];
-    } else {
-      const double y0 = (double)sig[i * sig_stride], y1 = (double)sig[(i + 1) * sig_stride];
-      // numpy's interp kernel: slope*(x - x0) + y0 with slope = (y1-y0)/(x1-x0), x1-x0 == 1
-      v = (float)__dadd_rn(__dmul_rn(y1 - y0, p - (double)i), y0);   // no FMA contraction
-    }
-  }
-  out[j * out_stride] = v;
-}
-
 // ---- host side: per-(device, NT) tap tables -------------------------------------------------------
 struct SincTable {
   float4* ab = nullptr;      // per-tap rows, see tap_R
@@ -590,18 +571,6 @@ int par_sinc_resample_f32(int device, const double* pos, int64_t len_out, const 
   PAR_REQUIRE(len_in >= 1 && sig_stride >= 1 && out_stride >= 1, PAR_ERR_ARG, "par_sinc_resample_f32: bad sizes");
   PAR_HIP_CHECK(hipSetDevice(device));
   return launch_sinc(device, pos, len_out, 0, len_out, sig, sig_stride, len_in, NT, out, out_stride, as_stream(stream));
-}
-
-int par_linear_resample_f32(int device, const double* pos, int64_t len_out, const float* sig, int64_t sig_stride,
-                            int64_t len_in, float* out, int64_t out_stride, void* stream) {
-  using namespace par;
-  PAR_REQUIRE(pos && sig && out && len_out >= 0 && len_in >= 1, PAR_ERR_ARG, "par_linear_resample_f32: bad args");
-  if (len_out == 0) return PAR_OK;
-  PAR_HIP_CHECK(hipSetDevice(device));
-  hipLaunchKernelGGL(k_lerp, dim3((unsigned)ceil_div(len_out, 256)), dim3(256), 0, as_stream(stream), pos, len_out, sig,
-                     sig_stride, len_in, out, out_stride);
-  PAR_HIP_CHECK(hipGetLastError());
-  return PAR_OK;
 }
 
 }  // extern "C"

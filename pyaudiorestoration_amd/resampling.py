@@ -263,6 +263,11 @@ def sinc_wrapper(sample_at, signal, lowpass, NT):
     dev = _dev.device_index(None)
     if len(sample_at) < 2:
         raise UnboundLocalError("local variable 'period_to' referenced before assignment")   # reference behaviour
+    sample_at = np.asarray(sample_at, dtype=np.float64)
+    if not np.isfinite(sample_at).all():            # the reference's int(round(p)) raises on these
+        if np.isnan(sample_at).any():
+            raise ValueError("cannot convert float NaN to integer")
+        raise OverflowError("cannot convert float infinity to integer")
     pos_t = _dev.to_dev(np.asarray(sample_at, dtype=np.float64), torch.float64, dev)
     sig_t = _dev.to_dev(signal, torch.float32, dev)
     return sinc_resample_dev(pos_t, sig_t, NT, dev=dev).cpu().numpy()

@@ -239,6 +239,37 @@ def test_sinc_exact_integer_positions_and_repeats(par):
     assert relerr(par.resampling.sinc_wrapper(pos, sig, 0, 32), C.sinc(pos, sig, 32)) < TOL
 
 
+def test_operator_slot_accepts_any_finite_positions(par):
+    """The open operator slot takes ANY float64 sample_at (found by tools/fuzz_operator_slot.py): positions beyond the
+    int64 range select an empty slice in the reference (Python integers) -> 0.0, never an out-of-range read;
+    non-monotonic / repeated / off-the-ends arrays match the oracle; non-finite ones raise like int(round(p));
+    Linear mode is bit-exact np.interp (no FMA contraction), NaN abscissae pass through."""
+    from oracle import oracle_c as C
+    from oracle import oracle_np as O
+    t = par.torch
+    rng = np.random.default_rng(4758)
+    sig = rng.standard_normal(60000).astype(np.float32)
+    for wild in (1e19, -1e19, 1e30, 1e300, -1e300):
+        pos = np.array([100.3, 101.2, wild, 103.0, 104.9])
+        got = par.resampling.sinc_wrapper(pos, sig, 0, 16)
+        assert got[2] == 0.0 and np.all(np.isfinite(got))
+        assert relerr(got, C.sinc(pos, sig, 16)) < TOL
+    pos = rng.uniform(-60, len(sig) + 60, 40000)
+    pos[::7] = pos[1::7][:len(pos[::7])]                                  # repeats -> zero periods
+    assert relerr(par.resampling.sinc_wrapper(pos, sig, 0, 32), C.sinc(pos, sig, 32)) < TOL
+    with pytest.raises(OverflowError):
+        par.resampling.sinc_wrapper(np.array([1.0, np.inf, 3.0]), sig, 0, 8)
+    with pytest.raises(ValueError):
+        par.resampling.sinc_wrapper(np.array([1.0, np.nan, 3.0]), sig, 0, 8)
+    lin_pos = rng.uniform(0, len(sig), 400000)
+    lin_pos[:5] = [-3.0, 1e300, float(len(sig) - 1), 0.0, 59998.999999999]
+    got = par.resampling.linear_resample_dev(t.from_numpy(lin_pos).cuda(), t.from_numpy(sig).cuda()).cpu().numpy()
+    assert np.array_equal(got, O.linear_resample(lin_pos, sig))
+    nan_out = par.resampling.linear_resample_dev(t.tensor([1.5, float("nan")], dtype=t.float64, device="cuda"),
+                                                 t.from_numpy(sig).cuda()).cpu().numpy()
+    assert np.isnan(nan_out[1]) and not np.isnan(nan_out[0])
+
+
 def test_linear_and_lag_golden(par, golden):
     g = golden["linear_lag"]
     sig = inputs.noise(5000, 50)
