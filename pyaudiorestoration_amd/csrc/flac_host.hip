@@ -14,6 +14,7 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <exception>
 #include <thread>
 #include <vector>
 #include "par_common.h"
@@ -494,9 +495,14 @@ static int flac_decode_impl(const void* data, size_t nbytes, float* out, int64_t
 
 extern "C" int par_flac_decode_f32(const void* data, size_t nbytes, float* out, int64_t frames_cap, int n_threads, int verify_md5,
                                    int64_t* frames_decoded) {
-  int rc = flac_decode_impl(data, nbytes, out, frames_cap, n_threads, verify_md5, frames_decoded);
-  // a chance false resync (a byte pattern passing CRC-8 and CRC-16 inside another frame) only breaks the parallel
-  // split, not the stream: decode serially before calling the file corrupt
-  if (rc == PAR_ERR_ARG && n_threads != 1) rc = flac_decode_impl(data, nbytes, out, frames_cap, 1, verify_md5, frames_decoded);
-  return rc;
+  try {
+    int rc = flac_decode_impl(data, nbytes, out, frames_cap, n_threads, verify_md5, frames_decoded);
+    // a chance false resync (a byte pattern passing CRC-8 and CRC-16 inside another frame) only breaks the parallel
+    // split, not the stream: decode serially before calling the file corrupt
+    if (rc == PAR_ERR_ARG && n_threads != 1) rc = flac_decode_impl(data, nbytes, out, frames_cap, 1, verify_md5, frames_decoded);
+    return rc;
+  } catch (const std::exception& e) {       // e.g. bad_alloc for the MD5 staging of a stream that claims 2^36 frames
+    par::set_error("par_flac_decode_f32: %s", e.what());
+    return PAR_ERR_WORKSPACE;
+  }
 }
