@@ -34,7 +34,7 @@ namespace par {
 constexpr int kSincBlock = 256;
 constexpr int kSincR = 4;                         // outputs per thread
 constexpr int kSincTile = kSincBlock * kSincR;    // outputs per workgroup
-constexpr int kSincCap = 6144;                    // LDS floats for the staged input span (24 KiB)
+constexpr int kSincCap = 4096;                    // LDS floats for the staged input span (16 KiB; speeds up to ~3.7)
 
 // sin(pi*x), cos(pi*x) on [-0.5, 0.5]; Taylor in (pi*x), abs error < 1e-7 at the interval ends.
 __device__ __forceinline__ float sinpi_half(float x) {
@@ -299,7 +299,8 @@ struct FusedArgs {
 };
 constexpr int kPosLds = kSincTile + 2;                 // positions jlo .. jhi of a tile (fused mode)
 constexpr int kPosLdsFloats = 2 * kPosLds + 2;         // float slots they occupy (keeps the tile 16-B aligned)
-constexpr int kSincCapFused = 4096;                    // signal floats staged in fused mode (speeds up to ~3.7)
+constexpr int kSincCapFused = kSincCap;                 // same staging limit in both forms: identical fast/edge-path
+                                                        // decisions, hence bit-identical outputs
 
 __device__ __forceinline__ void generate_tile_positions(const FusedArgs& fa, int64_t j0, int64_t len_out, int64_t jlo,
                                                         int64_t jhi, double* __restrict__ P, int t) {
@@ -375,13 +376,14 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
   float res[kSincR];
   int c[kSincR];                                   // first: index relative to the anchor, later: LDS index
   float s[kSincR], fc[kSincR], dd[kSincR];
-  bool valid[kSincR], fastlane[kSincR];
+  bool valid[kSincR], fastlane[kSincR], lowfc[kSincR];
   bool unity = true, wild = false;
   int mn = INT_MAX, mx = INT_MIN;
 #pragma unroll
   for (int r = 0; r < kSincR; ++r) {
     const int64_t j = j0 + t + (int64_t)r * kSincBlock;
     valid[r] = j < j_end;
+    lowfc[r] = false;
     c[r] = 0;
     s[r] = 0.25f;
     fc[r] = 1.0f;
@@ -396,6 +398,10 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
       const float sh = (float)(rel - rf);          // = p - rint(p)
       s[r] = (sh == 0.0f) ? 1e-20f : sh;           // np.sinc's own 0 -> 1e-20 substitution
       const bool one = !(dp > 1.0);                // fc == 1 (also catches the 1e-12 floor)
+      // fc < 1/8 (an 8x slow-down of the read head and more): the output is a long average, small against the
+      // signal, and float32 tap arithmetic (abs. error ~1e-6 of the signal level) would exceed 1e-5 of the OUTPUT
+      // peak -- those lanes take the float64 path (not an audio-restoration regime; found by tools/fuzz_resampler.py)
+      if (dp > 8.0) lowfc[r] = true;
       const float inv = fast_rcp((float)(dp > 1e-12 ? dp : 1e-12));
       fc[r] = one ? 1.0f : inv;
       dd[r] = one ? 0.0f : (float)(dp - 1.0) * inv;   // 1 - fc without cancellation
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
   const long long edge = (long long)NT - anchor;    // ind >= NT  <=>  rel index >= edge
 #pragma unroll
   for (int r = 0; r < kSincR; ++r) {
-    fastlane[r] = valid[r] && staged && (long long)c[r] >= edge;
+    fastlane[r] = valid[r] && staged && (long long)c[r] >= edge && !lowfc[r];
     c[r] = fastlane[r] ? c[r] - mn + margin : margin;      // LDS index of the window centre (idle lanes: harmless)
     anyfast = anyfast || fastlane[r];
     res[r] = 0.0f;

@@ -239,6 +239,39 @@ def test_sinc_exact_integer_positions_and_repeats(par):
     assert relerr(par.resampling.sinc_wrapper(pos, sig, 0, 32), C.sinc(pos, sig, 32)) < TOL
 
 
+def test_strong_slowdown_and_wide_tiles_found_by_fuzz(par):
+    """tools/fuzz_resampler.py findings: (1) with the read head moving > 8 input samples per output (fc < 1/8) the
+    output is a long average, small against the signal; float32 taps would exceed 1e-5 of the OUTPUT peak, so those
+    lanes run in float64; (2) both kernel forms share one staging limit, so a tile too wide for LDS takes the float64
+    path in both and the fused output stays bit-identical to the position-array output."""
+    from oracle import oracle_c as C
+    t = par.torch
+    rng = np.random.default_rng(516428)
+    n = 3000
+    sig = (30 * rng.standard_normal(n)).astype(np.float32)
+    st = np.linspace(0, n, 3)
+    for speeds in ([0.002, 1.0, 0.002], [0.02, 0.021, 0.02], [0.11, 0.12, 0.13]):
+        sp = np.array(speeds)
+        pos, _ = C.speed_to_pos(st, sp, n)
+        for NT in (32, 100):
+            want = C.sinc(pos, sig, NT)
+            got = par.resampling.sinc_wrapper(pos, sig, 0, NT)
+            assert np.max(np.abs(got - want)) < 1e-5 * np.max(np.abs(want)), (speeds, NT)      # relative to the OUTPUT peak
+    n = 60000
+    m = 235
+    st = np.linspace(0, n, m)
+    sp = 0.2 * (1.0 + 0.002 * np.sin(np.arange(m) * 0.1))                 # 5 input samples per output: tiles ~5.2 k wide
+    sig = rng.standard_normal(n).astype(np.float32)
+    st_t, sp_t, sig_t = t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), t.from_numpy(sig).cuda()
+    plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
+    assert plan.fused_ok
+    pos_t = par.resampling.speed_to_pos_dev(st_t, sp_t, n)
+    for NT in (2, 32):
+        fused = par.resampling.varispeed_fused_dev(plan, sig_t, NT)
+        assert t.equal(fused, par.resampling.sinc_resample_dev(pos_t, sig_t, NT))
+        assert relerr(fused.cpu().numpy(), C.sinc(pos_t.cpu().numpy(), sig, NT)) < TOL
+
+
 def test_operator_slot_accepts_any_finite_positions(par):
     """The open operator slot takes ANY float64 sample_at (found by tools/fuzz_operator_slot.py): positions beyond the
     int64 range select an empty slice in the reference (Python integers) -> 0.0, never an out-of-range read;

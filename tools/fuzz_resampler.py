@@ -27,7 +27,12 @@ while time.time() < t_end:
     seg = int(rng.choice([16, 64, 256, 1000, 5000]))
     m = max(2, n // seg)
     st = np.linspace(0, n, m)
-    style = int(rng.integers(0, 5))
+    grid = int(rng.integers(0, 4))
+    if grid == 1:                                             # curve that does not start at sample 0
+        st = st + float(rng.choice([-1000.0, 0.37, 12345.678, 2.0 ** 20 - 3, 2.0 ** 24 - 100]))
+    elif grid == 2:                                           # uneven spacing
+        st = np.concatenate(([0.0], np.cumsum(rng.uniform(0.3, 1.7, m - 1)))) * (n / max(m - 1, 1))
+    style = int(rng.integers(0, 7))
     if style == 0:
         sp = 1.0 + 0.01 * np.sin(np.arange(m) * 0.05 + rng.uniform(0, 6))
     elif style == 1:
@@ -37,8 +42,12 @@ while time.time() < t_end:
     elif style == 3:
         sp = np.exp(np.cumsum(rng.normal(0, 0.02, m)))
         sp = np.clip(sp, 0.3, 3.0)
-    else:
+    elif style == 4:
         sp = 1.0 + 0.2 * np.sign(np.sin(np.arange(m) * 0.3))
+    elif style == 5:
+        sp = rng.choice([0.02, 0.1, 7.0, 40.0]) * rng.uniform(0.9, 1.1, m)     # very slow / very fast tape
+    else:
+        sp = np.where(rng.random(m) < 0.5, 2.0 / seg, 1.0) * rng.uniform(0.99, 1.01, m)   # segments of ~2 samples
     sig = rng.standard_normal(n).astype(np.float32)
     sig[n // 3:n // 3 + 500] = 0.0
     sig[n // 2:] *= np.float32(rng.choice([1.0, 1e-3, 30.0]))
@@ -72,6 +81,6 @@ while time.time() < t_end:
         assert np.array_equal(out_f, out_a), (case, "fused != position-array", n, NT, seg, style)
     if max(errs) > worst:
         worst, worst_cfg = max(errs), (case, n, NT, seg, style)
-    assert max(errs) < 5e-6, (case, errs, n, NT, seg, style)       # north star: 1e-5; NT = 100 reaches ~2e-6
+    assert max(errs) < 1e-5, (case, errs, n, NT, seg, style)       # the north-star tolerance, relative to the OUTPUT peak
     case += 1
 print(f"fuzz ok: {case} cases ({refused} refused by both the oracle and the device), worst relative error {worst:.2e} at {worst_cfg}")
