@@ -17,9 +17,15 @@
 //    without any per-tap sin: the numerator obeys the 3-term recurrence u[n+1] = 2cos(theta)u[n]-u[n-1]
 //    (theta = pi*fc), seeded at the window centre and run outwards in both directions (its error
 //    grows ~n while the weight decays ~1/n); when a whole wave has fc == 1 (speed <= 1) the numerator
-//    collapses to (-1)^(n+1) sin(pi*shift) and is factored out of the sum.  Taps +n and -n share ONE
-//    v_rcp_f32 (the quarter-rate instruction that bounds this kernel): their denominators combine to
-//    (n^2 - shift^2)*pi/win_n, one v_fma_f32 against a wave-uniform table held in SGPRs.
+//    collapses to (-1)^(n+1) sin(pi*shift) and is factored out of the sum.  Taps +n and -n share one
+//    denominator R_n = (win_n/pi)/(n^2 - shift^2): a v_rcp_f32 (quarter rate on gfx950) only for n = 1..4, from
+//    n = 5 on a 2-term and from n = 13 on a 1-term series in shift^2 against a wave-uniform table that arrives by
+//    scalar loads and stays in SGPRs.  The kernel is VALU-bound (~80 % issue utilisation), not HBM-bound.
+//  * everything the float32 fast path is not built for runs lane-wise in float64, line by line like the
+//    reference (sinc_one_f64): the bug-compatible leading edge, tiles too wide for LDS, positions beyond the
+//    int32 offset range, and fc < 1/8 (long averages whose output is small against the signal).
+//  * FUSED form (k_sinc<true>): no position array in HBM; the tile's float64 positions are regenerated in LDS
+//    from the plan's cumsum checkpoints with the same sequential adds numpy's cumsum does (bit-identical).
 //  * positions stay float64 end to end (a 345.6 M-sample index does not fit float32); only the
 //    sub-sample shift in [-0.5, 0.5] and fc drop to float32.
 #include "par_common.h"
