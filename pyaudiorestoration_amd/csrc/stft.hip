@@ -276,8 +276,13 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
   if (!live) return;
   const float hs = 0.5f * scale;
   auto emit = [&](int k, float re, float im) {
-    if (mode == 0) reinterpret_cast<float2*>(out)[fr * bins + k] = make_float2(re, im);
-    else out[fr * bins + k] = sqrtf(re * re + im * im) + 1e-7f;
+    // streaming stores: the spectrogram is written once and not re-read by this kernel
+    if (mode == 0) {
+      __builtin_nontemporal_store(re, out + 2 * (fr * bins + k));
+      __builtin_nontemporal_store(im, out + 2 * (fr * bins + k) + 1);
+    } else {
+      __builtin_nontemporal_store(sqrtf(re * re + im * im) + 1e-7f, out + fr * bins + k);
+    }
   };
 #pragma unroll
   for (int i = 0; i <= P; ++i) {
