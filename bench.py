@@ -137,6 +137,52 @@ def heal_secondary(dev, tiles=256):
             "frac_of_hbm_peak": round(n * 136.5 / dt / 8e12, 4)}
 
 
+def stereo_secondary(dev, sr=192000, seconds=600.0, nt=32):
+    """Secondary line: one work item of BASELINE config 5 -- a 10-min 192 kHz STEREO file, interleaved (n, 2) like the
+    reference holds it: one plan per file, one fused K_sinc launch per channel on strided channel views."""
+    import torch
+    from pyaudiorestoration_amd import _dev, _lib
+    L = _lib.lib()
+    s = _dev.stream_ptr(dev)
+    n = int(sr * seconds)
+    m = int(seconds * sr / 256)
+    sig = torch.empty((n, 2), dtype=torch.float32, device=f"cuda:{dev}")
+    mono = torch.empty(n, dtype=torch.float32, device=f"cuda:{dev}")
+    for c in range(2):
+        _lib.check(L.par_synth_signal_f32(dev, _dev.ptr(mono), 0, n, float(sr), 0x5EED + c, s))
+        sig[:, c] = mono
+    del mono
+    st = torch.empty(m, dtype=torch.float64, device=f"cuda:{dev}")
+    sp = torch.empty(m, dtype=torch.float64, device=f"cuda:{dev}")
+    _lib.check(L.par_synth_speed_curve_f64(dev, _dev.ptr(st), _dev.ptr(sp), m, seconds, float(sr), 0.01, 0.55, 0.7, s))
+    cap = int(n * 1.02) + 1024
+    nbytes, aux_bytes = int(L.par_speed_plan_bytes(m)), int(L.par_fused_aux_bytes(cap, m))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{dev}")
+    aux = torch.empty(aux_bytes, dtype=torch.uint8, device=f"cuda:{dev}")
+    out = torch.empty((cap, 2), dtype=torch.float32, device=f"cuda:{dev}")
+    len_out, trimmed, ok = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int(0)
+    base_in, base_out = sig.data_ptr(), out.data_ptr()
+
+    def step():
+        _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(st), _dev.ptr(sp), m, n, _dev.ptr(work), nbytes, _dev.ptr(aux),
+                                                 aux_bytes, cap, ctypes.byref(len_out), ctypes.byref(trimmed), 0, None,
+                                                 ctypes.byref(ok), s))
+        for c in range(2):
+            _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(sp), m, _dev.ptr(work), _dev.ptr(aux), cap, len_out.value,
+                                                 ctypes.c_void_p(base_in + 4 * c), 2, n, nt, ctypes.c_void_p(base_out + 4 * c),
+                                                 2, s))
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    return {"workload": f"config 5 work item: {seconds:g}-s {sr} Hz stereo file, interleaved; 1 plan + 2 fused K_sinc launches",
+            "channel_samples_out": 2 * len_out.value, "ms_per_file": round(dt * 1e3, 3),
+            "Msamples/s": round(2 * len_out.value / dt / 1e6, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,6 +361,7 @@ def main():
         if world == 1:
             res["secondary"] = stft_secondary(sig, dev)
             res["secondary_config4"] = heal_secondary(dev)
+            res["secondary_config5"] = stereo_secondary(dev)
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(a.sr, a.nt)
         print(json.dumps(res), flush=True)
