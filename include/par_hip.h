@@ -170,6 +170,14 @@ int par_varispeed_fused_f32(int device, const double* speeds, int64_t m, const v
                             int64_t max_out, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in,
                             int NT, float* out, int64_t out_stride, void* stream);
 
+/* Stereo form: two channels of ONE file (same positions; sig0/sig1 and out0/out1 share the strides -- e.g. the two
+ * columns of an interleaved (n, 2) array: sig1 = sig0 + 1, stride 2) in one launch.  Outputs equal two
+ * par_varispeed_fused_f32 calls to float32 rounding (the lane/output map differs); position regeneration, prologue and tap weights are evaluated once for both. */
+int par_varispeed_fused_stereo_f32(int device, const double* speeds, int64_t m, const void* work, const void* aux,
+                                   int64_t max_out, int64_t len_out, const float* sig0, const float* sig1,
+                                   int64_t sig_stride, int64_t len_in, int NT, float* out0, float* out1,
+                                   int64_t out_stride, void* stream);
+
 /* Profiling hook (bench.py roofline leg): HIP-event timing, on the caller's stream, of the K_sinc launches
  * issued by the last par_varispeed_resample_f32 call on `device`. */
 int par_profile_enable(int device, int on);

@@ -58,6 +58,8 @@ SIGNATURES = {
                                             ctypes.POINTER(c_int), c_vp]),
     "par_varispeed_fused_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64,
                                         c_vp]),
+    "par_varispeed_fused_stereo_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_int,
+                                               c_vp, c_vp, c_i64, c_vp]),
     "par_profile_enable": (c_int, [c_int, c_int]),
     "par_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(c_int), ctypes.POINTER(c_i64)]),
     "par_linear_resample_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
@@ -103,6 +105,8 @@ def lib():
         import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("PAR_HIP_LIB") and not hasattr(L, name):
+                continue                   # developer A/B against an older build: newer entry points are simply absent
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args

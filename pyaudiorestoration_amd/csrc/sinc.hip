@@ -309,7 +309,7 @@ constexpr int kSincCapFused = kSincCap;                 // same staging limit in
                                                         // decisions, hence bit-identical outputs
 
 __device__ __forceinline__ void generate_tile_positions(const FusedArgs& fa, int64_t j0, int64_t len_out, int64_t jlo,
-                                                        int64_t jhi, double* __restrict__ P, int t) {
+                                                        int64_t jhi, double* __restrict__ P, int t, int n_threads) {
   const int64_t T = j0 / kSincTile;
   long long i0 = fa.tile_seg[T];
   if (jlo < fa.seg_start[i0]) i0 -= 1;                                    // j0 opens a segment: j0-1 is in the previous one
@@ -318,7 +318,7 @@ __device__ __forceinline__ void generate_tile_positions(const FusedArgs& fa, int
   const long long s0 = fa.seg_start[i0], s1 = fa.seg_start[i1];
   const long long g_lo = ck_slot0(s0, i0) + (jlo - s0) / kCk;
   const long long g_hi = ck_slot0(s1, i1) + (jhi - s1) / kCk;
-  for (long long g = g_lo + t; g <= g_hi; g += kSincBlock) {
+  for (long long g = g_lo + t; g <= g_hi; g += n_threads) {
     // slot -> (segment, block): slot0 is monotone in the segment index
     long long lo = i0, hi = i1;
     if (hi - lo <= 16) {
@@ -352,14 +352,23 @@ __device__ __forceinline__ void generate_tile_positions(const FusedArgs& fa, int
   }
 }
 
-template <bool FUSED>
-__global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict__ pos, int64_t len_out,
-                                                      const float* __restrict__ sig, int64_t sig_stride,
-                                                      int64_t len_in, int NT, const float4* __restrict__ tab,
-                                                      float* __restrict__ out, int64_t out_stride, int64_t j_begin,
-                                                      int64_t j_end, FusedArgs fa) {
+// NCH = 2: two channels of one file (same positions) in one launch.  A lane then owns 2 outputs x 2 channels instead of
+// 4 outputs x 1: the register state and the per-lane ILP are those of the mono kernel, the workgroup has 512 threads
+// for the same 1024-output tile, and everything that depends only on the POSITION -- regeneration from the plan,
+// prologue, window-centre search, and (because both channel slots of an output carry the very same shift / fc
+// values) the tap weights themselves -- is computed once for both channels.
+template <bool FUSED, int NCH>
+__global__ __launch_bounds__(kSincBlock * NCH, 6) void k_sinc(const double* __restrict__ pos, int64_t len_out,
+                                                            const float* __restrict__ sig, const float* __restrict__ sig1,
+                                                            int64_t sig_stride, int64_t len_in, int NT,
+                                                            const float4* __restrict__ tab, float* __restrict__ out,
+                                                            float* __restrict__ out1, int64_t out_stride, int64_t j_begin,
+                                                            int64_t j_end, FusedArgs fa) {
+  constexpr int kBlk = kSincBlock * NCH;        // threads per workgroup
+  constexpr int kOut = kSincR / NCH;            // outputs per lane; kOut * NCH = kSincR (output, channel) slots
+  static_assert(NCH == 1 || NCH == 2, "mono or stereo");
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-  __shared__ int red[2 * (kSincBlock / kWave)];
+  __shared__ int red[2 * (kBlk / kWave)];
   const int t = threadIdx.x;
   const int64_t j0 = j_begin + (int64_t)blockIdx.x * kSincTile;     // this launch covers outputs [j_begin, j_end)
   float* tile = FUSED ? lds_raw + kPosLdsFloats : lds_raw;
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
   const int64_t jlo = j0 > 0 ? j0 - 1 : 0;
   if (FUSED) {
     const int64_t jhi = (j0 + kSincTile < len_out) ? j0 + kSincTile : len_out - 1;
-    generate_tile_positions(fa, j0, len_out, jlo, jhi, P, t);
+    generate_tile_positions(fa, j0, len_out, jlo, jhi, P, t, kBlk);
     __syncthreads();
   }
   const double* psrc = FUSED ? P - jlo : pos;     // psrc[j] is the position of output j in both modes
@@ -379,15 +388,15 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
   const double p0 = psrc[j0];
   const long long anchor = (fabs(p0) < 4.0e18) ? (llrint(p0) & ~1ll) : 0ll;
   const double anchor_d = (double)anchor;
-  float res[kSincR];
-  int c[kSincR];                                   // first: index relative to the anchor, later: LDS index
-  float s[kSincR], fc[kSincR], dd[kSincR];
-  bool valid[kSincR], fastlane[kSincR], lowfc[kSincR];
+  float res[kSincR];                               // one per (output, channel) slot: slot = output * NCH + channel
+  int c[kOut];                                     // first: index relative to the anchor, later: LDS index
+  float s[kOut], fc[kOut], dd[kOut];
+  bool valid[kOut], fastlane[kOut], lowfc[kOut];
   bool unity = true, wild = false;
   int mn = INT_MAX, mx = INT_MIN;
 #pragma unroll
-  for (int r = 0; r < kSincR; ++r) {
-    const int64_t j = j0 + t + (int64_t)r * kSincBlock;
+  for (int r = 0; r < kOut; ++r) {
+    const int64_t j = j0 + t + (int64_t)r * kBlk;
     valid[r] = j < j_end;
     lowfc[r] = false;
     c[r] = 0;
@@ -425,13 +434,13 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
   if (__any(wild)) mn = INT_MIN;                    // poisons the span test below for the whole block
   if ((t & (kWave - 1)) == 0) {
     red[t / kWave] = mn;
-    red[kSincBlock / kWave + t / kWave] = mx;
+    red[kBlk / kWave + t / kWave] = mx;
   }
   __syncthreads();
 #pragma unroll
-  for (int w = 0; w < kSincBlock / kWave; ++w) {
+  for (int w = 0; w < kBlk / kWave; ++w) {
     mn = red[w] < mn ? red[w] : mn;
-    mx = red[kSincBlock / kWave + w] > mx ? red[kSincBlock / kWave + w] : mx;
+    mx = red[kBlk / kWave + w] > mx ? red[kBlk / kWave + w] : mx;
   }
   // the tap loops run in chunks of kChunk and may touch up to kChunk-1 taps beyond +-(NT-1); those
   // carry an exactly-zero weight (R_n = rcp(inf)) but must read finite data: stage a kChunk margin.
@@ -440,9 +449,11 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
   const bool staged = mn != INT_MIN && span <= cap;
   const long long lo = anchor + mn - margin;        // signal index of tile[0]
   if (staged) {
-    for (int q = t; q < (int)span; q += kSincBlock) {
+    for (int q = t; q < (int)span; q += kBlk) {
       const long long g = lo + q;
-      tile[q] = (g >= 0 && g < (long long)len_in) ? sig[g * sig_stride] : 0.0f;
+      const bool inside = g >= 0 && g < (long long)len_in;
+      tile[q] = inside ? sig[g * sig_stride] : 0.0f;
+      if (NCH == 2) tile[cap + q] = inside ? sig1[g * sig_stride] : 0.0f;      // channel 1 right behind channel 0
     }
   }
   __syncthreads();
@@ -451,23 +462,34 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
   bool anyfast = false;
   const long long edge = (long long)NT - anchor;    // ind >= NT  <=>  rel index >= edge
 #pragma unroll
-  for (int r = 0; r < kSincR; ++r) {
+  for (int r = 0; r < kOut; ++r) {
     fastlane[r] = valid[r] && staged && (long long)c[r] >= edge && !lowfc[r];
     c[r] = fastlane[r] ? c[r] - mn + margin : margin;      // LDS index of the window centre (idle lanes: harmless)
     anyfast = anyfast || fastlane[r];
-    res[r] = 0.0f;
+  }
+  // (output, channel) slots: channel ch of an output reads the tile `ch * cap` floats further on; shift, fc and
+  // 1 - fc are the SAME values for both slots of an output, so the compiler evaluates their tap weights once
+  int cs[kSincR];
+  float ss[kSincR], fcs[kSincR], dds[kSincR];
+#pragma unroll
+  for (int sl = 0; sl < kSincR; ++sl) {
+    cs[sl] = c[sl / NCH] + (sl % NCH) * cap;
+    ss[sl] = s[sl / NCH];
+    fcs[sl] = fc[sl / NCH];
+    dds[sl] = dd[sl / NCH];
+    res[sl] = 0.0f;
   }
   if (__any(anyfast)) {
     if (__all(unity)) {
-      taps_unity<kSincR>(tile, c, s, NT, tab, res);
+      taps_unity<kSincR>(tile, cs, ss, NT, tab, res);
     } else {
-      // the general path carries 10 live values per output: two passes over half of the lane's outputs keep
+      // the general path carries 10 live values per slot: two passes over half of the lane's slots keep
       // it inside the 80-VGPR budget (one pass spilled 48 B/lane = as much HBM write traffic as the output)
-      static_assert(kSincR == 4, "split assumes 4 outputs per lane");
-      const int ca[2] = {c[0], c[1]}, cb[2] = {c[2], c[3]};
-      const float sa[2] = {s[0], s[1]}, sb[2] = {s[2], s[3]};
-      const float fa_[2] = {fc[0], fc[1]}, fb_[2] = {fc[2], fc[3]};
-      const float da[2] = {dd[0], dd[1]}, db[2] = {dd[2], dd[3]};
+      static_assert(kSincR == 4, "split assumes 4 slots per lane");
+      const int ca[2] = {cs[0], cs[1]}, cb[2] = {cs[2], cs[3]};
+      const float sa[2] = {ss[0], ss[1]}, sb[2] = {ss[2], ss[3]};
+      const float fa_[2] = {fcs[0], fcs[1]}, fb_[2] = {fcs[2], fcs[3]};
+      const float da[2] = {dds[0], dds[1]}, db[2] = {dds[2], dds[3]};
       float ra[2], rb[2];
       taps_general<2>(tile, ca, sa, fa_, da, NT, tab, ra);
       taps_general<2>(tile, cb, sb, fb_, db, NT, tab, rb);
@@ -478,16 +500,19 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc(const double* __restrict
     }
   }
 #pragma unroll
-  for (int r = 0; r < kSincR; ++r) {
-    const int64_t j = j0 + t + (int64_t)r * kSincBlock;
+  for (int r = 0; r < kOut; ++r) {
+    const int64_t j = j0 + t + (int64_t)r * kBlk;
     if (j >= j_end) continue;
-    float v = res[r];
-    if (!fastlane[r]) {
-      const double pj = psrc[j];
-      const double dpj = (j + 1 < len_out) ? psrc[j + 1] - pj : pj - psrc[j - 1];
-      v = sinc_one_f64(pj, dpj, sig, sig_stride, len_in, NT);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      float v = res[r * NCH + ch];
+      if (!fastlane[r]) {
+        const double pj = psrc[j];
+        const double dpj = (j + 1 < len_out) ? psrc[j + 1] - pj : pj - psrc[j - 1];
+        v = sinc_one_f64(pj, dpj, ch ? sig1 : sig, sig_stride, len_in, NT);
+      }
+      (ch ? out1 : out)[j * out_stride] = v;
     }
-    out[j * out_stride] = v;
   }
 }
 
@@ -537,16 +562,18 @@ int launch_sinc(int device, const double* pos, int64_t len_out, int64_t j_begin,
   int rc = get_sinc_table(device, NT, &tab);
   if (rc != PAR_OK) return rc;
   const int64_t blocks = ceil_div(count, kSincTile);
-  hipLaunchKernelGGL(k_sinc<false>, dim3((unsigned)blocks), dim3(kSincBlock), kSincCap * sizeof(float), s, pos, len_out,
-                     sig, sig_stride, len_in, NT, tab.ab, out, out_stride, j_begin, j_begin + count, FusedArgs{});
+  hipLaunchKernelGGL((k_sinc<false, 1>), dim3((unsigned)blocks), dim3(kSincBlock), kSincCap * sizeof(float), s, pos, len_out,
+                     sig, (const float*)nullptr, sig_stride, len_in, NT, tab.ab, out, (float*)nullptr, out_stride, j_begin,
+                     j_begin + count, FusedArgs{});
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }
 
 // whole output range, positions regenerated in-kernel from the plan + checkpoints (no position array)
+// sig1 / out1 != nullptr: second channel of the same file (same strides), resampled in the same launch
 int launch_sinc_fused(int device, const double* speeds, int64_t m, const void* work, const void* aux, int64_t max_out,
-                      int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in, int NT, float* out,
-                      int64_t out_stride, hipStream_t s) {
+                      int64_t len_out, const float* sig, const float* sig1, int64_t sig_stride, int64_t len_in, int NT,
+                      float* out, float* out1, int64_t out_stride, hipStream_t s) {
   SincTable tab;
   int rc = get_sinc_table(device, NT, &tab);
   if (rc != PAR_OK) return rc;
@@ -562,9 +589,16 @@ int launch_sinc_fused(int device, const double* speeds, int64_t m, const void* w
   fa.tile_seg = reinterpret_cast<const int64_t*>(fa.ck + ck_len);
   fa.nseg = m - 1;
   const int64_t blocks = ceil_div(len_out, kSincTile);
-  hipLaunchKernelGGL(k_sinc<true>, dim3((unsigned)blocks), dim3(kSincBlock),
-                     (kPosLdsFloats + kSincCapFused) * sizeof(float), s, nullptr, len_out, sig, sig_stride, len_in, NT,
-                     tab.ab, out, out_stride, (int64_t)0, len_out, fa);
+  if (sig1 && out1) {
+    hipLaunchKernelGGL((k_sinc<true, 2>), dim3((unsigned)blocks), dim3(2 * kSincBlock),
+                       (kPosLdsFloats + 2 * kSincCapFused) * sizeof(float), s, (const double*)nullptr, len_out, sig, sig1,
+                       sig_stride, len_in, NT, tab.ab, out, out1, out_stride, (int64_t)0, len_out, fa);
+  } else {
+    hipLaunchKernelGGL((k_sinc<true, 1>), dim3((unsigned)blocks), dim3(kSincBlock),
+                       (kPosLdsFloats + kSincCapFused) * sizeof(float), s, (const double*)nullptr, len_out, sig,
+                       (const float*)nullptr, sig_stride, len_in, NT, tab.ab, out, (float*)nullptr, out_stride, (int64_t)0,
+                       len_out, fa);
+  }
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }

@@ -97,23 +97,22 @@ int par_varispeed_resample_f32(int device, const double* speeds, int64_t m, cons
 
 // Fused form: no position array at all.  Needs a plan made by par_speed_to_pos_plan_fused (checkpoints + tile map
 // in `aux`); K_sinc regenerates each tile's float64 positions in LDS, bit-identical to the materialised path.
-int par_varispeed_fused_f32(int device, const double* speeds, int64_t m, const void* work, const void* aux,
-                            int64_t max_out, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in,
-                            int NT, float* out, int64_t out_stride, void* stream) {
+static int varispeed_fused_impl(const char* who, int device, const double* speeds, int64_t m, const void* work, const void* aux,
+                                int64_t max_out, int64_t len_out, const float* sig, const float* sig1, int64_t sig_stride,
+                                int64_t len_in, int NT, float* out, float* out1, int64_t out_stride, void* stream) {
   using namespace par;
-  PAR_REQUIRE(speeds && work && aux && sig && out && m >= 2, PAR_ERR_ARG, "par_varispeed_fused_f32: null pointer");
-  PAR_REQUIRE(len_out >= 2 && len_out <= max_out, PAR_ERR_ARG,
-              "par_varispeed_fused_f32: len_out=%lld outside [2, max_out=%lld]", (long long)len_out, (long long)max_out);
-  PAR_REQUIRE(NT >= 1 && NT <= 512 && len_in >= 1 && sig_stride >= 1 && out_stride >= 1, PAR_ERR_ARG,
-              "par_varispeed_fused_f32: bad sizes");
+  PAR_REQUIRE(speeds && work && aux && sig && out && m >= 2, PAR_ERR_ARG, "%s: null pointer", who);
+  PAR_REQUIRE(len_out >= 2 && len_out <= max_out, PAR_ERR_ARG, "%s: len_out=%lld outside [2, max_out=%lld]", who,
+              (long long)len_out, (long long)max_out);
+  PAR_REQUIRE(NT >= 1 && NT <= 512 && len_in >= 1 && sig_stride >= 1 && out_stride >= 1, PAR_ERR_ARG, "%s: bad sizes", who);
   PAR_HIP_CHECK(hipSetDevice(device));
   Pipe* p = nullptr;
   int rc = get_pipe(device, &p);
   if (rc != PAR_OK) return rc;
   hipStream_t main = as_stream(stream);
   if (p->profile) PAR_HIP_CHECK(hipEventRecord(p->t0[0], main));
-  rc = launch_sinc_fused(device, speeds, m, work, aux, max_out, len_out, sig, sig_stride, len_in, NT, out, out_stride,
-                         main);
+  rc = launch_sinc_fused(device, speeds, m, work, aux, max_out, len_out, sig, sig1, sig_stride, len_in, NT, out, out1,
+                         out_stride, main);
   if (rc != PAR_OK) return rc;
   if (p->profile) {
     PAR_HIP_CHECK(hipEventRecord(p->t1[0], main));
@@ -121,6 +120,24 @@ int par_varispeed_fused_f32(int device, const double* speeds, int64_t m, const v
     p->timed_samples = len_out;
   }
   return PAR_OK;
+}
+
+int par_varispeed_fused_f32(int device, const double* speeds, int64_t m, const void* work, const void* aux,
+                            int64_t max_out, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in,
+                            int NT, float* out, int64_t out_stride, void* stream) {
+  return varispeed_fused_impl("par_varispeed_fused_f32", device, speeds, m, work, aux, max_out, len_out, sig, nullptr,
+                              sig_stride, len_in, NT, out, nullptr, out_stride, stream);
+}
+
+// Two channels of one file in one launch (same positions, same strides): position regeneration, prologue and tap
+// weights are computed once for both.
+int par_varispeed_fused_stereo_f32(int device, const double* speeds, int64_t m, const void* work, const void* aux,
+                                   int64_t max_out, int64_t len_out, const float* sig0, const float* sig1,
+                                   int64_t sig_stride, int64_t len_in, int NT, float* out0, float* out1,
+                                   int64_t out_stride, void* stream) {
+  PAR_REQUIRE(sig1 && out1, PAR_ERR_ARG, "par_varispeed_fused_stereo_f32: null pointer");
+  return varispeed_fused_impl("par_varispeed_fused_stereo_f32", device, speeds, m, work, aux, max_out, len_out, sig0, sig1,
+                              sig_stride, len_in, NT, out0, out1, out_stride, stream);
 }
 
 // profiling hook for bench.py: HIP-event timing of the K_sinc launches issued by the last pipelined call

@@ -110,6 +110,21 @@ def varispeed_fused_dev(plan, sig_t, NT, out_t=None, sig_stride=1, len_in=None, 
     return out_t
 
 
+def varispeed_fused_stereo_dev(plan, sig0_t, sig1_t, NT, out0_t, out1_t, sig_stride=1, len_in=None, out_stride=1):
+    """Two channels of one file in ONE fused K_sinc launch (positions, prologue and tap weights shared).  sig0/sig1 and
+    out0/out1 are channel views with common strides, e.g. the two columns of an interleaved (n, 2) tensor.  Equal to
+    two varispeed_fused_dev calls up to float32 rounding (different lane <-> output map)."""
+    if not plan.fused_ok:
+        raise ValueError("plan has no valid checkpoints: build it with speed_plan_dev(..., fused=True)")
+    if len_in is None:
+        len_in = sig0_t.numel() // sig_stride
+    _lib.check(_lib.lib().par_varispeed_fused_stereo_f32(
+        plan.dev, _dev.ptr(plan.speeds_t), plan.m, _dev.ptr(plan.work), _dev.ptr(plan.aux), plan.max_out, plan.len_out,
+        _dev.ptr(sig0_t), _dev.ptr(sig1_t), sig_stride, len_in, int(NT), _dev.ptr(out0_t), _dev.ptr(out1_t), out_stride,
+        _dev.stream_ptr(plan.dev)))
+    return out0_t, out1_t
+
+
 def varispeed_batch_dev(items, NT, dev=None):
     """Software-pipelined fused resampling of a batch of device-resident work items on one GPU (the per-GPU
     inner loop of a file batch): while K_sinc of item k runs on the current stream, the whole plan
@@ -346,17 +361,26 @@ def run(filenames, signal_data=None, speed_curve=None, resampling_mode="Linear",
             n_out_ch = len(use_channels)
             length = plan.len_out if pos_t is None else pos_t.numel()
             out_t = _dev.empty((length, n_out_ch), torch.float32, dev)
-            for k, ch in enumerate(use_channels):
-                src, dst = sig_t.reshape(-1)[ch:], out_t.reshape(-1)[k:]      # strided channel views, no copies
-                layout = dict(sig_stride=n_ch_in, len_in=n_in, out_stride=n_out_ch)
-                if resampling_mode == "Sinc":
+            layout = dict(sig_stride=n_ch_in, len_in=n_in, out_stride=n_out_ch)
+            flat_in, flat_out = sig_t.reshape(-1), out_t.reshape(-1)                # strided channel views, no copies
+            k = 0
+            while k < n_out_ch:
+                ch = use_channels[k]
+                if resampling_mode == "Sinc" and pos_t is None and k + 1 < n_out_ch:
+                    # two channels per launch: they share the positions, hence the whole weight computation
+                    varispeed_fused_stereo_dev(plan, flat_in[ch:], flat_in[use_channels[k + 1]:], sinc_quality,
+                                               flat_out[k:], flat_out[k + 1:], **layout)
+                    progress((k + 1) / n_out_ch * 100)
+                    k += 1
+                elif resampling_mode == "Sinc":
                     if pos_t is None:
-                        varispeed_fused_dev(plan, src, sinc_quality, dst, **layout)
+                        varispeed_fused_dev(plan, flat_in[ch:], sinc_quality, flat_out[k:], **layout)
                     else:
-                        sinc_resample_dev(pos_t, src, sinc_quality, dst, dev=dev, **layout)
+                        sinc_resample_dev(pos_t, flat_in[ch:], sinc_quality, flat_out[k:], dev=dev, **layout)
                 elif resampling_mode == "Linear":
-                    linear_resample_dev(pos_t, src, dst, dev=dev, **layout)
+                    linear_resample_dev(pos_t, flat_in[ch:], flat_out[k:], dev=dev, **layout)
                 progress((k + 1) / n_out_ch * 100)
+                k += 1
             # pinned staging for the one D2H of the file (4x the pageable rate, tools/bench_e2e.py)
             host = torch.empty(out_t.shape, dtype=torch.float32, pin_memory=True)
             host.copy_(out_t)

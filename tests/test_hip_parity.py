@@ -239,6 +239,35 @@ def test_sinc_exact_integer_positions_and_repeats(par):
     assert relerr(par.resampling.sinc_wrapper(pos, sig, 0, 32), C.sinc(pos, sig, 32)) < TOL
 
 
+def test_stereo_kernel_equals_two_mono_launches(par):
+    """k_sinc<fused, 2 channels>: one launch for both channels of a file (shared positions / prologue / tap weights)
+    equals one mono launch per channel to float32 rounding (the lane <-> output map differs, so at speed-1 crossings
+    different waves take the fc == 1 shortcut) and is bit-identical across memory layouts -- interleaved and planar, fc == 1 and fc < 1 stretches, the
+    leading-edge and wide-tile float64 paths, a tail shorter than a tile; resampling.run pairs channels automatically."""
+    t = par.torch
+    R = par.resampling
+    rng = np.random.default_rng(31)
+    for n, depth, NT in ((300000, 0.01, 32), (70000, 0.4, 16), (5000, 0.0, 50), (260000, 0.05, 4)):
+        m = max(3, n // 200)
+        st = np.linspace(0, n, m)
+        sp = 1.0 + depth * np.sin(np.arange(m) * 0.21) + 0.002 * rng.standard_normal(m)
+        st_t, sp_t = t.from_numpy(st).cuda(), t.from_numpy(sp).cuda()
+        inter = t.from_numpy(rng.standard_normal((n, 2)).astype(np.float32)).cuda()
+        plan = R.speed_plan_dev(st_t, sp_t, n, fused=True)
+        assert plan.fused_ok
+        L = plan.len_out
+        want = [R.varispeed_fused_dev(plan, inter.reshape(-1)[c:], NT, sig_stride=2, len_in=n).clone() for c in (0, 1)]
+        out = t.empty((L, 2), dtype=t.float32, device="cuda")
+        R.varispeed_fused_stereo_dev(plan, inter.reshape(-1)[0:], inter.reshape(-1)[1:], NT, out.reshape(-1)[0:],
+                                     out.reshape(-1)[1:], sig_stride=2, len_in=n, out_stride=2)
+        for c in (0, 1):
+            assert relerr(out[:, c].cpu().numpy(), want[c].cpu().numpy()) < 2e-6, (n, depth, NT, c)
+        planar = inter.T.contiguous()                                      # (2, n): stride 1, separate rows
+        o0, o1 = t.empty(L, dtype=t.float32, device="cuda"), t.empty(L, dtype=t.float32, device="cuda")
+        R.varispeed_fused_stereo_dev(plan, planar[0], planar[1], NT, o0, o1)
+        assert t.equal(o0, out[:, 0]) and t.equal(o1, out[:, 1])
+
+
 def test_strong_slowdown_and_wide_tiles_found_by_fuzz(par):
     """tools/fuzz_resampler.py findings: (1) with the read head moving > 8 input samples per output (fc < 1/8) the
     output is a long average, small against the signal; float32 taps would exceed 1e-5 of the OUTPUT peak, so those
