@@ -79,6 +79,15 @@ while time.time() < t_end:
     if plan.fused_ok:
         out_f = R.varispeed_fused_dev(plan, sig_t, NT).cpu().numpy()
         assert np.array_equal(out_f, out_a), (case, "fused != position-array", n, NT, seg, style)
+        # stereo form: both channels in one launch == one mono launch each (to float32 rounding)
+        sig2_t = torch.flip(sig_t, dims=(0,)).contiguous()
+        o0 = torch.empty(plan.len_out, dtype=torch.float32, device="cuda")
+        o1 = torch.empty(plan.len_out, dtype=torch.float32, device="cuda")
+        R.varispeed_fused_stereo_dev(plan, sig_t, sig2_t, NT, o0, o1)
+        m1 = R.varispeed_fused_dev(plan, sig2_t, NT).cpu().numpy()
+        sc = max(float(np.max(np.abs(out_f))), float(np.max(np.abs(m1))), 1e-30)
+        es = max(float(np.max(np.abs(o0.cpu().numpy() - out_f))), float(np.max(np.abs(o1.cpu().numpy() - m1)))) / sc
+        assert es < 5e-6, (case, "stereo != mono", es, n, NT, seg, style)
     if max(errs) > worst:
         worst, worst_cfg = max(errs), (case, n, NT, seg, style)
     assert max(errs) < 1e-5, (case, errs, n, NT, seg, style)       # the north-star tolerance, relative to the OUTPUT peak
