@@ -63,16 +63,22 @@ def respeed(signal, sr, trail, fft_size=1024, hop=256, zeropad=1, mode="Peak", t
     pos_t = resampling.speed_to_pos_dev(st_t, sp_t, n, dev)      # kept: the GUI shows / reuses sample_at
     plan = resampling.speed_plan_dev(st_t, sp_t, n, dev, fused=True) if resampling_mode == "Sinc" else None
     out_t = _dev.empty((pos_t.numel(), ch), torch.float32, dev)
-    for c in range(ch):
+    flat_in, flat_out = sig_t.reshape(-1), out_t.reshape(-1)
+    layout = dict(sig_stride=ch, len_in=n, out_stride=ch)
+    c = 0
+    while c < ch:
+        if resampling_mode == "Sinc" and plan.fused_ok and c + 1 < ch:      # channel pairs share one stereo launch
+            resampling.varispeed_fused_stereo_dev(plan, flat_in[c:], flat_in[c + 1:], sinc_quality, flat_out[c:],
+                                                  flat_out[c + 1:], **layout)
+            c += 2
+            continue
         if resampling_mode == "Sinc" and plan.fused_ok:
-            resampling.varispeed_fused_dev(plan, sig_t.reshape(-1)[c:], sinc_quality, out_t.reshape(-1)[c:], sig_stride=ch,
-                                           len_in=n, out_stride=ch)
+            resampling.varispeed_fused_dev(plan, flat_in[c:], sinc_quality, flat_out[c:], **layout)
         elif resampling_mode == "Sinc":
-            resampling.sinc_resample_dev(pos_t, sig_t.reshape(-1)[c:], sinc_quality, out_t.reshape(-1)[c:], sig_stride=ch,
-                                         len_in=n, out_stride=ch, dev=dev)
+            resampling.sinc_resample_dev(pos_t, flat_in[c:], sinc_quality, flat_out[c:], dev=dev, **layout)
         else:
-            resampling.linear_resample_dev(pos_t, sig_t.reshape(-1)[c:], out_t.reshape(-1)[c:], sig_stride=ch, len_in=n,
-                                           out_stride=ch, dev=dev)
+            resampling.linear_resample_dev(pos_t, flat_in[c:], flat_out[c:], dev=dev, **layout)
+        c += 1
     return {"spectrum": spec, "times": track.times, "freqs": track.freqs, "speed_curve": curve, "positions": pos_t,
             "output": out_t}
 
