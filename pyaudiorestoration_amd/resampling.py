@@ -133,7 +133,8 @@ def varispeed_batch_dev(items, NT, dev=None):
     reads it has finished.
 
     items: iterable of (sampletimes_t, speeds_t, sig_t) or (sampletimes_t, speeds_t, sig_t, sig_stride, len_in)
-    with float64 / float32 device tensors.  Yields (index, out_t, plan) in order; out_t is ready on the current
+    with float64 / float32 device tensors; a 2-D sig_t is an interleaved (n, ch) file whose channels share the plan
+    (channel pairs go through the stereo launch) and yields an (len_out, ch) output.  Yields (index, out_t, plan) in order; out_t is ready on the current
     stream (synchronise or keep using that stream).  An item whose plan has no valid checkpoints is resampled
     through the position-array path."""
     dev = _dev.device_index(dev)
@@ -143,7 +144,10 @@ def varispeed_batch_dev(items, NT, dev=None):
 
     def plan_item(item, slot, stream, ready=None):
         st_t, sp_t, sig_t = item[0], item[1], item[2]
-        len_in = item[4] if len(item) > 4 else sig_t.numel() // (item[3] if len(item) > 3 else 1)
+        if sig_t.ndim == 2:
+            len_in = sig_t.shape[0]
+        else:
+            len_in = item[4] if len(item) > 4 else sig_t.numel() // (item[3] if len(item) > 3 else 1)
         if stream is None:
             plan = speed_plan_dev(st_t, sp_t, len_in, dev, fused=True, work=work[slot], aux=aux[slot])
         else:
@@ -175,12 +179,34 @@ def varispeed_batch_dev(items, NT, dev=None):
         ready = torch.cuda.Event()
         ready.record(main)
         sig_t = cur_item[2]
-        stride = cur_item[3] if len(cur_item) > 3 else 1
-        len_in = cur_item[4] if len(cur_item) > 4 else sig_t.numel() // stride
-        if plan.fused_ok:
-            out_t = varispeed_fused_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)
+        if sig_t.ndim == 2:
+            # interleaved (n, ch) file: channel pairs share one stereo launch, an odd last channel goes alone
+            n_in, ch = sig_t.shape
+            out_t = _dev.empty((plan.len_out, ch), torch.float32, dev)
+            flat_in, flat_out = sig_t.reshape(-1), out_t.reshape(-1)
+            layout = dict(sig_stride=ch, len_in=n_in, out_stride=ch)
+            if not plan.fused_ok:
+                pos_t = _dev.empty(plan.len_out, torch.float64, dev)
+                _lib.check(_lib.lib().par_speed_to_pos_fill(dev, _dev.ptr(plan.speeds_t), plan.m, _dev.ptr(plan.work),
+                                                            _dev.ptr(pos_t), plan.len_out, _dev.stream_ptr(dev)))
+            c = 0
+            while c < ch:
+                if plan.fused_ok and c + 1 < ch:
+                    varispeed_fused_stereo_dev(plan, flat_in[c:], flat_in[c + 1:], NT, flat_out[c:], flat_out[c + 1:], **layout)
+                    c += 2
+                elif plan.fused_ok:
+                    varispeed_fused_dev(plan, flat_in[c:], NT, flat_out[c:], **layout)
+                    c += 1
+                else:
+                    sinc_resample_dev(pos_t, flat_in[c:], NT, flat_out[c:], dev=dev, **layout)
+                    c += 1
         else:
-            out_t, _ = varispeed_resample_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)
+            stride = cur_item[3] if len(cur_item) > 3 else 1
+            len_in = cur_item[4] if len(cur_item) > 4 else sig_t.numel() // stride
+            if plan.fused_ok:
+                out_t = varispeed_fused_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)
+            else:
+                out_t, _ = varispeed_resample_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)
         free[slot] = torch.cuda.Event()
         free[slot].record(main)
         nxt_plan = plan_item(nxt_item, (k + 1) % 2, side, ready) if nxt_item is not None else None
