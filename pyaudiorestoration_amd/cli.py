@@ -21,36 +21,48 @@ import numpy as np
 
 
 def _worker(dev, jobs, args, results):
+    """One host thread per GPU.  The next file of the queue is read and decoded (native FLAC decoder / numpy, both
+    release the GIL) on a helper thread while the current one is on the GPU."""
+    from concurrent.futures import ThreadPoolExecutor
     import torch
     from . import io_ops, pipeline, resampling
     torch.cuda.set_device(dev)
-    while True:
+
+    def take():
         try:
             path = jobs.get_nowait()
         except queue.Empty:
-            return
-        try:
-            if args.cmd in ("tapesync", "heal"):
-                flow = pipeline.tapesync if args.cmd == "tapesync" else pipeline.heal_project
-                flow(args.project, source=path, out_suffix=args.suffix, device=dev)
+            return None
+        if args.cmd in ("tapesync", "heal"):        # these flows read their source themselves
+            return path, None
+        return path, reader.submit(io_ops.read_file, path)
+
+    with ThreadPoolExecutor(max_workers=1) as reader:
+        nxt = take()
+        while nxt is not None:
+            (path, pending), nxt = nxt, take()       # the next file starts decoding now
+            try:
+                if args.cmd in ("tapesync", "heal"):
+                    flow = pipeline.tapesync if args.cmd == "tapesync" else pipeline.heal_project
+                    flow(args.project, source=path, out_suffix=args.suffix, device=dev)
+                    results.append((path, None))
+                    continue
+                signal, sr, ch = pending.result()
+                if args.cmd == "respeed":
+                    t0, f0, t1, f1 = args.trail
+                    r = pipeline.respeed(signal, sr, [(t0, f0), (t1, f1)], args.fft_size, args.hop, 1, args.mode,
+                                         args.tolerance, (0, args.lowpass), args.quality, device=dev)
+                    out = r["output"].cpu().numpy()
+                    io_ops.write_wav_float(f"{os.path.splitext(path)[0]}_res{args.suffix}.wav", out, sr)
+                    np.save(f"{os.path.splitext(path)[0]}_speed{args.suffix}.npy", r["speed_curve"])
+                else:
+                    curve = np.asarray(json.load(open(args.curve)), dtype=np.float64)
+                    resampling.run((path,), signal_data=((signal, sr),), speed_curve=curve, resampling_mode=args.resampling,
+                                   sinc_quality=args.quality, suffix=args.suffix)
                 results.append((path, None))
-                continue
-            signal, sr, ch = io_ops.read_file(path)
-            if args.cmd == "respeed":
-                t0, f0, t1, f1 = args.trail
-                r = pipeline.respeed(signal, sr, [(t0, f0), (t1, f1)], args.fft_size, args.hop, 1, args.mode,
-                                     args.tolerance, (0, args.lowpass), args.quality, device=dev)
-                out = r["output"].cpu().numpy()
-                io_ops.write_wav_float(f"{os.path.splitext(path)[0]}_res{args.suffix}.wav", out, sr)
-                np.save(f"{os.path.splitext(path)[0]}_speed{args.suffix}.npy", r["speed_curve"])
-            else:
-                curve = np.asarray(json.load(open(args.curve)), dtype=np.float64)
-                resampling.run((path,), signal_data=((signal, sr),), speed_curve=curve, resampling_mode=args.resampling,
-                               sinc_quality=args.quality, suffix=args.suffix)
-            results.append((path, None))
-        except Exception as e:                      # keep the other files going; report at the end
-            logging.exception(f"{path} failed")
-            results.append((path, e))
+            except Exception as e:                      # keep the other files going; report at the end
+                logging.exception(f"{path} failed")
+                results.append((path, e))
 
 
 def main(argv=None):

@@ -947,3 +947,14 @@ def test_headless_cli_respeed_and_resample(par, golden, tmp_path):
     assert cli.main(["resample", "--curve", str(tmp_path / "c.json"), "--quality", "32", "--suffix", "_b", f]) == 0
     y2, _, _ = io_ops.read_file(str(tmp_path / "tape_res_b.wav"))
     assert relerr(y2[g["c3_sel"], 0], g["c3_y_sel"]) < TOL
+    # several files in one call: the next one is decoded on a helper thread while the current one is on the GPU
+    more = []
+    for k in range(3):
+        more.append(str(tmp_path / f"copy{k}.flac"))
+        shutil.copy(os.path.join(GOLD, "flutter_192.flac"), more[-1])
+    bad = str(tmp_path / "broken.flac")
+    open(bad, "wb").write(b"fLaC" + bytes(100))
+    assert cli.main(["resample", "--curve", str(tmp_path / "c.json"), "--quality", "32", *more, bad]) == 1   # one failed
+    for k in range(3):
+        yk, _, _ = io_ops.read_file(str(tmp_path / f"copy{k}_res.wav"))
+        assert np.array_equal(yk, y2)
