@@ -903,6 +903,51 @@ def test_zero_crossing_compaction_sizes(par):
     assert np.array_equal(W.zero_crossings(np.array([0.5, -0.5, -0.1, 0.2])), [0, 2])
 
 
+def test_library_is_reentrant_across_host_threads_and_streams(par):
+    """SURVEY 8b threading contract: called from several host threads at once (QThreads in the GUI, one driver thread
+    per GPU), each on its own stream, the library keeps no cross-call state -- every thread gets the serial result."""
+    import threading
+    t = par.torch
+    R = par.resampling
+    rng = np.random.default_rng(77)
+    jobs = []
+    for k in range(6):
+        n = int(rng.choice([150000, 400000, 900000]))
+        m = n // 256
+        st = np.linspace(0, n, m)
+        sp = 1.0 + 0.02 * np.sin(np.arange(m) * 0.05 + k)
+        sig = rng.standard_normal(n).astype(np.float32)
+        jobs.append((t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), t.from_numpy(sig).cuda(), n, 8 + 8 * (k % 4)))
+    want = []
+    for st_t, sp_t, sig_t, n, NT in jobs:
+        plan = R.speed_plan_dev(st_t, sp_t, n, fused=True)
+        want.append((R.varispeed_fused_dev(plan, sig_t, NT).clone(), par.fourier.get_mag(sig_t, 1024, 256).clone()))
+    t.cuda.synchronize()
+    got = [None] * len(jobs)
+    errors = []
+
+    def work(i):
+        try:
+            st_t, sp_t, sig_t, n, NT = jobs[i]
+            with t.cuda.stream(t.cuda.Stream()):
+                for _ in range(3):                                          # interleave plans, resamples and STFTs
+                    plan = R.speed_plan_dev(st_t, sp_t, n, fused=True)
+                    y = R.varispeed_fused_dev(plan, sig_t, NT)
+                    mag = par.fourier.get_mag(sig_t, 1024, 256)
+                t.cuda.current_stream().synchronize()
+                got[i] = (y, mag)
+        except Exception as e:                                              # surfaced below
+            errors.append((i, repr(e)))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for (y, mag), (wy, wm) in zip(got, want):
+        assert t.equal(y, wy) and t.equal(mag, wm)
+
+
 def test_bench_contract_line():
     """bench.py prints ONE JSON line with the contract's keys, a roofline and a cpu_baseline object."""
     import json
