@@ -200,6 +200,8 @@ __global__ void k_init_header(PlanHeader* h, int64_t m) {
   h->ck_len = 0;
   h->ck_valid = 0;
   h->pad2 = 0;
+  h->n_long = 0;
+  h->pad3 = 0;
   h->written = 0;
 }
 
@@ -300,6 +302,27 @@ __global__ void __launch_bounds__(256) k_speed_sum(const double* __restrict__ sp
 // stores per instruction (one segment ~ 33 slots apart per lane: a 64-byte DRAM sector per 8 useful bytes);
 // transposed, a quarter wave writes 16 consecutive slots of ONE segment (128-byte runs).
 constexpr int kCkRound = 16;       // checkpoints per lane per transpose round (= 128 cumsum steps; 8.7 KB LDS per wave)
+__device__ __forceinline__ int f64_exponent(double x) { return (int)((__double_as_longlong(x) >> 52) & 0x7ff); }
+
+// ---- long segments (sparse speed curves) ------------------------------------------------------------------
+// One lane per segment is fine while segments are a few hundred samples long.  A curve with a handful of points
+// (a constant speed correction is TWO points) makes segments of 10^7..10^9 samples, and the sequential float64
+// cumsum of such a segment on one lane takes seconds.  Those segments are cut into chunks of 256 steps and their
+// cumsum chain c' = fl(c + r_k) is evaluated EXACTLY in parallel with the parity-translation algebra of the offset
+// chain (see the header comment): per chunk the 256 single-add maps are composed into one map (valid while the
+// running sum stays in one binade), chunk starts come from a scan of the maps, the ~30 chunks in which the sum
+// crosses a power of two are stepped through sequentially, and a final pass recomputes every chunk from its exact
+// start, writes the checkpoints and VERIFIES that it lands bit-exactly on the next chunk's start.
+constexpr long long kLongSeg = 4096;                    // longer segments take the chunked path (needs the ck buffer)
+constexpr int kLongChunk = 256;                         // steps per chunk; the last chunk of a segment takes the remainder
+constexpr int kLongSlots = kLongChunk / kCk;            // checkpoint slots a chunk owns: its scratch lives there first
+enum { kLsA = 8, kLsC0 = 9, kLsC1 = 10, kLsExp = 11, kLsStart = 12, kLsEnd = 13, kLsApprox = 14 };
+
+__host__ __device__ inline long long chunk_slot0(long long seg_start, long long i) { return seg_start / kLongChunk + i; }
+__device__ __forceinline__ bool long_segment(long long n, long long start, long long i, const double* ck, int64_t ck_len) {
+  return ck != nullptr && n > kLongSeg && ck_slot0(start, i) + (n + kCk - 1) / kCk <= ck_len;
+}
+
 __global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
                                                  int64_t nseg, double* __restrict__ S, double* __restrict__ ck,
                                                  int64_t ck_len, PlanHeader* __restrict__ h) {
@@ -310,7 +333,7 @@ __global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, c
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + lane;
   long long n = 0, slot0 = 0;
   Ramp r = make_ramp(1.0, 1.0, 2);
-  bool ck_ok = false;
+  bool ck_ok = false, is_long = false;
   if (i < nseg) {
     const long long start = seg_start[i];
     n = seg_start[i + 1] - start;
@@ -320,6 +343,10 @@ __global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, c
       // segments whose slots do not fit are skipped here; whether any of them is actually needed (starts
       // before len_out) is decided by k_tile_seg once the trim is known
       ck_ok = ck != nullptr && slot0 + (n + kCk - 1) / kCk <= ck_len;
+      if (long_segment(n, start, i, ck, ck_len)) {      // the k_long_* kernels own this segment (S[i] included)
+        is_long = true;
+        n = 0;
+      }
     } else {
       n = 0;
     }
@@ -358,7 +385,270 @@ __global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, c
     }
   }
   for (long long k = n_blocks * kCk; k < n; ++k) c = c + ramp_recip((double)k, r);
-  if (i < nseg) S[i] = c;
+  if (i < nseg && !is_long) S[i] = c;
+}
+
+__global__ void k_count_long(const int64_t* __restrict__ seg_start, int64_t nseg, const double* __restrict__ ck,
+                             int64_t ck_len, PlanHeader* __restrict__ h) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg) return;
+  const long long start = seg_start[i];
+  if (long_segment(seg_start[i + 1] - start, start, i, ck, ck_len)) atomicAdd(&h->n_long, 1);
+}
+
+struct ChunkRef {
+  long long i, j, J, n, k0, k1, base, slot0;
+  bool ok;
+};
+// global chunk slot g = chunk_slot0(start_i, i) + j is unique and monotone in (i, j) without any prefix sum
+__device__ __forceinline__ ChunkRef find_chunk(long long g, const int64_t* __restrict__ seg_start, int64_t nseg,
+                                               const double* ck, int64_t ck_len) {
+  long long lo = 0, hi = nseg - 1;
+  while (lo < hi) {
+    const long long mid = (lo + hi + 1) >> 1;
+    if (chunk_slot0(seg_start[mid], mid) <= g) lo = mid; else hi = mid - 1;
+  }
+  ChunkRef c;
+  c.i = lo;
+  const long long start = seg_start[lo];
+  c.n = seg_start[lo + 1] - start;
+  c.j = g - chunk_slot0(start, lo);
+  c.J = c.n / kLongChunk;
+  c.ok = c.j >= 0 && c.j < c.J && long_segment(c.n, start, lo, ck, ck_len);
+  c.k0 = c.j * kLongChunk;
+  c.k1 = (c.j == c.J - 1) ? c.n : c.k0 + kLongChunk;
+  c.slot0 = ck_slot0(start, lo);
+  c.base = c.slot0 + c.j * kLongSlots;
+  return c;
+}
+
+// pass A: plain float64 sum of the chunk's reciprocals (only used to PREDICT the binade of the running sum)
+__global__ __launch_bounds__(256) void k_long_approx(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                                     int64_t nseg, double* __restrict__ ck, int64_t ck_len, long long G,
+                                                     const PlanHeader* __restrict__ h) {
+  if (h->n_long == 0) return;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const ChunkRef c = find_chunk(g, seg_start, nseg, ck, ck_len);
+  if (!c.ok) return;
+  const Ramp r = make_ramp(sp[c.i], sp[c.i + 1], c.n);
+  double acc[kCk] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long k = c.k0;
+  for (; k + kCk <= c.k1; k += kCk) {
+    const double a0 = (double)k;
+#pragma unroll
+    for (int u = 0; u < kCk; ++u) acc[u] += ramp_recip(a0 + (double)u, r);
+  }
+  double A = 0.0;
+#pragma unroll
+  for (int u = 0; u < kCk; ++u) A += acc[u];
+  for (; k < c.k1; ++k) A += ramp_recip((double)k, r);
+  ck[c.base + kLsA] = A;
+}
+
+// pass B: per long segment, exclusive prefix of the chunk sums = approximate running sum at every chunk start
+__global__ __launch_bounds__(256) void k_long_prefix(const int64_t* __restrict__ seg_start, int64_t nseg,
+                                                     double* __restrict__ ck, int64_t ck_len,
+                                                     const PlanHeader* __restrict__ h) {
+  if (h->n_long == 0) return;
+  __shared__ double buf[256];
+  __shared__ double carry;
+  for (long long i = blockIdx.x; i < nseg; i += gridDim.x) {
+    const long long start = seg_start[i], n = seg_start[i + 1] - start;
+    if (!long_segment(n, start, i, ck, ck_len)) continue;            // uniform over the workgroup
+    const long long J = n / kLongChunk, slot0 = ck_slot0(start, i);
+    if (threadIdx.x == 0) carry = 0.0;
+    __syncthreads();
+    for (long long j0 = 0; j0 < J; j0 += 256) {
+      const long long j = j0 + threadIdx.x;
+      const double v = j < J ? ck[slot0 + j * kLongSlots + kLsA] : 0.0;
+      buf[threadIdx.x] = v;
+      __syncthreads();
+      for (int o = 1; o < 256; o <<= 1) {
+        const double t = (int)threadIdx.x >= o ? buf[threadIdx.x - o] : 0.0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+      }
+      if (j < J) ck[slot0 + j * kLongSlots + kLsApprox] = carry + (buf[threadIdx.x] - v);
+      __syncthreads();
+      if (threadIdx.x == 255) carry += buf[255];
+      __syncthreads();
+    }
+  }
+}
+
+// one float64 add x -> fl(x + r) inside binade e as a parity-dependent integer translation (units of ulp)
+__device__ __forceinline__ bool add_as_map(double r, int e, long long* d0, long long* d1) {
+  const double t = ldexp(r, 1075 - e);
+  if (!(t >= 0.0 && t < 0x1p62)) return false;
+  const double fl = floor(t);
+  const long long q = (long long)fl;
+  const double fr = t - fl;                    // exact
+  if (fr > 0.5) *d0 = *d1 = q + 1;
+  else if (fr < 0.5) *d0 = *d1 = q;
+  else {                                       // exact half: ties-to-even on the SUM's parity
+    *d0 = q + (q & 1);
+    *d1 = q + ((q + 1) & 1);
+  }
+  return true;
+}
+
+// pass C: compose the chunk's single-add maps when the running sum provably stays in one binade
+__global__ __launch_bounds__(256) void k_long_map(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                                  int64_t nseg, double* __restrict__ ck, int64_t ck_len, long long G,
+                                                  const PlanHeader* __restrict__ h) {
+  if (h->n_long == 0) return;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const ChunkRef c = find_chunk(g, seg_start, nseg, ck, ck_len);
+  if (!c.ok) return;
+  const double xa = ck[c.base + kLsApprox], xb = xa + ck[c.base + kLsA];
+  const double lo = 1.0 - 0x1p-30, hi = 1.0 + 0x1p-30;
+  const int e = f64_exponent(xa);
+  bool interior = c.j > 0 && xa > 0.0 && e > 64 && e < 2046 && f64_exponent(xa * lo) == e && f64_exponent(xa * hi) == e &&
+                  f64_exponent(xb * lo) == e && f64_exponent(xb * hi) == e;
+  long long c0 = 0, c1 = 0;
+  if (interior) {
+    const Ramp r = make_ramp(sp[c.i], sp[c.i + 1], c.n);
+    for (long long k = c.k0; k < c.k1 && interior; k += kCk) {
+      double rr[kCk];
+#pragma unroll
+      for (int u = 0; u < kCk; ++u) rr[u] = ramp_recip((double)(k + u), r);
+#pragma unroll
+      for (int u = 0; u < kCk; ++u) {
+        if (k + u < c.k1) {
+          long long d0, d1;
+          if (!add_as_map(rr[u], e, &d0, &d1)) interior = false;
+          else {
+            const long long n0 = c0 + ((c0 & 1) ? d1 : d0);
+            const long long n1 = c1 + (((1 + c1) & 1) ? d1 : d0);
+            c0 = n0;
+            c1 = n1;
+          }
+        }
+      }
+    }
+  }
+  ck[c.base + kLsC0] = __longlong_as_double(c0);
+  ck[c.base + kLsC1] = __longlong_as_double(c1);
+  ck[c.base + kLsExp] = interior ? (double)e : -1.0;
+}
+
+__device__ __forceinline__ double apply_map(long long c0, long long c1, double x) {
+  const int e = f64_exponent(x);
+  const long long X = (long long)ldexp(x, 1075 - e);      // exact integer in [2^52, 2^53)
+  const long long Y = X + ((X & 1) ? c1 : c0);
+  return ldexp((double)Y, e - 1075);
+}
+
+// pass D: per long segment, exact running sum at every chunk boundary.  Runs of single-binade chunks are resolved by a
+// workgroup scan of their maps; a chunk in which the sum crosses a power of two (and the first one, from 0) is
+// stepped through with real float64 adds by one thread.
+__global__ __launch_bounds__(256) void k_long_stitch(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                                     int64_t nseg, double* __restrict__ ck, int64_t ck_len,
+                                                     const PlanHeader* __restrict__ h) {
+  if (h->n_long == 0) return;
+  __shared__ long long s0[256], s1[256];
+  __shared__ int first_direct;
+  __shared__ double x_run;
+  const int t = threadIdx.x;
+  for (long long i = blockIdx.x; i < nseg; i += gridDim.x) {
+    const long long start = seg_start[i], n = seg_start[i + 1] - start;
+    if (!long_segment(n, start, i, ck, ck_len)) continue;
+    const long long J = n / kLongChunk, slot0 = ck_slot0(start, i);
+    const Ramp r = make_ramp(sp[i], sp[i + 1], n);
+    if (t == 0) x_run = 0.0;
+    long long j = 0;
+    while (j < J) {
+      if (t == 0) first_direct = 256;
+      __syncthreads();
+      const long long jj = j + t;
+      const long long base = slot0 + jj * kLongSlots;
+      const bool live = jj < J;
+      const bool direct = live && ck[base + kLsExp] < 0.0;
+      if (direct) atomicMin(&first_direct, t);
+      long long c0 = 0, c1 = 0;
+      if (live && !direct) {
+        c0 = __double_as_longlong(ck[base + kLsC0]);
+        c1 = __double_as_longlong(ck[base + kLsC1]);
+      }
+      __syncthreads();
+      long long L = first_direct;                                   // interior chunks in front of the first direct one
+      if (L > J - j) L = J - j;
+      // inclusive scan of the maps of chunks j .. j+L-1 (identity elsewhere)
+      s0[t] = t < L ? c0 : 0;
+      s1[t] = t < L ? c1 : 0;
+      __syncthreads();
+      for (int o = 1; o < 256; o <<= 1) {
+        long long a0 = 0, a1 = 0;
+        const bool take = t >= o;
+        if (take) {
+          a0 = s0[t - o];
+          a1 = s1[t - o];
+        }
+        __syncthreads();
+        if (take) {                                                   // apply a (earlier chunks) first, then own
+          const long long b0 = s0[t], b1 = s1[t];
+          s0[t] = a0 + ((a0 & 1) ? b1 : b0);
+          s1[t] = a1 + (((1 + a1) & 1) ? b1 : b0);
+        }
+        __syncthreads();
+      }
+      const double x0 = x_run;
+      if (t < L) {
+        const double xs_ = (t == 0) ? x0 : apply_map(s0[t - 1], s1[t - 1], x0);
+        const double xe_ = apply_map(s0[t], s1[t], x0);
+        ck[base + kLsStart] = xs_;
+        ck[base + kLsEnd] = xe_;
+      }
+      __syncthreads();
+      if (t == 0) {
+        double x = L > 0 ? apply_map(s0[L - 1], s1[L - 1], x0) : x0;
+        if (j + L < J && first_direct < 256) {                        // the direct chunk that ended the run
+          const long long jd = j + L, bd = slot0 + jd * kLongSlots;
+          const long long k0 = jd * kLongChunk, k1 = (jd == J - 1) ? n : k0 + kLongChunk;
+          ck[bd + kLsStart] = x;
+          double c = x;
+          for (long long k = k0; k < k1; ++k) c = c + ramp_recip((double)k, r);
+          ck[bd + kLsEnd] = c;
+          x = c;
+        }
+        x_run = x;
+      }
+      __syncthreads();
+      j += L + ((j + L < J && first_direct < 256) ? 1 : 0);
+      __syncthreads();
+    }
+  }
+}
+
+// pass E: every chunk recomputed sequentially from its exact start: checkpoints out, S_i from the last chunk, and the
+// proof -- the chunk must land bit-exactly on the value the scan promised to the next chunk.
+__global__ __launch_bounds__(256) void k_long_final(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                                    int64_t nseg, double* __restrict__ S, double* __restrict__ ck,
+                                                    int64_t ck_len, long long G, PlanHeader* __restrict__ h) {
+  if (h->n_long == 0) return;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const ChunkRef c = find_chunk(g, seg_start, nseg, ck, ck_len);
+  if (!c.ok) return;
+  const double x_start = ck[c.base + kLsStart], x_end = ck[c.base + kLsEnd];    // read before this chunk's slots are reused
+  const Ramp r = make_ramp(sp[c.i], sp[c.i + 1], c.n);
+  double x = x_start;
+  long long k = c.k0;
+  for (; k + kCk <= c.k1; k += kCk) {
+    double rr[kCk];
+    const double a0 = (double)k;
+#pragma unroll
+    for (int u = 0; u < kCk; ++u) rr[u] = ramp_recip(a0 + (double)u, r);
+#pragma unroll
+    for (int u = 0; u < kCk; ++u) x = x + rr[u];
+    if (k + kCk < c.n) ck[c.slot0 + k / kCk + 1] = x;               // cumsum after step k + kCk - 1 (steps follow)
+  }
+  for (; k < c.k1; ++k) x = x + ramp_recip((double)k, r);
+  if (__double_as_longlong(x) != __double_as_longlong(x_end)) atomicOr(&h->flags, kFlagVerify);
+  if (c.j == c.J - 1) S[c.i] = x;
 }
 
 // after k_tile_seg: publish checkpoint validity in the header (device side, so the host needs one read-back)
@@ -387,8 +677,6 @@ __global__ void k_tile_seg(const int64_t* __restrict__ seg_start, int64_t nseg, 
   if (a <= (long long)len_out - 1 && (long long)len_out - 1 < b)
     tile_seg[(len_out + kSincTileOutputs - 1) / kSincTileOutputs] = i;
 }
-
-__device__ __forceinline__ int f64_exponent(double x) { return (int)((__double_as_longlong(x) >> 52) & 0x7ff); }
 
 __device__ __forceinline__ void mark_direct(long long i, long long* direct, PlanHeader* h) {
   const int slot = atomicAdd(&h->n_direct, 1);
@@ -519,7 +807,8 @@ __global__ void k_off_apply(const double* __restrict__ sp, const PElem* __restri
 
 // np.argmin |pos - n_in| inside the trim segment (first occurrence), header finalisation
 __global__ void k_trim(const double* __restrict__ st, const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
-                       const double* __restrict__ seg_off, int64_t m, double n_in, PlanHeader* __restrict__ h) {
+                       const double* __restrict__ seg_off, int64_t m, double n_in, const double* __restrict__ ck,
+                       int64_t ck_len, PlanHeader* __restrict__ h) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int64_t nseg = m - 1;
   // int(np.mean(speeds) * (st[-1]-st[0]) * 1.01)  (:108)
@@ -536,8 +825,23 @@ __global__ void k_trim(const double* __restrict__ st, const double* __restrict__
     const Ramp r = make_ramp(sp[i], sp[i + 1], n);
     const double off = seg_off[i];
     double c = 0.0, best = INFINITY;
-    long long arg = 0;
-    for (long long k = 0; k < n; ++k) {
+    long long arg = 0, k_from = 0, k_to = n;
+    if (r.fast && long_segment(n, seg_start[i], i, ck, ck_len)) {
+      // positions rise monotonically (positive speeds), so |pos - n_in| has its minimum where they cross n_in:
+      // bisect the cumsum checkpoints for the last block that ends at or below n_in and search around it only
+      const long long slot0 = ck_slot0(seg_start[i], i), nb = (n - 1) / kCk;      // checkpoints 1 .. nb exist
+      long long lo = 0, hi = nb;                                                  // checkpoint 0 is the empty sum
+      while (lo < hi) {
+        const long long mid = (lo + hi + 1) >> 1;
+        if (ck[slot0 + mid] + off <= n_in) lo = mid; else hi = mid - 1;
+      }
+      const long long b = lo > 0 ? lo - 1 : 0;                                    // one block of slack on the low side
+      c = b ? ck[slot0 + b] : 0.0;
+      k_from = b * kCk;
+      k_to = (lo + 3) * kCk < n ? (lo + 3) * kCk : n;
+      if (k_from > 0) best = fabs((c + off) - n_in), arg = k_from - 1;            // the sample the checkpoint stands for
+    }
+    for (long long k = k_from; k < k_to; ++k) {
       c = c + ramp_recip((double)k, r);
       const double d = fabs((c + off) - n_in);
       if (d < best) {
@@ -746,6 +1050,25 @@ extern "C" {
 
 size_t par_speed_plan_bytes(int64_t m) { return par::plan_bytes(m < 2 ? 2 : m); }
 
+// Per-segment reciprocal sums (+ checkpoints): one lane per ordinary segment, the chunked exact path for long ones.
+// The five k_long_* launches return at once when the curve has no long segment (header counter).
+static void launch_seg_sums(const double* speeds, const par::PlanView& pv, int64_t nseg, double* ck, int64_t ck_len,
+                            int64_t max_out, int64_t m, hipStream_t s) {
+  using namespace par;
+  const unsigned g256 = (unsigned)ceil_div(nseg, 256);
+  if (ck) hipLaunchKernelGGL(k_count_long, dim3(g256), dim3(256), 0, s, pv.seg_start, nseg, (const double*)ck, ck_len, pv.hdr);
+  hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.S, ck,
+                     ck_len, pv.hdr);
+  if (!ck) return;
+  const long long G = max_out / kLongChunk + m + 8;                 // bound on the global chunk slots
+  const unsigned gc = (unsigned)ceil_div(G, 256), gs = (unsigned)(nseg < 2048 ? nseg : 2048);
+  hipLaunchKernelGGL(k_long_approx, dim3(gc), dim3(256), 0, s, speeds, pv.seg_start, nseg, ck, ck_len, G, pv.hdr);
+  hipLaunchKernelGGL(k_long_prefix, dim3(gs), dim3(256), 0, s, pv.seg_start, nseg, ck, ck_len, pv.hdr);
+  hipLaunchKernelGGL(k_long_map, dim3(gc), dim3(256), 0, s, speeds, pv.seg_start, nseg, ck, ck_len, G, pv.hdr);
+  hipLaunchKernelGGL(k_long_stitch, dim3(gs), dim3(256), 0, s, speeds, pv.seg_start, nseg, ck, ck_len, pv.hdr);
+  hipLaunchKernelGGL(k_long_final, dim3(gc), dim3(256), 0, s, speeds, pv.seg_start, nseg, pv.S, ck, ck_len, G, pv.hdr);
+}
+
 // Shared implementation.  aux (optional, device): cumsum checkpoints for the fused resampler.
 static int plan_impl(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in, void* work,
                      size_t work_bytes, void* aux, size_t aux_bytes, int64_t max_out, int64_t* len_out, int* trimmed,
@@ -777,8 +1100,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
     hipLaunchKernelGGL(k_seg_lengths, dim3(g256), dim3(256), 0, s, fix, nseg, pv.seg_start, pv.hdr);
     hipLaunchKernelGGL(k_speed_sum, dim3((unsigned)(m / 4096 + 1)), dim3(256), 0, s, speeds, m,
                        reinterpret_cast<double*>(pv.bsum), pv.hdr);     // bsum is idle between two scans
-    hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.S, ck,
-                       ck_len, pv.hdr);
+    launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s);
     PAR_HIP_CHECK(hipMemcpyAsync(pv.xs, pv.S, nseg * sizeof(double), hipMemcpyDeviceToDevice, s));
     rc = inclusive_scan<AddF64>(pv.xs, nseg, reinterpret_cast<double*>(pv.bsum), s);
     if (rc != PAR_OK) return rc;
@@ -791,7 +1113,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
     hipLaunchKernelGGL(k_off_apply, dim3(g256), dim3(256), 0, s, speeds, el, pv.runs, nseg, (double)n_in, pv.seg_off,
                        pv.hdr);
     hipLaunchKernelGGL(k_trim, dim3(1), dim3(1), 0, s, sampletimes, speeds, pv.seg_start, pv.seg_off, m, (double)n_in,
-                       pv.hdr);
+                       (const double*)ck, ck_len, pv.hdr);
     if (aux) {
       hipLaunchKernelGGL(k_tile_seg, dim3(g256), dim3(256), 0, s, pv.seg_start, nseg, ck_len, max_tiles,
                          reinterpret_cast<int64_t*>(ck + ck_len), pv.hdr);
@@ -802,14 +1124,27 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
     PAR_HIP_CHECK(hipStreamSynchronize(s));
     // any flag but the checkpoint one (near-tie length, n_i < 2, range, verification, too many crossings):
     // the serial path decides -- it also produces the reference's own diagnosis for genuinely bad curves.
+    if (h.flags == kFlagCapAmbiguous) {
+      // Only the buffer bound is in doubt: everything else the device computed stands.  Settle int(mean * span * 1.01)
+      // with numpy's own pairwise order on the host (one D2H of the speed samples, no serial re-plan).
+      std::vector<double> sp_h(m);
+      double ends[2];
+      PAR_HIP_CHECK(hipMemcpyAsync(sp_h.data(), speeds, m * sizeof(double), hipMemcpyDeviceToHost, s));
+      PAR_HIP_CHECK(hipMemcpyAsync(&ends[0], sampletimes, sizeof(double), hipMemcpyDeviceToHost, s));
+      PAR_HIP_CHECK(hipMemcpyAsync(&ends[1], sampletimes + (m - 1), sizeof(double), hipMemcpyDeviceToHost, s));
+      PAR_HIP_CHECK(hipStreamSynchronize(s));
+      h.cap = (int64_t)((np_pairwise_sum(sp_h.data(), m) / (double)m) * (ends[1] - ends[0]) * 1.01);
+      h.flags = 0;
+      PAR_HIP_CHECK(hipMemcpyAsync(pv.hdr, &h, sizeof(h), hipMemcpyHostToDevice, s));
+      PAR_HIP_CHECK(hipStreamSynchronize(s));
+    }
     if (h.flags) need_host = true;     // (the checkpoint flag has already been folded into ck_valid)
   }
   if (need_host) {
     int rc = host_plan(pv, sampletimes, speeds, m, n_in, &h, s);
     if (rc != PAR_OK) return rc;
     if (aux) {     // checkpoints + tile map for the serial path's segmentation: same exact device arithmetic
-      hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.S, ck,
-                         ck_len, pv.hdr);
+      launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s);
       hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, s, pv.seg_start, nseg, ck_len,
                          max_tiles, reinterpret_cast<int64_t*>(ck + ck_len), pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);

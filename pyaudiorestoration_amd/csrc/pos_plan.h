@@ -20,6 +20,8 @@ struct PlanHeader {
   int32_t ck_valid;       // 1: the aux buffer holds this plan's cumsum checkpoints (fused resampler may run)
   int32_t pad2;
   int64_t written;        // outputs the reference has written into its buffer when it stops (end of the trim segment)
+  int32_t n_long;         // segments handled by the chunked exact cumsum (sparse curves), see pos.hip
+  int32_t pad3;
 };
 constexpr int kFlagAmbiguous = 1;   // a cumulative length is too close to a rounding tie
 constexpr int kFlagBadLength = 2;   // some n_i < 2 (reference divides by zero / indexes an empty array)

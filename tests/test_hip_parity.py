@@ -859,10 +859,10 @@ def test_config4_on_the_reference_dropout_sample(par, tmp_path):
     assert relerr(healed[~touched, 0], x[~touched, 0]) < 1e-4         # the rest only sees the STFT round trip
 
 
-def test_buffer_bound_ambiguity_goes_to_the_serial_path(par):
+def test_buffer_bound_ambiguity_is_settled_with_numpys_order(par):
     """int(mean(speeds) * span * 1.01): when the product sits within the device sum's uncertainty of an integer the
-    plan is decided by the serial path (numpy's pairwise order); everywhere else by the device scans -- and both give
-    the oracle's positions."""
+    bound is recomputed on the host in numpy's pairwise order (one copy of the speed samples; the device plan itself
+    stands) -- positions equal the oracle's either way."""
     from oracle import oracle_c as C
     t = par.torch
     m, n = 400, 100000
@@ -873,7 +873,7 @@ def test_buffer_bound_ambiguity_goes_to_the_serial_path(par):
     assert abs(guess - round(guess)) < 1e-9
     info = {}
     pos = par.resampling.speed_to_pos_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), n, info=info).cpu().numpy()
-    assert info["path"] == 1                                            # ambiguous bound -> serial host path
+    assert info["path"] == 0                                            # no serial re-plan for the bound alone
     ref, _ = C.speed_to_pos(st, sp, n)
     assert np.array_equal(pos, ref)
     sp2 = sp * 1.0001                                                   # a bound far from an integer: device scans
@@ -882,6 +882,31 @@ def test_buffer_bound_ambiguity_goes_to_the_serial_path(par):
     assert info["path"] == 0
     ref2, _ = C.speed_to_pos(st, sp2, n)
     assert np.array_equal(pos2, ref2)
+
+
+def test_sparse_speed_curves_take_the_chunked_exact_cumsum(par):
+    """A curve with a handful of points makes segments of 10^5..10^7 samples.  Their sequential float64 cumsum is
+    evaluated exactly in parallel (chunk maps in the parity-translation algebra, scan, verified final pass): the fused
+    output must stay bit-identical to the position-array path, whose positions are bit-identical to the oracle."""
+    from oracle import oracle_c as C
+    t = par.torch
+    R = par.resampling
+    rng = np.random.default_rng(12)
+    cases = [(3_000_000, [1.015, 1.015], 0.0), (3_000_000, [0.97, 1.04], 0.0), (2_500_000, [1.0, 0.5, 1.7], 0.0),
+             (4_000_000, list(1.0 + 0.05 * np.sin(np.arange(11) * 0.9)), 123.25),
+             (1_000_000, list(rng.uniform(0.8, 1.25, 40)), 0.0), (700_000, [1.0, 1.0], 0.0)]
+    for n, speeds, st0 in cases:
+        sp = np.asarray(speeds, dtype=np.float64)
+        st = np.linspace(0, n, len(sp)) + st0
+        sig = rng.standard_normal(n).astype(np.float32)
+        st_t, sp_t, sig_t = t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), t.from_numpy(sig).cuda()
+        ref_pos, _ = C.speed_to_pos(st, sp, n)
+        plan = R.speed_plan_dev(st_t, sp_t, n, fused=True)
+        assert plan.fused_ok and plan.path == 0 and plan.len_out == len(ref_pos), (n, speeds[:3], plan.path, plan.len_out)
+        pos_t = R.speed_to_pos_dev(st_t, sp_t, n)                        # lane-per-segment fill: the slow exact form
+        assert t.equal(pos_t.cpu(), t.from_numpy(ref_pos))
+        for NT in (3, 32):
+            assert t.equal(R.varispeed_fused_dev(plan, sig_t, NT), R.sinc_resample_dev(pos_t, sig_t, NT)), (n, speeds[:3], NT)
 
 
 def test_zero_crossing_compaction_sizes(par):
