@@ -127,6 +127,10 @@ int par_speed_to_pos_plan_ex(int device, const double* sampletimes, const double
                              int* path_used, void* stream);
 int par_speed_to_pos_fill(int device, const double* speeds, int64_t m, const void* work,
                           double* pos, int64_t len_out, void* stream);
+/* The same fill from a FUSED plan (fused_ok): parallel over 8-sample blocks restarting from the cumsum checkpoints,
+ * so a curve with a handful of points (segments of 10^7..10^9 samples) fills in milliseconds; bit-identical. */
+int par_speed_to_pos_fill_fused(int device, const double* speeds, int64_t m, const void* work, const void* aux,
+                                int64_t max_out, double* pos, int64_t len_out, void* stream);
 
 /* ---- R2/R3: windowed-sinc varispeed interpolation --------------------------------------
  * Replaces sinc_wrapper / sinc_wrapper_mt / sinc_core (util/resampling.py:21-90), operator

@@ -49,6 +49,7 @@ SIGNATURES = {
     "par_speed_to_pos_plan_ex": (c_int, [c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_sz, ctypes.POINTER(c_i64),
                                          ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int), c_vp]),
     "par_speed_to_pos_fill": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "par_speed_to_pos_fill_fused": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "par_sinc_resample_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp]),
     "par_varispeed_resample_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_i64,
                                            c_int, c_vp]),

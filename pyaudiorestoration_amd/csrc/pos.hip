@@ -1033,6 +1033,38 @@ static int host_plan(const PlanView& pv, const double* d_st, const double* d_sp,
 
 
 
+// Position fill from the cumsum checkpoints of a fused plan: one lane per 8-sample block restarts from the block's
+// checkpoint (the same regeneration K_sinc<fused> does in LDS), so the work is spread over len_out/8 lanes whatever the
+// segment lengths are -- the lane-per-segment fill below needs seconds for a segment of 10^8 samples.
+__global__ __launch_bounds__(256) void k_pos_fill_ck(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                                     const double* __restrict__ seg_off, int64_t nseg,
+                                                     const double* __restrict__ ck, int64_t n_slots, int64_t len_out,
+                                                     double* __restrict__ pos) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_slots) return;
+  long long lo = 0, hi = nseg - 1;                        // largest segment whose first slot is <= g
+  while (lo < hi) {
+    const long long mid = (lo + hi + 1) >> 1;
+    if (ck_slot0(seg_start[mid], mid) <= g) lo = mid; else hi = mid - 1;
+  }
+  const long long i = lo, start = seg_start[i], n = seg_start[i + 1] - start;
+  const long long b = g - ck_slot0(start, i), k0 = b * kCk;
+  if (b < 0 || k0 >= n || start + k0 >= (long long)len_out) return;     // gap slot, or past the trim
+  const Ramp r = make_ramp(sp[i], sp[i + 1], n);
+  const double off = seg_off[i];
+  double c = b ? ck[g] : 0.0;
+  double rr[kCk];
+  const double a0 = (double)k0;
+#pragma unroll
+  for (int u = 0; u < kCk; ++u) rr[u] = ramp_recip(a0 + (double)u, r);
+#pragma unroll
+  for (int u = 0; u < kCk; ++u) {
+    c = c + rr[u];
+    const long long jj = start + k0 + u;
+    if (k0 + u < n && jj < (long long)len_out) pos[jj] = c + off;
+  }
+}
+
 // positions of the segments whose first output index lies in [j_lo, j_hi)  (used whole or chunked)
 int launch_pos_fill(const double* speeds, int64_t m, const void* work, double* pos, int64_t len_out, int64_t j_lo,
                     int64_t j_hi, hipStream_t s) {
@@ -1200,6 +1232,23 @@ int par_speed_to_pos_fill(int device, const double* speeds, int64_t m, const voi
   if (len_out == 0) return PAR_OK;
   PAR_HIP_CHECK(hipSetDevice(device));
   return launch_pos_fill(speeds, m, work, pos, len_out, 0, INT64_MAX, as_stream(stream));
+}
+
+// Fill from a FUSED plan (par_speed_to_pos_plan_fused with fused_ok): same positions, bit for bit, but parallel over
+// 8-sample blocks instead of over segments -- the form to use when the curve has few points.
+int par_speed_to_pos_fill_fused(int device, const double* speeds, int64_t m, const void* work, const void* aux,
+                                int64_t max_out, double* pos, int64_t len_out, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(speeds && work && aux && (pos || len_out == 0) && m >= 2 && len_out <= max_out, PAR_ERR_ARG,
+              "par_speed_to_pos_fill_fused: bad args");
+  if (len_out == 0) return PAR_OK;
+  PAR_HIP_CHECK(hipSetDevice(device));
+  PlanView pv = plan_view(const_cast<void*>(work), m);
+  const int64_t n_slots = max_out / kCk + m + 16;
+  hipLaunchKernelGGL(k_pos_fill_ck, dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, as_stream(stream), speeds,
+                     pv.seg_start, pv.seg_off, m - 1, static_cast<const double*>(aux), n_slots, len_out, pos);
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
 }
 
 }  // extern "C"

@@ -83,13 +83,22 @@ def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_h
 def speed_to_pos_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_host_chain=False, info=None):
     """Device speed curve (float64 tensors) -> float64 position tensor (the written prefix).
     force_host_chain runs the serial host evaluation of the two order-dependent chains (the exact
-    fallback of the device scans); `info`, if a dict, receives {"path": 0 device | 1 host, "trimmed"}."""
-    plan = speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev, force_host_chain)
+    fallback of the device scans); `info`, if a dict, receives {"path": 0 device | 1 host, "trimmed"}.
+    Curves with few points (segments of thousands of samples and more) go through a fused plan: its cumsum
+    checkpoints let the fill run in parallel over 8-sample blocks instead of one lane per segment."""
+    m = sampletimes_t.numel()
+    sparse = m >= 2 and int(num_imput_samples) // max(m - 1, 1) > 2048
+    plan = speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev, force_host_chain, fused=sparse)
     if info is not None:
         info.update(path=plan.path, trimmed=plan.trimmed)
     pos = _dev.empty(plan.len_out, torch.float64, plan.dev)
-    _lib.check(_lib.lib().par_speed_to_pos_fill(plan.dev, _dev.ptr(speeds_t), plan.m, _dev.ptr(plan.work), _dev.ptr(pos),
-                                                plan.len_out, _dev.stream_ptr(plan.dev)))
+    L = _lib.lib()
+    if sparse and plan.fused_ok:
+        _lib.check(L.par_speed_to_pos_fill_fused(plan.dev, _dev.ptr(speeds_t), plan.m, _dev.ptr(plan.work), _dev.ptr(plan.aux),
+                                                 plan.max_out, _dev.ptr(pos), plan.len_out, _dev.stream_ptr(plan.dev)))
+    else:
+        _lib.check(L.par_speed_to_pos_fill(plan.dev, _dev.ptr(speeds_t), plan.m, _dev.ptr(plan.work), _dev.ptr(pos),
+                                           plan.len_out, _dev.stream_ptr(plan.dev)))
     return pos
 
 
@@ -349,13 +358,11 @@ def _plan_positions(sig_shape, sr, speed_curve, lag_curve, want_fused, dev):
         curve = np.asarray(speed_curve, dtype=np.float64)
         st_t = _dev.to_dev(curve[:, 0] * sr, torch.float64, dev)
         sp_t = _dev.to_dev(np.ascontiguousarray(curve[:, 1]), torch.float64, dev)
-        plan = speed_plan_dev(st_t, sp_t, n_in, dev, fused=want_fused)
-        if plan.fused_ok:
-            return plan, None
-        pos_t = _dev.empty(plan.len_out, torch.float64, dev)
-        _lib.check(_lib.lib().par_speed_to_pos_fill(dev, _dev.ptr(sp_t), plan.m, _dev.ptr(plan.work), _dev.ptr(pos_t),
-                                                    plan.len_out, _dev.stream_ptr(dev)))
-        return plan, pos_t
+        if want_fused:
+            plan = speed_plan_dev(st_t, sp_t, n_in, dev, fused=True)
+            if plan.fused_ok:
+                return plan, None
+        return None, speed_to_pos_dev(st_t, sp_t, n_in, dev)
     if lag_curve is not None:
         return None, lag_to_pos_dev(lag_curve, sr, n_in, dev)
     # the reference reaches its channel loop with `sample_at` never assigned

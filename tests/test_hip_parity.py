@@ -903,8 +903,14 @@ def test_sparse_speed_curves_take_the_chunked_exact_cumsum(par):
         ref_pos, _ = C.speed_to_pos(st, sp, n)
         plan = R.speed_plan_dev(st_t, sp_t, n, fused=True)
         assert plan.fused_ok and plan.path == 0 and plan.len_out == len(ref_pos), (n, speeds[:3], plan.path, plan.len_out)
-        pos_t = R.speed_to_pos_dev(st_t, sp_t, n)                        # lane-per-segment fill: the slow exact form
+        pos_t = R.speed_to_pos_dev(st_t, sp_t, n)                        # block-parallel fill from the checkpoints
         assert t.equal(pos_t.cpu(), t.from_numpy(ref_pos))
+        if n <= 1_000_000:                                               # and the lane-per-segment fill (slow here)
+            from pyaudiorestoration_amd import _dev, _lib
+            old = t.empty_like(pos_t)
+            _lib.check(_lib.lib().par_speed_to_pos_fill(0, _dev.ptr(sp_t), plan.m, _dev.ptr(plan.work), _dev.ptr(old),
+                                                         plan.len_out, _dev.stream_ptr(0)))
+            assert t.equal(old, pos_t)
         for NT in (3, 32):
             assert t.equal(R.varispeed_fused_dev(plan, sig_t, NT), R.sinc_resample_dev(pos_t, sig_t, NT)), (n, speeds[:3], NT)
 
