@@ -121,7 +121,8 @@ int par_speed_to_pos_plan(int device, const double* sampletimes, const double* s
                           void* work, size_t work_bytes, int64_t* len_out, int* trimmed, void* stream);
 /* Same as par_speed_to_pos_plan; force_host != 0 runs the serial host evaluation of the two
  * order-dependent chains (the exact fallback the device scans defer to when they flag a near-tie),
- * *path_used (optional) reports 0 = device scans, 1 = serial host path. */
+ * *path_used (optional) reports 0 = device scans, 1 = serial host path, 2 = segment lengths redone on the host after a
+ * near-tie (O(m)) with everything else on the device. */
 int par_speed_to_pos_plan_ex(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
                              void* work, size_t work_bytes, int64_t* len_out, int* trimmed, int force_host,
                              int* path_used, void* stream);

@@ -946,6 +946,39 @@ static double np_pairwise_sum(const double* a, int64_t n) {
   return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
 }
 
+__global__ void k_set_total(PlanHeader* h, int64_t total) { h->total_written = total; }
+
+// Segment lengths n_i by the reference's own recurrence (:111-118), serially on the host: inerr = n + err in float64,
+// Python round (half to even), err carried.  O(m); used when the exact fixed-point scan on the device meets a sum too
+// close to a rounding tie to call.  *ok = false when some n_i < 2 (the serial path then words the diagnosis).
+static int host_lengths(const PlanView& pv, const double* d_st, const double* d_sp, int64_t m, hipStream_t s, bool* ok) {
+  const int64_t nseg = m - 1;
+  std::vector<double> sp(m), st(m);
+  PAR_HIP_CHECK(hipMemcpyAsync(sp.data(), d_sp, m * sizeof(double), hipMemcpyDeviceToHost, s));
+  PAR_HIP_CHECK(hipMemcpyAsync(st.data(), d_st, m * sizeof(double), hipMemcpyDeviceToHost, s));
+  PAR_HIP_CHECK(hipStreamSynchronize(s));
+  std::vector<int64_t> start(m);
+  double err = 0.0;
+  int64_t acc = 0;
+  *ok = true;
+  for (int64_t i = 0; i < nseg; ++i) {
+    const double inerr = (st[i + 1] - st[i]) * ((sp[i] + sp[i + 1]) / 2.0) + err;
+    const double rn = nearbyint(inerr);          // Python round(): half to even
+    if (!(rn >= 2.0 && rn < 9.0e15)) {
+      *ok = false;
+      return PAR_OK;
+    }
+    err = inerr - rn;
+    start[i] = acc;
+    acc += (int64_t)rn;
+  }
+  start[nseg] = acc;
+  PAR_HIP_CHECK(hipMemcpyAsync(pv.seg_start, start.data(), m * sizeof(int64_t), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, s, pv.hdr, acc);
+  PAR_HIP_CHECK(hipStreamSynchronize(s));        // `start` must outlive the copy
+  return PAR_OK;
+}
+
 static int host_plan(const PlanView& pv, const double* d_st, const double* d_sp, int64_t m, int64_t n_in,
                      PlanHeader* out, hipStream_t s) {
   const int64_t nseg = m - 1;
@@ -1122,14 +1155,30 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
   PlanHeader h;
   memset(&h, 0, sizeof(h));
   bool need_host = force_host != 0;
-  if (!need_host) {
+  // attempt 0: everything on the device.  attempt 1 (only after a near-tie in the segment lengths): the O(m) length
+  // recurrence is redone serially on the host in the reference's own float64 order, everything else -- the O(len_out)
+  // reciprocal sums, offsets, trim, checkpoints -- stays on the device.
+  bool host_made_lengths = false;
+  for (int attempt = 0; attempt < 2 && !need_host; ++attempt) {
     const unsigned g256 = (unsigned)ceil_div(nseg, 256);
     hipLaunchKernelGGL(k_init_header, dim3(1), dim3(1), 0, s, pv.hdr, m);
-    U128* fix = reinterpret_cast<U128*>(pv.scan);
-    hipLaunchKernelGGL(k_seg_want, dim3(g256), dim3(256), 0, s, sampletimes, speeds, nseg, fix, pv.hdr);
-    int rc = inclusive_scan<AddU128>(fix, nseg, reinterpret_cast<U128*>(pv.bsum), s);
-    if (rc != PAR_OK) return rc;
-    hipLaunchKernelGGL(k_seg_lengths, dim3(g256), dim3(256), 0, s, fix, nseg, pv.seg_start, pv.hdr);
+    int rc;
+    if (attempt == 0) {
+      U128* fix = reinterpret_cast<U128*>(pv.scan);
+      hipLaunchKernelGGL(k_seg_want, dim3(g256), dim3(256), 0, s, sampletimes, speeds, nseg, fix, pv.hdr);
+      rc = inclusive_scan<AddU128>(fix, nseg, reinterpret_cast<U128*>(pv.bsum), s);
+      if (rc != PAR_OK) return rc;
+      hipLaunchKernelGGL(k_seg_lengths, dim3(g256), dim3(256), 0, s, fix, nseg, pv.seg_start, pv.hdr);
+    } else {
+      bool lengths_ok = false;
+      rc = host_lengths(pv, sampletimes, speeds, m, s, &lengths_ok);
+      if (rc != PAR_OK) return rc;
+      if (!lengths_ok) {                 // n_i < 2 somewhere: the serial path words the diagnosis
+        need_host = true;
+        break;
+      }
+      host_made_lengths = true;
+    }
     hipLaunchKernelGGL(k_speed_sum, dim3((unsigned)(m / 4096 + 1)), dim3(256), 0, s, speeds, m,
                        reinterpret_cast<double*>(pv.bsum), pv.hdr);     // bsum is idle between two scans
     launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s);
@@ -1154,11 +1203,9 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
     PAR_HIP_CHECK(hipGetLastError());
     PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
     PAR_HIP_CHECK(hipStreamSynchronize(s));
-    // any flag but the checkpoint one (near-tie length, n_i < 2, range, verification, too many crossings):
-    // the serial path decides -- it also produces the reference's own diagnosis for genuinely bad curves.
-    if (h.flags == kFlagCapAmbiguous) {
-      // Only the buffer bound is in doubt: everything else the device computed stands.  Settle int(mean * span * 1.01)
-      // with numpy's own pairwise order on the host (one D2H of the speed samples, no serial re-plan).
+    if (h.flags & kFlagCapAmbiguous) {
+      // Only the buffer bound is in doubt: settle int(mean * span * 1.01) with numpy's own pairwise order on the host
+      // (one D2H of the speed samples); everything else the device computed stands.
       std::vector<double> sp_h(m);
       double ends[2];
       PAR_HIP_CHECK(hipMemcpyAsync(sp_h.data(), speeds, m * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1166,11 +1213,15 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
       PAR_HIP_CHECK(hipMemcpyAsync(&ends[1], sampletimes + (m - 1), sizeof(double), hipMemcpyDeviceToHost, s));
       PAR_HIP_CHECK(hipStreamSynchronize(s));
       h.cap = (int64_t)((np_pairwise_sum(sp_h.data(), m) / (double)m) * (ends[1] - ends[0]) * 1.01);
-      h.flags = 0;
+      h.flags &= ~kFlagCapAmbiguous;
       PAR_HIP_CHECK(hipMemcpyAsync(pv.hdr, &h, sizeof(h), hipMemcpyHostToDevice, s));
       PAR_HIP_CHECK(hipStreamSynchronize(s));
     }
-    if (h.flags) need_host = true;     // (the checkpoint flag has already been folded into ck_valid)
+    if (h.flags == 0) break;
+    // a near-tie in the lengths alone: one more round with host-made lengths; anything else (n_i < 2, range,
+    // verification, too many crossings, or a second failure): the serial path decides -- it also produces the
+    // reference's own diagnosis for genuinely bad curves.
+    if (!(attempt == 0 && h.flags == kFlagAmbiguous)) need_host = true;
   }
   if (need_host) {
     int rc = host_plan(pv, sampletimes, speeds, m, n_in, &h, s);
@@ -1190,7 +1241,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
                 "par_speed_to_pos_plan: positions overflow the reference's end_guess buffer (%lld > %lld); it raises here",
                 (long long)h.written, (long long)h.cap);
   }
-  if (path_used) *path_used = need_host ? 1 : 0;
+  if (path_used) *path_used = need_host ? 1 : (host_made_lengths ? 2 : 0);
   if (fused_ok) *fused_ok = aux ? h.ck_valid : 0;
   *len_out = h.len_out;
   *trimmed = h.trimmed;
@@ -1198,7 +1249,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
 }
 
 // force_host != 0 exercises the serial host path (tests use it to cross-check the device scans);
-// *path_used = 0 device scans, 1 serial host path.
+// *path_used = 0 device scans, 1 serial host path, 2 segment lengths from the host (near-tie) and the rest on the device.
 int par_speed_to_pos_plan_ex(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
                              void* work, size_t work_bytes, int64_t* len_out, int* trimmed, int force_host,
                              int* path_used, void* stream) {

@@ -597,7 +597,9 @@ def test_speed_plan_device_scans_vs_serial_host_chain(par, golden):
     info = {}
     a = par.resampling.speed_to_pos_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), 10**9, info=info)
     ref, _ = C.speed_to_pos(st, sp, 10**9)
-    assert info["path"] == 1 and np.array_equal(a.cpu().numpy(), ref)
+    assert info["path"] == 2 and np.array_equal(a.cpu().numpy(), ref)      # host-made lengths, device everything else
+    plan = par.resampling.speed_plan_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), 10**9, fused=True)
+    assert plan.path == 2 and plan.fused_ok and plan.len_out == len(ref)
 
 
 def test_pipelined_varispeed_equals_two_step_path(par):
