@@ -917,6 +917,26 @@ def test_sparse_speed_curves_take_the_chunked_exact_cumsum(par):
             assert t.equal(R.varispeed_fused_dev(plan, sig_t, NT), R.sinc_resample_dev(pos_t, sig_t, NT)), (n, speeds[:3], NT)
 
 
+def test_full_size_two_point_curve(par):
+    """Config-2 length (345.6 M samples) with the sparsest possible curve -- a constant 1.5 % speed correction given as
+    two points, i.e. ONE segment of 3.5e8 samples: the chunked exact cumsum and the block-parallel fill reproduce the C
+    oracle's positions bit for bit, and the fused resampler reproduces the position-array one."""
+    from oracle import oracle_c as C
+    t = par.torch
+    n = 345_600_000
+    st, sp = np.array([0.0, float(n)]), np.array([1.015, 1.015])
+    st_t, sp_t = t.from_numpy(st).cuda(), t.from_numpy(sp).cuda()
+    info = {}
+    pos_t = par.resampling.speed_to_pos_dev(st_t, sp_t, n, info=info)
+    ref, _ = C.speed_to_pos(st, sp, n)
+    assert info["path"] == 0 and t.equal(pos_t.cpu(), t.from_numpy(ref))
+    del ref
+    sig_t = t.empty(n, dtype=t.float32, device="cuda").normal_()
+    plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
+    assert plan.fused_ok and plan.len_out == pos_t.numel()
+    assert t.equal(par.resampling.varispeed_fused_dev(plan, sig_t, 32), par.resampling.sinc_resample_dev(pos_t, sig_t, 32))
+
+
 def test_zero_crossing_compaction_sizes(par):
     """K_track's sign-change compaction (count per tile, scan of tile counts in chunks of 1024, ordered write) against
     numpy for sizes around every boundary, incl. > 1024 tiles (multi-chunk scan), no crossings and all crossings."""
