@@ -24,7 +24,7 @@ while time.time() < t_end:
     rng = np.random.default_rng(seed0 + case)
     n = int(rng.choice([3000, 20000, 150000, 700000]))
     NT = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 13, 16, 31, 32, 33, 50, 64, 100]))
-    seg = int(rng.choice([16, 64, 256, 1000, 5000]))
+    seg = int(rng.choice([16, 64, 256, 1000, 5000, 60000, 400000]))        # the last two: sparse curves, chunked exact cumsum
     m = max(2, n // seg)
     st = np.linspace(0, n, m)
     grid = int(rng.integers(0, 4))
