@@ -115,6 +115,10 @@ int par_band_mean_db_f32(int device, const float* mag, int64_t n_frames, int64_t
  * sampletimes/speeds are DEVICE float64[m].  work is caller-owned device scratch of at least
  * par_speed_plan_bytes(m) bytes and must stay untouched between plan and fill (or the fused
  * resampler below).
+ * Curves with FEW points (segments of thousands of samples and more -- a constant speed correction is two points):
+ * use par_speed_to_pos_plan_fused + par_speed_to_pos_fill_fused.  This plain form walks every segment on one lane
+ * (seconds for a 10^8-sample segment); the fused plan's checkpoint buffer is what lets long segments be cut into
+ * chunks whose float64 cumsum chain is evaluated exactly in parallel.
  */
 size_t par_speed_plan_bytes(int64_t m);
 int par_speed_to_pos_plan(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
