@@ -36,6 +36,8 @@ for db in ("fetch", "write", "sq", "lds", "grbm"):
         if any(s in k for s in ("k_sinc", "k_pos_fill", "k_seg_sum", "k_stft")):
             lines.append(f"{k[:60]:60s} {n:24s} n={cnt:3d} avg={a:18.1f}")
             short = "k_sinc" if "k_sinc" in k else ("k_pos_fill" if "k_pos_fill" in k else ("k_seg_sum" if "k_seg_sum" in k else "k_stft"))
+            if short == "k_sinc" and ", 2>" in k:
+                short = "k_sinc_stereo"                       # the config-5 secondary line, not the timed workload
             vals[(short, n)] = a
 open(os.path.join(prof, f"{tag}_pmc.txt"), "w").write("\n".join(lines) + "\n")
 bench = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
