@@ -313,7 +313,8 @@ __device__ __forceinline__ int f64_exponent(double x) { return (int)((__double_a
 // running sum stays in one binade), chunk starts come from a scan of the maps, the ~30 chunks in which the sum
 // crosses a power of two are stepped through sequentially, and a final pass recomputes every chunk from its exact
 // start, writes the checkpoints and VERIFIES that it lands bit-exactly on the next chunk's start.
-constexpr long long kLongSeg = 4096;                    // longer segments take the chunked path (needs the ck buffer)
+constexpr long long kLongSeg = 32768;                   // longer segments take the chunked path (needs the ck buffer); below,
+                                                        // one lane per segment is faster (measured crossover 3e4..5e4)
 constexpr int kLongChunk = 256;                         // steps per chunk; the last chunk of a segment takes the remainder
 constexpr int kLongSlots = kLongChunk / kCk;            // checkpoint slots a chunk owns: its scratch lives there first
 enum { kLsA = 8, kLsC0 = 9, kLsC1 = 10, kLsExp = 11, kLsStart = 12, kLsEnd = 13, kLsApprox = 14 };

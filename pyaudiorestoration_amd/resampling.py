@@ -87,7 +87,7 @@ def speed_to_pos_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force
     Curves with few points (segments of thousands of samples and more) go through a fused plan: its cumsum
     checkpoints let the fill run in parallel over 8-sample blocks instead of one lane per segment."""
     m = sampletimes_t.numel()
-    sparse = m >= 2 and int(num_imput_samples) // max(m - 1, 1) > 2048
+    sparse = m >= 2 and int(num_imput_samples) // max(m - 1, 1) > 16384
     plan = speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev, force_host_chain, fused=sparse)
     if info is not None:
         info.update(path=plan.path, trimmed=plan.trimmed)

@@ -897,9 +897,12 @@ def test_sparse_speed_curves_take_the_chunked_exact_cumsum(par):
     cases = [(3_000_000, [1.015, 1.015], 0.0), (3_000_000, [0.97, 1.04], 0.0), (2_500_000, [1.0, 0.5, 1.7], 0.0),
              (4_000_000, list(1.0 + 0.05 * np.sin(np.arange(11) * 0.9)), 123.25),
              (1_000_000, list(rng.uniform(0.8, 1.25, 40)), 0.0), (700_000, [1.0, 1.0], 0.0)]
+    mixed = np.array([0, 100, 5000, 40000, 100000, 1_500_000, 1_500_010, 2_000_000], dtype=np.float64)
+    cases.append((2_000_000, [1.1, 1.1, 1.1, 1.05, 1.0, 0.95, 1.0, 0.97], mixed))    # lane-per-segment and chunked segments mixed
+    # (fast short segments: the reference sizes its output by the UNWEIGHTED mean speed and refuses curves that need more)
     for n, speeds, st0 in cases:
         sp = np.asarray(speeds, dtype=np.float64)
-        st = np.linspace(0, n, len(sp)) + st0
+        st = st0 if isinstance(st0, np.ndarray) else np.linspace(0, n, len(sp)) + st0
         sig = rng.standard_normal(n).astype(np.float32)
         st_t, sp_t, sig_t = t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), t.from_numpy(sig).cuda()
         ref_pos, _ = C.speed_to_pos(st, sp, n)
