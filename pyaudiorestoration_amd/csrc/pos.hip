@@ -447,33 +447,58 @@ __global__ __launch_bounds__(256) void k_long_approx(const double* __restrict__ 
   ck[c.base + kLsA] = A;
 }
 
+// Both per-segment passes (B and D) walk a segment in windows of 256 * kWinC chunks: a thread owns kWinC consecutive
+// chunks (serial in registers), the 256 thread totals are scanned with wave shuffles (two barriers per window instead
+// of sixteen), so a 7e8-sample segment (2.7 M chunks) is 660 windows, not 10 500.
+constexpr int kWinC = 16;
+constexpr int kWin = 256 * kWinC;
+
 // pass B: per long segment, exclusive prefix of the chunk sums = approximate running sum at every chunk start
 __global__ __launch_bounds__(256) void k_long_prefix(const int64_t* __restrict__ seg_start, int64_t nseg,
                                                      double* __restrict__ ck, int64_t ck_len,
                                                      const PlanHeader* __restrict__ h) {
   if (h->n_long == 0) return;
-  __shared__ double buf[256];
-  __shared__ double carry;
+  __shared__ double wave_tot[4];
+  const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
   for (long long i = blockIdx.x; i < nseg; i += gridDim.x) {
     const long long start = seg_start[i], n = seg_start[i + 1] - start;
     if (!long_segment(n, start, i, ck, ck_len)) continue;            // uniform over the workgroup
     const long long J = n / kLongChunk, slot0 = ck_slot0(start, i);
-    if (threadIdx.x == 0) carry = 0.0;
-    __syncthreads();
-    for (long long j0 = 0; j0 < J; j0 += 256) {
-      const long long j = j0 + threadIdx.x;
-      const double v = j < J ? ck[slot0 + j * kLongSlots + kLsA] : 0.0;
-      buf[threadIdx.x] = v;
-      __syncthreads();
-      for (int o = 1; o < 256; o <<= 1) {
-        const double t = (int)threadIdx.x >= o ? buf[threadIdx.x - o] : 0.0;
-        __syncthreads();
-        buf[threadIdx.x] += t;
-        __syncthreads();
+    double carry = 0.0;                                              // same value in every thread
+    for (long long j0 = 0; j0 < J; j0 += kWin) {
+      const long long jt = j0 + (long long)t * kWinC;
+      double v[kWinC];
+#pragma unroll
+      for (int u = 0; u < kWinC; ++u) {                                // unconditional loads: all in flight at once
+        const long long jc = jt + u < J ? jt + u : J - 1;
+        v[u] = ck[slot0 + jc * kLongSlots + kLsA];
       }
-      if (j < J) ck[slot0 + j * kLongSlots + kLsApprox] = carry + (buf[threadIdx.x] - v);
+#pragma unroll
+      for (int u = 0; u < kWinC; ++u) v[u] = jt + u < J ? v[u] : 0.0;
+      double mine = 0.0;
+#pragma unroll
+      for (int u = 0; u < kWinC; ++u) mine += v[u];
+      double inc = mine;                                             // inclusive scan inside the wave
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const double up = __shfl_up(inc, o, kWave);
+        if (lane >= o) inc += up;
+      }
+      if (lane == kWave - 1) wave_tot[wv] = inc;
       __syncthreads();
-      if (threadIdx.x == 255) carry += buf[255];
+      double before = carry, total = carry;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (w < wv) before += wave_tot[w];
+        total += wave_tot[w];
+      }
+      double run = before + (inc - mine);
+#pragma unroll
+      for (int u = 0; u < kWinC; ++u) {
+        if (jt + u < J) ck[slot0 + (jt + u) * kLongSlots + kLsApprox] = run;
+        run += v[u];
+      }
+      carry = total;
       __syncthreads();
     }
   }
@@ -543,6 +568,13 @@ __device__ __forceinline__ double apply_map(long long c0, long long c1, double x
   return ldexp((double)Y, e - 1075);
 }
 
+// (a then b) of two parity-translation maps
+__device__ __forceinline__ void map_then(long long a0, long long a1, long long b0, long long b1, long long* r0,
+                                         long long* r1) {
+  *r0 = a0 + ((a0 & 1) ? b1 : b0);
+  *r1 = a1 + (((1 + a1) & 1) ? b1 : b0);
+}
+
 // pass D: per long segment, exact running sum at every chunk boundary.  Runs of single-binade chunks are resolved by a
 // workgroup scan of their maps; a chunk in which the sum crosses a power of two (and the first one, from 0) is
 // stepped through with real float64 adds by one thread.
@@ -550,10 +582,10 @@ __global__ __launch_bounds__(256) void k_long_stitch(const double* __restrict__ 
                                                      int64_t nseg, double* __restrict__ ck, int64_t ck_len,
                                                      const PlanHeader* __restrict__ h) {
   if (h->n_long == 0) return;
-  __shared__ long long s0[256], s1[256];
-  __shared__ int first_direct;
+  __shared__ long long w0[4], w1[4];
+  __shared__ int wave_first[4];
   __shared__ double x_run;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
   for (long long i = blockIdx.x; i < nseg; i += gridDim.x) {
     const long long start = seg_start[i], n = seg_start[i + 1] - start;
     if (!long_segment(n, start, i, ck, ck_len)) continue;
@@ -562,51 +594,85 @@ __global__ __launch_bounds__(256) void k_long_stitch(const double* __restrict__ 
     if (t == 0) x_run = 0.0;
     long long j = 0;
     while (j < J) {
-      if (t == 0) first_direct = 256;
-      __syncthreads();
-      const long long jj = j + t;
-      const long long base = slot0 + jj * kLongSlots;
-      const bool live = jj < J;
-      const bool direct = live && ck[base + kLsExp] < 0.0;
-      if (direct) atomicMin(&first_direct, t);
-      long long c0 = 0, c1 = 0;
-      if (live && !direct) {
-        c0 = __double_as_longlong(ck[base + kLsC0]);
-        c1 = __double_as_longlong(ck[base + kLsC1]);
+      // this thread's kWinC chunks of the window that starts at chunk j
+      const long long jt = j + (long long)t * kWinC;
+      long long m0[kWinC], m1[kWinC];
+      int first = kWin;                                                // window offset of my first direct chunk
+      double ex[kWinC];
+#pragma unroll
+      for (int u = 0; u < kWinC; ++u) {                                // unconditional loads: all in flight at once
+        const long long jc = jt + u < J ? jt + u : J - 1;
+        const long long base = slot0 + jc * kLongSlots;
+        ex[u] = ck[base + kLsExp];
+        m0[u] = __double_as_longlong(ck[base + kLsC0]);
+        m1[u] = __double_as_longlong(ck[base + kLsC1]);
       }
+#pragma unroll
+      for (int u = kWinC - 1; u >= 0; --u) {
+        const bool live = jt + u < J, direct = live && ex[u] < 0.0;
+        if (direct) first = t * kWinC + u;
+        if (!live || direct) m0[u] = m1[u] = 0;
+      }
+      int wf = first;
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) {
+        const int other = __shfl_xor(wf, o, kWave);
+        wf = other < wf ? other : wf;
+      }
+      if (lane == 0) wave_first[wv] = wf;
       __syncthreads();
-      long long L = first_direct;                                   // interior chunks in front of the first direct one
+      int fd = wave_first[0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) fd = wave_first[w] < fd ? wave_first[w] : fd;
+      long long L = fd;                                               // interior chunks in front of the first direct one
       if (L > J - j) L = J - j;
-      // inclusive scan of the maps of chunks j .. j+L-1 (identity elsewhere)
-      s0[t] = t < L ? c0 : 0;
-      s1[t] = t < L ? c1 : 0;
+      // my share of the run, composed; then the scan over threads (identity beyond the run)
+      long long cnt = L - (long long)t * kWinC;
+      cnt = cnt < 0 ? 0 : (cnt > kWinC ? kWinC : cnt);
+      long long a0 = 0, a1 = 0;
+#pragma unroll
+      for (int u = 0; u < kWinC; ++u)
+        if (u < cnt) map_then(a0, a1, m0[u], m1[u], &a0, &a1);
+      long long i0 = a0, i1 = a1;                                     // inclusive inside the wave
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const long long u0 = __shfl_up(i0, o, kWave), u1 = __shfl_up(i1, o, kWave);
+        if (lane >= o) map_then(u0, u1, i0, i1, &i0, &i1);
+      }
+      if (lane == kWave - 1) {
+        w0[wv] = i0;
+        w1[wv] = i1;
+      }
+      long long e0 = __shfl_up(i0, 1, kWave), e1 = __shfl_up(i1, 1, kWave);      // exclusive inside the wave
+      if (lane == 0) e0 = e1 = 0;
       __syncthreads();
-      for (int o = 1; o < 256; o <<= 1) {
-        long long a0 = 0, a1 = 0;
-        const bool take = t >= o;
-        if (take) {
-          a0 = s0[t - o];
-          a1 = s1[t - o];
-        }
-        __syncthreads();
-        if (take) {                                                   // apply a (earlier chunks) first, then own
-          const long long b0 = s0[t], b1 = s1[t];
-          s0[t] = a0 + ((a0 & 1) ? b1 : b0);
-          s1[t] = a1 + (((1 + a1) & 1) ? b1 : b0);
-        }
-        __syncthreads();
+      long long p0 = 0, p1 = 0, all0 = 0, all1 = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (w < wv) map_then(p0, p1, w0[w], w1[w], &p0, &p1);
+        map_then(all0, all1, w0[w], w1[w], &all0, &all1);
       }
+      map_then(p0, p1, e0, e1, &p0, &p1);                             // everything in front of my first chunk
       const double x0 = x_run;
-      if (t < L) {
-        const double xs_ = (t == 0) ? x0 : apply_map(s0[t - 1], s1[t - 1], x0);
-        const double xe_ = apply_map(s0[t], s1[t], x0);
-        ck[base + kLsStart] = xs_;
-        ck[base + kLsEnd] = xe_;
+      if (cnt > 0) {
+        const int e = f64_exponent(x0);
+        long long X = (long long)ldexp(x0, 1075 - e);                 // exact integer in [2^52, 2^53)
+        X += (X & 1) ? p1 : p0;
+#pragma unroll
+        for (int u = 0; u < kWinC; ++u) {
+          if (u < cnt) {
+            const long long base = slot0 + (jt + u) * kLongSlots;
+            ck[base + kLsStart] = ldexp((double)X, e - 1075);
+            X += (X & 1) ? m1[u] : m0[u];
+            ck[base + kLsEnd] = ldexp((double)X, e - 1075);
+          }
+        }
       }
+      const bool has_direct = j + L < J && fd < kWin;
       __syncthreads();
       if (t == 0) {
-        double x = L > 0 ? apply_map(s0[L - 1], s1[L - 1], x0) : x0;
-        if (j + L < J && first_direct < 256) {                        // the direct chunk that ended the run
+        double x = L > 0 ? apply_map(all0, all1, x0) : x0;
+        if (has_direct) {                                             // the direct chunk that ended the run
           const long long jd = j + L, bd = slot0 + jd * kLongSlots;
           const long long k0 = jd * kLongChunk, k1 = (jd == J - 1) ? n : k0 + kLongChunk;
           ck[bd + kLsStart] = x;
@@ -618,8 +684,7 @@ __global__ __launch_bounds__(256) void k_long_stitch(const double* __restrict__ 
         x_run = x;
       }
       __syncthreads();
-      j += L + ((j + L < J && first_direct < 256) ? 1 : 0);
-      __syncthreads();
+      j += L + (has_direct ? 1 : 0);
     }
   }
 }
@@ -660,23 +725,31 @@ __global__ void k_publish_ck(PlanHeader* __restrict__ h, int64_t ck_len) {
 }
 
 // tile_seg[t] = segment that contains output t * kSincTileOutputs (tiles of the fused resampler)
+// Thread x serves two roles: segment x checks that its checkpoints fit, tile x looks its segment up (upper bound
+// over seg_start: a tile per thread, not a segment per thread -- one segment can cover 10^5..10^6 tiles).
 __global__ void k_tile_seg(const int64_t* __restrict__ seg_start, int64_t nseg, int64_t ck_len, int64_t max_tiles,
                            int64_t* __restrict__ tile_seg, PlanHeader* __restrict__ h) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nseg) return;
-  const int64_t len_out = h->len_out;                  // written by k_trim / the host path earlier on this stream
-  const long long a = seg_start[i], b = seg_start[i + 1];
-  if (b <= a || a >= (long long)len_out) return;
-  if (ck_slot0(a, i) + (b - a + kCk - 1) / kCk > ck_len ||
-      (len_out + kSincTileOutputs - 1) / kSincTileOutputs + 1 > max_tiles) {
-    atomicOr(&h->flags, kFlagCkOverflow);               // a needed segment has no checkpoints: fused path refused
+  const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long len_out = h->len_out;                // written by k_trim / the host path earlier on this stream
+  const long long n_tiles = (len_out + kSincTileOutputs - 1) / kSincTileOutputs;
+  if (n_tiles + 1 > max_tiles) {
+    if (x == 0 && len_out > 0) atomicOr(&h->flags, kFlagCkOverflow);
     return;
   }
-  for (long long t = (a + kSincTileOutputs - 1) / kSincTileOutputs; t * kSincTileOutputs < b; ++t)
-    if (t * kSincTileOutputs < (long long)len_out) tile_seg[t] = i;
-  // extra entry [n_tiles]: the segment that holds the LAST output
-  if (a <= (long long)len_out - 1 && (long long)len_out - 1 < b)
-    tile_seg[(len_out + kSincTileOutputs - 1) / kSincTileOutputs] = i;
+  if (x < nseg) {
+    const long long a = seg_start[x], b = seg_start[x + 1];
+    if (b > a && a < len_out && ck_slot0(a, x) + (b - a + kCk - 1) / kCk > ck_len)
+      atomicOr(&h->flags, kFlagCkOverflow);             // a needed segment has no checkpoints: fused path refused
+  }
+  if (x > n_tiles || len_out <= 0) return;
+  // entry [n_tiles] is extra: the segment that holds the LAST output
+  const long long sample = x < n_tiles ? x * kSincTileOutputs : len_out - 1;
+  long long lo = 0, hi = nseg;                         // last i with seg_start[i] <= sample (its successor is larger)
+  while (lo < hi) {
+    const long long mid = (lo + hi + 1) >> 1;
+    if (seg_start[mid] <= sample) lo = mid; else hi = mid - 1;
+  }
+  if (lo < nseg) tile_seg[x] = lo;
 }
 
 __device__ __forceinline__ void mark_direct(long long i, long long* direct, PlanHeader* h) {
@@ -1197,8 +1270,8 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
     hipLaunchKernelGGL(k_trim, dim3(1), dim3(1), 0, s, sampletimes, speeds, pv.seg_start, pv.seg_off, m, (double)n_in,
                        (const double*)ck, ck_len, pv.hdr);
     if (aux) {
-      hipLaunchKernelGGL(k_tile_seg, dim3(g256), dim3(256), 0, s, pv.seg_start, nseg, ck_len, max_tiles,
-                         reinterpret_cast<int64_t*>(ck + ck_len), pv.hdr);
+      hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(std::max<int64_t>(nseg, max_tiles), 256)), dim3(256), 0, s,
+                         pv.seg_start, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len), pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
     }
     PAR_HIP_CHECK(hipGetLastError());
@@ -1229,8 +1302,8 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
     if (rc != PAR_OK) return rc;
     if (aux) {     // checkpoints + tile map for the serial path's segmentation: same exact device arithmetic
       launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s);
-      hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, s, pv.seg_start, nseg, ck_len,
-                         max_tiles, reinterpret_cast<int64_t*>(ck + ck_len), pv.hdr);
+      hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(std::max<int64_t>(nseg, max_tiles), 256)), dim3(256), 0, s,
+                         pv.seg_start, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len), pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
       PAR_HIP_CHECK(hipGetLastError());
       PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
