@@ -315,8 +315,13 @@ __device__ __forceinline__ int f64_exponent(double x) { return (int)((__double_a
 // start, writes the checkpoints and VERIFIES that it lands bit-exactly on the next chunk's start.
 constexpr long long kLongSeg = 32768;                   // longer segments take the chunked path (needs the ck buffer); below,
                                                         // one lane per segment is faster (measured crossover 3e4..5e4)
-constexpr int kLongChunk = 256;                         // steps per chunk; the last chunk of a segment takes the remainder
-constexpr int kLongSlots = kLongChunk / kCk;            // checkpoint slots a chunk owns: its scratch lives there first
+constexpr int kLongChunk = 256;                         // least steps per chunk; the last chunk of a segment takes the remainder
+// Steps per chunk of a segment of n samples.  The two per-segment passes cost ~25 us per 4096 chunks on their one CU,
+// a chunk in which the sum crosses a binade (~20 per segment) costs ~21 ns per step on one lane: longer chunks pay
+// once a segment has more than ~1e5 of them.  A chunk owns len/kCk checkpoint slots: its scratch lives there first.
+__host__ __device__ inline long long long_chunk_len(long long n) {
+  return n > (1LL << 28) ? 2048 : n > (1LL << 25) ? 1024 : kLongChunk;
+}
 enum { kLsA = 8, kLsC0 = 9, kLsC1 = 10, kLsExp = 11, kLsStart = 12, kLsEnd = 13, kLsApprox = 14 };
 
 __host__ __device__ inline long long chunk_slot0(long long seg_start, long long i) { return seg_start / kLongChunk + i; }
@@ -414,12 +419,13 @@ __device__ __forceinline__ ChunkRef find_chunk(long long g, const int64_t* __res
   const long long start = seg_start[lo];
   c.n = seg_start[lo + 1] - start;
   c.j = g - chunk_slot0(start, lo);
-  c.J = c.n / kLongChunk;
+  const long long len = long_chunk_len(c.n);
+  c.J = c.n / len;
   c.ok = c.j >= 0 && c.j < c.J && long_segment(c.n, start, lo, ck, ck_len);
-  c.k0 = c.j * kLongChunk;
-  c.k1 = (c.j == c.J - 1) ? c.n : c.k0 + kLongChunk;
+  c.k0 = c.j * len;
+  c.k1 = (c.j == c.J - 1) ? c.n : c.k0 + len;
   c.slot0 = ck_slot0(start, lo);
-  c.base = c.slot0 + c.j * kLongSlots;
+  c.base = c.slot0 + c.j * (len / kCk);
   return c;
 }
 
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(256) void k_long_prefix(const int64_t* __restrict__
   for (long long i = blockIdx.x; i < nseg; i += gridDim.x) {
     const long long start = seg_start[i], n = seg_start[i + 1] - start;
     if (!long_segment(n, start, i, ck, ck_len)) continue;            // uniform over the workgroup
-    const long long J = n / kLongChunk, slot0 = ck_slot0(start, i);
+    const long long clen = long_chunk_len(n), cslots = clen / kCk, J = n / clen, slot0 = ck_slot0(start, i);
     double carry = 0.0;                                              // same value in every thread
     for (long long j0 = 0; j0 < J; j0 += kWin) {
       const long long jt = j0 + (long long)t * kWinC;
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(256) void k_long_prefix(const int64_t* __restrict__
 #pragma unroll
       for (int u = 0; u < kWinC; ++u) {                                // unconditional loads: all in flight at once
         const long long jc = jt + u < J ? jt + u : J - 1;
-        v[u] = ck[slot0 + jc * kLongSlots + kLsA];
+        v[u] = ck[slot0 + jc * cslots + kLsA];
       }
 #pragma unroll
       for (int u = 0; u < kWinC; ++u) v[u] = jt + u < J ? v[u] : 0.0;
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(256) void k_long_prefix(const int64_t* __restrict__
       double run = before + (inc - mine);
 #pragma unroll
       for (int u = 0; u < kWinC; ++u) {
-        if (jt + u < J) ck[slot0 + (jt + u) * kLongSlots + kLsApprox] = run;
+        if (jt + u < J) ck[slot0 + (jt + u) * cslots + kLsApprox] = run;
         run += v[u];
       }
       carry = total;
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(256) void k_long_stitch(const double* __restrict__ 
   for (long long i = blockIdx.x; i < nseg; i += gridDim.x) {
     const long long start = seg_start[i], n = seg_start[i + 1] - start;
     if (!long_segment(n, start, i, ck, ck_len)) continue;
-    const long long J = n / kLongChunk, slot0 = ck_slot0(start, i);
+    const long long clen = long_chunk_len(n), cslots = clen / kCk, J = n / clen, slot0 = ck_slot0(start, i);
     const Ramp r = make_ramp(sp[i], sp[i + 1], n);
     if (t == 0) x_run = 0.0;
     long long j = 0;
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(256) void k_long_stitch(const double* __restrict__ 
 #pragma unroll
       for (int u = 0; u < kWinC; ++u) {                                // unconditional loads: all in flight at once
         const long long jc = jt + u < J ? jt + u : J - 1;
-        const long long base = slot0 + jc * kLongSlots;
+        const long long base = slot0 + jc * cslots;
         ex[u] = ck[base + kLsExp];
         m0[u] = __double_as_longlong(ck[base + kLsC0]);
         m1[u] = __double_as_longlong(ck[base + kLsC1]);
@@ -661,7 +667,7 @@ __global__ __launch_bounds__(256) void k_long_stitch(const double* __restrict__ 
 #pragma unroll
         for (int u = 0; u < kWinC; ++u) {
           if (u < cnt) {
-            const long long base = slot0 + (jt + u) * kLongSlots;
+            const long long base = slot0 + (jt + u) * cslots;
             ck[base + kLsStart] = ldexp((double)X, e - 1075);
             X += (X & 1) ? m1[u] : m0[u];
             ck[base + kLsEnd] = ldexp((double)X, e - 1075);
@@ -673,8 +679,8 @@ __global__ __launch_bounds__(256) void k_long_stitch(const double* __restrict__ 
       if (t == 0) {
         double x = L > 0 ? apply_map(all0, all1, x0) : x0;
         if (has_direct) {                                             // the direct chunk that ended the run
-          const long long jd = j + L, bd = slot0 + jd * kLongSlots;
-          const long long k0 = jd * kLongChunk, k1 = (jd == J - 1) ? n : k0 + kLongChunk;
+          const long long jd = j + L, bd = slot0 + jd * cslots;
+          const long long k0 = jd * clen, k1 = (jd == J - 1) ? n : k0 + clen;
           ck[bd + kLsStart] = x;
           double c = x;
           for (long long k = k0; k < k1; ++k) c = c + ramp_recip((double)k, r);
