@@ -130,6 +130,11 @@ int par_speed_to_pos_plan(int device, const double* sampletimes, const double* s
 int par_speed_to_pos_plan_ex(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
                              void* work, size_t work_bytes, int64_t* len_out, int* trimmed, int force_host,
                              int* path_used, void* stream);
+/* Why this thread's most recent plan left the device path: the device scans' flag word (1 near-tie in the segment
+ * lengths, 2 some n_i < 2, 4 a_i outside the exact fixed-point range, 8 offset-chain verification failed, 16 more
+ * binade crossings than the stitch table holds, 64 end_guess within the device sum's error of an integer); 0 when the
+ * plan ran on the device (path_used 0) or the host path was forced.  Diagnostics only. */
+int par_last_plan_flags(void);
 int par_speed_to_pos_fill(int device, const double* speeds, int64_t m, const void* work,
                           double* pos, int64_t len_out, void* stream);
 /* The same fill from a FUSED plan (fused_ok): parallel over 8-sample blocks restarting from the cumsum checkpoints,

@@ -23,6 +23,7 @@ SIGNATURES = {
     "par_version": (c_int, []),
     "par_device_count": (c_int, []),
     "par_last_error": (c_int, [ctypes.c_char_p, c_int]),
+    "par_last_plan_flags": (c_int, []),
     "par_event_create": (c_int, [ctypes.POINTER(c_vp)]),
     "par_event_destroy": (c_int, [c_vp]),
     "par_event_record": (c_int, [c_vp, c_vp]),

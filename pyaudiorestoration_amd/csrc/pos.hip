@@ -203,6 +203,7 @@ __global__ void k_init_header(PlanHeader* h, int64_t m) {
   h->n_long = 0;
   h->pad3 = 0;
   h->written = 0;
+  h->first_bad = kNoTrim;
 }
 
 // a_i (util/resampling.py:103,:111) in numpy's order, converted EXACTLY to 64.64 fixed point.
@@ -246,7 +247,9 @@ __global__ void k_seg_lengths(const U128* __restrict__ A, int64_t nseg, int64_t*
   }
   int f = 0;
   if (amb) f |= kFlagAmbiguous;
-  if (Ni < Np + 2ull) f |= kFlagBadLength;
+  // n_i < 2: the reference divides by zero / indexes an empty array -- if it ever gets there.  Downstream the segment
+  // counts as empty (S_i = 0, cannot straddle n_in); k_trim raises the flag unless the trim fires in front of it.
+  if (Ni < Np + 2ull) atomicMin(&h->first_bad, (unsigned long long)i);
   if (f) atomicOr(&h->flags, f);
 }
 
@@ -899,6 +902,7 @@ __global__ void k_trim(const double* __restrict__ st, const double* __restrict__
   h->cap = (int64_t)guess;
   if (fabs(guess - rint(guess)) <= fabs(guess) * 1e-14 + 1e-12) atomicOr(&h->flags, kFlagCapAmbiguous);
   int64_t len = h->total_written;
+  if (h->first_bad != kNoTrim && !(h->trim_seg != kNoTrim && h->trim_seg < h->first_bad)) atomicOr(&h->flags, kFlagBadLength);
   if (h->trim_seg != kNoTrim && h->trim_seg < (unsigned long long)nseg) {
     const int64_t i = (int64_t)h->trim_seg;
     const long long n = seg_start[i + 1] - seg_start[i];
@@ -1026,7 +1030,10 @@ static double np_pairwise_sum(const double* a, int64_t n) {
   return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
 }
 
-__global__ void k_set_total(PlanHeader* h, int64_t total) { h->total_written = total; }
+__global__ void k_set_total(PlanHeader* h, int64_t total, unsigned long long first_bad) {
+  h->total_written = total;
+  h->first_bad = first_bad;
+}
 
 // Segment lengths n_i by the reference's own recurrence (:111-118), serially on the host: inerr = n + err in float64,
 // Python round (half to even), err carried.  O(m); used when the exact fixed-point scan on the device meets a sum too
@@ -1040,21 +1047,23 @@ static int host_lengths(const PlanView& pv, const double* d_st, const double* d_
   std::vector<int64_t> start(m);
   double err = 0.0;
   int64_t acc = 0;
+  unsigned long long first_bad = kNoTrim;
   *ok = true;
   for (int64_t i = 0; i < nseg; ++i) {
     const double inerr = (st[i + 1] - st[i]) * ((sp[i] + sp[i + 1]) / 2.0) + err;
     const double rn = nearbyint(inerr);          // Python round(): half to even
-    if (!(rn >= 2.0 && rn < 9.0e15)) {
+    if (!(rn >= 0.0 && rn < 9.0e15)) {
       *ok = false;
       return PAR_OK;
     }
+    if (rn < 2.0 && first_bad == kNoTrim) first_bad = (unsigned long long)i;   // harmless behind the trim: k_trim decides
     err = inerr - rn;
     start[i] = acc;
     acc += (int64_t)rn;
   }
   start[nseg] = acc;
   PAR_HIP_CHECK(hipMemcpyAsync(pv.seg_start, start.data(), m * sizeof(int64_t), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, s, pv.hdr, acc);
+  hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, s, pv.hdr, acc, first_bad);
   PAR_HIP_CHECK(hipStreamSynchronize(s));        // `start` must outlive the copy
   return PAR_OK;
 }
@@ -1137,6 +1146,7 @@ static int host_plan(const PlanView& pv, const double* d_st, const double* d_sp,
   out->ck_valid = 0;
   out->pad2 = 0;
   out->written = acc;
+  out->first_bad = kNoTrim;
   PAR_HIP_CHECK(hipMemcpyAsync(pv.seg_start, start.data(), m * sizeof(int64_t), hipMemcpyHostToDevice, s));
   PAR_HIP_CHECK(hipMemcpyAsync(pv.seg_off, off.data(), m * sizeof(double), hipMemcpyHostToDevice, s));
   PAR_HIP_CHECK(hipMemcpyAsync(pv.hdr, out, sizeof(PlanHeader), hipMemcpyHostToDevice, s));
@@ -1215,6 +1225,8 @@ static void launch_seg_sums(const double* speeds, const par::PlanView& pv, int64
 }
 
 // Shared implementation.  aux (optional, device): cumsum checkpoints for the fused resampler.
+static thread_local int g_last_plan_flags = 0;
+
 static int plan_impl(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in, void* work,
                      size_t work_bytes, void* aux, size_t aux_bytes, int64_t max_out, int64_t* len_out, int* trimmed,
                      int force_host, int* path_used, int* fused_ok, void* stream) {
@@ -1235,6 +1247,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
   PlanHeader h;
   memset(&h, 0, sizeof(h));
   bool need_host = force_host != 0;
+  g_last_plan_flags = 0;
   // attempt 0: everything on the device.  attempt 1 (only after a near-tie in the segment lengths): the O(m) length
   // recurrence is redone serially on the host in the reference's own float64 order, everything else -- the O(len_out)
   // reciprocal sums, offsets, trim, checkpoints -- stays on the device.
@@ -1253,7 +1266,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
       bool lengths_ok = false;
       rc = host_lengths(pv, sampletimes, speeds, m, s, &lengths_ok);
       if (rc != PAR_OK) return rc;
-      if (!lengths_ok) {                 // n_i < 2 somewhere: the serial path words the diagnosis
+      if (!lengths_ok) {                 // a negative or absurd length: the serial path words the diagnosis
         need_host = true;
         break;
       }
@@ -1298,6 +1311,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
       PAR_HIP_CHECK(hipStreamSynchronize(s));
     }
     if (h.flags == 0) break;
+    g_last_plan_flags |= h.flags;
     // a near-tie in the lengths alone: one more round with host-made lengths; anything else (n_i < 2, range,
     // verification, too many crossings, or a second failure): the serial path decides -- it also produces the
     // reference's own diagnosis for genuinely bad curves.
@@ -1327,6 +1341,8 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
   *trimmed = h.trimmed;
   return PAR_OK;
 }
+
+int par_last_plan_flags(void) { return g_last_plan_flags; }
 
 // force_host != 0 exercises the serial host path (tests use it to cross-check the device scans);
 // *path_used = 0 device scans, 1 serial host path, 2 segment lengths from the host (near-tie) and the rest on the device.

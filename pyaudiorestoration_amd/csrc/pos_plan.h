@@ -22,7 +22,10 @@ struct PlanHeader {
   int64_t written;        // outputs the reference has written into its buffer when it stops (end of the trim segment)
   int32_t n_long;         // segments handled by the chunked exact cumsum (sparse curves), see pos.hip
   int32_t pad3;
+  unsigned long long first_bad;  // first segment with n_i < 2 (~0: none).  Harmless when the trim fires before it: the
+                                 // reference stops there and never builds that segment (k_trim decides)
 };
+static_assert(sizeof(PlanHeader) <= 256, "PlanHeader must fit the reserved header bytes");
 constexpr int kFlagAmbiguous = 1;   // a cumulative length is too close to a rounding tie
 constexpr int kFlagBadLength = 2;   // some n_i < 2 (reference divides by zero / indexes an empty array)
 constexpr int kFlagRange = 4;       // a_i outside the exactly-representable fixed-point range

@@ -134,6 +134,39 @@ def varispeed_fused_stereo_dev(plan, sig0_t, sig1_t, NT, out0_t, out1_t, sig_str
     return out0_t, out1_t
 
 
+def _resample_item(plan, item, NT, dev):
+    """K_sinc launch(es) of one planned work item on the current stream: (.., sig_t[, sig_stride, len_in]) with a 1-D
+    sig_t, or an interleaved (n, ch) sig_t whose channel pairs share one stereo launch (an odd last channel goes
+    alone).  A plan without valid checkpoints takes the position-array path."""
+    sig_t = item[2]
+    if sig_t.ndim == 2:
+        n_in, ch = sig_t.shape
+        out_t = _dev.empty((plan.len_out, ch), torch.float32, dev)
+        flat_in, flat_out = sig_t.reshape(-1), out_t.reshape(-1)
+        layout = dict(sig_stride=ch, len_in=n_in, out_stride=ch)
+        if not plan.fused_ok:
+            pos_t = _dev.empty(plan.len_out, torch.float64, dev)
+            _lib.check(_lib.lib().par_speed_to_pos_fill(dev, _dev.ptr(plan.speeds_t), plan.m, _dev.ptr(plan.work),
+                                                        _dev.ptr(pos_t), plan.len_out, _dev.stream_ptr(dev)))
+        c = 0
+        while c < ch:
+            if plan.fused_ok and c + 1 < ch:
+                varispeed_fused_stereo_dev(plan, flat_in[c:], flat_in[c + 1:], NT, flat_out[c:], flat_out[c + 1:], **layout)
+                c += 2
+            elif plan.fused_ok:
+                varispeed_fused_dev(plan, flat_in[c:], NT, flat_out[c:], **layout)
+                c += 1
+            else:
+                sinc_resample_dev(pos_t, flat_in[c:], NT, flat_out[c:], dev=dev, **layout)
+                c += 1
+        return out_t
+    stride = item[3] if len(item) > 3 else 1
+    len_in = item[4] if len(item) > 4 else sig_t.numel() // stride
+    if plan.fused_ok:
+        return varispeed_fused_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)
+    return varispeed_resample_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)[0]
+
+
 def varispeed_batch_dev(items, NT, dev=None):
     """Software-pipelined fused resampling of a batch of device-resident work items on one GPU (the per-GPU
     inner loop of a file batch): while K_sinc of item k runs on the current stream, the whole plan
@@ -187,35 +220,7 @@ def varispeed_batch_dev(items, NT, dev=None):
             nxt_item = None
         ready = torch.cuda.Event()
         ready.record(main)
-        sig_t = cur_item[2]
-        if sig_t.ndim == 2:
-            # interleaved (n, ch) file: channel pairs share one stereo launch, an odd last channel goes alone
-            n_in, ch = sig_t.shape
-            out_t = _dev.empty((plan.len_out, ch), torch.float32, dev)
-            flat_in, flat_out = sig_t.reshape(-1), out_t.reshape(-1)
-            layout = dict(sig_stride=ch, len_in=n_in, out_stride=ch)
-            if not plan.fused_ok:
-                pos_t = _dev.empty(plan.len_out, torch.float64, dev)
-                _lib.check(_lib.lib().par_speed_to_pos_fill(dev, _dev.ptr(plan.speeds_t), plan.m, _dev.ptr(plan.work),
-                                                            _dev.ptr(pos_t), plan.len_out, _dev.stream_ptr(dev)))
-            c = 0
-            while c < ch:
-                if plan.fused_ok and c + 1 < ch:
-                    varispeed_fused_stereo_dev(plan, flat_in[c:], flat_in[c + 1:], NT, flat_out[c:], flat_out[c + 1:], **layout)
-                    c += 2
-                elif plan.fused_ok:
-                    varispeed_fused_dev(plan, flat_in[c:], NT, flat_out[c:], **layout)
-                    c += 1
-                else:
-                    sinc_resample_dev(pos_t, flat_in[c:], NT, flat_out[c:], dev=dev, **layout)
-                    c += 1
-        else:
-            stride = cur_item[3] if len(cur_item) > 3 else 1
-            len_in = cur_item[4] if len(cur_item) > 4 else sig_t.numel() // stride
-            if plan.fused_ok:
-                out_t = varispeed_fused_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)
-            else:
-                out_t, _ = varispeed_resample_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)
+        out_t = _resample_item(plan, cur_item, NT, dev)
         free[slot] = torch.cuda.Event()
         free[slot].record(main)
         nxt_plan = plan_item(nxt_item, (k + 1) % 2, side, ready) if nxt_item is not None else None
@@ -223,6 +228,86 @@ def varispeed_batch_dev(items, NT, dev=None):
         if nxt_item is None:
             return
         cur_item, plan, k = nxt_item, nxt_plan, k + 1
+
+
+# pinned staging / output slots of varispeed_batch_host, kept between calls (page-locking 0.5 GB costs ~0.1 s)
+_pinned_ring = {}
+
+
+def varispeed_batch_host(items, NT, dev=None):
+    """Fused resampling of a batch of HOST-resident files on one GPU with the bus kept busy in both directions: the
+    upload of file k+1 (its own stream) runs while file k's output is still going back (a third stream); plan and
+    K_sinc (2-7 ms per 10-min file) sit between them on the current stream.  PCIe, not the kernels, bounds this form
+    (DESIGN 5): it moves ~2x the samples per second of the upload -> compute -> download sequence.
+
+    items: iterable of (sampletimes, speeds, signal): float64 numpy curves in samples / speed factors, signal a
+    float32 numpy array or CPU tensor of shape (n,) or (n, ch) (interleaved, like soundfile returns it).  Pinned
+    tensors are uploaded in place; anything else is staged through a pinned ring slot first (a host memcpy).
+    Yields (index, out) in order, `out` a PINNED float32 CPU tensor (len_out,) or (len_out, ch) that stays valid until
+    the generator is advanced again (two output slots alternate; the slots are kept for the next call, so one batch
+    at a time per device)."""
+    dev = _dev.device_index(dev)
+    device = torch.device("cuda", dev)
+    main = torch.cuda.current_stream(dev)
+    up, down = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    pin_in, pin_out = _pinned_ring.setdefault(("in", dev), [None, None]), _pinned_ring.setdefault(("out", dev), [None, None])
+    in_done, out_done = [None, None], [None, None]      # events: upload from / download into the slot finished
+    work = aux = None
+    pending = None                                       # (index, view of pin_out, event) of the previous file
+
+    def pinned(buf, numel):
+        if buf is None or buf.numel() < numel:
+            buf = torch.empty(int(numel * 1.05) + 4096, dtype=torch.float32).pin_memory()
+        return buf
+
+    for k, (st, sp, sig) in enumerate(items):
+        slot = k % 2
+        st = np.ascontiguousarray(st, dtype=np.float64)
+        sp = np.ascontiguousarray(sp, dtype=np.float64)
+        if len(st) != len(sp) or len(st) < 2:
+            raise ValueError("sampletimes and speeds must have the same length >= 2")
+        src = sig if isinstance(sig, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(sig, dtype=np.float32))
+        if src.dtype != torch.float32 or src.ndim not in (1, 2):
+            raise ValueError("signal must be float32 of shape (n,) or (n, channels)")
+        src = src.contiguous()
+        if not src.is_pinned():
+            if in_done[slot] is not None:
+                in_done[slot].synchronize()              # the upload that last read this staging slot is through
+            pin_in[slot] = pinned(pin_in[slot], src.numel())
+            stage = pin_in[slot][:src.numel()].view(src.shape)
+            stage.copy_(src)
+            src = stage
+        with torch.cuda.stream(up):
+            st_t = torch.from_numpy(st).to(device, non_blocking=False)
+            sp_t = torch.from_numpy(sp).to(device, non_blocking=False)
+            sig_t = src.to(device, non_blocking=True)
+            in_done[slot] = torch.cuda.Event()
+            in_done[slot].record(up)
+        main.wait_event(in_done[slot])
+        # buffer bound from the host copy of the curve (fused_max_out's formula without a device read-back)
+        max_out = int(float(sp.mean()) * float(st[-1] - st[0]) * 1.01) + int(float(np.diff(st).max()) * float(sp.max())) + 1024
+        plan = speed_plan_dev(st_t, sp_t, src.shape[0], dev, fused=True, max_out=max_out, work=work, aux=aux)
+        work, aux = plan.work, plan.aux
+        out_t = _resample_item(plan, (st_t, sp_t, sig_t), NT, dev)
+        done = torch.cuda.Event()
+        done.record(main)
+        for t in (st_t, sp_t, sig_t):                    # allocated on `up`, read on `main`: the caching allocator must
+            t.record_stream(main)                        # not recycle them under the kernels
+        pin_out[slot] = pinned(pin_out[slot], out_t.numel())     # slot of file k-2: the caller let go of it by advancing
+        view = pin_out[slot][:out_t.numel()].view(out_t.shape)
+        down.wait_event(done)
+        with torch.cuda.stream(down):
+            view.copy_(out_t, non_blocking=True)
+            out_done[slot] = torch.cuda.Event()
+            out_done[slot].record(down)
+        out_t.record_stream(down)
+        if pending is not None:                          # hand out file k-1 while file k is on the device / the bus
+            pending[2].synchronize()
+            yield pending[0], pending[1]
+        pending = (k, view, out_done[slot])
+    if pending is not None:
+        pending[2].synchronize()
+        yield pending[0], pending[1]
 
 
 def varispeed_resample_dev(plan, sig_t, NT, out_t=None, pos_t=None, sig_stride=1, len_in=None, out_stride=1, n_chunks=0):

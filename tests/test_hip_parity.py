@@ -797,6 +797,67 @@ def test_batch_pipeline_equals_item_by_item(par):
     assert list(R.varispeed_batch_dev([], 16)) == []
 
 
+def test_degenerate_segment_behind_the_trim_is_harmless(par):
+    """A segment of fewer than 2 outputs makes the reference divide by zero -- when it gets there.  A curve that runs
+    past the end of the file is trimmed first, so such a segment BEHIND the trim never exists for the reference: the
+    device plan decides that itself (path 0, positions bit-identical to the C oracle); in front of the trim both refuse."""
+    from oracle import oracle_c as C
+    t = par.torch
+    n = 100_000
+    st = np.linspace(0.0, 2.0 * n, 201)
+    from pyaudiorestoration_amd import _lib
+    # slow = 1e-3 makes the neighbouring lengths exact rounding ties (500.5): those plans take the host-made lengths
+    # (path 2), which must treat the degenerate segment the same way
+    for bad_at, slow, want_path in ((150, 1.2e-3, 0), (101, 1.2e-3, 0), (150, 1e-3, 2), (50, 1.2e-3, None), (50, 1e-3, None)):
+        sp = np.ones(201)
+        sp[bad_at] = sp[bad_at + 1] = slow                      # 1000 samples * ~1e-3 -> n_i = 1
+        st_t, sp_t = t.from_numpy(st).cuda(), t.from_numpy(sp).cuda()
+        if want_path is not None:
+            ref, trimmed = C.speed_to_pos(st, sp, n)
+            info = {}
+            pos = par.resampling.speed_to_pos_dev(st_t, sp_t, n, info=info)
+            assert trimmed and info["path"] == want_path and t.equal(pos.cpu(), t.from_numpy(ref)), (bad_at, slow, info)
+            plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
+            assert plan.path == want_path and plan.fused_ok and plan.len_out == len(ref)
+            sig_t = t.from_numpy(inputs.noise(n, 3)).cuda()
+            assert t.equal(par.resampling.varispeed_fused_dev(plan, sig_t, 16), par.resampling.sinc_resample_dev(pos, sig_t, 16))
+        else:
+            with pytest.raises(ValueError):
+                C.speed_to_pos(st, sp, n)
+            with pytest.raises(_lib.ParError):
+                par.resampling.speed_plan_dev(st_t, sp_t, n)
+
+
+def test_host_batch_driver_equals_device_batch(par):
+    """varispeed_batch_host (host files in, pinned host buffers out; upload of file k+1 and download of file k on their
+    own streams) returns exactly what the device-resident batch pipeline computes -- for pageable numpy input (staged
+    through the pinned ring), pinned tensors (uploaded in place), mono, stereo and 3-channel interleaved files, slots
+    that grow and shrink, and it hands the outputs out in order."""
+    t = par.torch
+    R = par.resampling
+    rng = np.random.default_rng(21)
+    specs = [(300000, 1, False), (150000, 2, False), (900000, 1, True), (40000, 3, False), (900000, 2, True), (5000, 1, False)]
+    host_items, dev_items = [], []
+    for i, (n, ch, pin) in enumerate(specs):
+        m = max(3, n // 256)
+        st = np.linspace(0, n, m)
+        sp = 1.0 + 0.05 * np.sin(np.arange(m) * 0.21 + i) + 0.001 * rng.standard_normal(m)
+        sig = rng.standard_normal((n, ch) if ch > 1 else n).astype(np.float32)
+        host_items.append((st, sp, t.from_numpy(sig).pin_memory() if pin else sig))
+        dev_items.append((t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), t.from_numpy(sig).cuda()))
+    want = [out.clone() for _, out, _ in R.varispeed_batch_dev(dev_items, 16)]
+    got = []
+    for k, out in R.varispeed_batch_host(iter(host_items), 16):
+        assert out.is_pinned() and out.device.type == "cpu"
+        got.append((k, out.clone()))                     # the slot is reused two files later
+    assert [k for k, _ in got] == list(range(len(specs)))
+    for (k, out), w in zip(got, want):
+        assert out.shape == w.shape and t.equal(out, w.cpu()), k
+    assert list(R.varispeed_batch_host([], 16)) == []
+    with pytest.raises(ValueError):
+        list(R.varispeed_batch_host([(np.arange(3.0), np.ones(2), np.zeros(10, np.float32))], 16))
+
+
 def test_tapesync_project_on_reference_samples(par, tmp_path):
     """pytapesynch data flow on the reference's own demo data (fixtures under tests/golden/): rhythm+5percent.flac
     resampled with the lag curve of rhythm.tapesync must line up with rhythm.flac -- same length within a few

@@ -62,4 +62,36 @@ pos = resampling.speed_to_pos(curve[:, 0] * sr, curve[:, 1], n)
 dt, y3 = wall(lambda: resampling.sinc_wrapper(pos, sig, 0, 32), 2)
 res["sinc_wrapper(sample_at f64, signal) operator slot"] = {"s": round(dt, 4), "Msamples/s": round(len(y3) / dt / 1e6, 1)}
 assert np.array_equal(y, y2.numpy())
+
+# a batch of host files through varispeed_batch_host: upload of file k+1 under the download of file k
+n_files = 12
+st_np, sp_np = curve[:, 0] * sr, np.ascontiguousarray(curve[:, 1])
+for label, src in (("pinned inputs", pin_in), ("pageable numpy inputs (staged)", sig)):
+    def batch():
+        total = 0
+        for k, out in resampling.varispeed_batch_host(((st_np, sp_np, src) for _ in range(n_files)), 32):
+            total += out.shape[0]
+        return total
+    batch()
+    t0 = time.perf_counter()
+    total = batch()
+    dt = time.perf_counter() - t0
+    res[f"varispeed_batch_host, {n_files} files, {label}"] = {"s_per_file": round(dt / n_files, 4),
+                                                            "Msamples/s": round(total / dt / 1e6, 1)}
+stereo = torch.stack((pin_in, pin_in.flip(0)), dim=1).contiguous().pin_memory()
+
+
+def batch2():
+    total = 0
+    for k, out in resampling.varispeed_batch_host(((st_np, sp_np, stereo) for _ in range(n_files)), 32):
+        total += out.shape[0] * 2
+    return total
+
+
+batch2()
+t0 = time.perf_counter()
+total = batch2()
+dt = time.perf_counter() - t0
+res[f"varispeed_batch_host, {n_files} stereo files, pinned"] = {"s_per_file": round(dt / n_files, 4),
+                                                               "M channel-samples/s": round(total / dt / 1e6, 1)}
 print(json.dumps(res, indent=1))

@@ -19,6 +19,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 t_end = time.time() + budget
 case = worst = refused = 0
+why = {}
+paths = [0, 0, 0]            # plans that ran on the device / went to the serial host plan / took host-made lengths only
 worst_cfg = None
 while time.time() < t_end:
     rng = np.random.default_rng(seed0 + case)
@@ -70,6 +72,9 @@ while time.time() < t_end:
         plan = R.speed_plan_dev(st_t, sp_t, n, fused=True)
     except _lib.ParError as e:
         raise SystemExit(f"case {case}: device plan failed where the oracle succeeded: {e}")
+    paths[plan.path] += 1
+    if plan.path:
+        why[int(_lib.lib().par_last_plan_flags())] = why.get(int(_lib.lib().par_last_plan_flags()), 0) + 1
     pos = R.speed_to_pos_dev(st_t, sp_t, n).cpu().numpy()
     assert np.array_equal(pos, ref_pos), (case, "positions", n, NT, seg, style)
     ref = C.sinc(ref_pos, sig, NT, threads=8)
@@ -92,4 +97,5 @@ while time.time() < t_end:
         worst, worst_cfg = max(errs), (case, n, NT, seg, style)
     assert max(errs) < 1e-5, (case, errs, n, NT, seg, style)       # the north-star tolerance, relative to the OUTPUT peak
     case += 1
-print(f"fuzz ok: {case} cases ({refused} refused by both the oracle and the device), worst relative error {worst:.2e} at {worst_cfg}")
+print(f"fuzz ok: {case} cases ({refused} refused by both the oracle and the device), worst relative error {worst:.2e} at {worst_cfg}; "
+      f"plan path device/serial-host/host-lengths = {paths[0]}/{paths[1]}/{paths[2]}, device flag words behind the host paths: {why}")
