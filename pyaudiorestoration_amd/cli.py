@@ -6,6 +6,7 @@ resample on that GPU, results are written as <stem>_res<suffix>.wav like resampl
 
     python -m pyaudiorestoration_amd.cli respeed --trail 0.2,4000,4.0,4000 tape1.flac tape2.wav
     python -m pyaudiorestoration_amd.cli resample --curve curve.json tape.wav      # [[t_seconds, speed], ...]
+    python -m pyaudiorestoration_amd.cli resample --speed 1.015 tape.wav           # constant correction
     python -m pyaudiorestoration_amd.cli tapesync --project take.tapesync take2.flac
     python -m pyaudiorestoration_amd.cli heal --project tape.drop tape.flac
 """
@@ -56,7 +57,10 @@ def _worker(dev, jobs, args, results):
                     io_ops.write_wav_float(f"{os.path.splitext(path)[0]}_res{args.suffix}.wav", out, sr)
                     np.save(f"{os.path.splitext(path)[0]}_speed{args.suffix}.npy", r["speed_curve"])
                 else:
-                    curve = np.asarray(json.load(open(args.curve)), dtype=np.float64)
+                    if args.speed is not None:          # constant correction: a two-point curve over the whole file
+                        curve = np.array([[0.0, args.speed], [len(signal) / sr, args.speed]], dtype=np.float64)
+                    else:
+                        curve = np.asarray(json.load(open(args.curve)), dtype=np.float64)
                     resampling.run((path,), signal_data=((signal, sr),), speed_curve=curve, resampling_mode=args.resampling,
                                    sinc_quality=args.quality, suffix=args.suffix)
                 results.append((path, None))
@@ -76,7 +80,9 @@ def main(argv=None):
     a.add_argument("--hop", type=int, default=256)
     a.add_argument("--lowpass", type=float, default=20.0, help="speed-curve low-pass (Hz)")
     b = sub.add_parser("resample", help="apply a given speed curve")
-    b.add_argument("--curve", required=True, help="JSON [[t_seconds, speed], ...]")
+    how = b.add_mutually_exclusive_group(required=True)
+    how.add_argument("--curve", help="JSON [[t_seconds, speed], ...]")
+    how.add_argument("--speed", type=float, help="constant speed factor of the recording (1.015 = it ran 1.5 %% fast)")
     b.add_argument("--resampling", default="Sinc", choices=("Sinc", "Linear"))
     c = sub.add_parser("tapesync", help="apply the lag curve of a saved pytapesynch project (.tapesync) to files")
     c.add_argument("--project", required=True, help=".tapesync JSON written by the GUI")

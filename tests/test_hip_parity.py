@@ -1129,3 +1129,11 @@ def test_headless_cli_respeed_and_resample(par, golden, tmp_path):
     for k in range(3):
         yk, _, _ = io_ops.read_file(str(tmp_path / f"copy{k}_res.wav"))
         assert np.array_equal(yk, y2)
+    # constant correction = a two-point curve (one 8e5-sample segment: the chunked exact cumsum): against the C oracle
+    from oracle import oracle_c as C
+    assert cli.main(["resample", "--speed", "1.015", "--quality", "32", "--suffix", "_c", f]) == 0
+    y3, _, _ = io_ops.read_file(str(tmp_path / "tape_res_c.wav"))
+    x, _, _ = io_ops.read_file(f)
+    pos, _ = C.speed_to_pos(np.array([0.0, len(x) / 192000]) * 192000, np.array([1.015, 1.015]), len(x))   # run(): t * sr
+    ref3 = C.sinc(pos, np.ascontiguousarray(x[:, 0]), 32, threads=8)
+    assert len(y3) == len(ref3) and relerr(y3[:, 0], ref3) < TOL
