@@ -319,12 +319,7 @@ __device__ __forceinline__ int f64_exponent(double x) { return (int)((__double_a
 constexpr long long kLongSeg = 32768;                   // longer segments take the chunked path (needs the ck buffer); below,
                                                         // one lane per segment is faster (measured crossover 3e4..5e4)
 constexpr int kLongChunk = 256;                         // least steps per chunk; the last chunk of a segment takes the remainder
-// Steps per chunk of a segment of n samples.  The two per-segment passes cost ~25 us per 4096 chunks on their one CU,
-// a chunk in which the sum crosses a binade (~20 per segment) costs ~21 ns per step on one lane: longer chunks pay
-// once a segment has more than ~1e5 of them.  A chunk owns len/kCk checkpoint slots: its scratch lives there first.
-__host__ __device__ inline long long long_chunk_len(long long n) {
-  return n > (1LL << 28) ? 2048 : n > (1LL << 25) ? 1024 : kLongChunk;
-}
+constexpr int kLongSlots = kLongChunk / kCk;            // checkpoint slots a chunk owns: its scratch lives there first
 enum { kLsA = 8, kLsC0 = 9, kLsC1 = 10, kLsExp = 11, kLsStart = 12, kLsEnd = 13, kLsApprox = 14 };
 
 __host__ __device__ inline long long chunk_slot0(long long seg_start, long long i) { return seg_start / kLongChunk + i; }
@@ -422,13 +417,12 @@ __device__ __forceinline__ ChunkRef find_chunk(long long g, const int64_t* __res
   const long long start = seg_start[lo];
   c.n = seg_start[lo + 1] - start;
   c.j = g - chunk_slot0(start, lo);
-  const long long len = long_chunk_len(c.n);
-  c.J = c.n / len;
+  c.J = c.n / kLongChunk;
   c.ok = c.j >= 0 && c.j < c.J && long_segment(c.n, start, lo, ck, ck_len);
-  c.k0 = c.j * len;
-  c.k1 = (c.j == c.J - 1) ? c.n : c.k0 + len;
+  c.k0 = c.j * kLongChunk;
+  c.k1 = (c.j == c.J - 1) ? c.n : c.k0 + kLongChunk;
   c.slot0 = ck_slot0(start, lo);
-  c.base = c.slot0 + c.j * (len / kCk);
+  c.base = c.slot0 + c.j * kLongSlots;
   return c;
 }
 
@@ -456,60 +450,145 @@ __global__ __launch_bounds__(256) void k_long_approx(const double* __restrict__ 
   ck[c.base + kLsA] = A;
 }
 
-// Both per-segment passes (B and D) walk a segment in windows of 256 * kWinC chunks: a thread owns kWinC consecutive
-// chunks (serial in registers), the 256 thread totals are scanned with wave shuffles (two barriers per window instead
-// of sixteen), so a 7e8-sample segment (2.7 M chunks) is 660 windows, not 10 500.
+// The chunk records of a segment are reduced in WINDOWS of 256 * kWinC chunks, three phases per reduction: every window
+// on its own workgroup (a thread owns kWinC consecutive chunks, thread totals are scanned with wave shuffles), one
+// workgroup per segment over the window totals (256 windows per step), every window again to hand the result down to
+// its chunks.  A 7e8-sample segment is 2.7 M chunks = 660 windows: the only serial part left is 3 steps long.
+// Window records live in free fields of the window's first chunk (a chunk owns 32 checkpoint slots).
 constexpr int kWinC = 16;
 constexpr int kWin = 256 * kWinC;
+enum { kLsWSum = 16, kLsWPre = 17, kLsWC0 = 18, kLsWC1 = 19, kLsWClean = 20, kLsWStart = 21 };
+static_assert(kLsWStart < kLongChunk / kCk, "window record must fit the chunk's own slots");
 
-// pass B: per long segment, exclusive prefix of the chunk sums = approximate running sum at every chunk start
+// Global window slot, again without a prefix sum: chunk slots of consecutive segments are at least J_i + 1 apart and a
+// long segment has J_i >= 128 chunks, so floor(chunk_slot0 / 64) leaves floor((J_i + 1) / 64) >= ceil(J_i / kWin) + 1
+// slots between a long segment and whatever follows it: windows w = 0.. of segment i sit at win_slot0(i) + w, and the
+// LAST segment whose win_slot0 is <= a slot is its owner (short segments in front may share the value, none behind).
+constexpr int kWinSlotDiv = 64;
+static_assert(kLongSeg / kLongChunk >= 2 * kWinSlotDiv && kWin >= kWinSlotDiv, "window slots of long segments would collide");
+__host__ __device__ inline long long win_slot0(long long seg_start, long long i) { return chunk_slot0(seg_start, i) / kWinSlotDiv; }
+struct WinRef {
+  long long i, n, J, slot0, j0, j1, rec;      // rec: slot of the window record (= first chunk of the window)
+  bool ok;
+};
+__device__ __forceinline__ WinRef find_window(long long gw, const int64_t* __restrict__ seg_start, int64_t nseg,
+                                              const double* ck, int64_t ck_len) {
+  long long lo = 0, hi = nseg - 1;
+  while (lo < hi) {
+    const long long mid = (lo + hi + 1) >> 1;
+    if (win_slot0(seg_start[mid], mid) <= gw) lo = mid; else hi = mid - 1;
+  }
+  WinRef r;
+  r.i = lo;
+  const long long start = seg_start[lo];
+  r.n = seg_start[lo + 1] - start;
+  r.J = r.n / kLongChunk;
+  const long long w = gw - win_slot0(start, lo);
+  r.ok = w >= 0 && w * kWin < r.J && long_segment(r.n, start, lo, ck, ck_len);
+  r.slot0 = ck_slot0(start, lo);
+  r.j0 = w * kWin;
+  r.j1 = r.j0 + kWin < r.J ? r.j0 + kWin : r.J;
+  r.rec = r.slot0 + r.j0 * kLongSlots;
+  return r;
+}
+
+// exclusive prefix of `mine` over the 256 threads (+ the total), wave shuffles + one barrier; tot[] is 4 doubles of LDS
+__device__ __forceinline__ double block_scan_sum(double mine, double* tot, double* total) {
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  double inc = mine;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const double up = __shfl_up(inc, o, kWave);
+    if (lane >= o) inc += up;
+  }
+  if (lane == kWave - 1) tot[wv] = inc;
+  __syncthreads();
+  double before = 0.0, all = 0.0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wv) before += tot[w];
+    all += tot[w];
+  }
+  *total = all;
+  return before + (inc - mine);
+}
+
+// pass B1: approximate sum of every window
+__global__ __launch_bounds__(256) void k_long_wsum(const int64_t* __restrict__ seg_start, int64_t nseg, double* __restrict__ ck,
+                                                   int64_t ck_len, long long GW, const PlanHeader* __restrict__ h) {
+  if (h->n_long == 0) return;
+  __shared__ double tot[4];
+  for (long long gw = blockIdx.x; gw < GW; gw += gridDim.x) {       // window slots, grid-strided (most are empty)
+    const WinRef w = find_window(gw, seg_start, nseg, ck, ck_len);
+    if (!w.ok) continue;
+    const long long jt = w.j0 + (long long)threadIdx.x * kWinC;
+    double v[kWinC];
+#pragma unroll
+    for (int u = 0; u < kWinC; ++u) {                                  // unconditional loads: all in flight at once
+      const long long jc = jt + u < w.j1 ? jt + u : w.j1 - 1;
+      v[u] = ck[w.slot0 + jc * kLongSlots + kLsA];
+    }
+    double mine = 0.0;
+#pragma unroll
+    for (int u = 0; u < kWinC; ++u) mine += jt + u < w.j1 ? v[u] : 0.0;
+    double total;
+    block_scan_sum(mine, tot, &total);
+    if (threadIdx.x == 0) ck[w.rec + kLsWSum] = total;
+    __syncthreads();                                                 // LDS scratch is reused by the next slot
+  }
+}
+
+// pass B2: per long segment, exclusive prefix of the window sums (256 windows per step)
 __global__ __launch_bounds__(256) void k_long_prefix(const int64_t* __restrict__ seg_start, int64_t nseg,
                                                      double* __restrict__ ck, int64_t ck_len,
                                                      const PlanHeader* __restrict__ h) {
   if (h->n_long == 0) return;
-  __shared__ double wave_tot[4];
-  const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
+  __shared__ double tot[4];
   for (long long i = blockIdx.x; i < nseg; i += gridDim.x) {
     const long long start = seg_start[i], n = seg_start[i + 1] - start;
     if (!long_segment(n, start, i, ck, ck_len)) continue;            // uniform over the workgroup
-    const long long clen = long_chunk_len(n), cslots = clen / kCk, J = n / clen, slot0 = ck_slot0(start, i);
+    const long long J = n / kLongChunk, NW = (J + kWin - 1) / kWin, slot0 = ck_slot0(start, i);
     double carry = 0.0;                                              // same value in every thread
-    for (long long j0 = 0; j0 < J; j0 += kWin) {
-      const long long jt = j0 + (long long)t * kWinC;
-      double v[kWinC];
-#pragma unroll
-      for (int u = 0; u < kWinC; ++u) {                                // unconditional loads: all in flight at once
-        const long long jc = jt + u < J ? jt + u : J - 1;
-        v[u] = ck[slot0 + jc * cslots + kLsA];
-      }
-#pragma unroll
-      for (int u = 0; u < kWinC; ++u) v[u] = jt + u < J ? v[u] : 0.0;
-      double mine = 0.0;
-#pragma unroll
-      for (int u = 0; u < kWinC; ++u) mine += v[u];
-      double inc = mine;                                             // inclusive scan inside the wave
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const double up = __shfl_up(inc, o, kWave);
-        if (lane >= o) inc += up;
-      }
-      if (lane == kWave - 1) wave_tot[wv] = inc;
-      __syncthreads();
-      double before = carry, total = carry;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        if (w < wv) before += wave_tot[w];
-        total += wave_tot[w];
-      }
-      double run = before + (inc - mine);
-#pragma unroll
-      for (int u = 0; u < kWinC; ++u) {
-        if (jt + u < J) ck[slot0 + (jt + u) * cslots + kLsApprox] = run;
-        run += v[u];
-      }
-      carry = total;
+    for (long long w0 = 0; w0 < NW; w0 += 256) {
+      const long long w = w0 + threadIdx.x;
+      const long long rec = slot0 + (w < NW ? w : NW - 1) * kWin * kLongSlots;
+      const double v = w < NW ? ck[rec + kLsWSum] : 0.0;
+      double total;
+      const double before = block_scan_sum(v, tot, &total);
+      if (w < NW) ck[rec + kLsWPre] = carry + before;
+      carry += total;
       __syncthreads();
     }
+  }
+}
+
+// pass B3: approximate running sum at every chunk start
+__global__ __launch_bounds__(256) void k_long_wprefix(const int64_t* __restrict__ seg_start, int64_t nseg, double* __restrict__ ck,
+                                                      int64_t ck_len, long long GW, const PlanHeader* __restrict__ h) {
+  if (h->n_long == 0) return;
+  __shared__ double tot[4];
+  for (long long gw = blockIdx.x; gw < GW; gw += gridDim.x) {       // window slots, grid-strided (most are empty)
+    const WinRef w = find_window(gw, seg_start, nseg, ck, ck_len);
+    if (!w.ok) continue;
+    const long long jt = w.j0 + (long long)threadIdx.x * kWinC;
+    const double pre = ck[w.rec + kLsWPre];
+    double v[kWinC];
+#pragma unroll
+    for (int u = 0; u < kWinC; ++u) {
+      const long long jc = jt + u < w.j1 ? jt + u : w.j1 - 1;
+      v[u] = ck[w.slot0 + jc * kLongSlots + kLsA];
+    }
+    double mine = 0.0;
+#pragma unroll
+    for (int u = 0; u < kWinC; ++u) mine += jt + u < w.j1 ? v[u] : 0.0;
+    double total;
+    double run = pre + block_scan_sum(mine, tot, &total);
+#pragma unroll
+    for (int u = 0; u < kWinC; ++u) {
+      if (jt + u < w.j1) ck[w.slot0 + (jt + u) * kLongSlots + kLsApprox] = run;
+      run += v[u];
+    }
+    __syncthreads();                                                 // LDS scratch is reused by the next slot
   }
 }
 
@@ -584,117 +663,229 @@ __device__ __forceinline__ void map_then(long long a0, long long a1, long long b
   *r1 = a1 + (((1 + a1) & 1) ? b1 : b0);
 }
 
-// pass D: per long segment, exact running sum at every chunk boundary.  Runs of single-binade chunks are resolved by a
-// workgroup scan of their maps; a chunk in which the sum crosses a power of two (and the first one, from 0) is
-// stepped through with real float64 adds by one thread.
+// this thread's kWinC chunk maps of the chunk range [jt, jt + kWinC) clipped to j_end (identity beyond it and for
+// direct chunks); first = offset (from jt0, the range start handed to thread 0) of my first direct chunk, else kWin
+__device__ __forceinline__ void load_chunk_maps(const double* __restrict__ ck, long long slot0, long long jt, long long j_end,
+                                                long long (&m0)[kWinC], long long (&m1)[kWinC], int* first) {
+  double ex[kWinC];
+#pragma unroll
+  for (int u = 0; u < kWinC; ++u) {                                  // unconditional loads: all in flight at once
+    const long long jc = jt + u < j_end ? jt + u : j_end - 1;
+    const long long base = slot0 + jc * kLongSlots;
+    ex[u] = ck[base + kLsExp];
+    m0[u] = __double_as_longlong(ck[base + kLsC0]);
+    m1[u] = __double_as_longlong(ck[base + kLsC1]);
+  }
+  int f = kWin;
+#pragma unroll
+  for (int u = kWinC - 1; u >= 0; --u) {
+    const bool live = jt + u < j_end, direct = live && ex[u] < 0.0;
+    if (direct) f = (int)threadIdx.x * kWinC + u;
+    if (!live || direct) m0[u] = m1[u] = 0;
+  }
+  *first = f;
+}
+
+// minimum of v over the 256 threads (one barrier; buf is 4 ints of LDS)
+__device__ __forceinline__ int block_min(int v, int* buf) {
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    const int other = __shfl_xor(v, o, kWave);
+    v = other < v ? other : v;
+  }
+  if (lane == 0) buf[wv] = v;
+  __syncthreads();
+  int r = buf[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) r = buf[w] < r ? buf[w] : r;
+  return r;
+}
+
+// ordered composition over the 256 threads: (p0, p1) = everything in front of this thread, (all0, all1) = all of it;
+// one barrier, w0/w1 are 4 long longs of LDS each
+__device__ __forceinline__ void block_scan_maps(long long a0, long long a1, long long* w0, long long* w1, long long* p0,
+                                                long long* p1, long long* all0, long long* all1) {
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  long long i0 = a0, i1 = a1;                                         // inclusive inside the wave
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const long long u0 = __shfl_up(i0, o, kWave), u1 = __shfl_up(i1, o, kWave);
+    if (lane >= o) map_then(u0, u1, i0, i1, &i0, &i1);
+  }
+  if (lane == kWave - 1) {
+    w0[wv] = i0;
+    w1[wv] = i1;
+  }
+  long long e0 = __shfl_up(i0, 1, kWave), e1 = __shfl_up(i1, 1, kWave);          // exclusive inside the wave
+  if (lane == 0) e0 = e1 = 0;
+  __syncthreads();
+  long long q0 = 0, q1 = 0, t0 = 0, t1 = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wv) map_then(q0, q1, w0[w], w1[w], &q0, &q1);
+    map_then(t0, t1, w0[w], w1[w], &t0, &t1);
+  }
+  map_then(q0, q1, e0, e1, p0, p1);
+  *all0 = t0;
+  *all1 = t1;
+}
+
+// exact start / end of this thread's first `cnt` chunks from jt on, given the running sum x0 at the start of the range
+// and the composed map (p0, p1) of everything in the range in front of them
+__device__ __forceinline__ void write_chunk_bounds(double* __restrict__ ck, long long slot0, long long jt, long long cnt,
+                                                   double x0, long long p0, long long p1, const long long (&m0)[kWinC],
+                                                   const long long (&m1)[kWinC]) {
+  if (cnt <= 0) return;
+  const int e = f64_exponent(x0);
+  long long X = (long long)ldexp(x0, 1075 - e);                       // exact integer in [2^52, 2^53)
+  X += (X & 1) ? p1 : p0;
+#pragma unroll
+  for (int u = 0; u < kWinC; ++u) {
+    if (u < cnt) {
+      const long long base = slot0 + (jt + u) * kLongSlots;
+      ck[base + kLsStart] = ldexp((double)X, e - 1075);
+      X += (X & 1) ? m1[u] : m0[u];
+      ck[base + kLsEnd] = ldexp((double)X, e - 1075);
+    }
+  }
+}
+
+// pass D1: every window composes the maps of its chunks; a window with a direct chunk (the sum crosses a power of two
+// in it, or it is the segment's first) is marked and left to the per-segment pass
+__global__ __launch_bounds__(256) void k_long_wmap(const int64_t* __restrict__ seg_start, int64_t nseg, double* __restrict__ ck,
+                                                   int64_t ck_len, long long GW, const PlanHeader* __restrict__ h) {
+  if (h->n_long == 0) return;
+  __shared__ long long w0[4], w1[4];
+  __shared__ int mn[4];
+  for (long long gw = blockIdx.x; gw < GW; gw += gridDim.x) {       // window slots, grid-strided (most are empty)
+    const WinRef w = find_window(gw, seg_start, nseg, ck, ck_len);
+    if (!w.ok) continue;
+    const long long jt = w.j0 + (long long)threadIdx.x * kWinC;
+    long long m0[kWinC], m1[kWinC];
+    int first;
+    load_chunk_maps(ck, w.slot0, jt, w.j1, m0, m1, &first);
+    const int fd = block_min(first, mn);
+    long long a0 = 0, a1 = 0;
+#pragma unroll
+    for (int u = 0; u < kWinC; ++u) map_then(a0, a1, m0[u], m1[u], &a0, &a1);
+    long long p0, p1, all0, all1;
+    block_scan_maps(a0, a1, w0, w1, &p0, &p1, &all0, &all1);
+    if (threadIdx.x == 0) {
+      ck[w.rec + kLsWC0] = __longlong_as_double(all0);
+      ck[w.rec + kLsWC1] = __longlong_as_double(all1);
+      ck[w.rec + kLsWClean] = fd == kWin ? 1.0 : 0.0;
+    }
+    __syncthreads();                                                 // LDS scratch is reused by the next slot
+  }
+}
+
+// pass D2: per long segment, exact running sum at every WINDOW start.  Runs of clean windows are resolved by a scan of
+// their maps (256 windows per step); a marked window is walked chunk by chunk right here: runs of single-binade chunks
+// by a scan of the chunk maps, a direct chunk stepped through with real float64 adds by one thread.  The chunks of
+// marked windows get their exact start / end here, those of clean windows in pass D3.
 __global__ __launch_bounds__(256) void k_long_stitch(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
                                                      int64_t nseg, double* __restrict__ ck, int64_t ck_len,
                                                      const PlanHeader* __restrict__ h) {
   if (h->n_long == 0) return;
   __shared__ long long w0[4], w1[4];
-  __shared__ int wave_first[4];
+  __shared__ int mn[4];
   __shared__ double x_run;
-  const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
+  const int t = threadIdx.x;
   for (long long i = blockIdx.x; i < nseg; i += gridDim.x) {
     const long long start = seg_start[i], n = seg_start[i + 1] - start;
     if (!long_segment(n, start, i, ck, ck_len)) continue;
-    const long long clen = long_chunk_len(n), cslots = clen / kCk, J = n / clen, slot0 = ck_slot0(start, i);
+    const long long J = n / kLongChunk, NW = (J + kWin - 1) / kWin, slot0 = ck_slot0(start, i);
     const Ramp r = make_ramp(sp[i], sp[i + 1], n);
     if (t == 0) x_run = 0.0;
-    long long j = 0;
-    while (j < J) {
-      // this thread's kWinC chunks of the window that starts at chunk j
-      const long long jt = j + (long long)t * kWinC;
-      long long m0[kWinC], m1[kWinC];
-      int first = kWin;                                                // window offset of my first direct chunk
-      double ex[kWinC];
-#pragma unroll
-      for (int u = 0; u < kWinC; ++u) {                                // unconditional loads: all in flight at once
-        const long long jc = jt + u < J ? jt + u : J - 1;
-        const long long base = slot0 + jc * cslots;
-        ex[u] = ck[base + kLsExp];
-        m0[u] = __double_as_longlong(ck[base + kLsC0]);
-        m1[u] = __double_as_longlong(ck[base + kLsC1]);
-      }
-#pragma unroll
-      for (int u = kWinC - 1; u >= 0; --u) {
-        const bool live = jt + u < J, direct = live && ex[u] < 0.0;
-        if (direct) first = t * kWinC + u;
-        if (!live || direct) m0[u] = m1[u] = 0;
-      }
-      int wf = first;
-#pragma unroll
-      for (int o = kWave / 2; o > 0; o >>= 1) {
-        const int other = __shfl_xor(wf, o, kWave);
-        wf = other < wf ? other : wf;
-      }
-      if (lane == 0) wave_first[wv] = wf;
-      __syncthreads();
-      int fd = wave_first[0];
-#pragma unroll
-      for (int w = 1; w < 4; ++w) fd = wave_first[w] < fd ? wave_first[w] : fd;
-      long long L = fd;                                               // interior chunks in front of the first direct one
-      if (L > J - j) L = J - j;
-      // my share of the run, composed; then the scan over threads (identity beyond the run)
-      long long cnt = L - (long long)t * kWinC;
-      cnt = cnt < 0 ? 0 : (cnt > kWinC ? kWinC : cnt);
-      long long a0 = 0, a1 = 0;
-#pragma unroll
-      for (int u = 0; u < kWinC; ++u)
-        if (u < cnt) map_then(a0, a1, m0[u], m1[u], &a0, &a1);
-      long long i0 = a0, i1 = a1;                                     // inclusive inside the wave
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const long long u0 = __shfl_up(i0, o, kWave), u1 = __shfl_up(i1, o, kWave);
-        if (lane >= o) map_then(u0, u1, i0, i1, &i0, &i1);
-      }
-      if (lane == kWave - 1) {
-        w0[wv] = i0;
-        w1[wv] = i1;
-      }
-      long long e0 = __shfl_up(i0, 1, kWave), e1 = __shfl_up(i1, 1, kWave);      // exclusive inside the wave
-      if (lane == 0) e0 = e1 = 0;
-      __syncthreads();
-      long long p0 = 0, p1 = 0, all0 = 0, all1 = 0;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        if (w < wv) map_then(p0, p1, w0[w], w1[w], &p0, &p1);
-        map_then(all0, all1, w0[w], w1[w], &all0, &all1);
-      }
-      map_then(p0, p1, e0, e1, &p0, &p1);                             // everything in front of my first chunk
+    __syncthreads();
+    long long w = 0;
+    while (w < NW) {
+      // ---- a run of clean windows from w on (at most 256 per step)
+      const long long wt = w + t;
+      const long long rec = slot0 + (wt < NW ? wt : NW - 1) * kWin * kLongSlots;
+      const bool live = wt < NW;
+      const bool clean = ck[rec + kLsWClean] > 0.5;
+      long long a0 = __double_as_longlong(ck[rec + kLsWC0]), a1 = __double_as_longlong(ck[rec + kLsWC1]);
+      const int fdw = block_min(live && !clean ? t : 256, mn);
+      long long Lw = fdw;
+      if (Lw > NW - w) Lw = NW - w;
+      if (t >= Lw) a0 = a1 = 0;
+      long long p0, p1, all0, all1;
+      block_scan_maps(a0, a1, w0, w1, &p0, &p1, &all0, &all1);
       const double x0 = x_run;
-      if (cnt > 0) {
-        const int e = f64_exponent(x0);
-        long long X = (long long)ldexp(x0, 1075 - e);                 // exact integer in [2^52, 2^53)
-        X += (X & 1) ? p1 : p0;
+      if (t < Lw) ck[rec + kLsWStart] = apply_map(p0, p1, x0);
+      __syncthreads();
+      if (t == 0 && Lw > 0) x_run = apply_map(all0, all1, x0);
+      __syncthreads();
+      w += Lw;
+      if (w >= NW || fdw == 256) continue;
+      // ---- the marked window w: chunk by chunk
+      long long j = w * kWin;
+      const long long j_end = j + kWin < J ? j + kWin : J;
+      while (j < j_end) {
+        const long long jt = j + (long long)t * kWinC;
+        long long m0[kWinC], m1[kWinC];
+        int first;
+        load_chunk_maps(ck, slot0, jt, j_end, m0, m1, &first);
+        const int fd = block_min(first, mn);
+        long long L = fd;                                             // interior chunks in front of the first direct one
+        if (L > j_end - j) L = j_end - j;
+        long long cnt = L - (long long)t * kWinC;
+        cnt = cnt < 0 ? 0 : (cnt > kWinC ? kWinC : cnt);
+        long long c0 = 0, c1 = 0;
 #pragma unroll
-        for (int u = 0; u < kWinC; ++u) {
-          if (u < cnt) {
-            const long long base = slot0 + (jt + u) * cslots;
-            ck[base + kLsStart] = ldexp((double)X, e - 1075);
-            X += (X & 1) ? m1[u] : m0[u];
-            ck[base + kLsEnd] = ldexp((double)X, e - 1075);
+        for (int u = 0; u < kWinC; ++u)
+          if (u < cnt) map_then(c0, c1, m0[u], m1[u], &c0, &c1);
+        block_scan_maps(c0, c1, w0, w1, &p0, &p1, &all0, &all1);
+        const double xs = x_run;
+        write_chunk_bounds(ck, slot0, jt, cnt, xs, p0, p1, m0, m1);
+        const bool has_direct = j + L < j_end && fd < kWin;
+        __syncthreads();
+        if (t == 0) {
+          double x = L > 0 ? apply_map(all0, all1, xs) : xs;
+          if (has_direct) {                                           // the direct chunk that ended the run
+            const long long jd = j + L, bd = slot0 + jd * kLongSlots;
+            const long long k0 = jd * kLongChunk, k1 = (jd == J - 1) ? n : k0 + kLongChunk;
+            ck[bd + kLsStart] = x;
+            double c = x;
+            for (long long k = k0; k < k1; ++k) c = c + ramp_recip((double)k, r);
+            ck[bd + kLsEnd] = c;
+            x = c;
           }
+          x_run = x;
         }
+        __syncthreads();
+        j += L + (has_direct ? 1 : 0);
       }
-      const bool has_direct = j + L < J && fd < kWin;
-      __syncthreads();
-      if (t == 0) {
-        double x = L > 0 ? apply_map(all0, all1, x0) : x0;
-        if (has_direct) {                                             // the direct chunk that ended the run
-          const long long jd = j + L, bd = slot0 + jd * cslots;
-          const long long k0 = jd * clen, k1 = (jd == J - 1) ? n : k0 + clen;
-          ck[bd + kLsStart] = x;
-          double c = x;
-          for (long long k = k0; k < k1; ++k) c = c + ramp_recip((double)k, r);
-          ck[bd + kLsEnd] = c;
-          x = c;
-        }
-        x_run = x;
-      }
-      __syncthreads();
-      j += L + (has_direct ? 1 : 0);
+      w += 1;
     }
+  }
+}
+
+// pass D3: the chunks of every clean window get their exact start / end from the window's start
+__global__ __launch_bounds__(256) void k_long_wapply(const int64_t* __restrict__ seg_start, int64_t nseg, double* __restrict__ ck,
+                                                     int64_t ck_len, long long GW, const PlanHeader* __restrict__ h) {
+  if (h->n_long == 0) return;
+  __shared__ long long w0[4], w1[4];
+  for (long long gw = blockIdx.x; gw < GW; gw += gridDim.x) {       // window slots, grid-strided (most are empty)
+    const WinRef w = find_window(gw, seg_start, nseg, ck, ck_len);
+    if (!w.ok) continue;
+    if (!(ck[w.rec + kLsWClean] > 0.5)) continue;                         // uniform over the workgroup
+    const double x0 = ck[w.rec + kLsWStart];
+    const long long jt = w.j0 + (long long)threadIdx.x * kWinC;
+    long long m0[kWinC], m1[kWinC];
+    int first;
+    load_chunk_maps(ck, w.slot0, jt, w.j1, m0, m1, &first);
+    long long a0 = 0, a1 = 0;
+#pragma unroll
+    for (int u = 0; u < kWinC; ++u) map_then(a0, a1, m0[u], m1[u], &a0, &a1);
+    long long p0, p1, all0, all1;
+    block_scan_maps(a0, a1, w0, w1, &p0, &p1, &all0, &all1);
+    long long cnt = w.j1 - jt;
+    cnt = cnt < 0 ? 0 : (cnt > kWinC ? kWinC : cnt);
+    write_chunk_bounds(ck, w.slot0, jt, cnt, x0, p0, p1, m0, m1);
+    __syncthreads();                                                 // LDS scratch is reused by the next slot
   }
 }
 
@@ -1216,11 +1407,17 @@ static void launch_seg_sums(const double* speeds, const par::PlanView& pv, int64
                      ck_len, pv.hdr);
   if (!ck) return;
   const long long G = max_out / kLongChunk + m + 8;                 // bound on the global chunk slots
-  const unsigned gc = (unsigned)ceil_div(G, 256), gs = (unsigned)(nseg < 2048 ? nseg : 2048);
+  const long long GW = G / kWinSlotDiv + 8;                         // ... and on the global window slots
+  const unsigned gc = (unsigned)ceil_div(G, 256), gs = (unsigned)(nseg < 2048 ? nseg : 2048),
+                 gw = (unsigned)(GW < 8192 ? GW : 8192);
   hipLaunchKernelGGL(k_long_approx, dim3(gc), dim3(256), 0, s, speeds, pv.seg_start, nseg, ck, ck_len, G, pv.hdr);
+  hipLaunchKernelGGL(k_long_wsum, dim3(gw), dim3(256), 0, s, pv.seg_start, nseg, ck, ck_len, GW, pv.hdr);
   hipLaunchKernelGGL(k_long_prefix, dim3(gs), dim3(256), 0, s, pv.seg_start, nseg, ck, ck_len, pv.hdr);
+  hipLaunchKernelGGL(k_long_wprefix, dim3(gw), dim3(256), 0, s, pv.seg_start, nseg, ck, ck_len, GW, pv.hdr);
   hipLaunchKernelGGL(k_long_map, dim3(gc), dim3(256), 0, s, speeds, pv.seg_start, nseg, ck, ck_len, G, pv.hdr);
+  hipLaunchKernelGGL(k_long_wmap, dim3(gw), dim3(256), 0, s, pv.seg_start, nseg, ck, ck_len, GW, pv.hdr);
   hipLaunchKernelGGL(k_long_stitch, dim3(gs), dim3(256), 0, s, speeds, pv.seg_start, nseg, ck, ck_len, pv.hdr);
+  hipLaunchKernelGGL(k_long_wapply, dim3(gw), dim3(256), 0, s, pv.seg_start, nseg, ck, ck_len, GW, pv.hdr);
   hipLaunchKernelGGL(k_long_final, dim3(gc), dim3(256), 0, s, speeds, pv.seg_start, nseg, pv.S, ck, ck_len, G, pv.hdr);
 }
 
