@@ -1000,7 +1000,7 @@ def test_full_size_two_point_curve(par):
     assert plan.fused_ok and plan.len_out == pos_t.numel()
     assert t.equal(par.resampling.varispeed_fused_dev(plan, sig_t, 32), par.resampling.sinc_resample_dev(pos_t, sig_t, 32))
     del pos_t, plan
-    # segments of 2.7e8 (2048-step chunks), 5e7 (1024-step), 2e7 and 5.6e6 samples (256-step): every chunk-length tier in
+    # segments of 2.7e8 (258 windows of 4096 chunks: two steps of the window-level scan), 5e7, 2e7 and 5.6e6 samples in
     # one curve, positions against the C oracle
     st = np.array([0.0, 2.7e8, 3.2e8, 3.4e8, float(n)])
     sp = np.array([0.99, 0.99, 1.02, 1.03, 1.05])
