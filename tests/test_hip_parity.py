@@ -981,6 +981,32 @@ def test_sparse_speed_curves_take_the_chunked_exact_cumsum(par):
             assert t.equal(R.varispeed_fused_dev(plan, sig_t, NT), R.sinc_resample_dev(pos_t, sig_t, NT)), (n, speeds[:3], NT)
 
 
+def test_sparse_curves_random_window_layouts(par):
+    """Random curves of 2..7 points over 3..60 M samples: segments of 1..57 windows (4096 chunks of 256 steps each), power-
+    of-two crossings of the running sum at arbitrary chunks, partial last windows and chunks -- positions bit for bit
+    against the C oracle (whose cumsum is the plain sequential loop)."""
+    from oracle import oracle_c as C
+    t = par.torch
+    rng = np.random.default_rng(2024)
+    done = 0
+    for case in range(40):
+        n = int(rng.integers(3_000_000, 60_000_000))
+        m = int(rng.integers(2, 8))
+        cuts = np.sort(rng.uniform(0.05, 0.95, m - 2)) if m > 2 else np.zeros(0)
+        st = np.concatenate(([0.0], cuts * n, [float(n)]))
+        sp = rng.uniform(0.4, 2.5, m) if case % 3 else np.full(m, float(rng.uniform(0.5, 2.0)))
+        try:
+            ref, _ = C.speed_to_pos(st, sp, n)
+        except ValueError:
+            continue                                   # the reference's end_guess buffer is too small for this curve
+        info = {}
+        pos = par.resampling.speed_to_pos_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), n, info=info)
+        assert info["path"] == 0 and t.equal(pos.cpu(), t.from_numpy(ref)), (case, n, m)
+        del pos, ref
+        done += 1
+    assert done >= 15
+
+
 def test_full_size_two_point_curve(par):
     """Config-2 length (345.6 M samples) with the sparsest possible curve -- a constant 1.5 % speed correction given as
     two points, i.e. ONE segment of 3.5e8 samples: the chunked exact cumsum and the block-parallel fill reproduce the C
