@@ -1398,14 +1398,22 @@ size_t par_speed_plan_bytes(int64_t m) { return par::plan_bytes(m < 2 ? 2 : m); 
 
 // Per-segment reciprocal sums (+ checkpoints): one lane per ordinary segment, the chunked exact path for long ones.
 // The five k_long_* launches return at once when the curve has no long segment (header counter).
-static void launch_seg_sums(const double* speeds, const par::PlanView& pv, int64_t nseg, double* ck, int64_t ck_len,
+static int launch_seg_sums(const double* speeds, const par::PlanView& pv, int64_t nseg, double* ck, int64_t ck_len,
                             int64_t max_out, int64_t m, hipStream_t s) {
   using namespace par;
   const unsigned g256 = (unsigned)ceil_div(nseg, 256);
   if (ck) hipLaunchKernelGGL(k_count_long, dim3(g256), dim3(256), 0, s, pv.seg_start, nseg, (const double*)ck, ck_len, pv.hdr);
   hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.S, ck,
                      ck_len, pv.hdr);
-  if (!ck) return;
+  if (!ck) return PAR_OK;
+  // Curves without a long segment (every dense curve) skip the nine chunked-cumsum launches: one 4-byte read-back,
+  // issued behind k_seg_sum so the GPU stays busy while the host waits.  (It is not only the launches: under a
+  // concurrent K_sinc the side stream is served well for about a millisecond and then starves until K_sinc
+  // drains -- measured --, so a plan that is to hide under the previous file's K_sinc has to be short.)
+  int n_long = 0;
+  PAR_HIP_CHECK(hipMemcpyAsync(&n_long, &pv.hdr->n_long, sizeof(int), hipMemcpyDeviceToHost, s));
+  PAR_HIP_CHECK(hipStreamSynchronize(s));
+  if (n_long == 0) return PAR_OK;
   const long long G = max_out / kLongChunk + m + 8;                 // bound on the global chunk slots
   const long long GW = G / kWinSlotDiv + 8;                         // ... and on the global window slots
   const unsigned gc = (unsigned)ceil_div(G, 256), gs = (unsigned)(nseg < 2048 ? nseg : 2048),
@@ -1419,6 +1427,7 @@ static void launch_seg_sums(const double* speeds, const par::PlanView& pv, int64
   hipLaunchKernelGGL(k_long_stitch, dim3(gs), dim3(256), 0, s, speeds, pv.seg_start, nseg, ck, ck_len, pv.hdr);
   hipLaunchKernelGGL(k_long_wapply, dim3(gw), dim3(256), 0, s, pv.seg_start, nseg, ck, ck_len, GW, pv.hdr);
   hipLaunchKernelGGL(k_long_final, dim3(gc), dim3(256), 0, s, speeds, pv.seg_start, nseg, pv.S, ck, ck_len, G, pv.hdr);
+  return PAR_OK;
 }
 
 // Shared implementation.  aux (optional, device): cumsum checkpoints for the fused resampler.
@@ -1471,7 +1480,8 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
     }
     hipLaunchKernelGGL(k_speed_sum, dim3((unsigned)(m / 4096 + 1)), dim3(256), 0, s, speeds, m,
                        reinterpret_cast<double*>(pv.bsum), pv.hdr);     // bsum is idle between two scans
-    launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s);
+    rc = launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s);
+    if (rc != PAR_OK) return rc;
     PAR_HIP_CHECK(hipMemcpyAsync(pv.xs, pv.S, nseg * sizeof(double), hipMemcpyDeviceToDevice, s));
     rc = inclusive_scan<AddF64>(pv.xs, nseg, reinterpret_cast<double*>(pv.bsum), s);
     if (rc != PAR_OK) return rc;
@@ -1518,7 +1528,8 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
     int rc = host_plan(pv, sampletimes, speeds, m, n_in, &h, s);
     if (rc != PAR_OK) return rc;
     if (aux) {     // checkpoints + tile map for the serial path's segmentation: same exact device arithmetic
-      launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s);
+      rc = launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s);
+      if (rc != PAR_OK) return rc;
       hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(std::max<int64_t>(nseg, max_tiles), 256)), dim3(256), 0, s,
                          pv.seg_start, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len), pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
