@@ -205,6 +205,10 @@ def read_flac(path, verify_md5=True, n_threads=0):
     buf = data.ctypes.data_as(ctypes.c_void_p)
     sr, ch, bits, total = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
     _lib.check(L.par_flac_info(buf, data.size, ctypes.byref(sr), ctypes.byref(ch), ctypes.byref(bits), ctypes.byref(total), None))
+    # a frame is at least 10 bytes (header 6, one constant subframe 2, CRC-16 2) and holds at most 65 535 samples per
+    # channel: a STREAMINFO that claims more than the file can hold is corrupt -- refuse it before allocating for it
+    if total.value > (data.size // 8 + 1) * 65535:
+        raise ValueError(f"{path}: STREAMINFO claims {total.value} samples, more than a {data.size}-byte file can hold")
     out = np.empty((total.value, ch.value), dtype=np.float32)
     done = ctypes.c_int64(0)
     _lib.check(L.par_flac_decode_f32(buf, data.size, out.ctypes.data_as(ctypes.c_void_p), total.value, int(n_threads),
