@@ -665,12 +665,14 @@ __device__ __forceinline__ void map_then(long long a0, long long a1, long long b
 
 // this thread's kWinC chunk maps of the chunk range [jt, jt + kWinC) clipped to j_end (identity beyond it and for
 // direct chunks); first = offset (from jt0, the range start handed to thread 0) of my first direct chunk, else kWin
+// per: chunks per thread in this pass (kWinC, or 1 while a marked window is searched for its next direct chunk); the
+// thread's chunks are jt .. jt + per - 1
 __device__ __forceinline__ void load_chunk_maps(const double* __restrict__ ck, long long slot0, long long jt, long long j_end,
-                                                long long (&m0)[kWinC], long long (&m1)[kWinC], int* first) {
+                                                int per, long long (&m0)[kWinC], long long (&m1)[kWinC], int* first) {
   double ex[kWinC];
 #pragma unroll
   for (int u = 0; u < kWinC; ++u) {                                  // unconditional loads: all in flight at once
-    const long long jc = jt + u < j_end ? jt + u : j_end - 1;
+    const long long jc = (u < per && jt + u < j_end) ? jt + u : j_end - 1;
     const long long base = slot0 + jc * kLongSlots;
     ex[u] = ck[base + kLsExp];
     m0[u] = __double_as_longlong(ck[base + kLsC0]);
@@ -679,8 +681,8 @@ __device__ __forceinline__ void load_chunk_maps(const double* __restrict__ ck, l
   int f = kWin;
 #pragma unroll
   for (int u = kWinC - 1; u >= 0; --u) {
-    const bool live = jt + u < j_end, direct = live && ex[u] < 0.0;
-    if (direct) f = (int)threadIdx.x * kWinC + u;
+    const bool live = u < per && jt + u < j_end, direct = live && ex[u] < 0.0;
+    if (direct) f = (int)threadIdx.x * per + u;
     if (!live || direct) m0[u] = m1[u] = 0;
   }
   *first = f;
@@ -764,7 +766,7 @@ __global__ __launch_bounds__(256) void k_long_wmap(const int64_t* __restrict__ s
     const long long jt = w.j0 + (long long)threadIdx.x * kWinC;
     long long m0[kWinC], m1[kWinC];
     int first;
-    load_chunk_maps(ck, w.slot0, jt, w.j1, m0, m1, &first);
+    load_chunk_maps(ck, w.slot0, jt, w.j1, kWinC, m0, m1, &first);
     const int fd = block_min(first, mn);
     long long a0 = 0, a1 = 0;
 #pragma unroll
@@ -823,16 +825,19 @@ __global__ __launch_bounds__(256) void k_long_stitch(const double* __restrict__ 
       // ---- the marked window w: chunk by chunk
       long long j = w * kWin;
       const long long j_end = j + kWin < J ? j + kWin : J;
+      // Direct chunks cluster (the sum doubles at chunks 1, 3, 7, 15, ..): after one, look at 256 chunks only (one per
+      // thread); a search that finds none widens to the full 16 per thread again.
+      int per = 1;
       while (j < j_end) {
-        const long long jt = j + (long long)t * kWinC;
+        const long long jt = j + (long long)t * per;
         long long m0[kWinC], m1[kWinC];
         int first;
-        load_chunk_maps(ck, slot0, jt, j_end, m0, m1, &first);
+        load_chunk_maps(ck, slot0, jt, j_end, per, m0, m1, &first);
         const int fd = block_min(first, mn);
-        long long L = fd;                                             // interior chunks in front of the first direct one
+        long long L = fd < kWin ? fd : 256ll * per;                   // interior chunks in front of the first direct one
         if (L > j_end - j) L = j_end - j;
-        long long cnt = L - (long long)t * kWinC;
-        cnt = cnt < 0 ? 0 : (cnt > kWinC ? kWinC : cnt);
+        long long cnt = L - (long long)t * per;
+        cnt = cnt < 0 ? 0 : (cnt > per ? per : cnt);
         long long c0 = 0, c1 = 0;
 #pragma unroll
         for (int u = 0; u < kWinC; ++u)
@@ -857,6 +862,7 @@ __global__ __launch_bounds__(256) void k_long_stitch(const double* __restrict__ 
         }
         __syncthreads();
         j += L + (has_direct ? 1 : 0);
+        per = has_direct ? 1 : kWinC;
       }
       w += 1;
     }
@@ -876,7 +882,7 @@ __global__ __launch_bounds__(256) void k_long_wapply(const int64_t* __restrict__
     const long long jt = w.j0 + (long long)threadIdx.x * kWinC;
     long long m0[kWinC], m1[kWinC];
     int first;
-    load_chunk_maps(ck, w.slot0, jt, w.j1, m0, m1, &first);
+    load_chunk_maps(ck, w.slot0, jt, w.j1, kWinC, m0, m1, &first);
     long long a0 = 0, a1 = 0;
 #pragma unroll
     for (int u = 0; u < kWinC; ++u) map_then(a0, a1, m0[u], m1[u], &a0, &a1);
