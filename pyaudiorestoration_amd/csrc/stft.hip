@@ -378,8 +378,10 @@ __global__ __launch_bounds__(256) void k_istft_ola(const float* __restrict__ fra
 // rounds.  The summation order per sample is fixed (by round), so results are reproducible run to run.
 // The workgroup writes the (NF - s + 1)*hop samples that only its own frames cover; the s-1 frames on either side
 // are transformed by the neighbour as well ((s-1)/NF extra work: 12 % at 512/32).
+__host__ __device__ constexpr bool istft_tables_in_lds(int logh) { return logh <= 9; }
+
 template <int LOGH>
-__global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_istft_fused(const float2* __restrict__ spec, int64_t n_frames,
+__global__ __launch_bounds__(FftGeom<LOGH>::Threads) __attribute__((amdgpu_waves_per_eu(LOGH <= 9 ? 3 : 1))) void k_istft_fused(const float2* __restrict__ spec, int64_t n_frames,
                                                                          int hop, int s, const float* __restrict__ window,
                                                                          const float2* __restrict__ tw,
                                                                          const float2* __restrict__ post,
@@ -397,15 +399,19 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_istft_fused(const fl
   const int acc_len = (NF - 1) * hop + n_fft;
   const int64_t F0 = (int64_t)blockIdx.x * out_frames - (s - 1);      // first frame of the workgroup (may be < 0)
   for (int i = tid; i < acc_len; i += G::Threads) acc[i] = 0.0f;
-  // this lane's window taps are the same for every frame: keep them in registers
-  float2 wq[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) wq[q] = *reinterpret_cast<const float2*>(window + 2 * (j + q * T));
-  // the spectrum rows of round r+1 are fetched before round r is transformed (software double buffering: the
-  // global-load latency hides under the butterflies instead of stalling every round)
-  float2 pa[8], pb[8], pk[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) pk[q] = cconj(post[j + q * T]);
+  // window taps and untangle twiddles are the same for every frame: they live in LDS, not in 32 registers per lane
+  // (n_fft <= 1024; the larger transforms keep their LDS for the overlap-add span and read the tables from memory)
+  constexpr bool kTab = istft_tables_in_lds(LOGH);
+  float* wl = acc + acc_len;                                           // [n_fft]
+  float2* pl = reinterpret_cast<float2*>(wl + n_fft);                  // [H] conj(post)
+  if (kTab) {
+    for (int i = tid; i < n_fft; i += G::Threads) wl[i] = window[i];
+    for (int i = tid; i < H; i += G::Threads) pl[i] = cconj(post[i]);
+    __syncthreads();
+  }
+  // Occupancy hides the spectrum fetch: with the tables in LDS and no register double buffer the kernel fits 3 waves
+  // per SIMD (146 VGPRs at n_fft = 512; the double-buffered form needed 216 = 2 waves and was 16 % slower, measured).
+  float2 pa[8], pb[8];
   auto fetch = [&](int r) {
     const int64_t fr = F0 + r + u * s;
     const bool live = r < s && fr >= 0 && fr < n_frames;
@@ -416,8 +422,8 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_istft_fused(const fl
       pb[q] = live ? spec[fr * bins + (H - k)] : make_float2(0.0f, 0.0f);
     }
   };
-  fetch(0);
   for (int r = 0; r < s; ++r) {
+    fetch(r);
     const int lf = r + u * s;                                         // frame index inside the workgroup
     const int64_t fr = F0 + lf;
     const bool live = fr >= 0 && fr < n_frames;
@@ -432,10 +438,9 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_istft_fused(const fl
       }
       b = cconj(b);
       const float2 ev = cadd(a, b);
-      const float2 od = cmul(pk[q], csub(a, b));
+      const float2 od = cmul(kTab ? pl[k] : cconj(post[k]), csub(a, b));
       v[q] = make_float2(0.5f * (ev.x - od.y), -0.5f * (ev.y + od.x));   // zeros stay zeros for a dead frame
     }
-    fetch(r + 1);
     fft_core<LOGH>(v, X, j, tw);
     __syncthreads();                                                  // the previous round's adds (and the zeroing) are done
     if (live) {
@@ -444,7 +449,8 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_istft_fused(const fl
       for (int q = 0; q < 8; ++q) {
         const int i = j + q * T;
         const float2 z = X[lpad(i)];                                  // conj(FFT(conj Z)): y[2i] = re, y[2i+1] = -im
-        const float a0 = z.x * scale * wq[q].x, a1 = -z.y * scale * wq[q].y;
+        const float2 wv = kTab ? *reinterpret_cast<const float2*>(wl + 2 * i) : *reinterpret_cast<const float2*>(window + 2 * i);
+        const float a0 = z.x * scale * wv.x, a1 = -z.y * scale * wv.y;
         if ((hop & 1) == 0) {
           float2 t = *reinterpret_cast<float2*>(dst + 2 * i);
           t.x += a0;
@@ -458,9 +464,11 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_istft_fused(const fl
     }
   }
   __syncthreads();
-  float* wl = reinterpret_cast<float*>(lds);                           // frame slots are free now: stage the window there
-  for (int i = tid; i < n_fft; i += G::Threads) wl[i] = window[i];
-  __syncthreads();
+  if (!kTab) {
+    wl = reinterpret_cast<float*>(lds);                                // frame slots are free now: stage the window there
+    for (int i = tid; i < n_fft; i += G::Threads) wl[i] = window[i];
+    __syncthreads();
+  }
   const int64_t ola_len = (int64_t)n_fft + (int64_t)hop * (n_frames - 1);
   const int out_len = out_frames * hop;
   const int64_t TT0 = (int64_t)blockIdx.x * out_len;                  // overlap-add coordinate of the first owned sample
@@ -490,7 +498,8 @@ template <int LOGH>
 static inline size_t istft_fused_lds(int hop) {
   using G = FftGeom<LOGH>;
   const int64_t n_fft = 2 * G::H, s = (n_fft + hop - 1) / hop;
-  return (size_t)G::Frames * G::FrameLds * sizeof(float2) + (size_t)((G::Frames * s - 1) * hop + n_fft) * sizeof(float);
+  return (size_t)G::Frames * G::FrameLds * sizeof(float2) + (size_t)((G::Frames * s - 1) * hop + n_fft) * sizeof(float) +
+         (istft_tables_in_lds(LOGH) ? (size_t)n_fft * sizeof(float) + (size_t)G::H * sizeof(float2) : 0);   // + the tables
 }
 static inline size_t istft_fused_lds_any(int n_fft, int hop) {
   switch (n_fft) {
