@@ -411,7 +411,14 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) __attribute__((amdgpu_waves
   }
   // Occupancy hides the spectrum fetch: with the tables in LDS and no register double buffer the kernel fits 3 waves
   // per SIMD (146 VGPRs at n_fft = 512; the double-buffered form needed 216 = 2 waves and was 16 % slower, measured).
-  float2 pa[8], pb[8];
+  float2 pa[8], pb[8], pk[8], wq[8];        // pk / wq: the tables in registers, large transforms only
+  if (!kTab) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      pk[q] = cconj(post[j + q * T]);
+      wq[q] = *reinterpret_cast<const float2*>(window + 2 * (j + q * T));
+    }
+  }
   auto fetch = [&](int r) {
     const int64_t fr = F0 + r + u * s;
     const bool live = r < s && fr >= 0 && fr < n_frames;
@@ -422,8 +429,9 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) __attribute__((amdgpu_waves
       pb[q] = live ? spec[fr * bins + (H - k)] : make_float2(0.0f, 0.0f);
     }
   };
-  for (int r = 0; r < s; ++r) {
-    fetch(r);
+  if (!kTab) fetch(0);                       // large transforms run at 2 waves per SIMD either way: keep their register
+  for (int r = 0; r < s; ++r) {              // double buffer (round r+1 in flight under round r's butterflies)
+    if (kTab) fetch(r);
     const int lf = r + u * s;                                         // frame index inside the workgroup
     const int64_t fr = F0 + lf;
     const bool live = fr >= 0 && fr < n_frames;
@@ -438,9 +446,10 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) __attribute__((amdgpu_waves
       }
       b = cconj(b);
       const float2 ev = cadd(a, b);
-      const float2 od = cmul(kTab ? pl[k] : cconj(post[k]), csub(a, b));
+      const float2 od = cmul(kTab ? pl[k] : pk[q], csub(a, b));
       v[q] = make_float2(0.5f * (ev.x - od.y), -0.5f * (ev.y + od.x));   // zeros stay zeros for a dead frame
     }
+    if (!kTab) fetch(r + 1);
     fft_core<LOGH>(v, X, j, tw);
     __syncthreads();                                                  // the previous round's adds (and the zeroing) are done
     if (live) {
@@ -449,7 +458,7 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) __attribute__((amdgpu_waves
       for (int q = 0; q < 8; ++q) {
         const int i = j + q * T;
         const float2 z = X[lpad(i)];                                  // conj(FFT(conj Z)): y[2i] = re, y[2i+1] = -im
-        const float2 wv = kTab ? *reinterpret_cast<const float2*>(wl + 2 * i) : *reinterpret_cast<const float2*>(window + 2 * i);
+        const float2 wv = kTab ? *reinterpret_cast<const float2*>(wl + 2 * i) : wq[q];
         const float a0 = z.x * scale * wv.x, a1 = -z.y * scale * wv.y;
         if ((hop & 1) == 0) {
           float2 t = *reinterpret_cast<float2*>(dst + 2 * i);
