@@ -58,6 +58,21 @@ def test_no_cpu_fallback_without_gpu():
         filters.butter_bandpass_filter(np.zeros(100), 0, 20, 172.0, order=3)
 
 
+def test_cli_refuses_to_run_without_a_gpu(tmp_path):
+    """The headless tool has no CPU path either: without a ROCm GPU it stops before touching a file; its argument
+    contract (--curve xor --speed) is enforced by the parser."""
+    import torch
+    from pyaudiorestoration_amd import cli
+    with pytest.raises(SystemExit):
+        cli.main(["resample", "--curve", "c.json", "--speed", "1.01", "x.wav"])      # mutually exclusive
+    with pytest.raises(SystemExit):
+        cli.main(["resample", "x.wav"])                                              # one of them is required
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(SystemExit, match="no CPU fallback"):
+        cli.main(["resample", "--speed", "1.015", str(tmp_path / "missing.wav")])
+
+
 def test_product_package_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "pyaudiorestoration_amd")
     for dirpath, _, files in os.walk(pkg):
@@ -239,6 +254,13 @@ def test_native_flac_decoder_parallel_split_and_corruption(tmp_path):
         io_ops.read_flac(str(tmp_path / "short.flac"))
     x, sr, ch = io_ops.read_file(str(p))                            # the reference-named entry point uses it
     assert x.shape == want.shape and sr == 192000 and ch == 2
+    # a STREAMINFO that claims 2^35 samples for a 3 MB file is refused BEFORE anything is allocated for it
+    huge = bytearray(blob)
+    v = int.from_bytes(huge[18:26], "big")
+    huge[18:26] = ((v & ~((1 << 36) - 1)) | (1 << 35)).to_bytes(8, "big")
+    (tmp_path / "huge.flac").write_bytes(bytes(huge))
+    with pytest.raises(ValueError, match="more than a"):
+        io_ops.read_flac(str(tmp_path / "huge.flac"))
 
 
 def test_lag_curve_from_tapesync_markers():
