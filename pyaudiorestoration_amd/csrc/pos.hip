@@ -1403,7 +1403,6 @@ extern "C" {
 size_t par_speed_plan_bytes(int64_t m) { return par::plan_bytes(m < 2 ? 2 : m); }
 
 // Per-segment reciprocal sums (+ checkpoints): one lane per ordinary segment, the chunked exact path for long ones.
-// The five k_long_* launches return at once when the curve has no long segment (header counter).
 static int launch_seg_sums(const double* speeds, const par::PlanView& pv, int64_t nseg, double* ck, int64_t ck_len,
                             int64_t max_out, int64_t m, hipStream_t s) {
   using namespace par;
