@@ -926,15 +926,20 @@ __global__ __launch_bounds__(256) void k_long_final(const double* __restrict__ s
 // after k_tile_seg: publish checkpoint validity in the header (device side, so the host needs one read-back)
 __global__ void k_publish_ck(PlanHeader* __restrict__ h, int64_t ck_len) {
   h->ck_len = ck_len;
-  h->ck_valid = (h->flags & kFlagCkOverflow) ? 0 : 1;
+  // any flag still standing here (kFlagVerify from the chunked long-segment cumsum included) means some checkpoint
+  // was not verified: the fused resampler must not regenerate positions from them
+  // (kFlagCapAmbiguous only concerns the reference's buffer bound, which the host settles afterwards)
+  h->ck_valid = (h->flags & ~kFlagCapAmbiguous) ? 0 : 1;
   h->flags &= ~kFlagCkOverflow;
 }
 
 // tile_seg[t] = segment that contains output t * kSincTileOutputs (tiles of the fused resampler)
-// Thread x serves two roles: segment x checks that its checkpoints fit, tile x looks its segment up (upper bound
-// over seg_start: a tile per thread, not a segment per thread -- one segment can cover 10^5..10^6 tiles).
-__global__ void k_tile_seg(const int64_t* __restrict__ seg_start, int64_t nseg, int64_t ck_len, int64_t max_tiles,
-                           int64_t* __restrict__ tile_seg, PlanHeader* __restrict__ h) {
+// Thread x serves two roles: segment x checks that its checkpoints fit and writes its SegFast record, tile x looks its
+// segment up (upper bound over seg_start: a tile per thread, not a segment per thread -- one segment can cover
+// 10^5..10^6 tiles).
+__global__ void k_tile_seg(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                           const double* __restrict__ seg_off, int64_t nseg, int64_t ck_len, int64_t max_tiles,
+                           int64_t* __restrict__ tile_seg, SegFast* __restrict__ seg_fast, PlanHeader* __restrict__ h) {
   const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const long long len_out = h->len_out;                // written by k_trim / the host path earlier on this stream
   const long long n_tiles = (len_out + kSincTileOutputs - 1) / kSincTileOutputs;
@@ -946,6 +951,21 @@ __global__ void k_tile_seg(const int64_t* __restrict__ seg_start, int64_t nseg, 
     const long long a = seg_start[x], b = seg_start[x + 1];
     if (b > a && a < len_out && ck_slot0(a, x) + (b - a + kCk - 1) / kCk > ck_len)
       atomicOr(&h->flags, kFlagCkOverflow);             // a needed segment has no checkpoints: fused path refused
+    // closed-form placement record (sinc.hip place_fast).  `fast` bounds what the closed form leaves out: the
+    // fourth-order remainder of the <= kCk-term reciprocal sum is < 400 step^4 / smin^5, kept below 2e-10.
+    const long long n = b - a;
+    const double s0 = sp[x], s1 = sp[x + 1], off = seg_off[x];
+    SegFast f;
+    const bool off_ok = fabs(off) < 4.0e18;            // also false for NaN
+    const double ro = off_ok ? rint(off) : 0.0;
+    f.foff = off_ok ? off - ro : 0.0;
+    f.A = (long long)ro;
+    f.n = n < 0x7fffffffll ? (int)n : 0x7fffffff;
+    f.step = n >= 2 ? (s1 - s0) / (double)(n - 1) : 0.0;
+    const double smin = s0 < s1 ? s0 : s1, smax = s0 < s1 ? s1 : s0;
+    f.fast = off_ok && n >= 2 && n < 0x7fffffffll && smin >= 0.0625 && smax <= 64.0 &&
+             fabs(f.step) <= 6.0e-4 * smin * sqrt(sqrt(smin));
+    seg_fast[x] = f;
   }
   if (x > n_tiles || len_out <= 0) return;
   // entry [n_tiles] is extra: the segment that holds the LAST output
@@ -1342,6 +1362,8 @@ static int host_plan(const PlanView& pv, const double* d_st, const double* d_sp,
   out->ck_len = 0;
   out->ck_valid = 0;
   out->pad2 = 0;
+  out->n_long = 0;          // counted afresh by k_count_long when the checkpoints are redone for this segmentation
+  out->pad3 = 0;
   out->written = acc;
   out->first_bad = kNoTrim;
   PAR_HIP_CHECK(hipMemcpyAsync(pv.seg_start, start.data(), m * sizeof(int64_t), hipMemcpyHostToDevice, s));
@@ -1453,8 +1475,8 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
   const int64_t nseg = m - 1;
   PlanView pv = plan_view(work, m);
   double* ck = static_cast<double*>(aux);
-  const int64_t ck_len = aux ? max_out / kCk + m + 16 : 0;
-  const int64_t max_tiles = aux ? max_out / kSincTileOutputs + 4 : 0;
+  const int64_t ck_len = aux ? (int64_t)fused_ck_len(max_out, m) : 0;
+  const int64_t max_tiles = aux ? (int64_t)fused_tiles(max_out) : 0;
   PlanHeader h;
   memset(&h, 0, sizeof(h));
   bool need_host = force_host != 0;
@@ -1502,7 +1524,8 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
                        (const double*)ck, ck_len, pv.hdr);
     if (aux) {
       hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(std::max<int64_t>(nseg, max_tiles), 256)), dim3(256), 0, s,
-                         pv.seg_start, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len), pv.hdr);
+                         speeds, pv.seg_start, pv.seg_off, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len),
+                         reinterpret_cast<SegFast*>(ck + ck_len + max_tiles), pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
     }
     PAR_HIP_CHECK(hipGetLastError());
@@ -1536,7 +1559,8 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
       rc = launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s);
       if (rc != PAR_OK) return rc;
       hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(std::max<int64_t>(nseg, max_tiles), 256)), dim3(256), 0, s,
-                         pv.seg_start, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len), pv.hdr);
+                         speeds, pv.seg_start, pv.seg_off, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len),
+                         reinterpret_cast<SegFast*>(ck + ck_len + max_tiles), pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
       PAR_HIP_CHECK(hipGetLastError());
       PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -1604,7 +1628,7 @@ int par_speed_to_pos_fill_fused(int device, const double* speeds, int64_t m, con
   if (len_out == 0) return PAR_OK;
   PAR_HIP_CHECK(hipSetDevice(device));
   PlanView pv = plan_view(const_cast<void*>(work), m);
-  const int64_t n_slots = max_out / kCk + m + 16;
+  const int64_t n_slots = (int64_t)fused_ck_len(max_out, m);
   hipLaunchKernelGGL(k_pos_fill_ck, dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, as_stream(stream), speeds,
                      pv.seg_start, pv.seg_off, m - 1, static_cast<const double*>(aux), n_slots, len_out, pos);
   PAR_HIP_CHECK(hipGetLastError());

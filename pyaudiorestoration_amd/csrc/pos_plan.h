@@ -143,10 +143,22 @@ __device__ __forceinline__ double ramp_recip(double a, const Ramp& r) {
 // samples owns ceil(n/kCk) <= n/kCk + 1 slots.
 constexpr int kCk = 8;
 __host__ __device__ inline long long ck_slot0(long long seg_start, long long i) { return seg_start / kCk + i; }
+// Per-segment record of a fused plan: what K_sinc needs to place an output of that segment WITHOUT walking the
+// cumsum -- position = rint(seg_off) + [foff + checkpoint + closed-form sum of the <= kCk reciprocals behind it]
+// (midpoint rule + second-order term; remainder < 2e-10 when `fast`), see place_fast in sinc.hip.
+struct SegFast {
+  double foff;              // seg_off - rint(seg_off), exact
+  long long A;              // rint(seg_off)
+  double step;              // (s1 - s0) / (n - 1): ramp increment per output
+  int n;                    // outputs in the segment
+  int fast;                 // 1: closed-form placement valid (ramp gentle enough, speeds in range, n < 2^31)
+};
+static_assert(sizeof(SegFast) == 32, "SegFast is loaded as two 16-byte words");
+// aux buffer of a fused plan: [ck_len checkpoints (f64)] [tile map (int64)] [m SegFast records]
+inline size_t fused_ck_len(int64_t max_out, int64_t m) { return (size_t)(max_out / kCk + m + 16); }
+inline size_t fused_tiles(int64_t max_out) { return (size_t)(max_out / kSincTileOutputs + 4); }
 inline size_t fused_aux_bytes(int64_t max_out, int64_t m) {
-  const size_t ck = (size_t)(max_out / kCk + m + 16);
-  const size_t tiles = (size_t)(max_out / kSincTileOutputs + 4);
-  return (ck + tiles) * 8;
+  return (fused_ck_len(max_out, m) + fused_tiles(max_out)) * 8 + (size_t)m * sizeof(SegFast);
 }
 
 }  // namespace par

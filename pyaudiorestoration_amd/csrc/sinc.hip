@@ -18,22 +18,33 @@
 //    (theta = pi*fc), seeded at the window centre and run outwards in both directions (its error
 //    grows ~n while the weight decays ~1/n); when a whole wave has fc == 1 (speed <= 1) the numerator
 //    collapses to (-1)^(n+1) sin(pi*shift) and is factored out of the sum.  Taps +n and -n share one
-//    denominator R_n = (win_n/pi)/(n^2 - shift^2): a v_rcp_f32 (quarter rate on gfx950) only for n = 1..4, from
-//    n = 5 on a 2-term and from n = 13 on a 1-term series in shift^2 against a wave-uniform table that arrives by
-//    scalar loads and stays in SGPRs.  The kernel is VALU-bound (~80 % issue utilisation), not HBM-bound.
+//    denominator R_n = (win_n/pi)/(n^2 - shift^2): a v_rcp_f32 (quarter rate on gfx950) only for n = 1..4, further
+//    out a short polynomial in shift^2 (2-term series, linear minimax fit, constant: see TapModes) against a
+//    wave-uniform table that arrives by scalar loads and stays in SGPRs.  The kernel is VALU-bound, not HBM-bound.
 //  * everything the float32 fast path is not built for runs lane-wise in float64, line by line like the
 //    reference (sinc_one_f64): the bug-compatible leading edge, tiles too wide for LDS, positions beyond the
 //    int32 offset range, and fc < 1/8 (long averages whose output is small against the signal).
-//  * FUSED form (k_sinc<true>): no position array in HBM; the tile's float64 positions are regenerated in LDS
-//    from the plan's cumsum checkpoints with the same sequential adds numpy's cumsum does (bit-identical).
+//  * FUSED form (k_sinc_fused): no position array in HBM and no float64 cumsum in the kernel: every output is placed
+//    in closed form from the plan's per-segment record and the cumsum checkpoint below it (place_fast), accurate to
+//    ~1e-10 samples; outputs whose position lies within the reference's own rounding of a half-integer are redone with
+//    the reference's sequential float64 adds (place_exact), so every window centre rint(p) is the reference's.
 //  * positions stay float64 end to end (a 345.6 M-sample index does not fit float32); only the
 //    sub-sample shift in [-0.5, 0.5] and fc drop to float32.
 #include "par_common.h"
 #include "pos_plan.h"
+#include "sinc_taps_gen.h"
+#include <utility>
 #include <limits.h>
 #include <math.h>
 #include <map>
 #include <vector>
+
+// PAR_SINC_EXP (tools/build_variant.py): phase-timing builds, never shipped.  Bit mask: 1 tap loops skipped, 2 placement
+// replaced by identity positions, 4 (with 2) fc = 0.995 instead of 1, 8 anchor taken from the output index (no dependent
+// scalar loads at the top), 16 staging loads skipped, 32 stores skipped.
+#ifndef PAR_SINC_EXP
+#define PAR_SINC_EXP 0
+#endif
 
 namespace par {
 
@@ -107,13 +118,20 @@ constexpr int kChunk = 4;
 // shift+add per access).
 typedef __attribute__((address_space(3))) const float lds_cfloat;
 
-// How R_n(q) = (win_n/pi)/(n^2 - q), q = shift^2 <= 1/4, is evaluated for the taps of one chunk.  Only the
-// four innermost pairs pay for a v_rcp_f32 (quarter rate); from n = 5 on q/n^2 <= 0.01 and the geometric
-// series A_n*(1 + q/n^2 + q^2/n^4) is exact to 1e-6 relative (weight <= 0.06: 6e-8 absolute), from
-// n = 13 on one term suffices (2e-6 * weight 0.017).  The table rows change meaning accordingly.
-enum { kRcp = 0, kPoly2 = 1, kPoly1 = 2 };
-constexpr int kPoly2From = 5;     // rows n >= 5 : (A_n, B_n, n, C_n) with A = win/(pi n^2), B = A/n^2, C = B/n^2
-constexpr int kPoly1From = 13;    // rows n >= 13: only (A_n, B_n) are used
+// How R_n(q) = (win_n/pi)/(n^2 - q), q = shift^2 <= 1/4, is evaluated for the taps of one chunk.  Only the four
+// innermost pairs pay for a v_rcp_f32 (quarter rate).  Further out q/n^2 <= 0.01 and R_n is a short polynomial in q
+// against a wave-uniform table that arrives by scalar loads and stays in SGPRs: a 2-term Taylor series (n = 5..),
+// then the linear minimax fit over [0, 1/4], then a constant (the mid-range value: e and d then accumulate straight
+// against SGPR constants, 4 VALU per tap pair).  Where each form starts is decided per NT on the host from worst-case
+// error budgets (get_sinc_table: every tap pair's approximation error times its largest possible contribution,
+// summed over the pairs that use the form, stays below 3e-7 for the linear and 1.5e-6 for the constant form, against
+// the 1e-5 the reference is matched to); the table rows change meaning accordingly.
+enum { kRcp = 0, kPoly2 = 1, kPoly1 = 2, kPoly0 = 3 };
+constexpr int kPoly2From = 5;     // rows n >= 5: (A_n, B_n, n, C_n) with A = win/(pi n^2), B = A/n^2, C = B/n^2
+struct TapModes {
+  int p1_from;                    // rows n >= p1_from: (A_n, B_n, n, -) linear minimax;  p1_from = 1 (mod kChunk), >= 5
+  int p0_from;                    // rows n >= p0_from: (A_n, n A_n, n, -) constant;       p0_from = 1 (mod kChunk), >= p1_from
+};
 template <int MODE>
 __device__ __forceinline__ float tap_R(float q, const float4& t) {
   if (MODE == kRcp) return fast_rcp(fmaf(q, t.y, t.x));            // row = (pi n^2/win, -pi/win, n, -)
@@ -145,14 +163,24 @@ __device__ __forceinline__ void unity_chunk(lds_cfloat* (&tp)[R], lds_cfloat* (&
         if (n0 + k > NT) sm = 0.0f;
       }
       const float D = sp - sm, E = sp + sm;
-      const float Rn = tap_R<MODE>(q[r], ab[k]);
-      const float DR = D * Rn;
-      if (k & 1) {                           // n0 is odd, so odd k is an even n: +
-        e[r] = fmaf(E, Rn, e[r]);
-        d[r] = fmaf(DR, fn, d[r]);
-      } else {                               // odd n: -
-        e[r] = fmaf(-E, Rn, e[r]);
-        d[r] = fmaf(-DR, fn, d[r]);
+      if (MODE == kPoly0) {                    // R_n constant: straight against the SGPR pair (A_n, n A_n)
+        if (k & 1) {                           // n0 is odd, so odd k is an even n: +
+          e[r] = fmaf(E, ab[k].x, e[r]);
+          d[r] = fmaf(D, ab[k].y, d[r]);
+        } else {                               // odd n: -
+          e[r] = fmaf(-E, ab[k].x, e[r]);
+          d[r] = fmaf(-D, ab[k].y, d[r]);
+        }
+      } else {
+        const float Rn = tap_R<MODE>(q[r], ab[k]);
+        const float DR = D * Rn;
+        if (k & 1) {
+          e[r] = fmaf(E, Rn, e[r]);
+          d[r] = fmaf(DR, fn, d[r]);
+        } else {
+          e[r] = fmaf(-E, Rn, e[r]);
+          d[r] = fmaf(-DR, fn, d[r]);
+        }
       }
     }
   }
@@ -165,7 +193,7 @@ __device__ __forceinline__ void unity_chunk(lds_cfloat* (&tp)[R], lds_cfloat* (&
 
 template <int R>
 __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const int (&c)[R], const float (&s)[R],
-                                           int NT, const float4* __restrict__ tab, float (&res)[R]) {
+                                           int NT, const float4* __restrict__ tab, const TapModes tmd, float (&res)[R]) {
   float q[R], e[R], d[R];
   lds_cfloat* tp[R];
   lds_cfloat* tm[R];
@@ -184,13 +212,16 @@ __device__ __forceinline__ void taps_unity(const float* __restrict__ tile, const
     unity_chunk<kRcp, false, R>(tp, tm, q, e, d, tab, n0, NT);
     n0 += kChunk;
 #pragma unroll 1
-    for (; n0 + kChunk <= NT && n0 < kPoly1From; n0 += kChunk) unity_chunk<kPoly2, false, R>(tp, tm, q, e, d, tab, n0, NT);
+    for (; n0 + kChunk <= NT && n0 < tmd.p1_from; n0 += kChunk) unity_chunk<kPoly2, false, R>(tp, tm, q, e, d, tab, n0, NT);
 #pragma unroll 1
-    for (; n0 + kChunk <= NT; n0 += kChunk) unity_chunk<kPoly1, false, R>(tp, tm, q, e, d, tab, n0, NT);
+    for (; n0 + kChunk <= NT && n0 < tmd.p0_from; n0 += kChunk) unity_chunk<kPoly1, false, R>(tp, tm, q, e, d, tab, n0, NT);
+#pragma unroll 1
+    for (; n0 + kChunk <= NT; n0 += kChunk) unity_chunk<kPoly0, false, R>(tp, tm, q, e, d, tab, n0, NT);
   }
   if (n0 == 1) unity_chunk<kRcp, true, R>(tp, tm, q, e, d, tab, n0, NT);
-  else if (n0 < kPoly1From) unity_chunk<kPoly2, true, R>(tp, tm, q, e, d, tab, n0, NT);
-  else unity_chunk<kPoly1, true, R>(tp, tm, q, e, d, tab, n0, NT);
+  else if (n0 < tmd.p1_from) unity_chunk<kPoly2, true, R>(tp, tm, q, e, d, tab, n0, NT);
+  else if (n0 < tmd.p0_from) unity_chunk<kPoly1, true, R>(tp, tm, q, e, d, tab, n0, NT);
+  else unity_chunk<kPoly0, true, R>(tp, tm, q, e, d, tab, n0, NT);
   const float b0 = tab[0].y;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -221,9 +252,14 @@ __device__ __forceinline__ void general_chunk(lds_cfloat* (&tp)[R], lds_cfloat* 
         if (n0 + k > NT) sm = 0.0f;
       }
       const float G = sp * g.U[r], H = sm * g.V[r];
-      const float Rn = tap_R<MODE>(g.q[r], ab[k]);
-      g.accM[r] = fmaf(G - H, Rn, g.accM[r]);
-      g.accP[r] = fmaf((G + H) * Rn, fn, g.accP[r]);
+      if (MODE == kPoly0) {
+        g.accM[r] = fmaf(G - H, ab[k].x, g.accM[r]);
+        g.accP[r] = fmaf(G + H, ab[k].y, g.accP[r]);
+      } else {
+        const float Rn = tap_R<MODE>(g.q[r], ab[k]);
+        g.accM[r] = fmaf(G - H, Rn, g.accM[r]);
+        g.accP[r] = fmaf((G + H) * Rn, fn, g.accP[r]);
+      }
       const float un = fmaf(g.c2[r], g.U[r], -g.Up[r]);
       g.Up[r] = g.U[r];
       g.U[r] = un;
@@ -242,7 +278,7 @@ __device__ __forceinline__ void general_chunk(lds_cfloat* (&tp)[R], lds_cfloat* 
 template <int R>
 __device__ __forceinline__ void taps_general(const float* __restrict__ tile, const int (&c)[R], const float (&s)[R],
                                              const float (&fc)[R], const float (&dd)[R], int NT,
-                                             const float4* __restrict__ tab, float (&res)[R]) {
+                                             const float4* __restrict__ tab, const TapModes tmd, float (&res)[R]) {
   GenState<R> g;
   float centre[R];
   lds_cfloat* tp[R];
@@ -277,150 +313,362 @@ __device__ __forceinline__ void taps_general(const float* __restrict__ tile, con
     general_chunk<kRcp, false, R>(tp, tm, g, tab, n0, NT);
     n0 += kChunk;
 #pragma unroll 1
-    for (; n0 + kChunk <= NT && n0 < kPoly1From; n0 += kChunk) general_chunk<kPoly2, false, R>(tp, tm, g, tab, n0, NT);
+    for (; n0 + kChunk <= NT && n0 < tmd.p1_from; n0 += kChunk) general_chunk<kPoly2, false, R>(tp, tm, g, tab, n0, NT);
 #pragma unroll 1
-    for (; n0 + kChunk <= NT; n0 += kChunk) general_chunk<kPoly1, false, R>(tp, tm, g, tab, n0, NT);
+    for (; n0 + kChunk <= NT && n0 < tmd.p0_from; n0 += kChunk) general_chunk<kPoly1, false, R>(tp, tm, g, tab, n0, NT);
+#pragma unroll 1
+    for (; n0 + kChunk <= NT; n0 += kChunk) general_chunk<kPoly0, false, R>(tp, tm, g, tab, n0, NT);
   }
   if (n0 == 1) general_chunk<kRcp, true, R>(tp, tm, g, tab, n0, NT);
-  else if (n0 < kPoly1From) general_chunk<kPoly2, true, R>(tp, tm, g, tab, n0, NT);
-  else general_chunk<kPoly1, true, R>(tp, tm, g, tab, n0, NT);
+  else if (n0 < tmd.p1_from) general_chunk<kPoly2, true, R>(tp, tm, g, tab, n0, NT);
+  else if (n0 < tmd.p0_from) general_chunk<kPoly1, true, R>(tp, tm, g, tab, n0, NT);
+  else general_chunk<kPoly0, true, R>(tp, tm, g, tab, n0, NT);
 #pragma unroll
   for (int r = 0; r < R; ++r) res[r] = centre[r] + fmaf(s[r], g.accM[r], g.accP[r]);
 }
 
-// 6 waves/SIMD (80 VGPRs) measured best: 4 -> 1.39 ms, 5 -> 1.29, 6 -> 1.25, 7 -> 1.32, 8 -> 1.59 (spills) per
-// 115 M outputs.  Fully unrolling the tap loop (compile-time NT) was tried twice and spills badly.
-//
-// FUSED = true: there is no position array in HBM.  The workgroup regenerates the float64 positions of its
-// tile into LDS from the plan (segment starts / offsets / speeds) and the per-segment cumsum checkpoints:
-// one lane per checkpoint block advances kCk sequential float64 adds (bit-identical to numpy's cumsum) and
-// scatters pos = cumsum + offset into P[]; everything downstream is the same code as the position-array path.
+// ---- NT-specialised tap loops ---------------------------------------------------------------------------
+// Measured on gfx950 (tools/ubench2.hip): a VALU instruction with an SGPR source operand (or the same VGPR twice, or
+// a compare / convert / select / DPP / any float64 operation) issues in ~4 cycles per wave, one whose sources are
+// distinct VGPRs or an instruction literal in ~2.  The generic loops above keep their table in SGPRs (a third of their
+// instructions are therefore slow).  For the tap counts that matter (TapTab<NT>: NT = 32, the benchmark's 64 taps, and
+// NT = 50, the GUI default) the loops are fully unrolled instead: every coefficient is an instruction literal, LDS
+// offsets are immediates off ONE base pointer per output, and the polynomial forms are accumulated coefficient by
+// coefficient (e = e0 + q e1 + q^2 e2 is assembled once at the end) so that no per-tap weight is ever formed:
+//   constant form 4, linear 6, 2-term series 8 VALU per tap pair and output (unity path), all fast.
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+template <int NT, int R>
+__device__ __forceinline__ void taps_unity_ct(const float* __restrict__ tile, const int (&c)[R], const float (&s)[R],
+                                              const int nt_rt, float (&res)[R]) {
+  using T = TapTab<NT>;
+  float q[R], e0[R], e1[R], e2[R], d0[R], d1[R], d2[R];
+  lds_cfloat* base[R];
+  lds_cfloat* tl = (lds_cfloat*)tile;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    q[r] = s[r] * s[r];
+    e0[r] = e1[r] = e2[r] = d0[r] = d1[r] = d2[r] = 0.0f;
+    base[r] = tl + c[r] - NT;                // tap +n at [NT + n], tap -n at [NT - n]: immediates
+  }
+  // One basic block per chunk of kChunk taps: the (always true, but opaque to the compiler) test on the run-time NT keeps
+  // the instruction selector from interleaving the whole unrolled sequence -- left as ONE block it runs loads and
+  // recurrences dozens of taps ahead and spills hundreds of registers (measured twice with loop unrolling, once here).
+  static_for<(NT + kChunk - 1) / kChunk>([&](auto cidx) {
+   constexpr int n0 = decltype(cidx)::value * kChunk + 1;
+   if (nt_rt >= n0) static_for<(n0 + kChunk - 1 <= NT ? kChunk : NT - n0 + 1)>([&](auto idx) {
+    constexpr int n = n0 + decltype(idx)::value;          // 1 .. NT
+    constexpr int mode = T::mode[n];
+    constexpr float fn = (float)n;
+    if constexpr (n == T::p1_from && T::p1_from > kPoly2From) {   // the 2-term rows are behind us: fold their q^2 sums
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        e1[r] = fmaf(q[r], e2[r], e1[r]);
+        d1[r] = fmaf(q[r], d2[r], d1[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if constexpr (n == NT) {
+        // the reference's window is offsets -NT .. NT-1: tap -NT is in it with the Hann endpoint weight 0 (a NaN/Inf
+        // sample there still poisons the sum as 0 * NaN), tap +NT is not
+        e0[r] = fmaf(base[r][0], 0.0f, e0[r]);
+      } else {
+        const float sp = base[r][NT + n], sm = base[r][NT - n];
+        const float D = sp - sm, E = sp + sm;
+        if constexpr (mode == kRcp) {
+#pragma clang fp contract(off)
+          const float x = q[r] * T::B[n] + T::A[n];                 // two literals: a multiply and an add, both fast
+          const float Rn = fast_rcp(x);
+          const float DR = D * Rn;
+          if constexpr (n & 1) {
+            e0[r] = fmaf(-E, Rn, e0[r]);
+            d0[r] = fmaf(DR, -fn, d0[r]);
+          } else {
+            e0[r] = fmaf(E, Rn, e0[r]);
+            d0[r] = fmaf(DR, fn, d0[r]);
+          }
+        } else if constexpr (mode == kPoly2) {
+          e0[r] = fmaf(E, T::A[n], e0[r]);
+          e1[r] = fmaf(E, T::B[n], e1[r]);
+          e2[r] = fmaf(E, T::C[n], e2[r]);
+          d0[r] = fmaf(D, fn * T::A[n], d0[r]);
+          d1[r] = fmaf(D, fn * T::B[n], d1[r]);
+          d2[r] = fmaf(D, fn * T::C[n], d2[r]);
+        } else if constexpr (mode == kPoly1) {
+          e0[r] = fmaf(E, T::A[n], e0[r]);
+          e1[r] = fmaf(E, T::B[n], e1[r]);
+          d0[r] = fmaf(D, fn * T::A[n], d0[r]);
+          d1[r] = fmaf(D, fn * T::B[n], d1[r]);
+        } else {
+          e0[r] = fmaf(E, T::A[n], e0[r]);
+          d0[r] = fmaf(D, fn * T::A[n], d0[r]);
+        }
+      }
+    }
+   });
+  });
+  constexpr float b0 = T::B[0];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float e = fmaf(q[r], e1[r], e0[r]), d = fmaf(q[r], d1[r], d0[r]);
+    const float centre = tile[c[r]] * fast_rcp(s[r] * b0);
+    res[r] = -sinpi_half(s[r]) * (centre + fmaf(s[r], e, d));
+  }
+}
+
+template <int NT, int R>
+__device__ __forceinline__ void taps_general_ct(const float* __restrict__ tile, const int (&c)[R], const float (&s)[R],
+                                                const float (&fc)[R], const float (&dd)[R], const int nt_rt,
+                                                float (&res)[R]) {
+  using T = TapTab<NT>;
+  float q[R], U[R], Up[R], V[R], Vp[R], c2[R], M0[R], M1[R], M2[R], P0[R], P1[R], P2[R], centre[R];
+  lds_cfloat* base[R];
+  lds_cfloat* tl = (lds_cfloat*)tile;
+  constexpr float b0 = T::B[0];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float h = fc[r] * s[r];                    // phi / pi, |h| <= 0.5
+    const float sphi = sinpi_half(h), cphi = cospi_half(h);
+    float sth, cth;                                   // sin/cos(theta), theta = pi*fc = pi - pi*dd
+    if (dd[r] <= 0.5f) {
+      sth = sinpi_half(dd[r]);
+      cth = -cospi_half(dd[r]);
+    } else {
+      sth = sinpi_half(fc[r]);
+      cth = cospi_half(fc[r]);
+    }
+    Up[r] = -sphi;                                    // U_0 = sin(-phi)
+    Vp[r] = sphi;                                     // V_0 = sin(+phi)
+    U[r] = fmaf(sth, cphi, -cth * sphi);              // U_1 = sin(theta - phi)
+    V[r] = fmaf(sth, cphi, cth * sphi);               // V_1 = sin(theta + phi)
+    c2[r] = 2.0f * cth;
+    q[r] = s[r] * s[r];
+    centre[r] = tile[c[r]] * (Up[r] * fast_rcp(s[r] * b0));
+    M0[r] = M1[r] = M2[r] = P0[r] = P1[r] = P2[r] = 0.0f;
+    base[r] = tl + c[r] - NT;
+  }
+  static_for<(NT + kChunk - 1) / kChunk>([&](auto cidx) {
+   constexpr int n0 = decltype(cidx)::value * kChunk + 1;
+   if (nt_rt >= n0) static_for<(n0 + kChunk - 1 <= NT ? kChunk : NT - n0 + 1)>([&](auto idx) {
+    constexpr int n = n0 + decltype(idx)::value;
+    constexpr int mode = T::mode[n];
+    constexpr float fn = (float)n;
+    constexpr float sg = (n & 1) ? -1.0f : 1.0f;      // the numerators carry (-1)^n themselves: undo the table's sign
+    if constexpr (n == T::p1_from && T::p1_from > kPoly2From) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        M1[r] = fmaf(q[r], M2[r], M1[r]);
+        P1[r] = fmaf(q[r], P2[r], P1[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if constexpr (n == NT) {
+        M0[r] = fmaf(base[r][0] * V[r], 0.0f, M0[r]);             // tap -NT: weight 0, poison kept (see taps_unity_ct)
+      } else {
+        const float sp = base[r][NT + n], sm = base[r][NT - n];
+        const float G = sp * U[r], H = sm * V[r];
+        const float t1 = G - H, t2 = G + H;
+        if constexpr (mode == kRcp) {
+#pragma clang fp contract(off)
+          const float x = q[r] * T::B[n] + T::A[n];
+          const float Rn = fast_rcp(x);
+          M0[r] = fmaf(t1, Rn, M0[r]);
+          P0[r] = fmaf(t2 * Rn, fn, P0[r]);
+        } else if constexpr (mode == kPoly2) {
+          M0[r] = fmaf(t1, sg * T::A[n], M0[r]);
+          M1[r] = fmaf(t1, sg * T::B[n], M1[r]);
+          M2[r] = fmaf(t1, sg * T::C[n], M2[r]);
+          P0[r] = fmaf(t2, sg * fn * T::A[n], P0[r]);
+          P1[r] = fmaf(t2, sg * fn * T::B[n], P1[r]);
+          P2[r] = fmaf(t2, sg * fn * T::C[n], P2[r]);
+        } else if constexpr (mode == kPoly1) {
+          M0[r] = fmaf(t1, sg * T::A[n], M0[r]);
+          M1[r] = fmaf(t1, sg * T::B[n], M1[r]);
+          P0[r] = fmaf(t2, sg * fn * T::A[n], P0[r]);
+          P1[r] = fmaf(t2, sg * fn * T::B[n], P1[r]);
+        } else {
+          M0[r] = fmaf(t1, sg * T::A[n], M0[r]);
+          P0[r] = fmaf(t2, sg * fn * T::A[n], P0[r]);
+        }
+        const float vn = fmaf(c2[r], V[r], -Vp[r]);
+        Vp[r] = V[r];
+        V[r] = vn;
+        if constexpr (n + 1 < NT) {                   // U_NT is never used (tap +NT is outside the window)
+          const float un = fmaf(c2[r], U[r], -Up[r]);
+          Up[r] = U[r];
+          U[r] = un;
+        }
+      }
+    }
+   });
+  });
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float accM = fmaf(q[r], M1[r], M0[r]), accP = fmaf(q[r], P1[r], P0[r]);
+    res[r] = centre[r] + fmaf(s[r], accM, accP);
+  }
+}
+
+// ---- output placement -------------------------------------------------------------------------------
+// What the tap loops need per output: the integer window centre (relative to a block-uniform EVEN anchor, so that
+// indices are int32 and round-half-even ties equal rint(p)), the sub-sample shift, fc and 1 - fc.
 struct FusedArgs {
   const double* speeds;
   const int64_t* seg_start;
   const double* seg_off;
   const double* ck;
   const int64_t* tile_seg;
+  const SegFast* seg_fast;
   int64_t nseg;
 };
-constexpr int kPosLds = kSincTile + 2;                 // positions jlo .. jhi of a tile (fused mode)
-constexpr int kPosLdsFloats = 2 * kPosLds + 2;         // float slots they occupy (keeps the tile 16-B aligned)
-constexpr int kSincCapFused = kSincCap;                 // same staging limit in both forms: identical fast/edge-path
-                                                        // decisions, hence bit-identical outputs
 
-__device__ __forceinline__ void generate_tile_positions(const FusedArgs& fa, int64_t j0, int64_t len_out, int64_t jlo,
-                                                        int64_t jhi, double* __restrict__ P, int t, int n_threads) {
-  const int64_t T = j0 / kSincTile;
-  long long i0 = fa.tile_seg[T];
-  if (jlo < fa.seg_start[i0]) i0 -= 1;                                    // j0 opens a segment: j0-1 is in the previous one
-  const int64_t n_tiles = (len_out + kSincTile - 1) / kSincTile;
-  const long long i1 = (jhi == (T + 1) * kSincTile) ? fa.tile_seg[T + 1] : fa.tile_seg[n_tiles];   // segment holding jhi
-  const long long s0 = fa.seg_start[i0], s1 = fa.seg_start[i1];
-  const long long g_lo = ck_slot0(s0, i0) + (jlo - s0) / kCk;
-  const long long g_hi = ck_slot0(s1, i1) + (jhi - s1) / kCk;
-  for (long long g = g_lo + t; g <= g_hi; g += n_threads) {
-    // slot -> (segment, block): slot0 is monotone in the segment index
-    long long lo = i0, hi = i1;
-    if (hi - lo <= 16) {
-      while (lo < hi && ck_slot0(fa.seg_start[lo + 1], lo + 1) <= g) ++lo;
-    } else {
-      while (lo < hi) {
-        const long long mid = (lo + hi + 1) >> 1;
-        if (ck_slot0(fa.seg_start[mid], mid) <= g) lo = mid; else hi = mid - 1;
-      }
-    }
-    const long long i = lo;
-    const long long start = fa.seg_start[i];
-    const long long n = fa.seg_start[i + 1] - start;
-    const long long b = g - ck_slot0(start, i);
-    const long long k0 = b * kCk;
-    if (k0 >= n) continue;                                                // unused gap slot
-    const Ramp r = make_ramp(fa.speeds[i], fa.speeds[i + 1], n);
-    const double off = fa.seg_off[i];
-    double c = b ? fa.ck[g] : 0.0;
-    double rr[kCk];
-    const double a0 = (double)k0;
-#pragma unroll
-    for (int u = 0; u < kCk; ++u) rr[u] = ramp_recip(a0 + (double)u, r);
-#pragma unroll
-    for (int u = 0; u < kCk; ++u) {
-#pragma clang fp contract(off)
-      c = c + rr[u];
-      const long long jj = start + k0 + u;
-      if (k0 + u < n && jj >= jlo && jj <= jhi) P[jj - jlo] = c + off;
-    }
-  }
+// From a float64 position and the distance to the next one: util/resampling.py:66-79 (the position-array form, and
+// every output the closed form below hands over).
+__device__ __forceinline__ void place_from_pos(double p, double dp, double anchor_d, int& c, float& s, float& fc, float& dd,
+                                               bool& lowfc, bool& wild) {
+  const double rel = p - anchor_d;             // exact to ~1e-13: anchor is within a tile's span of p
+  const double rf = rint(rel);
+  wild = !(fabs(rel) < 1.0e9);
+  c = wild ? 0 : (int)rf;
+  const float sh = (float)(rel - rf);          // = p - rint(p)
+  s = (sh == 0.0f) ? 1e-20f : sh;              // np.sinc's own 0 -> 1e-20 substitution
+  const bool one = !(dp > 1.0);                // fc == 1 (also catches the 1e-12 floor)
+  // fc < 1/8 (an 8x slow-down of the read head and more): the output is a long average, small against the
+  // signal, and float32 tap arithmetic (abs. error ~1e-6 of the signal level) would exceed 1e-5 of the OUTPUT
+  // peak -- those lanes take the float64 path (not an audio-restoration regime; found by tools/fuzz_resampler.py)
+  lowfc = dp > 8.0;
+  const float inv = fast_rcp((float)(dp > 1e-12 ? dp : 1e-12));
+  fc = one ? 1.0f : inv;
+  dd = one ? 0.0f : (float)(dp - 1.0) * inv;   // 1 - fc without cancellation
 }
 
+// EXACT position of output j of segment i and the period to its successor, as numpy produces them
+// (util/resampling.py:120-126): the cumsum restarts from the checkpoint below j and repeats the reference's own
+// sequential float64 adds.  Slow (up to kCk + 1 correctly rounded reciprocals per output); only outputs the closed
+// form cannot vouch for come here.  (Pointers by value, result by value: a noinline function taking references would
+// force the kernel's argument struct into scratch memory.)
+struct PosDp {
+  double p, dp;
+};
+__device__ __noinline__ PosDp place_exact(const double* __restrict__ speeds, const int64_t* __restrict__ seg_start,
+                                          const double* __restrict__ seg_off, const double* __restrict__ ckp, long long i,
+                                          long long j, long long len_out) {
+#pragma clang fp contract(off)
+  const long long start = seg_start[i], n = seg_start[i + 1] - start;
+  const long long k = j - start, b = k / kCk;
+  const Ramp r = make_ramp(speeds[i], speeds[i + 1], n);
+  const double off = seg_off[i];
+  double c = b ? ckp[ck_slot0(start, i) + b] : 0.0;
+  double cprev = c;
+  for (long long v = b * kCk; v <= k; ++v) {
+    cprev = c;
+    c = c + ramp_recip((double)v, r);
+  }
+  PosDp o;
+  o.p = c + off;
+  if (j + 1 < len_out) {
+    double pn;
+    if (k + 1 < n) {
+      pn = (c + ramp_recip((double)(k + 1), r)) + off;
+    } else {                                             // first output of the next segment (cumsum restarts at 0)
+      const long long n2 = seg_start[i + 2] - seg_start[i + 1];
+      const Ramp r2 = make_ramp(speeds[i + 1], speeds[i + 2], n2);
+      pn = (0.0 + ramp_recip(0.0, r2)) + seg_off[i + 1];
+    }
+    o.dp = pn - o.p;
+  } else {                                               // last output reuses the previous period (:76-77)
+    const double pp = k > 0 ? cprev + off : off;         // k == 0: the offset IS the previous segment's last position
+    o.dp = o.p - pp;
+  }
+  return o;
+}
+
+// Closed-form placement (the fast path of the fused kernel).  The reference's position is
+//     p_j = fl( off_i + c_k ),   c_k = sum_{v <= k} 1/speed_v   (sequential float64 adds)
+// and the plan stores c at every kCk-th step.  Behind the checkpoint lie w = (k mod kCk) + 1 reciprocals of a LINEAR
+// ramp, whose sum is  w r_m (1 + (r_m step)^2 (w^2 - 1)/12)  up to a fourth-order remainder (r_m = reciprocal at the
+// midpoint step; the plan marks a segment `fast` only where that remainder is < 2e-10 samples).  Everything is kept
+// relative to the anchor and to rint(off_i), so the float64 operands are small and the result is accurate to ~1e-10 --
+// MORE accurate than the reference's own p_j, which carries the rounding of its last add (half an ulp of p: 6e-8 at
+// 7e8).  Consequences: shift differs from the reference's by <= ulp(p)/2 (output: ~2e-7 relative at worst), and
+// rint(p) can differ only when p lies within that distance of a half-integer -- such outputs are flagged (`exact`) and
+// recomputed with the reference's own arithmetic, so every window centre is the reference's.
+// The period to the next position is 1/speed at the next step, so fc = min(1, speed_next) needs no division at all.
+__device__ __forceinline__ void place_fast(const FusedArgs& fa, long long i, long long j, long long len_out, long long anchor,
+                                           double tol, int& c, float& s, float& fc, float& dd, bool& lowfc, bool& wild,
+                                           bool& exact) {
+  const long long start = fa.seg_start[i];
+  const SegFast sf = fa.seg_fast[i];
+  const double s0 = fa.speeds[i];
+  const int k = (int)(j - start);
+  const int u = k & (kCk - 1);                           // steps between the checkpoint and this output
+  const long long b = k >> 3;
+  static_assert(kCk == 8, "k >> 3");
+  const double ckv = b ? fa.ck[ck_slot0(start, i) + b] : 0.0;
+  const long long dA = sf.A - anchor;
+  wild = !(dA > -2000000000ll && dA < 2000000000ll);
+  const double base = ((double)(int)dA + sf.foff) + ckv;
+  const double tm = (double)k - 0.5 * (double)u;         // midpoint of steps k-u .. k
+  const double bsm = fma(sf.step, tm, s0);
+  double r = __builtin_amdgcn_rcp(bsm);                  // ~2^-26; one Newton step -> ~1e-15
+  r = fma(r, fma(-bsm, r, 1.0), r);
+  const double z = r * sf.step;
+  const double cw = (double)(u * (u + 2)) * (1.0 / 12.0);   // (w^2 - 1)/12 with w = u + 1
+  const double prel = fma(r * (double)(u + 1), fma(z * z, cw, 1.0), base);
+  const double rf = rint(prel);
+  const double shd = prel - rf;
+  if (!(fabs(prel) < 1.0e9)) wild = true;
+  c = wild ? 0 : (int)rf;
+  const float sh = (float)shd;
+  s = (sh == 0.0f) ? 1e-20f : sh;
+  // rint(p) is the reference's when p is farther from a half-integer than the reference's own roundings: half an ulp of
+  // p (tol) plus, per add behind the checkpoint, half an ulp of the running sum (matters for segments of > 10^7 outputs)
+  exact = !sf.fast || !(fabs(fabs(shd) - 0.5) > fma(ckv, 9.6e-16, tol));
+  int kn = k + 1 < sf.n ? k + 1 : sf.n - 1;              // the last output of a segment looks at the next segment's
+  if (j + 1 >= len_out) kn = k;                          // first speed = this ramp's end; the global last one back
+  const double bsn = fma(sf.step, (double)kn, s0);
+  const bool one = !(bsn < 1.0);
+  fc = one ? 1.0f : (float)bsn;
+  dd = one ? 0.0f : (float)(1.0 - bsn);
+  lowfc = bsn < 0.125;
+}
+
+// ---- the tile body shared by both kernel forms --------------------------------------------------------
+// Stages the tile's input span once, runs the tap loops, writes the outputs.  slow_pos(r, p, dp) yields the float64
+// position of the lane's r-th output for the (rare) lanes that leave the float32 path.
 // NCH = 2: two channels of one file (same positions) in one launch.  A lane then owns 2 outputs x 2 channels instead of
 // 4 outputs x 1: the register state and the per-lane ILP are those of the mono kernel, the workgroup has 512 threads
-// for the same 1024-output tile, and everything that depends only on the POSITION -- regeneration from the plan,
-// prologue, window-centre search, and (because both channel slots of an output carry the very same shift / fc
-// values) the tap weights themselves -- is computed once for both channels.
-template <bool FUSED, int NCH>
-__global__ __launch_bounds__(kSincBlock * NCH, 6) void k_sinc(const double* __restrict__ pos, int64_t len_out,
-                                                            const float* __restrict__ sig, const float* __restrict__ sig1,
-                                                            int64_t sig_stride, int64_t len_in, int NT,
-                                                            const float4* __restrict__ tab, float* __restrict__ out,
-                                                            float* __restrict__ out1, int64_t out_stride, int64_t j_begin,
-                                                            int64_t j_end, FusedArgs fa) {
+// for the same 1024-output tile, and everything that depends only on the POSITION -- placement, window-centre search,
+// and (because both channel slots of an output carry the very same shift / fc values) the tap weights themselves -- is
+// computed once for both channels.
+template <int NCH, int NTC, class SlowPos>
+__device__ __forceinline__ void sinc_tile_body(float* __restrict__ tile, int* __restrict__ red, const int t, const int64_t j0,
+                                               const int64_t j_end, const long long anchor, int (&c)[kSincR / NCH],
+                                               const float (&s)[kSincR / NCH], const float (&fc)[kSincR / NCH],
+                                               const float (&dd)[kSincR / NCH], const bool (&valid)[kSincR / NCH],
+                                               const bool (&lowfc)[kSincR / NCH], const bool unity_in, const bool wild,
+                                               const float* __restrict__ sig, const float* __restrict__ sig1,
+                                               const int64_t sig_stride, const int64_t len_in, const int NT,
+                                               const float4* __restrict__ tab, const TapModes tmd, float* __restrict__ out,
+                                               float* __restrict__ out1, const int64_t out_stride, SlowPos slow_pos) {
   constexpr int kBlk = kSincBlock * NCH;        // threads per workgroup
   constexpr int kOut = kSincR / NCH;            // outputs per lane; kOut * NCH = kSincR (output, channel) slots
-  static_assert(NCH == 1 || NCH == 2, "mono or stereo");
-  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-  __shared__ int red[2 * (kBlk / kWave)];
-  const int t = threadIdx.x;
-  const int64_t j0 = j_begin + (int64_t)blockIdx.x * kSincTile;     // this launch covers outputs [j_begin, j_end)
-  float* tile = FUSED ? lds_raw + kPosLdsFloats : lds_raw;
-  const int cap = FUSED ? kSincCapFused : kSincCap;
-  // position source: the caller's array, or the tile's positions regenerated into LDS
-  double* P = reinterpret_cast<double*>(lds_raw);
-  const int64_t jlo = j0 > 0 ? j0 - 1 : 0;
-  if (FUSED) {
-    const int64_t jhi = (j0 + kSincTile < len_out) ? j0 + kSincTile : len_out - 1;
-    generate_tile_positions(fa, j0, len_out, jlo, jhi, P, t, kBlk);
-    __syncthreads();
-  }
-  const double* psrc = FUSED ? P - jlo : pos;     // psrc[j] is the position of output j in both modes
-
-  // Block-uniform EVEN integer anchor: indices are handled as int32 offsets from it (no 64-bit integer
-  // math per output); an even anchor keeps round-half-even ties identical to rint(p).
-  const double p0 = psrc[j0];
-  const long long anchor = (fabs(p0) < 4.0e18) ? (llrint(p0) & ~1ll) : 0ll;
-  const double anchor_d = (double)anchor;
-  float res[kSincR];                               // one per (output, channel) slot: slot = output * NCH + channel
-  int c[kOut];                                     // first: index relative to the anchor, later: LDS index
-  float s[kOut], fc[kOut], dd[kOut];
-  bool valid[kOut], fastlane[kOut], lowfc[kOut];
-  bool unity = true, wild = false;
+  constexpr int cap = kSincCap;
+  float res[kSincR];                            // one per (output, channel) slot: slot = output * NCH + channel
+  bool fastlane[kOut];
   int mn = INT_MAX, mx = INT_MIN;
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
-    const int64_t j = j0 + t + (int64_t)r * kBlk;
-    valid[r] = j < j_end;
-    lowfc[r] = false;
-    c[r] = 0;
-    s[r] = 0.25f;
-    fc[r] = 1.0f;
-    dd[r] = 0.0f;
     if (valid[r]) {
-      const double p = psrc[j];
-      // last output reuses the previous period (util/resampling.py:76-77)
-      const double dp = (j + 1 < len_out) ? psrc[j + 1] - p : p - psrc[j - 1];
-      const double rel = p - anchor_d;             // exact to ~1e-13: anchor is within a tile's span of p
-      const double rf = rint(rel);
-      if (fabs(rel) < 1.0e9) c[r] = (int)rf; else wild = true;
-      const float sh = (float)(rel - rf);          // = p - rint(p)
-      s[r] = (sh == 0.0f) ? 1e-20f : sh;           // np.sinc's own 0 -> 1e-20 substitution
-      const bool one = !(dp > 1.0);                // fc == 1 (also catches the 1e-12 floor)
-      // fc < 1/8 (an 8x slow-down of the read head and more): the output is a long average, small against the
-      // signal, and float32 tap arithmetic (abs. error ~1e-6 of the signal level) would exceed 1e-5 of the OUTPUT
-      // peak -- those lanes take the float64 path (not an audio-restoration regime; found by tools/fuzz_resampler.py)
-      if (dp > 8.0) lowfc[r] = true;
-      const float inv = fast_rcp((float)(dp > 1e-12 ? dp : 1e-12));
-      fc[r] = one ? 1.0f : inv;
-      dd[r] = one ? 0.0f : (float)(dp - 1.0) * inv;   // 1 - fc without cancellation
-      unity = unity && one;
       mn = c[r] < mn ? c[r] : mn;
       mx = c[r] > mx ? c[r] : mx;
     }
@@ -452,6 +700,11 @@ __global__ __launch_bounds__(kSincBlock * NCH, 6) void k_sinc(const double* __re
     for (int q = t; q < (int)span; q += kBlk) {
       const long long g = lo + q;
       const bool inside = g >= 0 && g < (long long)len_in;
+      if (PAR_SINC_EXP & 16) {
+        tile[q] = 0.5f;
+        if (NCH == 2) tile[cap + q] = 0.25f;
+        continue;
+      }
       tile[q] = inside ? sig[g * sig_stride] : 0.0f;
       if (NCH == 2) tile[cap + q] = inside ? sig1[g * sig_stride] : 0.0f;      // channel 1 right behind channel 0
     }
@@ -459,7 +712,7 @@ __global__ __launch_bounds__(kSincBlock * NCH, 6) void k_sinc(const double* __re
   __syncthreads();
 
   // leading-edge outputs (ind < NT) keep the reference's mis-aligned taps: float64 slow path.
-  bool anyfast = false;
+  bool anyfast = false, unity = unity_in;
   const long long edge = (long long)NT - anchor;    // ind >= NT  <=>  rel index >= edge
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
@@ -479,11 +732,24 @@ __global__ __launch_bounds__(kSincBlock * NCH, 6) void k_sinc(const double* __re
     dds[sl] = dd[sl / NCH];
     res[sl] = 0.0f;
   }
-  if (__any(anyfast)) {
+  if (!(PAR_SINC_EXP & 1) && __any(anyfast)) {
     if (__all(unity)) {
-      taps_unity<kSincR>(tile, cs, ss, NT, tab, res);
+      if constexpr (NTC > 0) {
+        // two passes over half of the lane's slots: the unrolled form carries 6 accumulators per slot
+        const int ca[2] = {cs[0], cs[1]}, cb[2] = {cs[2], cs[3]};
+        const float sa[2] = {ss[0], ss[1]}, sb[2] = {ss[2], ss[3]};
+        float ra[2], rb[2];
+        taps_unity_ct<NTC, 2>(tile, ca, sa, NT, ra);
+        taps_unity_ct<NTC, 2>(tile, cb, sb, NT, rb);
+        res[0] = ra[0];
+        res[1] = ra[1];
+        res[2] = rb[0];
+        res[3] = rb[1];
+      } else {
+        taps_unity<kSincR>(tile, cs, ss, NT, tab, tmd, res);
+      }
     } else {
-      // the general path carries 10 live values per slot: two passes over half of the lane's slots keep
+      // the general path carries 10+ live values per slot: two passes over half of the lane's slots keep
       // it inside the 80-VGPR budget (one pass spilled 48 B/lane = as much HBM write traffic as the output)
       static_assert(kSincR == 4, "split assumes 4 slots per lane");
       const int ca[2] = {cs[0], cs[1]}, cb[2] = {cs[2], cs[3]};
@@ -491,8 +757,13 @@ __global__ __launch_bounds__(kSincBlock * NCH, 6) void k_sinc(const double* __re
       const float fa_[2] = {fcs[0], fcs[1]}, fb_[2] = {fcs[2], fcs[3]};
       const float da[2] = {dds[0], dds[1]}, db[2] = {dds[2], dds[3]};
       float ra[2], rb[2];
-      taps_general<2>(tile, ca, sa, fa_, da, NT, tab, ra);
-      taps_general<2>(tile, cb, sb, fb_, db, NT, tab, rb);
+      if constexpr (NTC > 0) {
+        taps_general_ct<NTC, 2>(tile, ca, sa, fa_, da, NT, ra);
+        taps_general_ct<NTC, 2>(tile, cb, sb, fb_, db, NT, rb);
+      } else {
+        taps_general<2>(tile, ca, sa, fa_, da, NT, tab, tmd, ra);
+        taps_general<2>(tile, cb, sb, fb_, db, NT, tab, tmd, rb);
+      }
       res[0] = ra[0];
       res[1] = ra[1];
       res[2] = rb[0];
@@ -503,25 +774,227 @@ __global__ __launch_bounds__(kSincBlock * NCH, 6) void k_sinc(const double* __re
   for (int r = 0; r < kOut; ++r) {
     const int64_t j = j0 + t + (int64_t)r * kBlk;
     if (j >= j_end) continue;
+    double pj = 0.0, dpj = 1.0;
+    if (!fastlane[r]) slow_pos(r, pj, dpj);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       float v = res[r * NCH + ch];
-      if (!fastlane[r]) {
-        const double pj = psrc[j];
-        const double dpj = (j + 1 < len_out) ? psrc[j + 1] - pj : pj - psrc[j - 1];
-        v = sinc_one_f64(pj, dpj, ch ? sig1 : sig, sig_stride, len_in, NT);
-      }
+      if (!fastlane[r]) v = sinc_one_f64(pj, dpj, ch ? sig1 : sig, sig_stride, len_in, NT);
+      if ((PAR_SINC_EXP & 32) && v != 12345.678f) continue;
       (ch ? out1 : out)[j * out_stride] = v;
     }
   }
 }
 
+// 6 waves/SIMD (80 VGPRs) measured best: 4 -> 1.39 ms, 5 -> 1.29, 6 -> 1.25, 7 -> 1.32, 8 -> 1.59 (spills) per
+// 115 M outputs.  Fully unrolling the tap loop (compile-time NT) was tried twice and spills badly.
+//
+// Position-array form (operator slot #2, sinc_wrapper): reads the caller's float64 sample_at.
+template <int NTC>
+__global__ __launch_bounds__(kSincBlock, 6) void k_sinc_pos(const double* __restrict__ pos, int64_t len_out,
+                                                             const float* __restrict__ sig, int64_t sig_stride,
+                                                             int64_t len_in, int NT, const float4* __restrict__ tab,
+                                                             TapModes tmd, float* __restrict__ out, int64_t out_stride,
+                                                             int64_t j_begin, int64_t j_end) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ int red[2 * (kSincBlock / kWave)];
+  const int t = threadIdx.x;
+  const int64_t j0 = j_begin + (int64_t)blockIdx.x * kSincTile;     // this launch covers outputs [j_begin, j_end)
+  const double p0 = pos[j0];
+  const long long anchor = (fabs(p0) < 4.0e18) ? (llrint(p0) & ~1ll) : 0ll;
+  const double anchor_d = (double)anchor;
+  int c[kSincR];
+  float s[kSincR], fc[kSincR], dd[kSincR];
+  bool valid[kSincR], lowfc[kSincR];
+  bool unity = true, wild = false;
+#pragma unroll
+  for (int r = 0; r < kSincR; ++r) {
+    const int64_t j = j0 + t + (int64_t)r * kSincBlock;
+    valid[r] = j < j_end;
+    lowfc[r] = false;
+    c[r] = 0;
+    s[r] = 0.25f;
+    fc[r] = 1.0f;
+    dd[r] = 0.0f;
+    if (valid[r]) {
+      const double p = pos[j];
+      // last output reuses the previous period (util/resampling.py:76-77)
+      const double dp = (j + 1 < len_out) ? pos[j + 1] - p : p - pos[j - 1];
+      bool w;
+      place_from_pos(p, dp, anchor_d, c[r], s[r], fc[r], dd[r], lowfc[r], w);
+      wild = wild || w;
+      unity = unity && fc[r] == 1.0f;
+    }
+  }
+  sinc_tile_body<1, NTC>(tile, red, t, j0, j_end, anchor, c, s, fc, dd, valid, lowfc, unity, wild, sig, (const float*)nullptr,
+                    sig_stride, len_in, NT, tab, tmd, out, (float*)nullptr, out_stride,
+                    [&](int r, double& p, double& dp) {
+                      const int64_t j = j0 + t + (int64_t)r * kSincBlock;
+                      p = pos[j];
+                      dp = (j + 1 < len_out) ? pos[j + 1] - p : p - pos[j - 1];
+                    });
+}
+
+// FUSED form: there is no position array in HBM.  Every output is placed straight from the plan: its segment comes
+// from a wave-uniform scan of the tile's segment boundaries (a wave's outputs of one pass are 64 consecutive indices),
+// its position from the segment record, the checkpoint below it and the closed form of place_fast.
+template <int NCH, int NTC>
+__global__ __launch_bounds__(kSincBlock * NCH, 6) void k_sinc_fused(int64_t len_out, const float* __restrict__ sig,
+                                                                  const float* __restrict__ sig1, int64_t sig_stride,
+                                                                  int64_t len_in, int NT, const float4* __restrict__ tab,
+                                                                  TapModes tmd, float* __restrict__ out,
+                                                                  float* __restrict__ out1, int64_t out_stride,
+                                                                  FusedArgs fa) {
+  constexpr int kBlk = kSincBlock * NCH;
+  constexpr int kOut = kSincR / NCH;
+  static_assert(NCH == 1 || NCH == 2, "mono or stereo");
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ int red[2 * (kBlk / kWave)];
+  const int t = threadIdx.x;
+  const int64_t T = blockIdx.x;
+  const int64_t j0 = T * kSincTile;
+#ifdef PAR_SINC_STAGGER
+  // The workgroups that fill the chip at launch start together, take the same time and are replaced together: the
+  // waves sharing a SIMD stay in lockstep, so one workgroup's load latency never hides behind another's tap loops.
+  // Delaying each first-generation wave by its hardware slot number spreads the phases for good.
+  if (T < PAR_SINC_STAGGER_BLOCKS) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);    // HW_ID.WAVE_ID
+    for (unsigned k = 0; k < slot * PAR_SINC_STAGGER; ++k) __builtin_amdgcn_s_sleep(64);
+  }
+#endif
+  // block-uniform even anchor next to the tile's first position: rint(offset) + the checkpoint below output j0
+  const long long iT = (PAR_SINC_EXP & 8) ? 0ll : fa.tile_seg[T];
+  const long long startT = fa.seg_start[iT];
+  const long long bT = (j0 - startT) >> 3;
+  const double ckT = bT ? fa.ck[ck_slot0(startT, iT) + bT] : 0.0;
+  const long long anchor = (PAR_SINC_EXP & 8) ? (long long)(j0 & ~1ll)
+                                              : (fa.seg_fast[iT].A + (fabs(ckT) < 4.0e18 ? llrint(ckT) : 0ll)) & ~1ll;
+  const double tol = (fabs((double)anchor) + 4.2e6) * 1.2e-16 + 2.0e-10;
+  const int tw = __builtin_amdgcn_readfirstlane(t);   // first thread of this wave: its outputs are tw .. tw + 63 (+ pass)
+  // the next kSegAhead segment boundaries behind the tile's first segment, wave-uniform (scalar loads, SGPRs): a wave's
+  // outputs of one pass are 64 consecutive indices, so its lanes find their segments by comparing against a few of these
+  constexpr int kSegAhead = 8;
+  long long B[kSegAhead];
+#pragma unroll
+  for (int q = 0; q < kSegAhead; ++q)
+    B[q] = (!(PAR_SINC_EXP & 8) && iT + 1 + q < fa.nseg) ? fa.seg_start[iT + 1 + q] : LLONG_MAX;
+  int c[kOut], seg[kOut];                              // seg: segment index relative to iT
+  float s[kOut], fc[kOut], dd[kOut];
+  bool valid[kOut], lowfc[kOut], exact[kOut];
+  bool unity = true, wild = false, anyexact = false;
+#pragma unroll
+  for (int r = 0; r < kOut; ++r) {
+    const int64_t j = j0 + t + (int64_t)r * kBlk;
+    valid[r] = j < len_out;
+    lowfc[r] = false;
+    exact[r] = false;
+    c[r] = 0;
+    s[r] = 0.25f;
+    fc[r] = 1.0f;
+    dd[r] = 0.0f;
+    const long long jl = j0 + tw + (long long)r * kBlk + (kWave - 1);     // the wave's last output of this pass
+    int si = 0, q = 0;
+#pragma unroll
+    for (; q < kSegAhead; ++q) {
+      if (B[q] > jl) break;
+      si += j >= B[q];
+    }
+    if (q == kSegAhead) {                               // segments shorter than 1/8 tile: keep scanning in memory
+      for (long long iu = iT + kSegAhead; iu + 1 < fa.nseg; ++iu) {
+        const long long nx = fa.seg_start[iu + 1];
+        if (nx > jl) break;
+        si += j >= nx;
+      }
+    }
+    seg[r] = si;
+    if (PAR_SINC_EXP & 2) {
+      if (valid[r]) {
+        c[r] = (int)(j - anchor) + 64;
+        s[r] = 0.3f - 1e-4f * (float)(t & 63);
+        if (PAR_SINC_EXP & 4) {
+          fc[r] = 0.995f;
+          dd[r] = 0.005f;
+        }
+      }
+    } else if (valid[r]) {
+      bool w;
+      place_fast(fa, iT + si, j, len_out, anchor, tol, c[r], s[r], fc[r], dd[r], lowfc[r], w, exact[r]);
+      wild = wild || (w && !exact[r]);
+      anyexact = anyexact || exact[r];
+    }
+  }
+  if (__any(anyexact)) {                                // rare: near a rounding tie, or a segment the closed form skips
+#pragma unroll
+    for (int r = 0; r < kOut; ++r) {
+      if (valid[r] && exact[r]) {
+        const PosDp e = place_exact(fa.speeds, fa.seg_start, fa.seg_off, fa.ck, iT + seg[r], j0 + t + (int64_t)r * kBlk, len_out);
+        bool w;
+        place_from_pos(e.p, e.dp, (double)anchor, c[r], s[r], fc[r], dd[r], lowfc[r], w);
+        wild = wild || w;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kOut; ++r) unity = unity && fc[r] == 1.0f;
+  sinc_tile_body<NCH, NTC>(tile, red, t, j0, len_out, anchor, c, s, fc, dd, valid, lowfc, unity, wild, sig, sig1, sig_stride,
+                      len_in, NT, tab, tmd, out, out1, out_stride, [&](int r, double& p, double& dp) {
+                        // (the segment is looked up again rather than kept in a register across the tap loops)
+                        const long long j = j0 + t + (int64_t)r * kBlk;
+                        long long i = iT;
+                        while (i + 1 < fa.nseg && fa.seg_start[i + 1] <= j) ++i;
+                        const PosDp e = place_exact(fa.speeds, fa.seg_start, fa.seg_off, fa.ck, i, j, len_out);
+                        p = e.p;
+                        dp = e.dp;
+                      });
+}
+
 // ---- host side: per-(device, NT) tap tables -------------------------------------------------------
 struct SincTable {
   float4* ab = nullptr;      // per-tap rows, see tap_R
+  TapModes modes{kPoly2From, kPoly2From};
 };
 static std::mutex g_tab_mu;
 static std::map<std::pair<int, int>, SincTable> g_tabs;
+
+// Which polynomial form each tap pair uses (see TapModes): worst-case error of a pair = approximation error of R_n
+// over q in [0, 1/4] times the largest the bracket n(G+H) + s(G-H) can get for unit-peak input, 2n + 1.  The forms
+// start at the first chunk boundary from which the errors of ALL pairs further out sum to less than the budget.
+static void choose_tap_modes(int NT, TapModes* tm, std::vector<double>* lin_a, std::vector<double>* lin_b,
+                             std::vector<double>* cst) {
+  std::vector<double> e0(NT + kChunk, 0.0), e1(NT + kChunk, 0.0);
+  lin_a->assign(NT + kChunk, 0.0);
+  lin_b->assign(NT + kChunk, 0.0);
+  cst->assign(NT + kChunk, 0.0);
+  for (int n = 1; n < NT; ++n) {
+    const double win = (double)(float)(0.5 + 0.5 * cos(M_PI * (double)n / (double)NT));
+    const double K = win / M_PI, n2 = (double)n * (double)n;
+    if (K <= 0.0) continue;
+    const double f0 = K / n2, f1 = K / (n2 - 0.25);
+    (*cst)[n] = 0.5 * (f0 + f1);                          // constant minimax: mid-range
+    e0[n] = 0.5 * (f1 - f0) * (2.0 * n + 1.0);
+    // linear minimax of the convex f(q) = K/(n^2 - q) on [0, 1/4]: chord slope, intercept halfway between the chord
+    // and the parallel tangent (touching at q* with f'(q*) = slope)
+    const double slope = (f1 - f0) / 0.25;
+    const double qs = n2 - sqrt(K / slope);
+    const double gap = (f0 + slope * qs) - K / (n2 - qs);
+    (*lin_b)[n] = slope;
+    (*lin_a)[n] = f0 - 0.5 * gap;
+    e1[n] = 0.5 * gap * (2.0 * n + 1.0);
+  }
+  auto first_from = [&](const std::vector<double>& e, double budget) {
+    int from = ((NT + kChunk) / kChunk) * kChunk + 1;     // beyond every chunk: form unused
+    double tail = 0.0;
+    for (int n0 = ((NT - 1) / kChunk) * kChunk + 1; n0 >= kPoly2From; n0 -= kChunk) {
+      for (int n = n0; n < n0 + kChunk && n < NT; ++n) tail += e[n];
+      if (tail > budget) break;
+      from = n0;
+    }
+    return from;
+  };
+  tm->p1_from = first_from(e1, 3.0e-7);
+  tm->p0_from = first_from(e0, 1.5e-6);
+  if (tm->p0_from < tm->p1_from) tm->p0_from = tm->p1_from;
+}
 
 static int get_sinc_table(int device, int NT, SincTable* out) {
   std::lock_guard<std::mutex> lk(g_tab_mu);
@@ -531,6 +1004,9 @@ static int get_sinc_table(int device, int NT, SincTable* out) {
     *out = it->second;
     return PAR_OK;
   }
+  SincTable t;
+  std::vector<double> lin_a, lin_b, cst;
+  choose_tap_modes(NT, &t.modes, &lin_a, &lin_b, &cst);
   // a2[n] = pi*n^2/win, b[n] = -pi/win with win = float32(np.hanning(2NT+1)[NT+n]), n = 0..NT-1
   std::vector<float4> ab(NT + kChunk);
   for (int n = 0; n < NT + kChunk; ++n) {
@@ -539,12 +1015,15 @@ static int get_sinc_table(int device, int NT, SincTable* out) {
     if (n < kPoly2From) {            // reciprocal rows; padded taps: rcp(q*b + inf) == 0
       ab[n] = n < NT ? make_float4((float)(M_PI * n2 / win), (float)(-M_PI / win), (float)n, 0.0f)
                      : make_float4(INFINITY, (float)(-M_PI), (float)n, 0.0f);
-    } else {                         // series rows; padded taps: all-zero coefficients
+    } else if (n < t.modes.p1_from) {   // 2-term series rows; padded taps: all-zero coefficients
       const double A = win / (M_PI * n2);
       ab[n] = make_float4((float)A, (float)(A / n2), (float)n, (float)(A / (n2 * n2)));
+    } else if (n < t.modes.p0_from) {   // linear minimax rows
+      ab[n] = n < NT ? make_float4((float)lin_a[n], (float)lin_b[n], (float)n, 0.0f) : make_float4(0.0f, 0.0f, (float)n, 0.0f);
+    } else {                            // constant rows: (A, n A)
+      ab[n] = n < NT ? make_float4((float)cst[n], (float)(cst[n] * n), (float)n, 0.0f) : make_float4(0.0f, 0.0f, (float)n, 0.0f);
     }
   }
-  SincTable t;
   PAR_HIP_CHECK(hipMalloc(&t.ab, ab.size() * sizeof(float4)));
   PAR_HIP_CHECK(hipMemcpy(t.ab, ab.data(), ab.size() * sizeof(float4), hipMemcpyHostToDevice));
   g_tabs[key] = t;
@@ -562,14 +1041,18 @@ int launch_sinc(int device, const double* pos, int64_t len_out, int64_t j_begin,
   int rc = get_sinc_table(device, NT, &tab);
   if (rc != PAR_OK) return rc;
   const int64_t blocks = ceil_div(count, kSincTile);
-  hipLaunchKernelGGL((k_sinc<false, 1>), dim3((unsigned)blocks), dim3(kSincBlock), kSincCap * sizeof(float), s, pos, len_out,
-                     sig, (const float*)nullptr, sig_stride, len_in, NT, tab.ab, out, (float*)nullptr, out_stride, j_begin,
-                     j_begin + count, FusedArgs{});
+#define PAR_LAUNCH_POS(NTC)                                                                                              \
+  hipLaunchKernelGGL((k_sinc_pos<NTC>), dim3((unsigned)blocks), dim3(kSincBlock), kSincCap * sizeof(float), s, pos, len_out, \
+                     sig, sig_stride, len_in, NT, tab.ab, tab.modes, out, out_stride, j_begin, j_begin + count)
+  if (NT == 32) PAR_LAUNCH_POS(32);
+  else if (NT == 50) PAR_LAUNCH_POS(50);
+  else PAR_LAUNCH_POS(0);
+#undef PAR_LAUNCH_POS
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }
 
-// whole output range, positions regenerated in-kernel from the plan + checkpoints (no position array)
+// whole output range, every output placed in-kernel from the plan + checkpoints (no position array)
 // sig1 / out1 != nullptr: second channel of the same file (same strides), resampled in the same launch
 int launch_sinc_fused(int device, const double* speeds, int64_t m, const void* work, const void* aux, int64_t max_out,
                       int64_t len_out, const float* sig, const float* sig1, int64_t sig_stride, int64_t len_in, int NT,
@@ -580,25 +1063,31 @@ int launch_sinc_fused(int device, const double* speeds, int64_t m, const void* w
   PlanView pv = plan_view(const_cast<void*>(work), m);
   // No header read-back here (it would cost a stream sync per channel): the caller vouches, through the
   // fused_ok flag of par_speed_to_pos_plan_fused, that aux holds this plan's checkpoints for max_out.
-  const int64_t ck_len = max_out / kCk + m + 16;
+  const int64_t ck_len = (int64_t)fused_ck_len(max_out, m);
   FusedArgs fa;
   fa.speeds = speeds;
   fa.seg_start = pv.seg_start;
   fa.seg_off = pv.seg_off;
   fa.ck = static_cast<const double*>(aux);
   fa.tile_seg = reinterpret_cast<const int64_t*>(fa.ck + ck_len);
+  fa.seg_fast = reinterpret_cast<const SegFast*>(fa.tile_seg + fused_tiles(max_out));
   fa.nseg = m - 1;
   const int64_t blocks = ceil_div(len_out, kSincTile);
+#define PAR_LAUNCH_FUSED(NCH, NTC)                                                                                         \
+  hipLaunchKernelGGL((k_sinc_fused<NCH, NTC>), dim3((unsigned)blocks), dim3(NCH * kSincBlock), NCH * kSincCap * sizeof(float), \
+                     s, len_out, sig, sig1, sig_stride, len_in, NT, tab.ab, tab.modes, out, out1, out_stride, fa)
   if (sig1 && out1) {
-    hipLaunchKernelGGL((k_sinc<true, 2>), dim3((unsigned)blocks), dim3(2 * kSincBlock),
-                       (kPosLdsFloats + 2 * kSincCapFused) * sizeof(float), s, (const double*)nullptr, len_out, sig, sig1,
-                       sig_stride, len_in, NT, tab.ab, out, out1, out_stride, (int64_t)0, len_out, fa);
+    if (NT == 32) PAR_LAUNCH_FUSED(2, 32);
+    else if (NT == 50) PAR_LAUNCH_FUSED(2, 50);
+    else PAR_LAUNCH_FUSED(2, 0);
   } else {
-    hipLaunchKernelGGL((k_sinc<true, 1>), dim3((unsigned)blocks), dim3(kSincBlock),
-                       (kPosLdsFloats + kSincCapFused) * sizeof(float), s, (const double*)nullptr, len_out, sig,
-                       (const float*)nullptr, sig_stride, len_in, NT, tab.ab, out, (float*)nullptr, out_stride, (int64_t)0,
-                       len_out, fa);
+    sig1 = nullptr;
+    out1 = nullptr;
+    if (NT == 32) PAR_LAUNCH_FUSED(1, 32);
+    else if (NT == 50) PAR_LAUNCH_FUSED(1, 50);
+    else PAR_LAUNCH_FUSED(1, 0);
   }
+#undef PAR_LAUNCH_FUSED
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }

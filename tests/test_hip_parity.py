@@ -21,6 +21,21 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
+FUSED_TOL = 2e-6
+
+
+def same_resample(fused, via_pos):
+    """Fused K_sinc against the position-array K_sinc on the oracle-exact float64 positions.  Every window centre
+    rint(p) is the same (near-ties are redone with the reference's own arithmetic); the sub-sample shift comes from the
+    closed form, which is accurate to 1e-10 where the reference's own position carries half an ulp of rounding (6e-8 at
+    7e8), so the two outputs agree to a few 1e-7 of the peak, not bit for bit."""
+    a, b = fused.float(), via_pos.float()
+    if a.shape != b.shape:
+        return False
+    return bool(((a - b).abs().max() <= FUSED_TOL * b.abs().max()).item()) and bool((a.isnan() == b.isnan()).all().item())
+
+
+
 @pytest.fixture(scope="module")
 def par():
     import torch
@@ -297,7 +312,7 @@ def test_strong_slowdown_and_wide_tiles_found_by_fuzz(par):
     pos_t = par.resampling.speed_to_pos_dev(st_t, sp_t, n)
     for NT in (2, 32):
         fused = par.resampling.varispeed_fused_dev(plan, sig_t, NT)
-        assert t.equal(fused, par.resampling.sinc_resample_dev(pos_t, sig_t, NT))
+        assert same_resample(fused, par.resampling.sinc_resample_dev(pos_t, sig_t, NT))
         assert relerr(fused.cpu().numpy(), C.sinc(pos_t.cpu().numpy(), sig, NT)) < TOL
 
 
@@ -536,7 +551,7 @@ def test_full_size_config2_properties(par):
     # 3. fused output == position-array output everywhere, == oracle on 24 windows across the hour
     out = par.resampling.varispeed_fused_dev(plan, sig_t, 32)
     out2 = par.resampling.sinc_resample_dev(pos_t, sig_t, 32)
-    assert t.equal(out, out2)
+    assert same_resample(out, out2)
     del out2
     for i in np.linspace(0, len(ref_pos) - 3000, 24).astype(np.int64):
         lo = max(0, int(ref_pos[i]) - 200)
@@ -695,14 +710,14 @@ def test_fused_varispeed_equals_position_array_path(par):
             assert plan.fused_ok and plan.len_out == pos_ref.numel(), (name, force_host)
             out = par.resampling.varispeed_fused_dev(plan, sig_t, 32)
             t.cuda.synchronize()
-            assert t.equal(out, out_ref), (name, force_host, float((out - out_ref).abs().max()))
+            assert same_resample(out, out_ref), (name, force_host, float((out - out_ref).abs().max()))
     # other qualities through the same fused path
     sig_t = t.from_numpy(inputs.noise(n, 6)).cuda()
     st_t, sp_t = t.from_numpy(sc[:, 0] * sr).cuda(), t.from_numpy(np.ascontiguousarray(sc[:, 1])).cuda()
     pos_ref = par.resampling.speed_to_pos_dev(st_t, sp_t, n)
     for NT in (5, 50):
         plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
-        assert t.equal(par.resampling.varispeed_fused_dev(plan, sig_t, NT), par.resampling.sinc_resample_dev(pos_ref, sig_t, NT))
+        assert same_resample(par.resampling.varispeed_fused_dev(plan, sig_t, NT), par.resampling.sinc_resample_dev(pos_ref, sig_t, NT))
 
 
 def test_config1_and_config3_on_reference_samples(par, golden):
@@ -759,7 +774,7 @@ def test_fused_extreme_curves_and_channels(par):
             par.resampling.sinc_resample_dev(pos_ref, sig_t.reshape(-1)[c:], NT, ref.reshape(-1)[c:], sig_stride=2,
                                              len_in=400000, out_stride=2)
         t.cuda.synchronize()
-        assert t.equal(out, ref), name
+        assert same_resample(out, ref), name
         # and the position-array path itself against the C oracle on a slice
         pos = pos_ref.cpu().numpy()
         k = min(len(pos) - 1, 60000)
@@ -820,7 +835,7 @@ def test_degenerate_segment_behind_the_trim_is_harmless(par):
             plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
             assert plan.path == want_path and plan.fused_ok and plan.len_out == len(ref)
             sig_t = t.from_numpy(inputs.noise(n, 3)).cuda()
-            assert t.equal(par.resampling.varispeed_fused_dev(plan, sig_t, 16), par.resampling.sinc_resample_dev(pos, sig_t, 16))
+            assert same_resample(par.resampling.varispeed_fused_dev(plan, sig_t, 16), par.resampling.sinc_resample_dev(pos, sig_t, 16))
         else:
             with pytest.raises(ValueError):
                 C.speed_to_pos(st, sp, n)
@@ -978,7 +993,7 @@ def test_sparse_speed_curves_take_the_chunked_exact_cumsum(par):
                                                          plan.len_out, _dev.stream_ptr(0)))
             assert t.equal(old, pos_t)
         for NT in (3, 32):
-            assert t.equal(R.varispeed_fused_dev(plan, sig_t, NT), R.sinc_resample_dev(pos_t, sig_t, NT)), (n, speeds[:3], NT)
+            assert same_resample(R.varispeed_fused_dev(plan, sig_t, NT), R.sinc_resample_dev(pos_t, sig_t, NT)), (n, speeds[:3], NT)
 
 
 def test_sparse_curves_random_window_layouts(par):
@@ -1024,7 +1039,7 @@ def test_full_size_two_point_curve(par):
     sig_t = t.empty(n, dtype=t.float32, device="cuda").normal_()
     plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
     assert plan.fused_ok and plan.len_out == pos_t.numel()
-    assert t.equal(par.resampling.varispeed_fused_dev(plan, sig_t, 32), par.resampling.sinc_resample_dev(pos_t, sig_t, 32))
+    assert same_resample(par.resampling.varispeed_fused_dev(plan, sig_t, 32), par.resampling.sinc_resample_dev(pos_t, sig_t, 32))
     del pos_t, plan
     # segments of 2.7e8 (258 windows of 4096 chunks: two steps of the window-level scan), 5e7, 2e7 and 5.6e6 samples in
     # one curve, positions against the C oracle
