@@ -965,6 +965,8 @@ __global__ void k_tile_seg(const double* __restrict__ sp, const int64_t* __restr
     const double smin = s0 < s1 ? s0 : s1, smax = s0 < s1 ? s1 : s0;
     f.fast = off_ok && n >= 2 && n < 0x7fffffffll && smin >= 0.0625 && smax <= 64.0 &&
              fabs(f.step) <= 6.0e-4 * smin * sqrt(sqrt(smin));
+    // level 2 (BlockRec): over 8 steps the reciprocal increments are linear up to 42 step^2 / smin^3 < 2e-8 samples
+    if (f.fast && fabs(f.step) <= 2.18e-5 * smin * sqrt(smin)) f.fast = 2;
     seg_fast[x] = f;
   }
   if (x > n_tiles || len_out <= 0) return;
@@ -976,6 +978,126 @@ __global__ void k_tile_seg(const double* __restrict__ sp, const int64_t* __restr
     if (seg_start[mid] <= sample) lo = mid; else hi = mid - 1;
   }
   if (lo < nseg) tile_seg[x] = lo;
+}
+
+// ---- block records and tile headers of the fused resampler (BlockRec / TileHdr, pos_plan.h) -----------------------
+// One lane per block of 8 consecutive outputs: finds the block's segment (binary search between the tile map entries),
+// takes the cumsum checkpoint below the block's first output, adds the closed-form sum of the <= 7 reciprocals in
+// between, and expands the 8 positions of the block as a quadratic in u around the block centre.  A block that contains
+// a segment boundary gets a second piece for the segment that starts inside it.  Positions are kept relative to
+// rint(seg_off), so every float64 operand is small and the polynomial constant is accurate to ~1e-12.
+struct BlockPoly {
+  double a0;       // position of output u = 0 relative to rint(seg_off) of the piece's segment
+  double a1m1;     // first-order coefficient - 1
+  double a2;
+};
+// cprev = cumsum before the block's first step (c_{k-1}); k = step index of the block's output u = 0 in its segment
+__device__ __forceinline__ BlockPoly block_poly(double foff, double step, double s0, double k, double cprev) {
+  const double rc = 1.0 / fma(step, k + 3.5, s0);          // reciprocal speed at the block centre
+  const double rp = -(rc * rc) * step;                      // its change per step
+  const double alpha = fma(-3.5, rp, rc);
+  BlockPoly q;
+  q.a0 = (foff + cprev) + alpha;                            // sum_{v=k}^{k+u} r_v = (u+1) alpha + rp u(u+1)/2
+  q.a1m1 = (alpha - 1.0) + 0.5 * rp;
+  q.a2 = 0.5 * rp;
+  return q;
+}
+
+__global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                                   int64_t nseg, const double* __restrict__ ck,
+                                                   const int64_t* __restrict__ tile_seg, const SegFast* __restrict__ seg_fast,
+                                                   TileHdr* __restrict__ hdr, BlockRec* __restrict__ rec,
+                                                   const PlanHeader* __restrict__ h) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long len_out = h->len_out;
+  const long long jb = g * kCk;
+  if (jb >= len_out || !h->ck_valid) return;
+  const long long T = g / kBlocksPerTile;
+  long long lo = tile_seg[T], hi = tile_seg[T + 1];          // entry [n_tiles] is the segment of the last output
+  while (lo < hi) {
+    const long long mid = (lo + hi + 1) >> 1;
+    if (seg_start[mid] <= jb) lo = mid; else hi = mid - 1;
+  }
+  const long long i = lo;
+  const long long start = seg_start[i], next = seg_start[i + 1];
+  const SegFast sf = seg_fast[i];
+  const double s0 = sp[i];
+  const long long k = jb - start;
+  const long long b = k >> 3;
+  const int uk = (int)(k & 7);
+  static_assert(kCk == 8, "k >> 3");
+  // cumsum before step k: checkpoint + the uk reciprocals of steps 8b .. k-1
+  double cprev = b ? ck[ck_slot0(start, i) + b] : 0.0;
+  if (uk) {
+    if (sf.fast) {                                            // midpoint rule + second-order term (remainder < 2e-10)
+      const double r = 1.0 / fma(sf.step, (double)k - 0.5 * (double)(uk + 1), s0);
+      const double z = r * sf.step;
+      cprev += r * (double)uk * fma(z * z, (double)(uk * uk - 1) * (1.0 / 12.0), 1.0);
+    } else {
+      for (int v = 0; v < uk; ++v) cprev += 1.0 / fma(sf.step, (double)(k - uk + v), s0);
+    }
+  }
+  const BlockPoly q0 = block_poly(sf.foff, sf.step, s0, (double)k, cprev);
+  const double r0 = rint(q0.a0);
+  const long long I0 = sf.A + (long long)r0;
+  BlockRec o;
+  o.I = (int)(unsigned)(unsigned long long)I0;
+  o.F = (float)(q0.a0 - r0);
+  o.e1 = (float)q0.a1m1;
+  o.e2 = (float)q0.a2;
+  const bool range0 = fabs(q0.a0) < 1.0e9 && sf.A > -(1ll << 61) && sf.A < (1ll << 61);
+  unsigned slow0 = !(sf.fast == 2 && range0 && fabs(q0.a1m1) <= 0.03125);
+  const long long rem = next - jb;                            // outputs of segment i from jb on (>= 1)
+  unsigned ustar = rem < 8 ? (unsigned)rem : 8u;
+  unsigned uend0 = rem <= 8 ? (unsigned)(rem - 1) : 15u, uend1 = 15u, slow1 = 0u;
+  o.I2 = 0;
+  o.F2 = 0.0f;
+  o.e1b = 0.0f;
+  BlockPoly q1 = q0;
+  long long A1 = sf.A;
+  if (ustar < 8 && i + 1 < nseg) {                            // second piece: segment i + 1 starts at u = ustar
+    const SegFast s1 = seg_fast[i + 1];
+    const BlockPoly b1 = block_poly(s1.foff, s1.step, sp[i + 1], 0.0, 0.0);
+    const double us = (double)ustar;
+    q1.a0 = (b1.a0 - (1.0 + b1.a1m1) * us) + b1.a2 * us * us;  // polynomial in u' = u - ustar, rewritten in u
+    q1.a1m1 = b1.a1m1 - 2.0 * b1.a2 * us;
+    q1.a2 = b1.a2;
+    A1 = s1.A;
+    const double r1 = rint(q1.a0);
+    o.I2 = (int)(unsigned)(unsigned long long)(s1.A + (long long)r1);
+    o.F2 = (float)(q1.a0 - r1);
+    o.e1b = (float)q1.a1m1;
+    const long long need = 8 - (long long)ustar;              // outputs of the block that fall to segment i + 1
+    if ((long long)s1.n == need) uend1 = 7u;
+    // the record keeps ONE curvature term: the second piece rides on the first one's when they agree to 1e-8 over u^2
+    slow1 = !(s1.fast == 2 && (long long)s1.n >= need && fabs(q1.a0) < 1.0e9 && s1.A > -(1ll << 61) && s1.A < (1ll << 61) &&
+              fabs(q1.a1m1) <= 0.03125 && fabs(b1.a2 - q0.a2) * 49.0 <= 1.0e-8);
+  } else if (ustar < 8) {
+    slow1 = 1u;
+  }
+  const long long ul = len_out - 1 - jb;                      // the global last output reuses the previous period
+  if (ul >= 0 && ul < 8) {
+    if (ul < (long long)ustar) uend0 = (unsigned)ul; else uend1 = (unsigned)ul;
+  }
+  o.meta = ustar | (uend0 << 4) | (uend1 << 8) | (slow0 << 12) | (slow1 << 13);
+  rec[g] = o;
+  // tile header: the block that opens the tile writes anchor / first centre, the one that holds the tile's last output
+  // writes the last centre (approximate placements are fine here: K_sinc stages one sample of slack on either side)
+  if (g % kBlocksPerTile == 0) {
+    TileHdr* hd = hdr + T;
+    const long long anchor = I0 & ~1ll;
+    hd->anchor = anchor;
+    hd->iT = i;
+    hd->mn_rel = (int)(I0 - anchor);
+    hd->flags = range0 ? 0 : 1;
+  }
+  const long long jt = ((T + 1) * kSincTileOutputs < len_out ? (T + 1) * kSincTileOutputs : len_out) - 1;
+  if (jt >= jb && jt < jb + 8) {
+    const double u = (double)(jt - jb);
+    const bool second = (unsigned)(jt - jb) >= ustar;
+    const BlockPoly& q = second ? q1 : q0;
+    hdr[T].c_last = (second ? A1 : sf.A) + (long long)rint(q.a0 + u * (1.0 + q.a1m1) + u * u * q.a2);
+  }
 }
 
 __device__ __forceinline__ void mark_direct(long long i, long long* direct, PlanHeader* h) {
@@ -1457,6 +1579,17 @@ static int launch_seg_sums(const double* speeds, const par::PlanView& pv, int64_
   return PAR_OK;
 }
 
+// block records + tile headers for every block that may hold outputs (the kernel reads len_out on the device)
+static void launch_block_rec(const double* speeds, const par::PlanView& pv, int64_t nseg, void* aux, int64_t max_out, int64_t m,
+                             hipStream_t s) {
+  using namespace par;
+  const FusedAux a = fused_aux_view(aux, max_out, m);
+  const int64_t blocks = (int64_t)fused_blocks(max_out);
+  hipLaunchKernelGGL(k_block_rec, dim3((unsigned)ceil_div(blocks, 256)), dim3(256), 0, s, speeds, pv.seg_start, nseg,
+                     (const double*)a.ck, (const int64_t*)a.tile_seg, (const SegFast*)a.seg_fast, a.hdr, a.rec,
+                     (const PlanHeader*)pv.hdr);
+}
+
 // Shared implementation.  aux (optional, device): cumsum checkpoints for the fused resampler.
 static thread_local int g_last_plan_flags = 0;
 
@@ -1527,6 +1660,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
                          speeds, pv.seg_start, pv.seg_off, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len),
                          reinterpret_cast<SegFast*>(ck + ck_len + max_tiles), pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
+      launch_block_rec(speeds, pv, nseg, aux, max_out, m, s);
     }
     PAR_HIP_CHECK(hipGetLastError());
     PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -1562,6 +1696,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
                          speeds, pv.seg_start, pv.seg_off, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len),
                          reinterpret_cast<SegFast*>(ck + ck_len + max_tiles), pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
+      launch_block_rec(speeds, pv, nseg, aux, max_out, m, s);
       PAR_HIP_CHECK(hipGetLastError());
       PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
       PAR_HIP_CHECK(hipStreamSynchronize(s));

@@ -152,13 +152,61 @@ struct SegFast {
   double step;              // (s1 - s0) / (n - 1): ramp increment per output
   int n;                    // outputs in the segment
   int fast;                 // 1: closed-form placement valid (ramp gentle enough, speeds in range, n < 2^31)
+                            // 2: also the per-block quadratic (BlockRec): the cubic term of 8 steps stays < 2e-8
 };
 static_assert(sizeof(SegFast) == 32, "SegFast is loaded as two 16-byte words");
-// aux buffer of a fused plan: [ck_len checkpoints (f64)] [tile map (int64)] [m SegFast records]
+// Block record of a fused plan: one per 8 consecutive outputs (absolute index j = 8 g + u).  Within the block the
+// positions are a quadratic in u (the speed ramp is linear, so the reciprocal increments are linear to second order):
+//     p_u = I + F + u (1 + e1) + u^2 e2            u = 0..7
+// with I the integer part (low 32 bits of the absolute value: differences to the tile anchor are exact in int32
+// arithmetic) and |F| <= 1/2.  A block that contains a segment boundary carries a second piece (I2, F2, e1b; same e2)
+// for the outputs u >= ustar.  K_sinc reads nothing else per output: no segment lookup, no float64.
+//   meta: ustar (bits 0-3; 8: no second piece) | uend0 (4-7) | uend1 (8-11) | slow0 (12) | slow1 (13)
+//   uendX: the output of piece X (0..7; 15: none) whose period to the next output is the PREVIOUS increment -- the last
+//          output of a segment (the next segment starts at this ramp's end speed) and the global last output (:76-77)
+//   slowX: piece X is not covered by the model (steep ramp, speed far from 1, very short segments, |p| out of range):
+//          its outputs are placed by place_fast / place_exact instead
+struct BlockRec {
+  int I;
+  float F, e1, e2;
+  int I2;
+  float F2, e1b;
+  unsigned meta;
+};
+static_assert(sizeof(BlockRec) == 32, "BlockRec is loaded as two 16-byte words");
+// Tile header: everything K_sinc needs before it can stage a tile's input span, in ONE scalar load.
+struct TileHdr {
+  long long anchor;         // even integer next to the tile's first position
+  long long c_last;         // rint(position) of the tile's last output (absolute)
+  long long iT;             // segment of the tile's first output
+  int mn_rel;               // rint(first position) - anchor
+  int flags;                // 1: positions out of the int32 range around the anchor (tile takes the float64 path)
+};
+static_assert(sizeof(TileHdr) == 32, "TileHdr is one s_load_dwordx8");
+constexpr int kBlocksPerTile = (int)(kSincTileOutputs / kCk);
+// aux buffer of a fused plan: [ck_len checkpoints (f64)] [tile map (int64)] [m SegFast] [tiles TileHdr] [blocks BlockRec]
 inline size_t fused_ck_len(int64_t max_out, int64_t m) { return (size_t)(max_out / kCk + m + 16); }
 inline size_t fused_tiles(int64_t max_out) { return (size_t)(max_out / kSincTileOutputs + 4); }
+inline size_t fused_blocks(int64_t max_out) { return fused_tiles(max_out) * kBlocksPerTile; }
 inline size_t fused_aux_bytes(int64_t max_out, int64_t m) {
-  return (fused_ck_len(max_out, m) + fused_tiles(max_out)) * 8 + (size_t)m * sizeof(SegFast);
+  return (fused_ck_len(max_out, m) + fused_tiles(max_out)) * 8 + (size_t)m * sizeof(SegFast) +
+         fused_tiles(max_out) * sizeof(TileHdr) + fused_blocks(max_out) * sizeof(BlockRec);
+}
+struct FusedAux {            // views into the aux buffer
+  double* ck;
+  int64_t* tile_seg;
+  SegFast* seg_fast;
+  TileHdr* hdr;
+  BlockRec* rec;
+};
+inline FusedAux fused_aux_view(void* aux, int64_t max_out, int64_t m) {
+  FusedAux v;
+  v.ck = static_cast<double*>(aux);
+  v.tile_seg = reinterpret_cast<int64_t*>(v.ck + fused_ck_len(max_out, m));
+  v.seg_fast = reinterpret_cast<SegFast*>(v.tile_seg + fused_tiles(max_out));
+  v.hdr = reinterpret_cast<TileHdr*>(v.seg_fast + m);
+  v.rec = reinterpret_cast<BlockRec*>(v.hdr + fused_tiles(max_out));
+  return v;
 }
 
 }  // namespace par

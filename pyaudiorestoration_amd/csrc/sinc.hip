@@ -45,8 +45,26 @@
 #ifndef PAR_SINC_EXP
 #define PAR_SINC_EXP 0
 #endif
+#ifndef PAR_SINC_WAVES
+#define PAR_SINC_WAVES 6      // waves per SIMD the fused kernel is built for (register budget 512 / this)
+#endif
 
 namespace par {
+
+#if PAR_SINC_EXP & 64
+__device__ unsigned int* g_sinc_phase;           // [wave][8] cycle counts, one row per wave of the launch (no atomics)
+#define PAR_PHASE_MARK(k)                                                                   \
+  do {                                                                                      \
+    const unsigned long long now_ = __builtin_readcyclecounter();                           \
+    if ((threadIdx.x & 63) == 0)                                                            \
+      g_sinc_phase[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (k)] = (unsigned)(now_ - phase_t_); \
+    phase_t_ = now_;                                                                        \
+  } while (0)
+#define PAR_PHASE_BEGIN() unsigned long long phase_t_ = __builtin_readcyclecounter()
+#else
+#define PAR_PHASE_MARK(k) do { } while (0)
+#define PAR_PHASE_BEGIN() do { } while (0)
+#endif
 
 constexpr int kSincBlock = 256;
 constexpr int kSincR = 4;                         // outputs per thread
@@ -528,6 +546,8 @@ struct FusedArgs {
   const double* ck;
   const int64_t* tile_seg;
   const SegFast* seg_fast;
+  const TileHdr* hdr;
+  const BlockRec* rec;
   int64_t nseg;
 };
 
@@ -642,7 +662,44 @@ __device__ __forceinline__ void place_fast(const FusedArgs& fa, long long i, lon
   lowfc = bsn < 0.125;
 }
 
-// ---- the tile body shared by both kernel forms --------------------------------------------------------
+// The tap loops of one lane: 4 (output, channel) slots.  `all_unity`: fc == 1 for every lane of the wave.
+template <int NTC>
+__device__ __forceinline__ void run_taps(const float* __restrict__ tile, const int (&cs)[kSincR], const float (&ss)[kSincR],
+                                         const float (&fcs)[kSincR], const float (&dds)[kSincR], const bool all_unity,
+                                         const int NT, const float4* __restrict__ tab, const TapModes tmd,
+                                         float (&res)[kSincR]) {
+  static_assert(kSincR == 4, "split assumes 4 slots per lane");
+  // two passes over half of the lane's slots where the loops carry 6-10 live values per slot (80-VGPR budget:
+  // one pass spilled 48 B/lane = as much HBM write traffic as the output)
+  const int ca[2] = {cs[0], cs[1]}, cb[2] = {cs[2], cs[3]};
+  const float sa[2] = {ss[0], ss[1]}, sb[2] = {ss[2], ss[3]};
+  float ra[2], rb[2];
+  if (all_unity) {
+    if constexpr (NTC > 0) {
+      taps_unity_ct<NTC, 2>(tile, ca, sa, NT, ra);
+      taps_unity_ct<NTC, 2>(tile, cb, sb, NT, rb);
+    } else {
+      taps_unity<kSincR>(tile, cs, ss, NT, tab, tmd, res);
+      return;
+    }
+  } else {
+    const float fa_[2] = {fcs[0], fcs[1]}, fb_[2] = {fcs[2], fcs[3]};
+    const float da[2] = {dds[0], dds[1]}, db[2] = {dds[2], dds[3]};
+    if constexpr (NTC > 0) {
+      taps_general_ct<NTC, 2>(tile, ca, sa, fa_, da, NT, ra);
+      taps_general_ct<NTC, 2>(tile, cb, sb, fb_, db, NT, rb);
+    } else {
+      taps_general<2>(tile, ca, sa, fa_, da, NT, tab, tmd, ra);
+      taps_general<2>(tile, cb, sb, fb_, db, NT, tab, tmd, rb);
+    }
+  }
+  res[0] = ra[0];
+  res[1] = ra[1];
+  res[2] = rb[0];
+  res[3] = rb[1];
+}
+
+// ---- the tile body of the position-array form --------------------------------------------------------
 // Stages the tile's input span once, runs the tap loops, writes the outputs.  slow_pos(r, p, dp) yields the float64
 // position of the lane's r-th output for the (rare) lanes that leave the float32 path.
 // NCH = 2: two channels of one file (same positions) in one launch.  A lane then owns 2 outputs x 2 channels instead of
@@ -732,44 +789,7 @@ __device__ __forceinline__ void sinc_tile_body(float* __restrict__ tile, int* __
     dds[sl] = dd[sl / NCH];
     res[sl] = 0.0f;
   }
-  if (!(PAR_SINC_EXP & 1) && __any(anyfast)) {
-    if (__all(unity)) {
-      if constexpr (NTC > 0) {
-        // two passes over half of the lane's slots: the unrolled form carries 6 accumulators per slot
-        const int ca[2] = {cs[0], cs[1]}, cb[2] = {cs[2], cs[3]};
-        const float sa[2] = {ss[0], ss[1]}, sb[2] = {ss[2], ss[3]};
-        float ra[2], rb[2];
-        taps_unity_ct<NTC, 2>(tile, ca, sa, NT, ra);
-        taps_unity_ct<NTC, 2>(tile, cb, sb, NT, rb);
-        res[0] = ra[0];
-        res[1] = ra[1];
-        res[2] = rb[0];
-        res[3] = rb[1];
-      } else {
-        taps_unity<kSincR>(tile, cs, ss, NT, tab, tmd, res);
-      }
-    } else {
-      // the general path carries 10+ live values per slot: two passes over half of the lane's slots keep
-      // it inside the 80-VGPR budget (one pass spilled 48 B/lane = as much HBM write traffic as the output)
-      static_assert(kSincR == 4, "split assumes 4 slots per lane");
-      const int ca[2] = {cs[0], cs[1]}, cb[2] = {cs[2], cs[3]};
-      const float sa[2] = {ss[0], ss[1]}, sb[2] = {ss[2], ss[3]};
-      const float fa_[2] = {fcs[0], fcs[1]}, fb_[2] = {fcs[2], fcs[3]};
-      const float da[2] = {dds[0], dds[1]}, db[2] = {dds[2], dds[3]};
-      float ra[2], rb[2];
-      if constexpr (NTC > 0) {
-        taps_general_ct<NTC, 2>(tile, ca, sa, fa_, da, NT, ra);
-        taps_general_ct<NTC, 2>(tile, cb, sb, fb_, db, NT, rb);
-      } else {
-        taps_general<2>(tile, ca, sa, fa_, da, NT, tab, tmd, ra);
-        taps_general<2>(tile, cb, sb, fb_, db, NT, tab, tmd, rb);
-      }
-      res[0] = ra[0];
-      res[1] = ra[1];
-      res[2] = rb[0];
-      res[3] = rb[1];
-    }
-  }
+  if (!(PAR_SINC_EXP & 1) && __any(anyfast)) run_taps<NTC>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res);
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
     const int64_t j = j0 + t + (int64_t)r * kBlk;
@@ -835,11 +855,22 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc_pos(const double* __rest
                     });
 }
 
-// FUSED form: there is no position array in HBM.  Every output is placed straight from the plan: its segment comes
-// from a wave-uniform scan of the tile's segment boundaries (a wave's outputs of one pass are 64 consecutive indices),
-// its position from the segment record, the checkpoint below it and the closed form of place_fast.
+// FUSED form: there is no position array in HBM.  The plan leaves a 32-byte record per block of 8 outputs (BlockRec:
+// the block's positions as a quadratic in u) and a header per tile (anchor, first and last window centre), both at
+// addresses that follow from the output index alone.  A workgroup therefore issues ALL its loads up front -- the
+// records of its outputs, the header, then the signal span the header names -- instead of walking
+// tile map -> segment -> checkpoint -> positions -> span (five dependent HBM round trips per tile, which 6 waves per
+// SIMD could not cover: measured, phases were additive).  Per output the placement is ~20 float32 / integer
+// instructions; outputs within the reference's own rounding of a half-integer position, and blocks the record model
+// does not cover, are redone through place_fast / place_exact, so every window centre rint(p) is the reference's.
+// Every WAVE is on its own: it owns 64 kOut consecutive outputs of the tile, places them, stages just their input span
+// into its own quarter of the workgroup's LDS and runs the tap loops -- no workgroup barrier anywhere (measured with
+// the per-phase wave clock, tools/phase_clock.py: with one span per workgroup a wave spent 28 % of its life waiting at
+// the barrier for the slowest of its three siblings).  The halo (2 NT + margin samples per 64 kOut outputs) is fetched
+// by neighbouring waves too; they sit on the same CU, so the repeats are L1/L2 hits.
+constexpr int kStageRegs = 6;                   // signal words a lane holds in registers between load and LDS write
 template <int NCH, int NTC>
-__global__ __launch_bounds__(kSincBlock * NCH, 6) void k_sinc_fused(int64_t len_out, const float* __restrict__ sig,
+__global__ __launch_bounds__(kSincBlock * NCH, PAR_SINC_WAVES) void k_sinc_fused(int64_t len_out, const float* __restrict__ sig,
                                                                   const float* __restrict__ sig1, int64_t sig_stride,
                                                                   int64_t len_in, int NT, const float4* __restrict__ tab,
                                                                   TapModes tmd, float* __restrict__ out,
@@ -847,105 +878,182 @@ __global__ __launch_bounds__(kSincBlock * NCH, 6) void k_sinc_fused(int64_t len_
                                                                   FusedArgs fa) {
   constexpr int kBlk = kSincBlock * NCH;
   constexpr int kOut = kSincR / NCH;
+  constexpr int kWaveOut = kWave * kOut;          // outputs per wave: 256 (mono) / 128 (stereo)
+  constexpr int capw = kSincCap / (kBlk / kWave);   // floats of one channel's span a wave may stage: 1024 (mono) / 512
   static_assert(NCH == 1 || NCH == 2, "mono or stereo");
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  __shared__ int red[2 * (kBlk / kWave)];
+  static_assert(capw * (kBlk / kWave) == kSincCap, "LDS split");
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int t = threadIdx.x;
+  const int l = t & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  float* tile = lds_all + wv * (capw * NCH);      // this wave's span: channel 0, then channel 1 `capw` floats on
   const int64_t T = blockIdx.x;
   const int64_t j0 = T * kSincTile;
-#ifdef PAR_SINC_STAGGER
-  // The workgroups that fill the chip at launch start together, take the same time and are replaced together: the
-  // waves sharing a SIMD stay in lockstep, so one workgroup's load latency never hides behind another's tap loops.
-  // Delaying each first-generation wave by its hardware slot number spreads the phases for good.
-  if (T < PAR_SINC_STAGGER_BLOCKS) {
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);    // HW_ID.WAVE_ID
-    for (unsigned k = 0; k < slot * PAR_SINC_STAGGER; ++k) __builtin_amdgcn_s_sleep(64);
-  }
-#endif
-  // block-uniform even anchor next to the tile's first position: rint(offset) + the checkpoint below output j0
-  const long long iT = (PAR_SINC_EXP & 8) ? 0ll : fa.tile_seg[T];
-  const long long startT = fa.seg_start[iT];
-  const long long bT = (j0 - startT) >> 3;
-  const double ckT = bT ? fa.ck[ck_slot0(startT, iT) + bT] : 0.0;
-  const long long anchor = (PAR_SINC_EXP & 8) ? (long long)(j0 & ~1ll)
-                                              : (fa.seg_fast[iT].A + (fabs(ckT) < 4.0e18 ? llrint(ckT) : 0ll)) & ~1ll;
-  const double tol = (fabs((double)anchor) + 4.2e6) * 1.2e-16 + 2.0e-10;
-  const int tw = __builtin_amdgcn_readfirstlane(t);   // first thread of this wave: its outputs are tw .. tw + 63 (+ pass)
-  // the next kSegAhead segment boundaries behind the tile's first segment, wave-uniform (scalar loads, SGPRs): a wave's
-  // outputs of one pass are 64 consecutive indices, so its lanes find their segments by comparing against a few of these
-  constexpr int kSegAhead = 8;
-  long long B[kSegAhead];
-#pragma unroll
-  for (int q = 0; q < kSegAhead; ++q)
-    B[q] = (!(PAR_SINC_EXP & 8) && iT + 1 + q < fa.nseg) ? fa.seg_start[iT + 1 + q] : LLONG_MAX;
-  int c[kOut], seg[kOut];                              // seg: segment index relative to iT
-  float s[kOut], fc[kOut], dd[kOut];
-  bool valid[kOut], lowfc[kOut], exact[kOut];
-  bool unity = true, wild = false, anyexact = false;
+  const int64_t jw = j0 + (int64_t)wv * kWaveOut; // the wave's outputs: jw + l + 64 r, r < kOut
+  PAR_PHASE_BEGIN();
+  // 1. records of this lane's outputs: block (jw >> 3) + (l >> 3) + 8 r, u = l & 7 for every r
+  const uint4* rp = reinterpret_cast<const uint4*>(fa.rec + (jw >> 3) + (l >> 3));
+  uint4 ra[kOut], rb[kOut];
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
-    const int64_t j = j0 + t + (int64_t)r * kBlk;
-    valid[r] = j < len_out;
-    lowfc[r] = false;
-    exact[r] = false;
-    c[r] = 0;
-    s[r] = 0.25f;
-    fc[r] = 1.0f;
-    dd[r] = 0.0f;
-    const long long jl = j0 + tw + (long long)r * kBlk + (kWave - 1);     // the wave's last output of this pass
-    int si = 0, q = 0;
+    const bool v = jw + l + (int64_t)r * kWave < len_out;
+    ra[r] = v ? rp[r * 16] : make_uint4(0, 0, 0, 0);
+    rb[r] = v ? rp[r * 16 + 1] : make_uint4(0, 0, 0, 8u | (15u << 4) | (15u << 8));
+  }
+  // 2. tile header: the anchor all window centres are relative to
+  const TileHdr hd = fa.hdr[T];
+  const long long anchor = hd.anchor;
+  PAR_PHASE_MARK(0);                 // issue of the record loads, arrival of the header
+  // 3. placement
+  const double tol = (fabs((double)anchor) + 4.2e6) * 1.2e-16 + 2.0e-10;     // the reference's own rounding of p (half an ulp)
+  const float tolf = (float)tol + 1.5e-7f;                                    // + float32 evaluation of the block quadratic
+  const unsigned alo = (unsigned)(unsigned long long)anchor;
+  const int u = l & 7;
+  const float uf = (float)u, u2f = uf * uf, tw1 = 2.0f * uf + 1.0f, tw0 = 2.0f * uf - 1.0f;
+  int c[kOut];
+  float s[kOut], fc[kOut], dd[kOut];
+  bool valid[kOut], lowfc[kOut], redo[kOut], slow[kOut];
+  bool unity = true, wild = (hd.flags & 1) != 0, anyredo = false;
 #pragma unroll
-    for (; q < kSegAhead; ++q) {
-      if (B[q] > jl) break;
-      si += j >= B[q];
-    }
-    if (q == kSegAhead) {                               // segments shorter than 1/8 tile: keep scanning in memory
-      for (long long iu = iT + kSegAhead; iu + 1 < fa.nseg; ++iu) {
-        const long long nx = fa.seg_start[iu + 1];
-        if (nx > jl) break;
-        si += j >= nx;
-      }
-    }
-    seg[r] = si;
+  for (int r = 0; r < kOut; ++r) {
+    const int64_t j = jw + l + (int64_t)r * kWave;
+    valid[r] = j < len_out;
+    const unsigned m = rb[r].w;
+    const bool second = (unsigned)u >= (m & 15u);
+    const unsigned I = second ? rb[r].x : ra[r].x;
+    const float F = __uint_as_float(second ? rb[r].y : ra[r].y);
+    const float e1 = __uint_as_float(second ? rb[r].z : ra[r].z);
+    const float e2 = __uint_as_float(ra[r].w);
+    const unsigned uend = (second ? (m >> 8) : (m >> 4)) & 15u;
+    slow[r] = valid[r] && (((second ? (m >> 13) : (m >> 12)) & 1u) != 0u);
+    const float frac = fmaf(u2f, e2, fmaf(uf, e1, F));
+    const float ri = rintf(frac);
+    const float sh = frac - ri;
+    c[r] = (int)(I - alo) + u + (int)ri;
+    s[r] = (sh == 0.0f) ? 1e-20f : sh;              // np.sinc's own 0 -> 1e-20 substitution
+    const float e = fmaf(e2, (unsigned)u == uend ? tw0 : tw1, e1);          // period to the next position, minus 1
+    const bool one = !(e > 0.0f);
+    const float inv = fast_rcp(1.0f + e);
+    fc[r] = one ? 1.0f : inv;
+    dd[r] = one ? 0.0f : e * inv;
+    lowfc[r] = e > 7.0f;
+    redo[r] = slow[r] || (valid[r] && !(fabsf(fabsf(sh) - 0.5f) > tolf));
+    anyredo = anyredo || redo[r];
     if (PAR_SINC_EXP & 2) {
-      if (valid[r]) {
-        c[r] = (int)(j - anchor) + 64;
-        s[r] = 0.3f - 1e-4f * (float)(t & 63);
-        if (PAR_SINC_EXP & 4) {
-          fc[r] = 0.995f;
-          dd[r] = 0.005f;
-        }
-      }
-    } else if (valid[r]) {
-      bool w;
-      place_fast(fa, iT + si, j, len_out, anchor, tol, c[r], s[r], fc[r], dd[r], lowfc[r], w, exact[r]);
-      wild = wild || (w && !exact[r]);
-      anyexact = anyexact || exact[r];
+      c[r] = (int)(j - anchor) + 64;
+      s[r] = 0.3f - 1e-4f * (float)(t & 63);
+      fc[r] = (PAR_SINC_EXP & 4) ? 0.995f : 1.0f;
+      dd[r] = (PAR_SINC_EXP & 4) ? 0.005f : 0.0f;
+      lowfc[r] = false;
+      redo[r] = false;
+      anyredo = false;
     }
   }
-  if (__any(anyexact)) {                                // rare: near a rounding tie, or a segment the closed form skips
+  if (__any(anyredo)) {      // rare: a rounding tie to settle, or a block outside the record model
 #pragma unroll
     for (int r = 0; r < kOut; ++r) {
-      if (valid[r] && exact[r]) {
-        const PosDp e = place_exact(fa.speeds, fa.seg_start, fa.seg_off, fa.ck, iT + seg[r], j0 + t + (int64_t)r * kBlk, len_out);
-        bool w;
-        place_from_pos(e.p, e.dp, (double)anchor, c[r], s[r], fc[r], dd[r], lowfc[r], w);
+      if (redo[r]) {
+        const long long j = jw + l + (int64_t)r * kWave;
+        long long i = hd.iT;
+        while (i + 1 < fa.nseg && fa.seg_start[i + 1] <= j) ++i;
+        bool ex = !slow[r], w = false;
+        if (slow[r]) place_fast(fa, i, j, len_out, anchor, tol, c[r], s[r], fc[r], dd[r], lowfc[r], w, ex);
+        if (ex) {
+          const PosDp e = place_exact(fa.speeds, fa.seg_start, fa.seg_off, fa.ck, i, j, len_out);
+          place_from_pos(e.p, e.dp, (double)anchor, c[r], s[r], fc[r], dd[r], lowfc[r], w);
+        }
         wild = wild || w;
       }
     }
   }
+  int cmin = INT_MAX, cmax = INT_MIN;
 #pragma unroll
-  for (int r = 0; r < kOut; ++r) unity = unity && fc[r] == 1.0f;
-  sinc_tile_body<NCH, NTC>(tile, red, t, j0, len_out, anchor, c, s, fc, dd, valid, lowfc, unity, wild, sig, sig1, sig_stride,
-                      len_in, NT, tab, tmd, out, out1, out_stride, [&](int r, double& p, double& dp) {
-                        // (the segment is looked up again rather than kept in a register across the tap loops)
-                        const long long j = j0 + t + (int64_t)r * kBlk;
-                        long long i = iT;
-                        while (i + 1 < fa.nseg && fa.seg_start[i + 1] <= j) ++i;
-                        const PosDp e = place_exact(fa.speeds, fa.seg_start, fa.seg_off, fa.ck, i, j, len_out);
-                        p = e.p;
-                        dp = e.dp;
-                      });
+  for (int r = 0; r < kOut; ++r) {
+    unity = unity && (fc[r] == 1.0f || !valid[r]);
+    if (valid[r]) {
+      cmin = c[r] < cmin ? c[r] : cmin;
+      cmax = c[r] > cmax ? c[r] : cmax;
+    }
+  }
+  PAR_PHASE_MARK(1);                 // placement (waits for the records)
+  // 4. the wave's input span.  Positions increase with the output index: the first centre is lane 0's first output,
+  // the last one the last valid lane's last output (one sample of slack: a centre redone exactly may move by one).
+  // the tap loops run in chunks of kChunk and may touch up to kChunk-1 taps beyond +-(NT-1); those carry an
+  // exactly-zero weight but must read finite data: stage a kChunk margin
+  const int margin = NT + kChunk + 1;
+  const unsigned long long vmask = __ballot(valid[0]);
+  const int lastl = vmask ? 63 - __builtin_clzll(vmask) : 0;
+  const int mn = __builtin_amdgcn_readlane(cmin, 0);
+  const int mx = __builtin_amdgcn_readlane(cmax, lastl);
+  const long long span = (long long)mx - (long long)mn + 2ll * margin;     // <= capw for the LDS path
+  const bool usable = !__any(wild) && vmask != 0 && span <= capw && span > 0;
+  const long long lo = anchor + mn - margin;                               // signal index of tile[0]
+  const int nspan = usable ? (int)span : 0;
+  for (int q = l; q < nspan; q += kWave) {
+    const long long g = lo + q;
+    const bool inside = g >= 0 && g < (long long)len_in;
+    tile[q] = (inside && !(PAR_SINC_EXP & 16)) ? sig[g * sig_stride] : 0.0f;
+    if (NCH == 2) tile[capw + q] = (inside && !(PAR_SINC_EXP & 16)) ? sig1[g * sig_stride] : 0.0f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the wave's own LDS writes before its LDS reads
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  PAR_PHASE_MARK(2);                 // span in LDS (waits for the signal loads)
+  // 5. taps
+  // leading-edge outputs (ind < NT) keep the reference's mis-aligned taps: float64 slow path.
+  bool fastlane[kOut];
+  bool anyfast = false;
+  const long long edge = (long long)NT - anchor;    // ind >= NT  <=>  rel index >= edge
+#pragma unroll
+  for (int r = 0; r < kOut; ++r) {
+    fastlane[r] = valid[r] && usable && (long long)c[r] >= edge && !lowfc[r] && c[r] >= mn - 1 && c[r] <= mx + 1;
+    c[r] = fastlane[r] ? c[r] - mn + margin : margin;      // LDS index of the window centre (idle lanes: harmless)
+    anyfast = anyfast || fastlane[r];
+  }
+  // (output, channel) slots: channel ch of an output reads the tile `ch * capw` floats further on; shift, fc and
+  // 1 - fc are the SAME values for both slots of an output, so the compiler evaluates their tap weights once
+  int cs[kSincR];
+  float ss[kSincR], fcs[kSincR], dds[kSincR], res[kSincR];
+#pragma unroll
+  for (int sl = 0; sl < kSincR; ++sl) {
+    cs[sl] = c[sl / NCH] + (sl % NCH) * capw;
+    ss[sl] = s[sl / NCH];
+    fcs[sl] = fc[sl / NCH];
+    dds[sl] = dd[sl / NCH];
+    res[sl] = 0.0f;
+  }
+  if (!(PAR_SINC_EXP & 1) && __any(anyfast)) run_taps<NTC>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res);
+#if PAR_SINC_EXP & 128
+  {                                   // the tap loops a second time (what does ONE more pass cost?)
+    float res2[kSincR];
+#pragma unroll
+    for (int sl = 0; sl < kSincR; ++sl) ss[sl] += 1e-3f * res[sl];
+    if (__any(anyfast)) run_taps<NTC>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res2);
+#pragma unroll
+    for (int sl = 0; sl < kSincR; ++sl) res[sl] += 1e-9f * res2[sl];
+  }
+#endif
+  PAR_PHASE_MARK(4);                 // taps
+  // 6. stores
+#pragma unroll
+  for (int r = 0; r < kOut; ++r) {
+    const int64_t j = jw + l + (int64_t)r * kWave;
+    if (j >= len_out) continue;
+    PosDp e{0.0, 1.0};
+    if (!fastlane[r]) {
+      long long i = hd.iT;
+      while (i + 1 < fa.nseg && fa.seg_start[i + 1] <= j) ++i;
+      e = place_exact(fa.speeds, fa.seg_start, fa.seg_off, fa.ck, i, j, len_out);
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      float v = res[r * NCH + ch];
+      if (!fastlane[r]) v = sinc_one_f64(e.p, e.dp, ch ? sig1 : sig, sig_stride, len_in, NT);
+      if ((PAR_SINC_EXP & 32) && v != 12345.678f) continue;
+      (ch ? out1 : out)[j * out_stride] = v;
+    }
+  }
+  PAR_PHASE_MARK(5);                 // stores issued
 }
 
 // ---- host side: per-(device, NT) tap tables -------------------------------------------------------
@@ -1063,14 +1171,16 @@ int launch_sinc_fused(int device, const double* speeds, int64_t m, const void* w
   PlanView pv = plan_view(const_cast<void*>(work), m);
   // No header read-back here (it would cost a stream sync per channel): the caller vouches, through the
   // fused_ok flag of par_speed_to_pos_plan_fused, that aux holds this plan's checkpoints for max_out.
-  const int64_t ck_len = (int64_t)fused_ck_len(max_out, m);
+  const FusedAux av = fused_aux_view(const_cast<void*>(aux), max_out, m);
   FusedArgs fa;
   fa.speeds = speeds;
   fa.seg_start = pv.seg_start;
   fa.seg_off = pv.seg_off;
-  fa.ck = static_cast<const double*>(aux);
-  fa.tile_seg = reinterpret_cast<const int64_t*>(fa.ck + ck_len);
-  fa.seg_fast = reinterpret_cast<const SegFast*>(fa.tile_seg + fused_tiles(max_out));
+  fa.ck = av.ck;
+  fa.tile_seg = av.tile_seg;
+  fa.seg_fast = av.seg_fast;
+  fa.hdr = av.hdr;
+  fa.rec = av.rec;
   fa.nseg = m - 1;
   const int64_t blocks = ceil_div(len_out, kSincTile);
 #define PAR_LAUNCH_FUSED(NCH, NTC)                                                                                         \
@@ -1095,6 +1205,13 @@ int launch_sinc_fused(int device, const double* speeds, int64_t m, const void* w
 }  // namespace par
 
 extern "C" {
+
+#if PAR_SINC_EXP & 64
+// experiment builds (tools/phase_clock.py): set the per-wave phase buffer ([waves][8] uint32)
+int par_debug_sinc_phase_buffer(unsigned int* dev_buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(par::g_sinc_phase), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int par_sinc_resample_f32(int device, const double* pos, int64_t len_out, const float* sig, int64_t sig_stride,
                           int64_t len_in, int NT, float* out, int64_t out_stride, void* stream) {
