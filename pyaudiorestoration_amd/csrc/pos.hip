@@ -939,7 +939,8 @@ __global__ void k_publish_ck(PlanHeader* __restrict__ h, int64_t ck_len) {
 // 10^5..10^6 tiles).
 __global__ void k_tile_seg(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
                            const double* __restrict__ seg_off, int64_t nseg, int64_t ck_len, int64_t max_tiles,
-                           int64_t* __restrict__ tile_seg, SegFast* __restrict__ seg_fast, PlanHeader* __restrict__ h) {
+                           int64_t* __restrict__ tile_seg, SegFast* __restrict__ seg_fast, long long* __restrict__ tile_st,
+                           PlanHeader* __restrict__ h) {
   const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const long long len_out = h->len_out;                // written by k_trim / the host path earlier on this stream
   const long long n_tiles = (len_out + kSincTileOutputs - 1) / kSincTileOutputs;
@@ -977,113 +978,176 @@ __global__ void k_tile_seg(const double* __restrict__ sp, const int64_t* __restr
     const long long mid = (lo + hi + 1) >> 1;
     if (seg_start[mid] <= sample) lo = mid; else hi = mid - 1;
   }
-  if (lo < nseg) tile_seg[x] = lo;
+  if (lo < nseg) {
+    tile_seg[x] = lo;
+    // boundaries the tile's blocks may meet, for k_block_rec's lookup: one 48-byte scalar load per wave there
+    for (int q = 0; q < kTileStarts; ++q) tile_st[x * kTileStarts + q] = lo + q <= nseg ? seg_start[lo + q] : LLONG_MAX;
+  }
 }
 
 // ---- block records and tile headers of the fused resampler (BlockRec / TileHdr, pos_plan.h) -----------------------
-// One lane per block of 8 consecutive outputs: finds the block's segment (binary search between the tile map entries),
-// takes the cumsum checkpoint below the block's first output, adds the closed-form sum of the <= 7 reciprocals in
-// between, and expands the 8 positions of the block as a quadratic in u around the block centre.  A block that contains
-// a segment boundary gets a second piece for the segment that starts inside it.  Positions are kept relative to
-// rint(seg_off), so every float64 operand is small and the polynomial constant is accurate to ~1e-12.
+// One lane per block of 8 consecutive outputs: finds the block's segment (the tile map, then a short walk), takes the
+// cumsum checkpoint below the block's first output, adds the closed-form sum of the <= 7 reciprocals in between, and
+// expands the 8 positions of the block as a quadratic in u around the block centre.  A block that contains a segment
+// boundary gets a second piece for the segment that starts inside it.  Positions are kept relative to rint(seg_off), so
+// every float64 operand is small and the polynomial constant is accurate to ~1e-12.  ONE reciprocal per piece: the
+// speed at the midpoint of the steps behind the checkpoint is at most 7.5 steps from the block centre, so its
+// reciprocal follows from the centre's by a 2-term series in x = r step d (|x| < 2e-4 where the model applies).
 struct BlockPoly {
   double a0;       // position of output u = 0 relative to rint(seg_off) of the piece's segment
   double a1m1;     // first-order coefficient - 1
   double a2;
 };
-// cprev = cumsum before the block's first step (c_{k-1}); k = step index of the block's output u = 0 in its segment
-__device__ __forceinline__ BlockPoly block_poly(double foff, double step, double s0, double k, double cprev) {
-  const double rc = 1.0 / fma(step, k + 3.5, s0);          // reciprocal speed at the block centre
-  const double rp = -(rc * rc) * step;                      // its change per step
-  const double alpha = fma(-3.5, rp, rc);
+__device__ __forceinline__ double recip_nr(double b) {       // 1/b to ~1e-15 relative (no IEEE corner cases needed)
+  double x = __builtin_amdgcn_rcp(b);
+  x = __builtin_fma(x, __builtin_fma(-b, x, 1.0), x);
+  return __builtin_fma(x, __builtin_fma(-b, x, 1.0), x);
+}
+// k = step index of the block's output u = 0 in its segment; uk = steps between the checkpoint and k; ckv = checkpoint
+__device__ __forceinline__ BlockPoly block_poly(double foff, double step, double s0, double k, int uk, double ckv, bool fast) {
+  const double rc = recip_nr(__builtin_fma(step, k + 3.5, s0));   // reciprocal speed at the block centre
+  const double z = rc * step;
+  const double rp = -(rc * z);                                      // its change per step
+  double cprev = ckv;                                               // cumsum before step k
+  if (uk) {
+    if (fast) {                                                     // uk steps centred (uk + 1)/2 + 3.5 before the block centre
+      const double x = z * (-0.5 * (double)(uk + 1) - 3.5);
+      const double r = rc * __builtin_fma(x, x - 1.0, 1.0);        // 1/(b + step d) = rc (1 - x + x^2 ..)
+      cprev += r * (double)uk * __builtin_fma(z * z, (double)(uk * uk - 1) * (1.0 / 12.0), 1.0);
+    } else {
+      for (int v = 0; v < uk; ++v) cprev += recip_nr(__builtin_fma(step, k - (double)(uk - v), s0));
+    }
+  }
+  const double alpha = __builtin_fma(-3.5, rp, rc);
   BlockPoly q;
-  q.a0 = (foff + cprev) + alpha;                            // sum_{v=k}^{k+u} r_v = (u+1) alpha + rp u(u+1)/2
+  q.a0 = (foff + cprev) + alpha;                                    // sum_{v=k}^{k+u} r_v = (u+1) alpha + rp u(u+1)/2
   q.a1m1 = (alpha - 1.0) + 0.5 * rp;
   q.a2 = 0.5 * rp;
   return q;
 }
 
+// second piece of the blocks that contain a segment start: one lane per SEGMENT (m lanes instead of a divergent branch in
+// every wave of k_block_rec)
+__global__ __launch_bounds__(256) void k_block_rec2(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                                    int64_t nseg, const SegFast* __restrict__ seg_fast,
+                                                    BlockRec2* __restrict__ rec2, const PlanHeader* __restrict__ h) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 1 || i >= nseg || !h->ck_valid) return;
+  const long long start = seg_start[i];
+  const int us = (int)(start & 7);
+  if (us == 0 || start >= h->len_out) return;
+  const SegFast s1 = seg_fast[i];
+  const BlockPoly b1 = block_poly(s1.foff, s1.step, sp[i], 0.0, 0, 0.0, true);
+  const double u = (double)us;
+  const double a0 = (b1.a0 - (1.0 + b1.a1m1) * u) + b1.a2 * u * u;   // polynomial in u' = u - ustar, rewritten in u
+  const double r1 = rint(a0);
+  BlockRec2 o2;
+  o2.I2 = (int)(unsigned)(unsigned long long)(s1.A + (long long)r1);
+  o2.F2 = (float)(a0 - r1);
+  o2.e1b = (float)(b1.a1m1 - 2.0 * b1.a2 * u);
+  o2.pad = 0u;
+  rec2[start >> 3] = o2;
+}
+
 __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
                                                    int64_t nseg, const double* __restrict__ ck,
-                                                   const int64_t* __restrict__ tile_seg, const SegFast* __restrict__ seg_fast,
-                                                   TileHdr* __restrict__ hdr, BlockRec* __restrict__ rec,
-                                                   const PlanHeader* __restrict__ h) {
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+                                                   const int64_t* __restrict__ tile_seg, const long long* __restrict__ tile_st,
+                                                   const SegFast* __restrict__ seg_fast, TileHdr* __restrict__ hdr,
+                                                   BlockRec* __restrict__ rec, const PlanHeader* __restrict__ h) {
+  // One wave per tile, two blocks per lane (lane and lane + 64): the scalar loads and the two dependent memory round
+  // trips are paid once per 128 blocks, and the second block's loads fly under the first one's arithmetic.
   const long long len_out = h->len_out;
+  if (!h->ck_valid) return;
+  const long long gbase = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kBlocksPerTile + (threadIdx.x & 63);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+  const long long g = gbase + 64 * half;
   const long long jb = g * kCk;
-  if (jb >= len_out || !h->ck_valid) return;
-  const long long T = g / kBlocksPerTile;
-  long long lo = tile_seg[T], hi = tile_seg[T + 1];          // entry [n_tiles] is the segment of the last output
-  while (lo < hi) {
-    const long long mid = (lo + hi + 1) >> 1;
-    if (seg_start[mid] <= jb) lo = mid; else hi = mid - 1;
+  if (jb >= len_out) continue;
+  // A wave's blocks lie in ONE tile.  The tile's first segment and the starts of the six segments from it on arrive
+  // by scalar loads and everything below is 32-bit arithmetic relative to the tile's first output; the lane counts the
+  // boundaries at or below its block.  Tiles with more segments (shorter than ~170 outputs) bisect the rest in memory.
+  const unsigned g0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)g);
+  const unsigned g1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)g >> 32));
+  const long long gw = (long long)(((unsigned long long)g1 << 32) | g0);      // the wave's first block
+  const long long T = gw / kBlocksPerTile;
+  const long long j0 = T * kSincTileOutputs;
+  const long long iT = tile_seg[T];
+  int Sr[kTileStarts];                                        // segment starts relative to j0 (first one may be negative)
+#pragma unroll
+  for (int q = 0; q < kTileStarts; ++q) {
+    const long long d = tile_st[T * kTileStarts + q] - j0;
+    Sr[q] = d < -0x40000000ll ? -0x40000000 : (d > 0x40000000ll ? 0x40000000 : (int)d);
   }
-  const long long i = lo;
-  const long long start = seg_start[i], next = seg_start[i + 1];
+  const int jr = (int)(jb - j0);                              // 0 .. 1016
+  int si = 0;
+#pragma unroll
+  for (int q = 1; q < kTileStarts; ++q) si += jr >= Sr[q];
+  long long i = iT + si;
+  long long k;                                                // step index of the block's first output in its segment
+  int rem;                                                    // outputs of segment i from jb on (>= 1), clamped to 9
+  long long slot0;                                            // checkpoint slot of the segment's step 0
+  if (si < kTileStarts - 1 && Sr[0] > -0x40000000) {
+    int sr = Sr[0], nr = Sr[1];
+#pragma unroll
+    for (int q = 1; q < kTileStarts - 1; ++q) {
+      if (si == q) {
+        sr = Sr[q];
+        nr = Sr[q + 1];
+      }
+    }
+    k = jr - sr;
+    const int d = nr - jr;
+    rem = d < 9 ? d : 9;
+    slot0 = ck_slot0(j0 + sr, i);
+  } else {                                                    // beyond the table (or a segment of > 10^9 outputs)
+    long long hi = tile_seg[T + 1];                           // entry [n_tiles] is the segment of the last output
+    while (i < hi) {
+      const long long mid = (i + hi + 1) >> 1;
+      if (seg_start[mid] <= jb) i = mid; else hi = mid - 1;
+    }
+    const long long start = seg_start[i], d = seg_start[i + 1] - jb;
+    k = jb - start;
+    rem = d < 9 ? (int)d : 9;
+    slot0 = ck_slot0(start, i);
+  }
+  // everything the block needs, in one round of independent loads (the next segment's record speculatively: boundary
+  // blocks need its flags)
+  const long long i1 = i + 1 < nseg ? i + 1 : i;
   const SegFast sf = seg_fast[i];
-  const double s0 = sp[i];
-  const long long k = jb - start;
+  const SegFast s1 = seg_fast[i1];
+  const double sp0 = sp[i], sp1 = sp[i1];
   const long long b = k >> 3;
   const int uk = (int)(k & 7);
   static_assert(kCk == 8, "k >> 3");
-  // cumsum before step k: checkpoint + the uk reciprocals of steps 8b .. k-1
-  double cprev = b ? ck[ck_slot0(start, i) + b] : 0.0;
-  if (uk) {
-    if (sf.fast) {                                            // midpoint rule + second-order term (remainder < 2e-10)
-      const double r = 1.0 / fma(sf.step, (double)k - 0.5 * (double)(uk + 1), s0);
-      const double z = r * sf.step;
-      cprev += r * (double)uk * fma(z * z, (double)(uk * uk - 1) * (1.0 / 12.0), 1.0);
-    } else {
-      for (int v = 0; v < uk; ++v) cprev += 1.0 / fma(sf.step, (double)(k - uk + v), s0);
-    }
-  }
-  const BlockPoly q0 = block_poly(sf.foff, sf.step, s0, (double)k, cprev);
+  const double ckv = b ? ck[slot0 + b] : 0.0;
+  const BlockPoly q0 = block_poly(sf.foff, sf.step, sp0, (double)k, uk, ckv, sf.fast != 0);
   const double r0 = rint(q0.a0);
   const long long I0 = sf.A + (long long)r0;
+  const bool range0 = fabs(q0.a0) < 1.0e9 && sf.A > -(1ll << 61) && sf.A < (1ll << 61);
+  const unsigned ustar = rem < 8 ? (unsigned)rem : 8u;
+  const long long ul = len_out - 1 - jb;                      // the file's last output reuses the previous period: slow path
+  const unsigned slow0 = !(sf.fast == 2 && range0 && fabs(q0.a1m1) <= 0.03125) || (ul >= 0 && ul < (long long)ustar);
+  unsigned slow1 = 0u, end1 = 0u;
+  if (ustar < 8) {                                            // a segment starts at u = ustar (its piece: k_block_rec2)
+    const int need = 8 - (int)ustar;                          // outputs of the block that fall to segment i + 1
+    end1 = s1.n == need;
+    // the record keeps ONE curvature term (e2 ~ -step/(2 speed^2)): the second piece rides on the first one's when the
+    // two agree to 1e-8 over u^2 <= 49; its first-order term must be inside the float32 budget like the first piece's
+    slow1 = !(i + 1 < nseg && s1.fast == 2 && s1.n >= need && s1.A > -(1ll << 61) && s1.A < (1ll << 61) && sp1 >= 0.971 &&
+              sp1 <= 1.031 && fabs(s1.step - sf.step) * 24.5 <= 1.0e-8 * sp1 * sp1) ||
+            (ul >= (long long)ustar && ul < 8);
+  }
   BlockRec o;
   o.I = (int)(unsigned)(unsigned long long)I0;
   o.F = (float)(q0.a0 - r0);
   o.e1 = (float)q0.a1m1;
-  o.e2 = (float)q0.a2;
-  const bool range0 = fabs(q0.a0) < 1.0e9 && sf.A > -(1ll << 61) && sf.A < (1ll << 61);
-  unsigned slow0 = !(sf.fast == 2 && range0 && fabs(q0.a1m1) <= 0.03125);
-  const long long rem = next - jb;                            // outputs of segment i from jb on (>= 1)
-  unsigned ustar = rem < 8 ? (unsigned)rem : 8u;
-  unsigned uend0 = rem <= 8 ? (unsigned)(rem - 1) : 15u, uend1 = 15u, slow1 = 0u;
-  o.I2 = 0;
-  o.F2 = 0.0f;
-  o.e1b = 0.0f;
-  BlockPoly q1 = q0;
-  long long A1 = sf.A;
-  if (ustar < 8 && i + 1 < nseg) {                            // second piece: segment i + 1 starts at u = ustar
-    const SegFast s1 = seg_fast[i + 1];
-    const BlockPoly b1 = block_poly(s1.foff, s1.step, sp[i + 1], 0.0, 0.0);
-    const double us = (double)ustar;
-    q1.a0 = (b1.a0 - (1.0 + b1.a1m1) * us) + b1.a2 * us * us;  // polynomial in u' = u - ustar, rewritten in u
-    q1.a1m1 = b1.a1m1 - 2.0 * b1.a2 * us;
-    q1.a2 = b1.a2;
-    A1 = s1.A;
-    const double r1 = rint(q1.a0);
-    o.I2 = (int)(unsigned)(unsigned long long)(s1.A + (long long)r1);
-    o.F2 = (float)(q1.a0 - r1);
-    o.e1b = (float)q1.a1m1;
-    const long long need = 8 - (long long)ustar;              // outputs of the block that fall to segment i + 1
-    if ((long long)s1.n == need) uend1 = 7u;
-    // the record keeps ONE curvature term: the second piece rides on the first one's when they agree to 1e-8 over u^2
-    slow1 = !(s1.fast == 2 && (long long)s1.n >= need && fabs(q1.a0) < 1.0e9 && s1.A > -(1ll << 61) && s1.A < (1ll << 61) &&
-              fabs(q1.a1m1) <= 0.03125 && fabs(b1.a2 - q0.a2) * 49.0 <= 1.0e-8);
-  } else if (ustar < 8) {
-    slow1 = 1u;
-  }
-  const long long ul = len_out - 1 - jb;                      // the global last output reuses the previous period
-  if (ul >= 0 && ul < 8) {
-    if (ul < (long long)ustar) uend0 = (unsigned)ul; else uend1 = (unsigned)ul;
-  }
-  o.meta = ustar | (uend0 << 4) | (uend1 << 8) | (slow0 << 12) | (slow1 << 13);
+  o.e2m = (__float_as_uint((float)q0.a2) & ~kRecFlagBits) | (ustar - 1u) | ((unsigned)(rem == 8) << 3) | (end1 << 4) |
+          (slow0 << 5) | (slow1 << 6);
   rec[g] = o;
   // tile header: the block that opens the tile writes anchor / first centre, the one that holds the tile's last output
   // writes the last centre (approximate placements are fine here: K_sinc stages one sample of slack on either side)
-  if (g % kBlocksPerTile == 0) {
+  if (jr == 0) {
     TileHdr* hd = hdr + T;
     const long long anchor = I0 & ~1ll;
     hd->anchor = anchor;
@@ -1091,12 +1155,22 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
     hd->mn_rel = (int)(I0 - anchor);
     hd->flags = range0 ? 0 : 1;
   }
-  const long long jt = ((T + 1) * kSincTileOutputs < len_out ? (T + 1) * kSincTileOutputs : len_out) - 1;
+  const long long jt = (j0 + kSincTileOutputs < len_out ? j0 + kSincTileOutputs : len_out) - 1;
   if (jt >= jb && jt < jb + 8) {
-    const double u = (double)(jt - jb);
-    const bool second = (unsigned)(jt - jb) >= ustar;
-    const BlockPoly& q = second ? q1 : q0;
-    hdr[T].c_last = (second ? A1 : sf.A) + (long long)rint(q.a0 + u * (1.0 + q.a1m1) + u * u * q.a2);
+    const int ut = (int)(jt - jb);
+    double pl;
+    long long Al = sf.A;
+    if ((unsigned)ut < ustar) {
+      const double u = (double)ut;
+      pl = q0.a0 + u * (1.0 + q0.a1m1) + u * u * q0.a2;
+    } else {                                                  // in the next segment: its step ut - ustar
+      const BlockPoly b1 = block_poly(s1.foff, s1.step, sp1, 0.0, 0, 0.0, true);
+      const double u = (double)(ut - (int)ustar);
+      pl = b1.a0 + u * (1.0 + b1.a1m1) + u * u * b1.a2;
+      Al = s1.A;
+    }
+    hdr[T].c_last = Al + (long long)rint(pl);
+  }
   }
 }
 
@@ -1585,9 +1659,11 @@ static void launch_block_rec(const double* speeds, const par::PlanView& pv, int6
   using namespace par;
   const FusedAux a = fused_aux_view(aux, max_out, m);
   const int64_t blocks = (int64_t)fused_blocks(max_out);
-  hipLaunchKernelGGL(k_block_rec, dim3((unsigned)ceil_div(blocks, 256)), dim3(256), 0, s, speeds, pv.seg_start, nseg,
-                     (const double*)a.ck, (const int64_t*)a.tile_seg, (const SegFast*)a.seg_fast, a.hdr, a.rec,
-                     (const PlanHeader*)pv.hdr);
+  hipLaunchKernelGGL(k_block_rec, dim3((unsigned)ceil_div(blocks, 512)), dim3(256), 0, s, speeds, pv.seg_start, nseg,
+                     (const double*)a.ck, (const int64_t*)a.tile_seg, (const long long*)a.tile_st, (const SegFast*)a.seg_fast,
+                     a.hdr, a.rec, (const PlanHeader*)pv.hdr);
+  hipLaunchKernelGGL(k_block_rec2, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, s, speeds, pv.seg_start, nseg,
+                     (const SegFast*)a.seg_fast, a.rec2, (const PlanHeader*)pv.hdr);
 }
 
 // Shared implementation.  aux (optional, device): cumsum checkpoints for the fused resampler.
@@ -1658,7 +1734,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
     if (aux) {
       hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(std::max<int64_t>(nseg, max_tiles), 256)), dim3(256), 0, s,
                          speeds, pv.seg_start, pv.seg_off, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len),
-                         reinterpret_cast<SegFast*>(ck + ck_len + max_tiles), pv.hdr);
+                         reinterpret_cast<SegFast*>(ck + ck_len + max_tiles), fused_aux_view(aux, max_out, m).tile_st, pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
       launch_block_rec(speeds, pv, nseg, aux, max_out, m, s);
     }
@@ -1694,7 +1770,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
       if (rc != PAR_OK) return rc;
       hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(std::max<int64_t>(nseg, max_tiles), 256)), dim3(256), 0, s,
                          speeds, pv.seg_start, pv.seg_off, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len),
-                         reinterpret_cast<SegFast*>(ck + ck_len + max_tiles), pv.hdr);
+                         reinterpret_cast<SegFast*>(ck + ck_len + max_tiles), fused_aux_view(aux, max_out, m).tile_st, pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
       launch_block_rec(speeds, pv, nseg, aux, max_out, m, s);
       PAR_HIP_CHECK(hipGetLastError());

@@ -159,21 +159,29 @@ static_assert(sizeof(SegFast) == 32, "SegFast is loaded as two 16-byte words");
 // positions are a quadratic in u (the speed ramp is linear, so the reciprocal increments are linear to second order):
 //     p_u = I + F + u (1 + e1) + u^2 e2            u = 0..7
 // with I the integer part (low 32 bits of the absolute value: differences to the tile anchor are exact in int32
-// arithmetic) and |F| <= 1/2.  A block that contains a segment boundary carries a second piece (I2, F2, e1b; same e2)
-// for the outputs u >= ustar.  K_sinc reads nothing else per output: no segment lookup, no float64.
-//   meta: ustar (bits 0-3; 8: no second piece) | uend0 (4-7) | uend1 (8-11) | slow0 (12) | slow1 (13)
-//   uendX: the output of piece X (0..7; 15: none) whose period to the next output is the PREVIOUS increment -- the last
-//          output of a segment (the next segment starts at this ramp's end speed) and the global last output (:76-77)
-//   slowX: piece X is not covered by the model (steep ramp, speed far from 1, very short segments, |p| out of range):
-//          its outputs are placed by place_fast / place_exact instead
+// arithmetic) and |F| <= 1/2.  16 bytes per 8 outputs: K_sinc reads nothing else per output -- no segment lookup, no
+// float64.  The low 7 mantissa bits of e2 (a term of at most ~5e-4 samples, so 2^-17 of it is nothing) carry
+//   bits 0-2  ustar - 1: outputs u >= ustar belong to the NEXT segment and use the block's second piece (ustar = 8: none)
+//   bit  3    end0: (ustar = 8 only) the segment ends with the block's last output
+//   bit  4    end1: the second piece's segment ends with the block's last output
+//   bit  5/6  slow0 / slow1: that piece is not covered by the model (steep ramp, speed far from 1, very short segments,
+//             |p| out of range, the file's last output): its outputs are placed by place_fast / place_exact instead
+// The last output of a segment matters because its period to the next position is the PREVIOUS increment (the next
+// segment starts at this ramp's end speed); u = ustar - 1 is always such an output.
+// The second piece (I2, F2, e1b; it shares e2) lives in a parallel array that only boundary blocks touch.
 struct BlockRec {
   int I;
-  float F, e1, e2;
+  float F, e1;
+  unsigned e2m;             // float e2 with the flags in its low 7 bits
+};
+static_assert(sizeof(BlockRec) == 16, "BlockRec is one 16-byte word");
+constexpr unsigned kRecFlagBits = 0x7fu;
+struct BlockRec2 {
   int I2;
   float F2, e1b;
-  unsigned meta;
+  unsigned pad;
 };
-static_assert(sizeof(BlockRec) == 32, "BlockRec is loaded as two 16-byte words");
+static_assert(sizeof(BlockRec2) == 16, "BlockRec2 is one 16-byte word");
 // Tile header: everything K_sinc needs before it can stage a tile's input span, in ONE scalar load.
 struct TileHdr {
   long long anchor;         // even integer next to the tile's first position
@@ -184,13 +192,16 @@ struct TileHdr {
 };
 static_assert(sizeof(TileHdr) == 32, "TileHdr is one s_load_dwordx8");
 constexpr int kBlocksPerTile = (int)(kSincTileOutputs / kCk);
+constexpr int kTileStarts = 6;     // seg_start of the tile's first segment and the five behind it (k_block_rec's lookup)
 // aux buffer of a fused plan: [ck_len checkpoints (f64)] [tile map (int64)] [m SegFast] [tiles TileHdr] [blocks BlockRec]
+// [blocks BlockRec2 (sparse)] [tiles x kTileStarts int64]
 inline size_t fused_ck_len(int64_t max_out, int64_t m) { return (size_t)(max_out / kCk + m + 16); }
 inline size_t fused_tiles(int64_t max_out) { return (size_t)(max_out / kSincTileOutputs + 4); }
 inline size_t fused_blocks(int64_t max_out) { return fused_tiles(max_out) * kBlocksPerTile; }
 inline size_t fused_aux_bytes(int64_t max_out, int64_t m) {
   return (fused_ck_len(max_out, m) + fused_tiles(max_out)) * 8 + (size_t)m * sizeof(SegFast) +
-         fused_tiles(max_out) * sizeof(TileHdr) + fused_blocks(max_out) * sizeof(BlockRec);
+         fused_tiles(max_out) * (sizeof(TileHdr) + kTileStarts * 8) +
+         fused_blocks(max_out) * (sizeof(BlockRec) + sizeof(BlockRec2));
 }
 struct FusedAux {            // views into the aux buffer
   double* ck;
@@ -198,6 +209,8 @@ struct FusedAux {            // views into the aux buffer
   SegFast* seg_fast;
   TileHdr* hdr;
   BlockRec* rec;
+  BlockRec2* rec2;
+  long long* tile_st;
 };
 inline FusedAux fused_aux_view(void* aux, int64_t max_out, int64_t m) {
   FusedAux v;
@@ -206,6 +219,8 @@ inline FusedAux fused_aux_view(void* aux, int64_t max_out, int64_t m) {
   v.seg_fast = reinterpret_cast<SegFast*>(v.tile_seg + fused_tiles(max_out));
   v.hdr = reinterpret_cast<TileHdr*>(v.seg_fast + m);
   v.rec = reinterpret_cast<BlockRec*>(v.hdr + fused_tiles(max_out));
+  v.rec2 = reinterpret_cast<BlockRec2*>(v.rec + fused_blocks(max_out));
+  v.tile_st = reinterpret_cast<long long*>(v.rec2 + fused_blocks(max_out));
   return v;
 }
 

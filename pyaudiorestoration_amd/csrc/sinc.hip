@@ -548,6 +548,7 @@ struct FusedArgs {
   const SegFast* seg_fast;
   const TileHdr* hdr;
   const BlockRec* rec;
+  const BlockRec2* rec2;
   int64_t nseg;
 };
 
@@ -885,20 +886,31 @@ __global__ __launch_bounds__(kSincBlock * NCH, PAR_SINC_WAVES) void k_sinc_fused
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int t = threadIdx.x;
   const int l = t & (kWave - 1);
+#ifdef PAR_SINC_WG1                                 // experiment: one wave per workgroup (grid = waves)
+  const int wv = 0;
+  float* tile = lds_all;
+  const int64_t jw = (int64_t)blockIdx.x * kWaveOut;
+  const int64_t T = jw / kSincTile;
+#else
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   float* tile = lds_all + wv * (capw * NCH);      // this wave's span: channel 0, then channel 1 `capw` floats on
   const int64_t T = blockIdx.x;
-  const int64_t j0 = T * kSincTile;
-  const int64_t jw = j0 + (int64_t)wv * kWaveOut; // the wave's outputs: jw + l + 64 r, r < kOut
+  const int64_t jw = T * kSincTile + (int64_t)wv * kWaveOut; // the wave's outputs: jw + l + 64 r, r < kOut
+#endif
   PAR_PHASE_BEGIN();
-  // 1. records of this lane's outputs: block (jw >> 3) + (l >> 3) + 8 r, u = l & 7 for every r
-  const uint4* rp = reinterpret_cast<const uint4*>(fa.rec + (jw >> 3) + (l >> 3));
-  uint4 ra[kOut], rb[kOut];
+#ifdef PAR_SINC_PRIO
+  __builtin_amdgcn_s_setprio(PAR_SINC_PRIO);     // a young wave gets its loads out ahead of its neighbours' tap loops
+#endif
+  // 1. records of this lane's outputs: block (jw >> 3) + (l >> 3) + 8 r, u = l & 7 for every r.  Unconditional 16-byte
+  // loads off a wave-uniform base (indices past the file's last block are clamped to it)
+  const int nrem = (int)(len_out - jw < (int64_t)kWaveOut ? (len_out - jw > 0 ? len_out - jw : 0) : kWaveOut);   // valid outputs of the wave
+  const int gmax = nrem > 0 ? (nrem - 1) >> 3 : 0;
+  const uint4* rp = reinterpret_cast<const uint4*>(fa.rec + (jw >> 3));
+  uint4 ra[kOut];
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
-    const bool v = jw + l + (int64_t)r * kWave < len_out;
-    ra[r] = v ? rp[r * 16] : make_uint4(0, 0, 0, 0);
-    rb[r] = v ? rp[r * 16 + 1] : make_uint4(0, 0, 0, 8u | (15u << 4) | (15u << 8));
+    const int gr = (l >> 3) + 8 * r;
+    ra[r] = rp[gr < gmax ? gr : gmax];
   }
   // 2. tile header: the anchor all window centres are relative to
   const TileHdr hd = fa.hdr[T];
@@ -912,26 +924,46 @@ __global__ __launch_bounds__(kSincBlock * NCH, PAR_SINC_WAVES) void k_sinc_fused
   const float uf = (float)u, u2f = uf * uf, tw1 = 2.0f * uf + 1.0f, tw0 = 2.0f * uf - 1.0f;
   int c[kOut];
   float s[kOut], fc[kOut], dd[kOut];
-  bool valid[kOut], lowfc[kOut], redo[kOut], slow[kOut];
-  bool unity = true, wild = (hd.flags & 1) != 0, anyredo = false;
+  bool valid[kOut], lowfc[kOut], redo[kOut], slow[kOut], second[kOut];
+  bool unity = true, wild = (hd.flags & 1) != 0, anyredo = false, anysecond = false;
+  unsigned I[kOut];
+  float F[kOut], e1[kOut];
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
-    const int64_t j = jw + l + (int64_t)r * kWave;
-    valid[r] = j < len_out;
-    const unsigned m = rb[r].w;
-    const bool second = (unsigned)u >= (m & 15u);
-    const unsigned I = second ? rb[r].x : ra[r].x;
-    const float F = __uint_as_float(second ? rb[r].y : ra[r].y);
-    const float e1 = __uint_as_float(second ? rb[r].z : ra[r].z);
-    const float e2 = __uint_as_float(ra[r].w);
-    const unsigned uend = (second ? (m >> 8) : (m >> 4)) & 15u;
-    slow[r] = valid[r] && (((second ? (m >> 13) : (m >> 12)) & 1u) != 0u);
-    const float frac = fmaf(u2f, e2, fmaf(uf, e1, F));
+    valid[r] = l + kWave * r < nrem;
+    second[r] = (unsigned)u > (ra[r].w & 7u);            // u >= ustar, ustar - 1 in bits 0-2
+    anysecond = anysecond || second[r];
+    I[r] = ra[r].x;
+    F[r] = __uint_as_float(ra[r].y);
+    e1[r] = __uint_as_float(ra[r].z);
+  }
+  if (__any(anysecond)) {            // a segment starts inside some lane's block: those lanes take its second piece
+    const uint4* rp2 = reinterpret_cast<const uint4*>(fa.rec2 + (jw >> 3));
+#pragma unroll
+    for (int r = 0; r < kOut; ++r) {
+      if (second[r]) {
+        const int gr = (l >> 3) + 8 * r;
+        const uint4 q = rp2[gr < gmax ? gr : gmax];
+        I[r] = q.x;
+        F[r] = __uint_as_float(q.y);
+        e1[r] = __uint_as_float(q.z);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kOut; ++r) {
+    const unsigned m = ra[r].w;
+    const float e2 = __uint_as_float(m & ~kRecFlagBits);
+    const unsigned ustar1 = m & 7u;                      // ustar - 1
+    // the segment's last output (period = previous increment): u = ustar - 1 in a boundary block, else u = 7 with end0/end1
+    const bool plateau = second[r] ? (u == 7 && (m & 16u)) : (ustar1 < 7u ? (unsigned)u == ustar1 : (u == 7 && (m & 8u)));
+    slow[r] = valid[r] && ((second[r] ? (m & 64u) : (m & 32u)) != 0u);
+    const float frac = fmaf(u2f, e2, fmaf(uf, e1[r], F[r]));
     const float ri = rintf(frac);
     const float sh = frac - ri;
-    c[r] = (int)(I - alo) + u + (int)ri;
+    c[r] = (int)(I[r] - alo) + u + (int)ri;
     s[r] = (sh == 0.0f) ? 1e-20f : sh;              // np.sinc's own 0 -> 1e-20 substitution
-    const float e = fmaf(e2, (unsigned)u == uend ? tw0 : tw1, e1);          // period to the next position, minus 1
+    const float e = fmaf(e2, plateau ? tw0 : tw1, e1[r]);                    // period to the next position, minus 1
     const bool one = !(e > 0.0f);
     const float inv = fast_rcp(1.0f + e);
     fc[r] = one ? 1.0f : inv;
@@ -940,7 +972,7 @@ __global__ __launch_bounds__(kSincBlock * NCH, PAR_SINC_WAVES) void k_sinc_fused
     redo[r] = slow[r] || (valid[r] && !(fabsf(fabsf(sh) - 0.5f) > tolf));
     anyredo = anyredo || redo[r];
     if (PAR_SINC_EXP & 2) {
-      c[r] = (int)(j - anchor) + 64;
+      c[r] = (int)(jw + l + kWave * r - anchor) + 64;
       s[r] = 0.3f - 1e-4f * (float)(t & 63);
       fc[r] = (PAR_SINC_EXP & 4) ? 0.995f : 1.0f;
       dd[r] = (PAR_SINC_EXP & 4) ? 0.005f : 0.0f;
@@ -1003,10 +1035,11 @@ __global__ __launch_bounds__(kSincBlock * NCH, PAR_SINC_WAVES) void k_sinc_fused
   // leading-edge outputs (ind < NT) keep the reference's mis-aligned taps: float64 slow path.
   bool fastlane[kOut];
   bool anyfast = false;
-  const long long edge = (long long)NT - anchor;    // ind >= NT  <=>  rel index >= edge
+  const long long edge64 = (long long)NT - anchor;    // ind >= NT  <=>  rel index >= edge
+  const int edge = edge64 < -2000000000ll ? -2000000000 : (edge64 > 2000000000ll ? 2000000000 : (int)edge64);
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
-    fastlane[r] = valid[r] && usable && (long long)c[r] >= edge && !lowfc[r] && c[r] >= mn - 1 && c[r] <= mx + 1;
+    fastlane[r] = valid[r] && usable && c[r] >= edge && !lowfc[r] && c[r] >= mn - 1 && c[r] <= mx + 1;
     c[r] = fastlane[r] ? c[r] - mn + margin : margin;      // LDS index of the window centre (idle lanes: harmless)
     anyfast = anyfast || fastlane[r];
   }
@@ -1022,7 +1055,13 @@ __global__ __launch_bounds__(kSincBlock * NCH, PAR_SINC_WAVES) void k_sinc_fused
     dds[sl] = dd[sl / NCH];
     res[sl] = 0.0f;
   }
+#ifdef PAR_SINC_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   if (!(PAR_SINC_EXP & 1) && __any(anyfast)) run_taps<NTC>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res);
+#ifdef PAR_SINC_PRIO
+  __builtin_amdgcn_s_setprio(PAR_SINC_PRIO_OUT);
+#endif
 #if PAR_SINC_EXP & 128
   {                                   // the tap loops a second time (what does ONE more pass cost?)
     float res2[kSincR];
@@ -1035,12 +1074,14 @@ __global__ __launch_bounds__(kSincBlock * NCH, PAR_SINC_WAVES) void k_sinc_fused
 #endif
   PAR_PHASE_MARK(4);                 // taps
   // 6. stores
+  float* const op0 = out + (jw + l) * out_stride;
+  float* const op1 = NCH == 2 ? out1 + (jw + l) * out_stride : nullptr;
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
-    const int64_t j = jw + l + (int64_t)r * kWave;
-    if (j >= len_out) continue;
+    if (!valid[r]) continue;
     PosDp e{0.0, 1.0};
     if (!fastlane[r]) {
+      const long long j = jw + l + (int64_t)r * kWave;
       long long i = hd.iT;
       while (i + 1 < fa.nseg && fa.seg_start[i + 1] <= j) ++i;
       e = place_exact(fa.speeds, fa.seg_start, fa.seg_off, fa.ck, i, j, len_out);
@@ -1050,7 +1091,7 @@ __global__ __launch_bounds__(kSincBlock * NCH, PAR_SINC_WAVES) void k_sinc_fused
       float v = res[r * NCH + ch];
       if (!fastlane[r]) v = sinc_one_f64(e.p, e.dp, ch ? sig1 : sig, sig_stride, len_in, NT);
       if ((PAR_SINC_EXP & 32) && v != 12345.678f) continue;
-      (ch ? out1 : out)[j * out_stride] = v;
+      (ch ? op1 : op0)[(int64_t)(r * kWave) * out_stride] = v;
     }
   }
   PAR_PHASE_MARK(5);                 // stores issued
@@ -1181,11 +1222,19 @@ int launch_sinc_fused(int device, const double* speeds, int64_t m, const void* w
   fa.seg_fast = av.seg_fast;
   fa.hdr = av.hdr;
   fa.rec = av.rec;
+  fa.rec2 = av.rec2;
   fa.nseg = m - 1;
   const int64_t blocks = ceil_div(len_out, kSincTile);
+#ifdef PAR_SINC_WG1
+#define PAR_LAUNCH_FUSED(NCH, NTC)                                                                                         \
+  hipLaunchKernelGGL((k_sinc_fused<NCH, NTC>), dim3((unsigned)ceil_div(len_out, kWave * kSincR / NCH)), dim3(kWave),       \
+                     kSincCap / (NCH * kSincBlock / kWave) * NCH * sizeof(float), s, len_out, sig, sig1, sig_stride, len_in, NT, \
+                     tab.ab, tab.modes, out, out1, out_stride, fa)
+#else
 #define PAR_LAUNCH_FUSED(NCH, NTC)                                                                                         \
   hipLaunchKernelGGL((k_sinc_fused<NCH, NTC>), dim3((unsigned)blocks), dim3(NCH * kSincBlock), NCH * kSincCap * sizeof(float), \
                      s, len_out, sig, sig1, sig_stride, len_in, NT, tab.ab, tab.modes, out, out1, out_stride, fa)
+#endif
   if (sig1 && out1) {
     if (NT == 32) PAR_LAUNCH_FUSED(2, 32);
     else if (NT == 50) PAR_LAUNCH_FUSED(2, 50);

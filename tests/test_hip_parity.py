@@ -1178,3 +1178,141 @@ def test_headless_cli_respeed_and_resample(par, golden, tmp_path):
     pos, _ = C.speed_to_pos(np.array([0.0, len(x) / 192000]) * 192000, np.array([1.015, 1.015]), len(x))   # run(): t * sr
     ref3 = C.sinc(pos, np.ascontiguousarray(x[:, 0]), 32, threads=8)
     assert len(y3) == len(ref3) and relerr(y3[:, 0], ref3) < TOL
+
+
+# --------------------------------------------------------------------------------- round-2 additions
+def test_stereo_kernel_against_the_oracle(par, golden, tmp_path):
+    """The stereo K_sinc form checked against the REFERENCE's arithmetic directly (not against the mono kernel):
+    both channels of interleaved files against the C oracle on the oracle's own positions, for the specialised tap
+    counts (32, 50) and a generic one, over fc == 1 and fc < 1 stretches; and resampling.run's channel-pairing branch
+    (util/resampling.py:225-227) on a 2-channel Sinc-mode file against the reference-generated golden."""
+    from oracle import oracle_c as C
+    from pyaudiorestoration_amd import io_ops
+    t = par.torch
+    R = par.resampling
+    rng = np.random.default_rng(77)
+    for n, depth, NT in ((300000, 0.01, 32), (120000, 0.03, 50), (90000, 0.2, 12), (40000, 0.0, 32)):
+        m = max(3, n // 256)
+        st = np.linspace(0, n, m)
+        sp = 1.0 + depth * np.sin(np.arange(m) * 0.05 + 0.3) + 0.0005 * rng.standard_normal(m)
+        sig = rng.standard_normal((n, 2)).astype(np.float32)
+        pos, _ = C.speed_to_pos(st, sp, n)
+        plan = R.speed_plan_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), n, fused=True)
+        assert plan.fused_ok and plan.len_out == len(pos)
+        inter = t.from_numpy(sig).cuda()
+        out = t.empty((plan.len_out, 2), dtype=t.float32, device="cuda")
+        R.varispeed_fused_stereo_dev(plan, inter.reshape(-1)[0:], inter.reshape(-1)[1:], NT, out.reshape(-1)[0:],
+                                     out.reshape(-1)[1:], sig_stride=2, len_in=n, out_stride=2)
+        got = out.cpu().numpy()
+        for c in (0, 1):
+            want = C.sinc(pos, np.ascontiguousarray(sig[:, c]), NT)
+            assert relerr(got[:, c], want) < TOL, (n, depth, NT, c)
+    # run(): both channels selected -> one stereo launch; channel 0 is the golden's signal, channel 1 goes to the oracle
+    g, gp = golden["sinc"], golden["speed_to_pos"]
+    sr = 48000
+    sig = np.stack((inputs.bench_signal(0, 96000, sr), inputs.noise(96000, 1)), axis=-1)
+    curve = inputs.bench_speed_curve(2.0, sr)
+    fn = str(tmp_path / "pair.flac")
+    R.run((fn,), signal_data=((sig, sr),), speed_curve=curve, resampling_mode="Sinc", sinc_quality=32)
+    y, sr2, ch = io_ops.read_file(str(tmp_path / "pair_res.wav"))
+    assert sr2 == sr and ch == 2 and y.shape == (len(gp["bench_pos"]), 2)
+    assert relerr(y[:, 0], g["bench_y"]) < TOL
+    assert relerr(y[:, 1], C.sinc(gp["bench_pos"], np.ascontiguousarray(sig[:, 1]), 32)) < TOL
+
+
+def test_full_size_config5_work_item(par):
+    """One work item of BASELINE config 5 at FULL size -- a 600-s 192 kHz STEREO file (2 x 115.2 M samples,
+    interleaved), per-file seed and curve phase as SURVEY 8d -- through size-independent properties: positions
+    bit-equal to the C oracle's over the whole file, 24 oracle windows per channel spread over the ten minutes, the
+    two channels independent of each other (a NaN in one poisons exactly its own +-NT neighbourhood), and the stereo
+    launch equal to one mono launch per channel."""
+    from oracle import oracle_c as C
+    from pyaudiorestoration_amd import _lib, _dev
+    t = par.torch
+    R = par.resampling
+    sr, dur, file_idx = 192000, 600.0, 3
+    n = int(sr * dur)
+    L = _lib.lib()
+    s0 = _dev.stream_ptr(0)
+    sig = t.empty((n, 2), dtype=t.float32, device="cuda")
+    mono = t.empty(n, dtype=t.float32, device="cuda")
+    for c in range(2):
+        _lib.check(L.par_synth_signal_f32(0, _dev.ptr(mono), 0, n, float(sr), 0x5EED ^ (2 * file_idx + c), s0))
+        sig[:, c] = mono
+    del mono
+    m = int(dur * sr / 256)
+    st_t = t.empty(m, dtype=t.float64, device="cuda")
+    sp_t = t.empty(m, dtype=t.float64, device="cuda")
+    _lib.check(L.par_synth_speed_curve_f64(0, _dev.ptr(st_t), _dev.ptr(sp_t), m, dur, float(sr), 0.01, 0.55, 0.7 + file_idx, s0))
+    plan = R.speed_plan_dev(st_t, sp_t, n, fused=True)
+    assert plan.fused_ok and plan.path == 0
+    ref_pos, _ = C.speed_to_pos(st_t.cpu().numpy(), sp_t.cpu().numpy(), n)
+    pos_t = R.speed_to_pos_dev(st_t, sp_t, n)
+    assert plan.len_out == len(ref_pos) and t.equal(pos_t.cpu(), t.from_numpy(ref_pos))
+    flat = sig.reshape(-1)
+    out = t.empty((plan.len_out, 2), dtype=t.float32, device="cuda")
+    R.varispeed_fused_stereo_dev(plan, flat[0:], flat[1:], 32, out.reshape(-1)[0:], out.reshape(-1)[1:], sig_stride=2, len_in=n,
+                                 out_stride=2)
+    for c in range(2):
+        one = R.varispeed_fused_dev(plan, flat[c:], 32, sig_stride=2, len_in=n)
+        assert relerr(out[:, c].cpu().numpy(), one.cpu().numpy()) < 2e-6, c
+        del one
+        for i in np.linspace(0, len(ref_pos) - 3000, 24).astype(np.int64):
+            lo = max(0, int(ref_pos[i]) - 200)
+            hi = min(n, int(ref_pos[i + 2000]) + 200)
+            win = sig[lo:hi, c].contiguous().cpu().numpy()
+            ref = C.sinc(ref_pos[i:i + 2001] - lo, win, 32)[:2000]
+            if lo == 0:
+                ref = C.sinc(ref_pos[i:i + 2001], win, 32)[:2000]
+            assert relerr(out[i:i + 2000, c].cpu().numpy(), ref) < TOL, (c, i)
+    bad = 77_000_000
+    sig[bad, 1] = float("nan")
+    out_n = t.empty_like(out)
+    R.varispeed_fused_stereo_dev(plan, flat[0:], flat[1:], 32, out_n.reshape(-1)[0:], out_n.reshape(-1)[1:], sig_stride=2,
+                                 len_in=n, out_stride=2)
+    ind = t.round(pos_t).to(t.int64)
+    expect = (ind - 32 <= bad) & (bad < ind + 32)
+    assert 60 <= int(expect.sum()) <= 68
+    assert t.equal(t.isnan(out_n[:, 1]), expect) and not bool(t.isnan(out_n[:, 0]).any())
+    assert t.equal(out_n[:, 0], out[:, 0]) and t.equal(out_n[:, 1][~expect], out[:, 1][~expect])
+
+
+def test_config4_x256_tiles_one_launch(par):
+    """BASELINE config 4 at its benchmarked size: the reference's dropouts_sample signal (padded to a whole number of
+    hops) tiled x256 = 82.6 M samples with the project's 32 markers repeated per tile -- 8192 gain boxes in ONE K_heal
+    launch, 2.58 M frames through K_stft and the fused ISTFT.  Frames and boxes of every tile are the first tile's
+    shifted by a whole number of frames, so every tile's interior must equal the oracle's output for ONE tile
+    (dropout_healer_gui.py:111-166 restated in oracle_np)."""
+    import json
+    import os
+    from oracle import oracle_np as O
+    from pyaudiorestoration_amd import io_ops
+    from test_oracle_golden import GOLD
+    x, sr, _ = io_ops.read_file(os.path.join(GOLD, "dropouts_sample.flac"))
+    cfg = json.load(open(os.path.join(GOLD, "dropouts_sample.drop")))
+    n_fft, hop, tiles = 512, 32, 256
+    n1 = -(-len(x) // hop) * hop                                     # 322 560 = 10 080 hops
+    x1 = np.zeros(n1, dtype=np.float32)
+    x1[:len(x)] = x[:, 0]
+    marks = [(m[0], m[1], m[2], m[3], cfg["surrounding"]) for m in cfg["dropouts"]]
+    geo1 = [par.pipeline.marker_geometry(mk, sr, hop, n_fft) for mk in marks]
+    all_marks = []
+    for k in range(tiles):
+        off = k * n1 / sr
+        for (a0, a1, b0, b1, s), g1 in zip(marks, geo1):
+            mk = (a0 + off, a1, b0 + off, b1, s)
+            gk = par.pipeline.marker_geometry(mk, sr, hop, n_fft)
+            shift = k * (n1 // hop)                                       # same box, a whole number of frames on
+            assert gk[0] - g1[0] == shift and gk[1] - g1[1] == shift and tuple(gk[2:]) == tuple(g1[2:]), (k, gk, g1)
+            all_marks.append(mk)
+    assert len(all_marks) == 8192
+    want = O.heal_dropouts(x1, sr, marks, n_fft, hop)[:, 0]
+    got = par.pipeline.heal_dropouts(np.tile(x1, tiles), sr, all_marks, n_fft, hop)[:, 0]
+    assert got.shape == (n1 * tiles,)
+    edge = 2 * n_fft                                                  # tile edges see the neighbour tile, not the reflection
+    scale = np.max(np.abs(want))
+    worst = 0.0
+    for k in range(tiles):
+        d = np.max(np.abs(got[k * n1 + edge:(k + 1) * n1 - edge] - want[edge:n1 - edge])) / scale
+        worst = max(worst, d)
+    assert worst < TOL, worst
