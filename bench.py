@@ -7,9 +7,10 @@ speed curve -> segment plan -> float64 positions (K_pos) -> Hann-windowed sinc i
 60-min mono float32, speed 1 + 0.01 sin(2 pi 0.55 t + 0.7) sampled every 256 samples, NT = 32
 (SURVEY 8d).  Inputs are synthesised on the device (closed form + stateless hash noise).
 
-N > 1: one process per GPU (torch.distributed.run), every rank resamples its OWN file (seed = rank)
--- files/channels are independent in the reference (util/resampling.py:168,225), so there is no
-data-path collective; the only communication is the timing barrier / MAX reduction.  Weak scaling.
+N > 1 (or --config5): BASELINE config 5 -- the 512-file archive (192 kHz stereo, 10 min each) as ONE step,
+shared out over the ranks through a host-side work queue (files/channels are independent in the reference,
+util/resampling.py:168,225): one process per GPU, no data-path collective, no RCCL (gloo barrier + MAX/SUM of
+time and sample counts).  Strong scaling: the batch is fixed, `value` = aggregate channel-samples/s.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event-timed
 K_sinc launches vs the 8 TB/s HBM peak, 8 algorithmic bytes per output sample) and `cpu_baseline`
@@ -57,7 +58,7 @@ def cpu_baseline(sr, nt, budget_s=15.0):
                       f"C speed_to_pos on 1 thread + C sinc on {cores} threads (contiguous chunks like sinc_wrapper_mt)"}
 
 
-def stft_secondary(sig, dev, n_fft=1024, hop=256):
+def stft_secondary(sig, dev, n_fft=1024, hop=256, cpu=True):
     """Secondary line (not the metric): K_stft magnitude throughput on the same resident signal, against
     its 12.02 B/sample HBM roofline and the reference's own GPU route torch.stft + abs
     (util/fourier.py:101-107, rocFFT) -- a reported baseline, not the optimisation target."""
@@ -88,9 +89,29 @@ def stft_secondary(sig, dev, n_fft=1024, hop=256):
         return r.abs() + 1e-7
     t_ref = t_of(ref, 3)
     bps = 4 + 4 * (n_fft / 2 + 1) / hop
-    return {"kernel": "k_stft get_mag 1024/256", "samples": n, "Msamples/s": round(n / t_mag / 1e6, 1),
-            "algorithmic_GB/s": round(n * bps / t_mag / 1e9, 1), "frac_of_hbm_peak": round(n * bps / t_mag / 8e12, 4),
-            "torch_stft_abs_Msamples/s": round(n / t_ref / 1e6, 1)}
+    res = {"kernel": "k_stft get_mag 1024/256", "samples": n, "Msamples/s": round(n / t_mag / 1e6, 1),
+           "algorithmic_GB/s": round(n * bps / t_mag / 1e9, 1), "frac_of_hbm_peak": round(n * bps / t_mag / 8e12, 4),
+           "torch_stft_abs_Msamples/s": round(n / t_ref / 1e6, 1)}
+    if cpu:
+        # CPU lines of BASELINE.md section 4 (reported baselines, bounded samples): (a) the reference's numpy route --
+        # np.fft.rfft over reflect-padded windowed frames, 1 thread (oracle_np restates util/fourier.py:136-157);
+        # (b) the C port, frames split over the host cores
+        from oracle import oracle_c as C
+        from oracle import oracle_np as O
+        xs = x[:min(n, 20 * 192000)].cpu().numpy()
+        wn = win.cpu().numpy()
+        t0 = time.perf_counter()
+        O.get_mag(xs[:4 * 192000], n_fft, hop, "blackmanharris")
+        t_np = time.perf_counter() - t0
+        res["numpy_rfft_1thread_Msamples/s"] = round(4 * 192000 / t_np / 1e6, 2)
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        C.stft(xs, n_fft, hop, wn, 1, mode=1, threads=cores)
+        t_c = time.perf_counter() - t0
+        res["c_port_Msamples/s"] = round(len(xs) / t_c / 1e6, 2)
+        res["c_port_threads"] = cores
+        res["cpu_sample"] = f"numpy: 4 s of audio, 1 thread; C port: {len(xs) / 192000:g} s of audio, {cores} threads (frames split)"
+    return res
 
 
 def heal_secondary(dev, tiles=256):
@@ -183,6 +204,79 @@ def stereo_secondary(dev, sr=192000, seconds=600.0, nt=32):
             "Msamples/s": round(2 * len_out.value / dt / 1e6, 1)}
 
 
+def config5_batch(a, ctx):
+    """BASELINE config 5 as the timed workload (N > 1, or --config5): 512 stereo 10-min files at 192 kHz, one step =
+    the whole archive.  Every rank pulls files from the shared longest-first queue (multi_gpu.WorkQueue: a host-side
+    fetch-add, no collective) and runs them through resampling.varispeed_batch_dev: one plan per file (each file has
+    its own speed curve: phase 0.7 + file index) and ONE stereo K_sinc launch, the next file's plan on a
+    side stream under it.  Inputs resident in HBM before the timed region: a ring of `--ring` synthetic stereo files
+    per GPU (the archive itself is 472 GB; signal content does not change the work) and all 512 speed curves."""
+    import torch
+    from pyaudiorestoration_amd import _dev, _lib, multi_gpu, resampling
+    world, rank, dev = ctx.world, ctx.rank, ctx.local
+    L = _lib.lib()
+    s = _dev.stream_ptr(dev)
+    sr, seconds, files = a.sr, 600.0, a.files
+    n, m = int(sr * seconds), int(seconds * sr / 256)
+    ring = []
+    mono = torch.empty(n, dtype=torch.float32, device=f"cuda:{dev}")
+    for k in range(a.ring):
+        sig = torch.empty((n, 2), dtype=torch.float32, device=f"cuda:{dev}")
+        for c in range(2):
+            _lib.check(L.par_synth_signal_f32(dev, _dev.ptr(mono), 0, n, float(sr), 0x5EED ^ (2 * (rank * a.ring + k) + c), s))
+            sig[:, c] = mono
+        ring.append(sig)
+    del mono
+    curves = torch.empty((files, 2, m), dtype=torch.float64, device=f"cuda:{dev}")
+    for f in range(files):
+        _lib.check(L.par_synth_speed_curve_f64(dev, _dev.ptr(curves[f, 0]), _dev.ptr(curves[f, 1]), m, seconds, float(sr), 0.01,
+                                               0.55, 0.7 + f, s))
+    torch.cuda.synchronize()
+    done = {"samples": 0, "files": 0}
+    step_no = [0]
+
+    def step():
+        q = multi_gpu.WorkQueue(ctx, range(files), f"s{step_no[0]}")
+        step_no[0] += 1
+
+        def produce():
+            for k, f in enumerate(q):
+                yield curves[f, 0], curves[f, 1], ring[k % a.ring]
+        n_s = n_f = 0
+        for _, out, plan in resampling.varispeed_batch_dev(produce(), a.nt, dev):
+            n_s += 2 * plan.len_out
+            n_f += 1
+        done["samples"], done["files"] = n_s, n_f
+
+    for _ in range(a.warmup):
+        step()
+    dt = ctx.timed(step, a.steps)
+    total = ctx.reduce_sum(done["samples"])            # channel-samples of one step, all ranks
+    files_max, files_min = ctx.reduce_max(done["files"]), -ctx.reduce_max(-done["files"])
+    if rank == 0:
+        value = total * a.steps / dt / 1e6
+        res = {
+            "metric": "Msamples/sec resampled (192 kHz varispeed)", "value": round(value, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 taps / f64 positions",
+            "data": "synthetic",
+            "config": {"workload": f"config 5: {files}-file archive, {seconds:g}-s {sr} Hz stereo float32 each, +-1% sinusoidal speed "
+                                   f"curve per file (0.55 Hz, hop 256, phase 0.7 + file index), {2 * a.nt}-tap Hann sinc; one step = the "
+                                   "whole archive, files pulled by the ranks from a shared host-side queue (no collective, no RCCL)",
+                       "files": files, "channel_samples_per_step": int(total), "files_per_rank_min_max": [int(files_min), int(files_max)],
+                       "NT": a.nt, "resident": f"ring of {a.ring} synthetic stereo files per GPU + all {files} speed curves",
+                       "step": "per file: plan (device scans, cumsum checkpoints, block records) + ONE stereo fused K_sinc launch; "
+                               "the next file's plan runs on a side stream under K_sinc"},
+            "roofline": {"bound": "hbm", "achieved": round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / world, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / world / HBM_PEAK_GBS, 5),
+                         "traffic": None, "kernel": "k_sinc_fused<2> (whole step, per GPU)",
+                         "note": "per-GPU whole-step rate x 8 algorithmic B per channel-sample; the per-kernel roofline with HIP-event "
+                                 "timing and PMC traffic is the N = 1 line's"},
+        }
+        print(json.dumps(res), flush=True)
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,13 +290,18 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="serial steps (plan, then K_sinc); default: the plan of file k+1 runs on a side stream under K_sinc of file k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config5", action="store_true", help="time the 512-file stereo archive (default when --gpus > 1)")
+    ap.add_argument("--files", type=int, default=512, help="files of the config-5 archive")
+    ap.add_argument("--ring", type=int, default=6, help="resident synthetic stereo files per GPU in the config-5 mode")
     a = ap.parse_args()
 
     import torch
     from pyaudiorestoration_amd import _dev, _lib, multi_gpu
 
-    ctx = multi_gpu.RankContext()                      # nccl (= RCCL) when WORLD_SIZE > 1, else single process
+    ctx = multi_gpu.RankContext()                      # gloo (host-side barrier / reductions) when WORLD_SIZE > 1: no RCCL
     world, rank, local, dist = ctx.world, ctx.rank, ctx.local, ctx.dist
+    if world > 1 or a.config5:
+        return config5_batch(a, ctx)
     dev = local
     L = _lib.lib()
     sp_ = _dev.stream_ptr(dev)
@@ -335,11 +434,12 @@ def main():
         res = {
             "metric": "Msamples/sec resampled (192 kHz varispeed)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 taps / f64 positions",
+            "data": "synthetic",
             "config": {"workload": f"{a.seconds:g}-s {a.sr} Hz mono float32 varispeed resample, +-1% sinusoidal speed "
                                    f"curve (0.55 Hz, hop 256), {2 * a.nt}-tap Hann sinc; one file per GPU",
                        "samples_in_per_gpu": n_in, "samples_out_per_gpu": int(len_out.value), "NT": a.nt,
-                       "step": ("plan (device scans, cumsum checkpoints) + fused K_sinc (float64 positions regenerated per tile in LDS)" if fused else "plan (device scans) + K_pos fill (float64 position array) + K_sinc") + "; inputs resident in HBM"
+                       "step": ("plan (device scans, cumsum checkpoints, block records) + fused K_sinc (outputs placed from 16-byte block records, no position array)" if fused else "plan (device scans) + K_pos fill (float64 position array) + K_sinc") + "; inputs resident in HBM"
                                + ("; batch pipelining: the plan of file k+1 runs on a side stream under K_sinc of file k (every step = one full plan + one full K_sinc)" if overlap else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": "k_sinc",
@@ -349,7 +449,7 @@ def main():
                                  "traffic = PMC HBM bytes/sample (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json) at this "
                                  "run's rate" + (": signal + output + 1 B/sample cumsum checkpoints + tile halos"
                                                  if fused else " incl. the 8 B float64 position read") +
-                                 "; the kernel is VALU-bound (~80 % VALU issue utilisation), see DESIGN.md"},
+                                 "; HBM is NOT what limits this kernel (64 taps per output against 8 B): see roofline_valu"},
         }
         if overlap:
             k_alone = min(alone)
@@ -358,8 +458,24 @@ def main():
             res["roofline"]["note"] += ("; kernel_ms is measured in the timed region, where the next file's plan kernels "
                                         "share the GPU with K_sinc; kernel_ms_alone / frac_alone = the same launch with the "
                                         "GPU to itself, measured before the timed region")
+        # What actually limits the kernel: VALU issue.  Instruction count per output from the committed PMC pass
+        # (SQ_INSTS_VALU, profiles/), rate from this run's HIP-event time; ceilings: 2 cycles per wave64 instruction
+        # per SIMD at the 2.4 GHz peak clock (MI355X_MICROARCH.md) and the rate a pure v_fma_f32 stream measured
+        # (tools/ubench.hip, profiles/r01_ubench_gfx950.txt).
+        try:
+            vp = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu.json")))
+            ipo = vp["valu_lane_instr_per_output"]
+            ach = ipo * samples_per_launch / (k_ms * 1e-3) / 1e12
+            res["roofline_valu"] = {"limited_by": "valu", "valu_lane_instr_per_output": round(ipo, 1),
+                                    "achieved_Tlaneops": round(ach, 2), "ceiling_spec_Tlaneops": 78.64,
+                                    "ceiling_measured_fma_stream_Tlaneops": vp.get("fma_stream_Tlaneops", 58.76),
+                                    "frac_of_spec": round(ach / 78.64, 4),
+                                    "frac_of_measured": round(ach / vp.get("fma_stream_Tlaneops", 58.76), 4),
+                                    "source": vp.get("source", "profiles/")}
+        except Exception:
+            pass
         if world == 1:
-            res["secondary"] = stft_secondary(sig, dev)
+            res["secondary"] = stft_secondary(sig, dev, cpu=not a.no_cpu_baseline)
             res["secondary_config4"] = heal_secondary(dev)
             if hasattr(L, "par_varispeed_fused_stereo_f32"):        # absent only in an older build under PAR_HIP_LIB
                 res["secondary_config5"] = stereo_secondary(dev)

@@ -34,6 +34,8 @@ def lib():
         L.oracle_sinc_mt.argtypes = [vp, i64, vp, i64, i64, ci, vp, i64, ci]
         L.oracle_stft.restype = ci
         L.oracle_stft.argtypes = [vp, i64, i64, ci, ci, ci, vp, vp, ci]
+        L.oracle_stft_mt.restype = ci
+        L.oracle_stft_mt.argtypes = [vp, i64, i64, ci, ci, ci, vp, vp, ci, ci]
         L.oracle_synth_signal.restype = None
         L.oracle_synth_signal.argtypes = [vp, i64, i64, dbl, ctypes.c_uint64]
         L.oracle_synth_curve.restype = None
@@ -74,13 +76,16 @@ def sinc(pos, sig, NT, threads=1):
     return out
 
 
-def stft(x, n_fft, hop, window, zeropad=1, mode=0):
+def stft(x, n_fft, hop, window, zeropad=1, mode=0, threads=1):
     x = np.ascontiguousarray(x, dtype=np.float32)
     window = np.ascontiguousarray(window, dtype=np.float32)
     bins = n_fft * zeropad // 2 + 1
     frames = (len(x) + 2 * (n_fft // 2) - n_fft) // hop + 1
     out = np.empty((frames, bins * (2 if mode == 0 else 1)), dtype=np.float32)
-    rc = lib().oracle_stft(_p(x), len(x), 1, n_fft, hop, zeropad, _p(window), _p(out), mode)
+    if threads > 1:
+        rc = lib().oracle_stft_mt(_p(x), len(x), 1, n_fft, hop, zeropad, _p(window), _p(out), mode, int(threads))
+    else:
+        rc = lib().oracle_stft(_p(x), len(x), 1, n_fft, hop, zeropad, _p(window), _p(out), mode)
     if rc != 0:
         raise ValueError(f"oracle_stft status {rc}")
     if mode == 0:

@@ -12,7 +12,7 @@
  *   oracle_speed_to_pos   util/resampling.py:93-137   speed_to_pos
  *   oracle_sinc           util/resampling.py:21-27, 51-90  sinc_wrapper -> sinc_core (float64 math like numba)
  *   oracle_sinc_mt        util/resampling.py:30-46    sinc_wrapper_mt: one contiguous chunk per thread
- *   oracle_stft_mag       util/fourier.py:23-29, 37-82, 136-166  get_mag via the numpy framing
+ *   oracle_stft(_mt)      util/fourier.py:23-29, 37-82, 136-166  stft / get_mag via the numpy framing (frames over threads)
  *   oracle_synth_*        SURVEY 8d closed-form workload (same as tests/inputs.py)
  * Build: gcc -O2 -fPIC -shared -pthread par_oracle.c -lm   (no -ffast-math: numpy order is kept)
  */
@@ -223,16 +223,14 @@ static void fft_c(double* re, double* im, int n) {
 }
 
 /* out: frame-major [frames][bins]; mode 0 complex interleaved (re,im) float, mode 1 |X|+1e-7 float */
-int oracle_stft(const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad, const float* window,
-                float* out, int mode) {
+static int stft_frames(const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad, const float* window,
+                       float* out, int mode, int64_t f_lo, int64_t f_hi) {
   const int M = n_fft * zeropad;
-  if (M < 2 || (M & (M - 1))) return -1;
   const int bins = M / 2 + 1;
-  const int64_t frames = (n + 2 * (int64_t)(n_fft / 2) - n_fft) / hop + 1;
   double* re = (double*)malloc(sizeof(double) * M);
   double* im = (double*)malloc(sizeof(double) * M);
   const double scale = 1.0 / sqrt((double)n_fft);
-  for (int64_t f = 0; f < frames; ++f) {
+  for (int64_t f = f_lo; f < f_hi; ++f) {
     for (int t = 0; t < M; ++t) {
       im[t] = 0.0;
       re[t] = t < n_fft ? (double)(window[t] * x[reflect_idx(f * hop - n_fft / 2 + t, n) * x_stride]) : 0.0;
@@ -250,6 +248,54 @@ int oracle_stft(const float* x, int64_t n, int64_t x_stride, int n_fft, int hop,
   }
   free(re);
   free(im);
+  return 0;
+}
+
+int oracle_stft(const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad, const float* window,
+                float* out, int mode) {
+  const int M = n_fft * zeropad;
+  if (M < 2 || (M & (M - 1))) return -1;
+  const int64_t frames = (n + 2 * (int64_t)(n_fft / 2) - n_fft) / hop + 1;
+  return stft_frames(x, n, x_stride, n_fft, hop, zeropad, window, out, mode, 0, frames);
+}
+
+/* the same transform with the frames split over `threads` host threads (bench.py's CPU baseline of the STFT) */
+typedef struct {
+  const float* x;
+  int64_t n, x_stride;
+  int n_fft, hop, zeropad;
+  const float* window;
+  float* out;
+  int mode;
+  int64_t f_lo, f_hi;
+} stft_job;
+static void* stft_worker(void* p) {
+  stft_job* j = (stft_job*)p;
+  stft_frames(j->x, j->n, j->x_stride, j->n_fft, j->hop, j->zeropad, j->window, j->out, j->mode, j->f_lo, j->f_hi);
+  return NULL;
+}
+int oracle_stft_mt(const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad, const float* window,
+                   float* out, int mode, int threads) {
+  const int M = n_fft * zeropad;
+  if (M < 2 || (M & (M - 1))) return -1;
+  const int64_t frames = (n + 2 * (int64_t)(n_fft / 2) - n_fft) / hop + 1;
+  if (threads < 1) threads = 1;
+  if (threads > 1024) threads = 1024;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+  stft_job* jobs = (stft_job*)malloc(sizeof(stft_job) * threads);
+  const int64_t per = (frames + threads - 1) / threads;
+  int started = 0;
+  for (int t = 0; t < threads; ++t) {
+    const int64_t lo = t * per, hi = lo + per < frames ? lo + per : frames;
+    if (lo >= hi) break;
+    stft_job j = {x, n, x_stride, n_fft, hop, zeropad, window, out, mode, lo, hi};
+    jobs[t] = j;
+    pthread_create(&th[t], NULL, stft_worker, &jobs[t]);
+    ++started;
+  }
+  for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+  free(th);
+  free(jobs);
   return 0;
 }
 

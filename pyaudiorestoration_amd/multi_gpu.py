@@ -4,8 +4,9 @@ per GPU, NO data-path collective.
 The reference processes files and channels independently (`for filename ...` util/resampling.py:168,
 `for out_channel, in_channel ...` :225), so the work shards embarrassingly: every rank owns a
 disjoint slice of the work-item list, keeps its results (the host gathers them by writing files),
-and the only communication is the benchmark's barrier plus a MAX (time) / SUM (sample count)
-reduction -- over RCCL when the ranks hold GPUs ("nccl" backend), over gloo in the CPU tests.
+and the only communication is host-side: the benchmark's barrier, a MAX (time) / SUM (sample count) reduction and
+the shared work queue's fetch-add -- all over gloo / the c10d TCP store on the loopback interface.  RCCL is never
+initialised: nothing on this path touches another GPU's memory (BASELINE north_star: "no RCCL collectives").
 """
 import os
 import time
@@ -38,19 +39,13 @@ class RankContext:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             if backend is None:
-                # PAR_DIST_BACKEND=gloo lets the N>1 flow be exercised on a box with fewer GPUs than ranks
-                backend = os.environ.get("PAR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-            if backend == "nccl":
+                backend = os.environ.get("PAR_DIST_BACKEND") or "gloo"      # host-side coordination only
+            dist.init_process_group(backend)
+            if torch.cuda.is_available():
+                self.local %= torch.cuda.device_count()    # more ranks than GPUs: exercise the flow on what there is
                 torch.cuda.set_device(self.local)
                 self.device = f"cuda:{self.local}"
-                dist.init_process_group("nccl", device_id=torch.device(self.device))
-            else:
-                dist.init_process_group(backend)
-                if torch.cuda.is_available():
-                    self.local %= torch.cuda.device_count()
-                    torch.cuda.set_device(self.local)
-                    self.device = f"cuda:{self.local}"
-            self.reduce_device = self.device if backend == "nccl" else "cpu"
+            self.reduce_device = "cpu"
             self.dist = dist
         elif torch.cuda.is_available():
             torch.cuda.set_device(self.local)
@@ -87,3 +82,32 @@ class RankContext:
     def close(self):
         if self.dist:
             self.dist.destroy_process_group()
+
+
+class WorkQueue:
+    """Shared longest-first queue of work items for the ranks of one node: every rank pulls the next
+    item with ONE fetch-add on a key of a c10d TCP store -- host-side, no collective, no GPU traffic.  `order` is the
+    item list, longest first (equal-sized items: any order); `tag` separates queues (one per benchmark step)."""
+    _store = None
+
+    def __init__(self, ctx, order, tag):
+        self.ctx, self.order, self.key, self._next = ctx, list(order), f"par_queue_{tag}", 0
+        if ctx.dist and WorkQueue._store is None:
+            port = int(os.environ.get("MASTER_PORT", "29533")) + 1
+            WorkQueue._store = ctx.dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, ctx.world,
+                                                 is_master=(ctx.rank == 0), wait_for_workers=True)
+
+    def pull(self):
+        """Next item, or None when the queue is empty."""
+        if self.ctx.dist:
+            k = WorkQueue._store.add(self.key, 1) - 1
+        else:
+            k, self._next = self._next, self._next + 1
+        return self.order[k] if k < len(self.order) else None
+
+    def __iter__(self):
+        while True:
+            item = self.pull()
+            if item is None:
+                return
+            yield item

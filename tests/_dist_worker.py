@@ -21,8 +21,18 @@ def main():
     dt = ctx.timed(step, 3)
     total = ctx.reduce_sum(len(mine))
     first = ctx.reduce_sum(mine[0])
+    # the shared queue bench.py's batch mode pulls from: every item exactly once across the ranks, uneven paces
+    pulled = []
+    for it in multi_gpu.WorkQueue(ctx, range(40), "t0"):
+        pulled.append(it)
+        time.sleep(0.002 * (1 + 3 * ctx.rank))
+    ctx.barrier()
+    q_total = ctx.reduce_sum(len(pulled))
+    q_sum = ctx.reduce_sum(sum(pulled))
+    q_min = -ctx.reduce_max(-len(pulled))
     if ctx.rank == 0:
-        print(json.dumps({"world": ctx.world, "dt": dt, "total": total, "first_sum": first, "per_rank": len(mine)}))
+        print(json.dumps({"world": ctx.world, "dt": dt, "total": total, "first_sum": first, "per_rank": len(mine),
+                          "q_total": q_total, "q_sum": q_sum, "q_min": q_min}))
     ctx.close()
 
 

@@ -30,3 +30,10 @@ def test_world2_gloo_timing_and_reduction():
     r = json.loads(line)
     assert r["world"] == 2 and r["total"] == 1024 and r["per_rank"] == 512 and r["first_sum"] == 1
     assert r["dt"] >= 0.055            # MAX over ranks: the slow rank (3 x 20 ms) sets the time
+    # shared work queue: 40 items pulled exactly once in total, the faster rank took more of them
+    assert r["q_total"] == 40 and r["q_sum"] == sum(range(40)) and 1 <= r["q_min"] < 20
+
+
+def test_work_queue_single_process():
+    ctx = multi_gpu.RankContext()
+    assert list(multi_gpu.WorkQueue(ctx, [5, 3, 9], "solo")) == [5, 3, 9]
