@@ -663,41 +663,37 @@ __device__ __forceinline__ void place_fast(const FusedArgs& fa, long long i, lon
   lowfc = bsn < 0.125;
 }
 
-// The tap loops of one lane: 4 (output, channel) slots.  `all_unity`: fc == 1 for every lane of the wave.
-template <int NTC>
-__device__ __forceinline__ void run_taps(const float* __restrict__ tile, const int (&cs)[kSincR], const float (&ss)[kSincR],
-                                         const float (&fcs)[kSincR], const float (&dds)[kSincR], const bool all_unity,
+// The tap loops of one lane: NS (output, channel) slots, two at a time where the loops carry 6-10 live values per slot
+// (one pass over four spilled 48 B/lane = as much HBM write traffic as the output).  `all_unity`: fc == 1 for every lane
+// of the wave.
+template <int NTC, int NS>
+__device__ __forceinline__ void run_taps(const float* __restrict__ tile, const int (&cs)[NS], const float (&ss)[NS],
+                                         const float (&fcs)[NS], const float (&dds)[NS], const bool all_unity,
                                          const int NT, const float4* __restrict__ tab, const TapModes tmd,
-                                         float (&res)[kSincR]) {
-  static_assert(kSincR == 4, "split assumes 4 slots per lane");
-  // two passes over half of the lane's slots where the loops carry 6-10 live values per slot (80-VGPR budget:
-  // one pass spilled 48 B/lane = as much HBM write traffic as the output)
-  const int ca[2] = {cs[0], cs[1]}, cb[2] = {cs[2], cs[3]};
-  const float sa[2] = {ss[0], ss[1]}, sb[2] = {ss[2], ss[3]};
-  float ra[2], rb[2];
-  if (all_unity) {
-    if constexpr (NTC > 0) {
-      taps_unity_ct<NTC, 2>(tile, ca, sa, NT, ra);
-      taps_unity_ct<NTC, 2>(tile, cb, sb, NT, rb);
-    } else {
-      taps_unity<kSincR>(tile, cs, ss, NT, tab, tmd, res);
+                                         float (&res)[NS]) {
+  static_assert(NS == 2 || NS == 4, "2 or 4 slots per lane");
+  if constexpr (NTC == 0) {
+    if (all_unity) {
+      taps_unity<NS>(tile, cs, ss, NT, tab, tmd, res);
       return;
     }
-  } else {
-    const float fa_[2] = {fcs[0], fcs[1]}, fb_[2] = {fcs[2], fcs[3]};
-    const float da[2] = {dds[0], dds[1]}, db[2] = {dds[2], dds[3]};
-    if constexpr (NTC > 0) {
-      taps_general_ct<NTC, 2>(tile, ca, sa, fa_, da, NT, ra);
-      taps_general_ct<NTC, 2>(tile, cb, sb, fb_, db, NT, rb);
-    } else {
-      taps_general<2>(tile, ca, sa, fa_, da, NT, tab, tmd, ra);
-      taps_general<2>(tile, cb, sb, fb_, db, NT, tab, tmd, rb);
-    }
   }
-  res[0] = ra[0];
-  res[1] = ra[1];
-  res[2] = rb[0];
-  res[3] = rb[1];
+#pragma unroll
+  for (int h = 0; h < NS / 2; ++h) {
+    const int ca[2] = {cs[2 * h], cs[2 * h + 1]};
+    const float sa[2] = {ss[2 * h], ss[2 * h + 1]};
+    float ra[2];
+    if (all_unity) {
+      if constexpr (NTC > 0) taps_unity_ct<NTC, 2>(tile, ca, sa, NT, ra);
+    } else {
+      const float fa_[2] = {fcs[2 * h], fcs[2 * h + 1]};
+      const float da[2] = {dds[2 * h], dds[2 * h + 1]};
+      if constexpr (NTC > 0) taps_general_ct<NTC, 2>(tile, ca, sa, fa_, da, NT, ra);
+      else taps_general<2>(tile, ca, sa, fa_, da, NT, tab, tmd, ra);
+    }
+    res[2 * h] = ra[0];
+    res[2 * h + 1] = ra[1];
+  }
 }
 
 // ---- the tile body of the position-array form --------------------------------------------------------
@@ -790,7 +786,7 @@ __device__ __forceinline__ void sinc_tile_body(float* __restrict__ tile, int* __
     dds[sl] = dd[sl / NCH];
     res[sl] = 0.0f;
   }
-  if (!(PAR_SINC_EXP & 1) && __any(anyfast)) run_taps<NTC>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res);
+  if (!(PAR_SINC_EXP & 1) && __any(anyfast)) run_taps<NTC, kSincR>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res);
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
     const int64_t j = j0 + t + (int64_t)r * kBlk;
@@ -869,34 +865,30 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc_pos(const double* __rest
 // the per-phase wave clock, tools/phase_clock.py: with one span per workgroup a wave spent 28 % of its life waiting at
 // the barrier for the slowest of its three siblings).  The halo (2 NT + margin samples per 64 kOut outputs) is fetched
 // by neighbouring waves too; they sit on the same CU, so the repeats are L1/L2 hits.
-constexpr int kStageRegs = 6;                   // signal words a lane holds in registers between load and LDS write
-template <int NCH, int NTC>
-__global__ __launch_bounds__(kSincBlock * NCH, PAR_SINC_WAVES) void k_sinc_fused(int64_t len_out, const float* __restrict__ sig,
+// LDS floats per wave and channel: room for the span of 64 NS/NCH outputs at speeds up to ~3.7 plus the halo
+__host__ __device__ constexpr int fused_capw(int NS, int NCH) { return (kWave * NS / NCH) * 4 >= 1024 ? 1024 : (NS / NCH == 2 ? 640 : 448); }
+template <int NCH, int NTC, int NS>
+__global__ __launch_bounds__(kSincBlock, PAR_SINC_WAVES) void k_sinc_fused(int64_t len_out, const float* __restrict__ sig,
                                                                   const float* __restrict__ sig1, int64_t sig_stride,
                                                                   int64_t len_in, int NT, const float4* __restrict__ tab,
                                                                   TapModes tmd, float* __restrict__ out,
                                                                   float* __restrict__ out1, int64_t out_stride,
                                                                   FusedArgs fa) {
-  constexpr int kBlk = kSincBlock * NCH;
-  constexpr int kOut = kSincR / NCH;
-  constexpr int kWaveOut = kWave * kOut;          // outputs per wave: 256 (mono) / 128 (stereo)
-  constexpr int capw = kSincCap / (kBlk / kWave);   // floats of one channel's span a wave may stage: 1024 (mono) / 512
+  // NS (output, channel) slots per lane: a wave owns kWaveOut = 64 NS / NCH consecutive outputs and its own piece of LDS;
+  // workgroups are 4 waves whatever NS is (the plan's tiles, 1024 outputs, hold a whole number of waves)
+  constexpr int kOut = NS / NCH;                    // outputs per lane
+  constexpr int kWaveOut = kWave * kOut;            // outputs per wave: 256 / 128 / 64
+  constexpr int kWaves = kSincBlock / kWave;
+  constexpr int capw = fused_capw(NS, NCH);         // floats of one channel's span a wave may stage
   static_assert(NCH == 1 || NCH == 2, "mono or stereo");
-  static_assert(capw * (kBlk / kWave) == kSincCap, "LDS split");
+  static_assert(kSincTile % kWaveOut == 0, "tiles hold whole waves");
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int t = threadIdx.x;
   const int l = t & (kWave - 1);
-#ifdef PAR_SINC_WG1                                 // experiment: one wave per workgroup (grid = waves)
-  const int wv = 0;
-  float* tile = lds_all;
-  const int64_t jw = (int64_t)blockIdx.x * kWaveOut;
-  const int64_t T = jw / kSincTile;
-#else
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  float* tile = lds_all + wv * (capw * NCH);      // this wave's span: channel 0, then channel 1 `capw` floats on
-  const int64_t T = blockIdx.x;
-  const int64_t jw = T * kSincTile + (int64_t)wv * kWaveOut; // the wave's outputs: jw + l + 64 r, r < kOut
-#endif
+  float* tile = lds_all + wv * (capw * NCH);        // this wave's span: channel 0, then channel 1 `capw` floats on
+  const int64_t jw = ((int64_t)blockIdx.x * kWaves + wv) * kWaveOut;   // the wave's outputs: jw + l + 64 r, r < kOut
+  const int64_t T = jw / kSincTile;
   PAR_PHASE_BEGIN();
 #ifdef PAR_SINC_PRIO
   __builtin_amdgcn_s_setprio(PAR_SINC_PRIO);     // a young wave gets its loads out ahead of its neighbours' tap loops
@@ -1045,10 +1037,10 @@ __global__ __launch_bounds__(kSincBlock * NCH, PAR_SINC_WAVES) void k_sinc_fused
   }
   // (output, channel) slots: channel ch of an output reads the tile `ch * capw` floats further on; shift, fc and
   // 1 - fc are the SAME values for both slots of an output, so the compiler evaluates their tap weights once
-  int cs[kSincR];
-  float ss[kSincR], fcs[kSincR], dds[kSincR], res[kSincR];
+  int cs[NS];
+  float ss[NS], fcs[NS], dds[NS], res[NS];
 #pragma unroll
-  for (int sl = 0; sl < kSincR; ++sl) {
+  for (int sl = 0; sl < NS; ++sl) {
     cs[sl] = c[sl / NCH] + (sl % NCH) * capw;
     ss[sl] = s[sl / NCH];
     fcs[sl] = fc[sl / NCH];
@@ -1058,18 +1050,18 @@ __global__ __launch_bounds__(kSincBlock * NCH, PAR_SINC_WAVES) void k_sinc_fused
 #ifdef PAR_SINC_PRIO
   __builtin_amdgcn_s_setprio(0);
 #endif
-  if (!(PAR_SINC_EXP & 1) && __any(anyfast)) run_taps<NTC>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res);
+  if (!(PAR_SINC_EXP & 1) && __any(anyfast)) run_taps<NTC, NS>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res);
 #ifdef PAR_SINC_PRIO
   __builtin_amdgcn_s_setprio(PAR_SINC_PRIO_OUT);
 #endif
 #if PAR_SINC_EXP & 128
   {                                   // the tap loops a second time (what does ONE more pass cost?)
-    float res2[kSincR];
+    float res2[NS];
 #pragma unroll
-    for (int sl = 0; sl < kSincR; ++sl) ss[sl] += 1e-3f * res[sl];
-    if (__any(anyfast)) run_taps<NTC>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res2);
+    for (int sl = 0; sl < NS; ++sl) ss[sl] += 1e-3f * res[sl];
+    if (__any(anyfast)) run_taps<NTC, NS>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res2);
 #pragma unroll
-    for (int sl = 0; sl < kSincR; ++sl) res[sl] += 1e-9f * res2[sl];
+    for (int sl = 0; sl < NS; ++sl) res[sl] += 1e-9f * res2[sl];
   }
 #endif
   PAR_PHASE_MARK(4);                 // taps
@@ -1224,27 +1216,30 @@ int launch_sinc_fused(int device, const double* speeds, int64_t m, const void* w
   fa.rec = av.rec;
   fa.rec2 = av.rec2;
   fa.nseg = m - 1;
-  const int64_t blocks = ceil_div(len_out, kSincTile);
-#ifdef PAR_SINC_WG1
-#define PAR_LAUNCH_FUSED(NCH, NTC)                                                                                         \
-  hipLaunchKernelGGL((k_sinc_fused<NCH, NTC>), dim3((unsigned)ceil_div(len_out, kWave * kSincR / NCH)), dim3(kWave),       \
-                     kSincCap / (NCH * kSincBlock / kWave) * NCH * sizeof(float), s, len_out, sig, sig1, sig_stride, len_in, NT, \
-                     tab.ab, tab.modes, out, out1, out_stride, fa)
-#else
-#define PAR_LAUNCH_FUSED(NCH, NTC)                                                                                         \
-  hipLaunchKernelGGL((k_sinc_fused<NCH, NTC>), dim3((unsigned)blocks), dim3(NCH * kSincBlock), NCH * kSincCap * sizeof(float), \
-                     s, len_out, sig, sig1, sig_stride, len_in, NT, tab.ab, tab.modes, out, out1, out_stride, fa)
+  // slots per lane (PAR_SINC_SLOTS_*: experiment knobs; 4 = 256 mono / 128 stereo outputs per wave)
+#ifndef PAR_SINC_SLOTS_MONO
+#define PAR_SINC_SLOTS_MONO 4
 #endif
+#ifndef PAR_SINC_SLOTS_STEREO
+#define PAR_SINC_SLOTS_STEREO 4
+#endif
+  // experiment knob: extra (unused) LDS per workgroup lowers K_sinc's occupancy and leaves wave slots to a concurrent plan
+  static const size_t lds_pad = getenv("PAR_SINC_LDS_PAD") ? (size_t)atoi(getenv("PAR_SINC_LDS_PAD")) : 0;
+#define PAR_LAUNCH_FUSED(NCH, NTC, NS)                                                                                     \
+  hipLaunchKernelGGL((k_sinc_fused<NCH, NTC, NS>),                                                                         \
+                     dim3((unsigned)ceil_div(len_out, (int64_t)(kSincBlock / kWave) * kWave * (NS) / (NCH))),             \
+                     dim3(kSincBlock), (kSincBlock / kWave) * fused_capw(NS, NCH) * (NCH) * sizeof(float) + lds_pad, s,    \
+                     len_out, sig, sig1, sig_stride, len_in, NT, tab.ab, tab.modes, out, out1, out_stride, fa)
   if (sig1 && out1) {
-    if (NT == 32) PAR_LAUNCH_FUSED(2, 32);
-    else if (NT == 50) PAR_LAUNCH_FUSED(2, 50);
-    else PAR_LAUNCH_FUSED(2, 0);
+    if (NT == 32) PAR_LAUNCH_FUSED(2, 32, PAR_SINC_SLOTS_STEREO);
+    else if (NT == 50) PAR_LAUNCH_FUSED(2, 50, PAR_SINC_SLOTS_STEREO);
+    else PAR_LAUNCH_FUSED(2, 0, PAR_SINC_SLOTS_STEREO);
   } else {
     sig1 = nullptr;
     out1 = nullptr;
-    if (NT == 32) PAR_LAUNCH_FUSED(1, 32);
-    else if (NT == 50) PAR_LAUNCH_FUSED(1, 50);
-    else PAR_LAUNCH_FUSED(1, 0);
+    if (NT == 32) PAR_LAUNCH_FUSED(1, 32, PAR_SINC_SLOTS_MONO);
+    else if (NT == 50) PAR_LAUNCH_FUSED(1, 50, PAR_SINC_SLOTS_MONO);
+    else PAR_LAUNCH_FUSED(1, 0, PAR_SINC_SLOTS_MONO);
   }
 #undef PAR_LAUNCH_FUSED
   PAR_HIP_CHECK(hipGetLastError());
