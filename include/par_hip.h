@@ -30,6 +30,7 @@ extern "C" {
 #define PAR_ERR_UNSUPPORTED 3    /* valid for the reference, not implemented here (caller falls through) */
 #define PAR_ERR_WORKSPACE 4      /* caller-provided workspace too small */
 #define PAR_ERR_EMPTY_BAND 5     /* a tracker band is empty: the reference raises ValueError (argmax of an empty slice) */
+#define PAR_ERR_INDEX 6          /* the reference indexes past the end of an array here and raises IndexError */
 
 /* ---- library / device ---------------------------------------------------------- */
 int par_version(void);
@@ -244,6 +245,22 @@ int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins,
 /* CenterOfGravity.trace (util/wow_detection.py:256-291): sequential band adaptation. */
 int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
                       double* freqs, int fft_size, double sr, double tolerance_oct, int32_t* status, void* stream);
+
+/* W4: CorrelationTracker.trace (util/wow_detection.py:396-436) for all frames in one call: the band [NL, NU) of frames
+ * 0 .. count-1 (the reference ignores frame_0 here) is resampled onto n = 4 (NU - NL) log2-frequency points by the
+ * quadratic spline of scipy.interpolate.interp1d(kind='quadratic'), Hann-windowed, cross-correlated frame against next
+ * frame (util/correlation.py:6-13, mode 'same'; the frame behind the last is all ones), peak refined by parabolic()
+ * (:42-46), changes summed in order.
+ *   M        device f64 [n][NU-NL] row-major: the spline as a matrix (band values -> grid values; the spline is linear
+ *            in the data, the host applies scipy's own construction to the identity)
+ *   wind     device f64 [n] = np.hanning(n)
+ *   log_span = log2 f[NU-1] - log2 f[NL], log_mean = log2((fL + fU)/2): the reference's final scaling
+ *   work     device f64 [par_track_corr_work_len(count, n)];  freqs  device f64 [count] out
+ *   status   device int32 scratch.  A peak on the last lag is the reference's IndexError: PAR_ERR_INDEX.  Synchronises. */
+int64_t par_track_corr_work_len(int64_t count, int n);
+int par_track_corr_f64(int device, const float* mag, int64_t n_frames, int bins, int NL, int NU, int64_t count,
+                       const double* M, const double* wind, int n, double log_span, double log_mean, double* work,
+                       double* freqs, int32_t* status, void* stream);
 
 /* W3: sign-change indices of a (band-passed) float64 signal, ascending -- zero_crossings(a) =
  * np.where(np.bitwise_xor(a[1:] > 0, a[:-1] > 0))[0] (util/wow_detection.py:448-450), the full-rate pass of

@@ -71,6 +71,9 @@ SIGNATURES = {
     "par_sosfiltfilt_work_len": (c_i64, [c_i64, c_i64]),
     "par_sosfiltfilt_f64": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "par_track_cog_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]),
+    "par_track_corr_work_len": (c_i64, [c_i64, c_int]),
+    "par_track_corr_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_int, c_int, c_i64, c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp,
+                                   c_vp, c_vp]),
 }
 
 _lib = None
@@ -86,6 +89,10 @@ class ParError(RuntimeError):
 
 class ParUnsupported(ParError):
     """Valid for the reference but not implemented by the HIP path (status PAR_ERR_UNSUPPORTED)."""
+
+
+class ParIndexError(ParError, IndexError):
+    """The reference indexes past the end of an array at this point (status PAR_ERR_INDEX)."""
 
 
 class ParEmptyBand(ParError, ValueError):
@@ -125,4 +132,4 @@ def last_error():
 def check(rc):
     if rc != 0:
         msg = last_error()
-        raise {3: ParUnsupported, 5: ParEmptyBand}.get(rc, ParError)(rc, msg)
+        raise {3: ParUnsupported, 5: ParEmptyBand, 6: ParIndexError}.get(rc, ParError)(rc, msg)

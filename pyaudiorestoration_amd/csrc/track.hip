@@ -118,6 +118,96 @@ __global__ __launch_bounds__(64) void k_track_cog(const float* __restrict__ mag,
   }
 }
 
+// ---- CorrelationTracker (util/wow_detection.py:396-436) ----------------------------------------------------------
+// Per frame i of the band [NL, NU): the band's magnitudes are resampled onto a uniform log2-frequency grid of
+// n = 4 (NU - NL) points by a quadratic interpolating spline (interp1d(kind='quadratic')), Hann-windowed,
+// cross-correlated with the next frame's (the frame behind the last one is all ones, as the reference's buffer is
+// initialised), and the parabola-refined peak offset from the centre is that frame's log-frequency change.  The spline
+// is linear in the data and its abscissae are the same for every frame, so the host hands over the n x nb matrix that
+// maps band values to grid values (scipy's own spline applied to the identity) and the resampling is a small dense
+// product.  Everything in float64 like the reference; all frames in one launch.
+//   k_corr_resample: R[i][g] = hann_g * sum_b M[g][b] mag[i][NL + b]   (i = count: R = hann_g)
+//   k_corr_peak:     same[j] = sum_m a[m + j - n/2] b[m] / (|a| |b|)  ('same' part of scipy.signal.correlate), first
+//                    argmax, parabolic() with the reference's f[-1] wrap at peak 0; peak n-1 is its IndexError
+//   k_corr_finish:   np.cumsum in order, scaled to octaves, freqs = 2^(log2 mean + drift)
+__global__ __launch_bounds__(256) void k_corr_resample(const float* __restrict__ mag, int bins, int NL, int nb, int64_t count,
+                                                       const double* __restrict__ M, const double* __restrict__ wind, int n,
+                                                       double* __restrict__ R) {
+  extern __shared__ double yb[];                           // the frame's band
+  const int64_t i = blockIdx.x;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) yb[b] = i < count ? (double)mag[i * bins + NL + b] : 0.0;
+  __syncthreads();
+  for (int g = threadIdx.x; g < n; g += blockDim.x) {
+    double acc = 1.0;
+    if (i < count) {
+      acc = 0.0;
+      const double* row = M + (int64_t)g * nb;
+      for (int b = 0; b < nb; ++b) acc += row[b] * yb[b];
+    }
+    R[i * n + g] = acc * wind[g];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_corr_peak(const double* __restrict__ R, int n, double* __restrict__ changes,
+                                                   int* __restrict__ status) {
+  extern __shared__ double sh[];                           // a[n], b[n], same[n]
+  double* a = sh;
+  double* b = sh + n;
+  double* same = sh + 2 * n;
+  __shared__ double red[2][4];
+  const int64_t i = blockIdx.x;
+  double na = 0.0, nbv = 0.0;
+  for (int g = threadIdx.x; g < n; g += blockDim.x) {
+    a[g] = R[i * n + g];
+    b[g] = R[(i + 1) * n + g];
+    na += a[g] * a[g];
+    nbv += b[g] * b[g];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    na += __shfl_xor(na, o, kWave);
+    nbv += __shfl_xor(nbv, o, kWave);
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    red[0][threadIdx.x / kWave] = na;
+    red[1][threadIdx.x / kWave] = nbv;
+  }
+  __syncthreads();
+  const double inv = 1.0 / (sqrt(red[0][0] + red[0][1] + red[0][2] + red[0][3]) * sqrt(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+  const int half = n / 2;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    double acc = 0.0;
+    const int lo = half - j > 0 ? half - j : 0;            // m + j - half >= 0
+    const int hi = n + half - j < n ? n + half - j : n;    // m + j - half < n
+    for (int m = lo; m < hi; ++m) acc += a[m + j - half] * b[m];
+    same[j] = acc * inv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int arg = 0;
+    double best = same[0];
+    for (int j = 1; j < n; ++j) {
+      if (same[j] > best) {                                // first occurrence of the maximum (np.argmax)
+        best = same[j];
+        arg = j;
+      }
+    }
+    if (arg == n - 1) atomicOr(status, 2);                 // parabolic() reads f[x + 1]: IndexError in the reference
+    const double fm = same[arg == 0 ? n - 1 : arg - 1], f0 = same[arg], fp = same[arg == n - 1 ? arg : arg + 1];
+    const double refined = 0.5 * (fm - fp) / (fm - 2.0 * f0 + fp) + (double)arg;
+    changes[i] = (double)half - refined;
+  }
+}
+
+__global__ void k_corr_finish(const double* __restrict__ changes, int64_t count, int n, double log_span, double log_mean,
+                              double* __restrict__ freqs) {
+  double c = 0.0;
+  for (int64_t i = 0; i < count; ++i) {                    // np.cumsum: strictly in order
+    c = c + changes[i];
+    freqs[i] = exp2(log_mean + c / (double)n * log_span);
+  }
+}
+
 // ---- zero crossings (ZeroCrossingTracker, util/wow_detection.py:340, 448-450) -----------------------------
 // indices i with (x[i+1] > 0) != (x[i] > 0), ascending: count per 1024-sample tile, scan of the tile counts,
 // ordered write (ballot + popcount inside a wave, LDS prefix across the 4 waves of a tile).
@@ -269,6 +359,41 @@ int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, 
                      tolerance_oct, status);
   PAR_HIP_CHECK(hipGetLastError());
   return check_empty(status, as_stream(stream), "par_track_cog_f64");
+}
+
+// CorrelationTracker on the band [NL, NU) of frames 0 .. count-1 (the reference ignores frame_0 here).  M: [n][nb]
+// float64 row-major spline matrix, wind: np.hanning(n), both on the device; work: (count + 1) * n + count doubles.
+// freqs[count] receives 2^(log_mean + cumulative drift).  status bit 1: a correlation peak sat on the last lag
+// (the reference's parabolic() raises IndexError there).
+int64_t par_track_corr_work_len(int64_t count, int n) { return (count + 1) * (int64_t)n + count; }
+
+int par_track_corr_f64(int device, const float* mag, int64_t n_frames, int bins, int NL, int NU, int64_t count,
+                       const double* M, const double* wind, int n, double log_span, double log_mean, double* work,
+                       double* freqs, int32_t* status, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(mag && M && wind && work && freqs && status, PAR_ERR_ARG, "par_track_corr_f64: null pointer");
+  PAR_REQUIRE(NL >= 0 && NU > NL && NU <= bins && count >= 0 && count <= n_frames && n == 4 * (NU - NL) && n <= 4096,
+              PAR_ERR_ARG, "par_track_corr_f64: bad band / grid (NL=%d NU=%d bins=%d n=%d count=%lld)", NL, NU, bins, n,
+              (long long)count);
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipStream_t s = as_stream(stream);
+  PAR_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), s));
+  if (count == 0) return PAR_OK;
+  const int nb = NU - NL;
+  double* R = work;
+  double* changes = work + (count + 1) * (int64_t)n;
+  hipLaunchKernelGGL(k_corr_resample, dim3((unsigned)(count + 1)), dim3(256), nb * sizeof(double), s, mag, bins, NL, nb, count,
+                     M, wind, n, R);
+  hipLaunchKernelGGL(k_corr_peak, dim3((unsigned)count), dim3(256), 3 * n * sizeof(double), s, (const double*)R, n, changes,
+                     status);
+  hipLaunchKernelGGL(k_corr_finish, dim3(1), dim3(1), 0, s, (const double*)changes, count, n, log_span, log_mean, freqs);
+  PAR_HIP_CHECK(hipGetLastError());
+  int h = 0;
+  PAR_HIP_CHECK(hipMemcpyAsync(&h, status, sizeof(h), hipMemcpyDeviceToHost, s));
+  PAR_HIP_CHECK(hipStreamSynchronize(s));
+  PAR_REQUIRE(!(h & 2), PAR_ERR_INDEX, "par_track_corr_f64: correlation peak on the last lag (index %d is out of bounds for "
+              "axis 0 with size %d in the reference's parabolic())", n, n);
+  return PAR_OK;
 }
 
 }  // extern "C"

@@ -10,8 +10,9 @@ span).  `fit_sin` / `trace_sine_reg` keep their return contracts.  Everything el
   float32 magnitude spectrogram K_stft wrote -- no spectrogram ever returns to the host;
 * Zero-Crossing: band-pass in K_sosfiltfilt, sign-change compaction in K_track (`par_zero_crossings_f64`); only
   the crossing indices come back for the O(#crossings) smoothing;
-* Correlation: batched -- one quadratic-spline evaluation for all frames (the band rows are the only part of the
-  spectrogram copied to the host), one batched FFT cross-correlation, vectorised peak refinement;
+* Correlation: all frames in one K_track launch sequence (`par_track_corr_f64`): the quadratic-spline resampling as
+  a small dense product with the spline's matrix, windowed cross-correlation and parabolic refinement per frame, the
+  cumulative sum in order -- the spectrogram stays in HBM;
 * Partials needs librosa + an interactive matplotlib window and is not provided.
 
 Reference semantics each piece reproduces are cited at the definitions.
@@ -26,7 +27,6 @@ from scipy.interpolate import make_interp_spline
 from scipy.signal import get_window
 
 from . import _dev, _lib, filters, fourier
-from .correlation import xcorr_rows
 
 MIN_BAND_BINS = 4
 
@@ -216,43 +216,41 @@ class FreehandTracker(Track):
     name = 'Freehand Draw'     # returns the interpolated trail itself
 
 
-def correlation_drift(band, log_freqs):
-    """Cumulative log2-frequency drift between consecutive spectrogram frames (util/wow_detection.py:404-431).
-
-    band: (n_band_bins, F) magnitudes of the band, log_freqs: log2 of the band's bin frequencies.  Every frame is
-    resampled onto a uniform log-frequency grid (4x oversampled) by a quadratic interpolating spline -- what
-    `interp1d(kind='quadratic')` builds -- for all frames in one call; consecutive frames (the last one against
-    an all-ones frame, as the reference's buffer is initialised) are Hann-windowed and cross-correlated in one
-    batched FFT; the parabola-refined peak offset from the centre is the per-frame change."""
-    n_grid = band.shape[0] * 4
-    grid = np.linspace(log_freqs[0], log_freqs[-1], n_grid)
-    frames = make_interp_spline(log_freqs, band, k=2, axis=0, check_finite=False)(grid)       # (n_grid, F)
-    frames = np.concatenate((frames, np.ones((n_grid, 1))), axis=1) * np.hanning(n_grid)[:, None]
-    full = xcorr_rows(frames[:, :-1].T, frames[:, 1:].T)                                      # (F, 2 n_grid - 1)
-    same = full[:, (n_grid - 1) // 2:(n_grid - 1) // 2 + n_grid]
-    peak = np.argmax(same, axis=1)
-    if np.any(peak == n_grid - 1):
-        raise IndexError(f"index {n_grid} is out of bounds for axis 0 with size {n_grid}")   # the reference's f[x + 1]
-    rows = np.arange(len(peak))
-    left, mid, right = same[rows, peak - 1], same[rows, peak], same[rows, peak + 1]           # peak 0: wraps like f[-1]
-    refined = peak + 0.5 * (left - right) / (left - 2 * mid + right)
-    return np.cumsum((n_grid // 2) - refined) / n_grid * (log_freqs[-1] - log_freqs[0])
+def correlation_spline_matrix(log_freqs):
+    """The quadratic interpolating spline of `interp1d(log_freqs, y, kind='quadratic')` evaluated on the reference's
+    4x oversampled uniform grid, as a matrix: grid values = M @ band values (the spline is linear in y and its
+    abscissae are the same for every frame, so scipy's own construction is applied once, to the identity)."""
+    nb = len(log_freqs)
+    grid = np.linspace(log_freqs[0], log_freqs[-1], 4 * nb)
+    return np.ascontiguousarray(make_interp_spline(log_freqs, np.eye(nb), k=2, axis=0, check_finite=False)(grid))
 
 
 class CorrelationTracker(Track):
     name = 'Correlation'
     tooltip = "Compare the spectra for each segment and track the offsets between"
 
-    def trace(self):          # util/wow_detection.py:396-436 (reads frames 0.. whatever frame_0 is: kept)
+    def trace(self):          # util/wow_detection.py:396-436 (reads frames 0.. whatever frame_0 is: kept) -> k_corr_*
         f_lo, f_hi = float(np.min(self.freqs)), float(np.max(self.freqs))
         self.NL, self.NU = band_to_bins(f_lo, f_hi, self.fft_size, self.sr, self.num_bins)
-        n = len(self.freqs)
-        if isinstance(self.spectrum, torch.Tensor):
-            band = self.spectrum[self.NL:self.NU, :n].to(torch.float64).cpu().numpy()     # the band rows only
-        else:
-            band = np.asarray(self.spectrum[self.NL:self.NU, :n], dtype=np.float64)
-        drift = correlation_drift(band, np.log2(self.fft_freqs[self.NL:self.NU]))
-        self.freqs[:] = np.power(2, np.log2((f_lo + f_hi) / 2) + drift)
+        count = len(self.freqs)
+        if count == 0:
+            return
+        if self.NL < 0 or count > self.spectrum.shape[1]:
+            raise IndexError(f"index {count - 1} is out of bounds for axis 1 with size {self.spectrum.shape[1]}"
+                             if self.NL >= 0 else "correlation band reaches below bin 0")
+        log_f = np.log2(self.fft_freqs[self.NL:self.NU])
+        n = 4 * (self.NU - self.NL)
+        dev, mag = self._device_spectrum()
+        L = _lib.lib()
+        M_t = _dev.to_dev(correlation_spline_matrix(log_f), torch.float64, dev)
+        w_t = _dev.to_dev(np.hanning(n), torch.float64, dev)
+        work = _dev.empty(int(L.par_track_corr_work_len(count, n)), torch.float64, dev)
+        f_t = _dev.empty(count, torch.float64, dev)
+        status = _dev.empty(1, torch.int32, dev)
+        _lib.check(L.par_track_corr_f64(dev, _dev.ptr(mag), mag.shape[0], mag.shape[1], self.NL, self.NU, count, _dev.ptr(M_t),
+                                        _dev.ptr(w_t), n, float(log_f[-1] - log_f[0]), float(np.log2((f_lo + f_hi) / 2)),
+                                        _dev.ptr(work), _dev.ptr(f_t), _dev.ptr(status), _dev.stream_ptr(dev)))
+        self.freqs[:] = f_t.cpu().numpy()
 
 
 class SineRegression(Track):

@@ -147,8 +147,9 @@ def test_correlation_module_matches_golden(golden):
 
 
 def test_tracker_host_geometry_and_correlation_core(golden):
-    """sample_trail / band_to_bins / correlation_drift (batched spline + batched FFT correlation) reproduce the
-    reference's Correlation and Freehand traces; fit_sin recovers a planted sine."""
+    """sample_trail / band_to_bins reproduce the reference's trail sampling and Freehand trace; the spline matrix the
+    device CorrelationTracker is fed equals scipy's interp1d(kind='quadratic') on the reference's grid; fit_sin
+    recovers a planted sine."""
     import inputs
     from oracle import oracle_np as O
     from pyaudiorestoration_amd import wow_detection as W
@@ -161,10 +162,14 @@ def test_tracker_host_geometry_and_correlation_core(golden):
     assert np.array_equal(times, g["freehand_draw_times"]) and np.array_equal(freqs, g["freehand_draw_freqs"])
     lo, hi = W.band_to_bins(freqs.min(), freqs.max(), n_fft, sr, spec.shape[0])
     assert hi - lo >= 4
-    drift = W.correlation_drift(np.asarray(spec[lo:hi, :len(freqs)], dtype=np.float64),
-                                np.log2(O.fft_freqs(n_fft, sr)[lo:hi]))
-    got = np.power(2, np.log2((freqs.min() + freqs.max()) / 2) + drift)
-    assert relerr(got, g["correlation_freqs"]) < 1e-6
+    import scipy.interpolate
+    log_f = np.log2(O.fft_freqs(n_fft, sr)[lo:hi])
+    M = W.correlation_spline_matrix(log_f)
+    grid = np.linspace(log_f[0], log_f[-1], 4 * (hi - lo))
+    for col in (3, 57):
+        y = np.asarray(spec[lo:hi, col], dtype=np.float64)
+        want = scipy.interpolate.interp1d(log_f, y, kind="quadratic")(grid)      # util/wow_detection.py:413-414
+        assert M.shape == (4 * (hi - lo), hi - lo) and np.max(np.abs(M @ y - want)) < 1e-12 * np.max(np.abs(want))
     assert W.band_to_bins(10.0, 12.0, 1024, 44100, 513) == (-1, 3)       # widened symmetrically from (1, 1)
     assert set(W.wow_detectors) == {"Center of Gravity", "Peak", "Peak Track", "Zero-Crossing", "Partials",
                                     "Freehand Draw", "Correlation", "Sine Regression"}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised fuzz of the trackers against the numpy oracle (GPU box): random spectrogram sizes, trails (2-5 points,
 unsorted, starting at 0 or inside the file), tolerances, FM pilots with noise; Peak / Peak Track / Center of Gravity
-on the device (K_track), Correlation (batched host core) and Zero-Crossing (device filter + compaction)."""
+on the device (K_track), Correlation (device, par_track_corr_f64) and Zero-Crossing (device filter + compaction)."""
 import os
 import sys
 import time
