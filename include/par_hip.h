@@ -56,11 +56,18 @@ int par_stream_sync(int device, void* stream);
  *   out      device, FRAME-MAJOR: mode 0 -> complex64 [frames][bins] interleaved re,im
  *                                 mode 1 -> float32   [frames][bins]
  *            bins = n_fft*zeropad/2+1, frames = par_stft_frames(n, n_fft, hop)
- * n_fft*zeropad must be a power of two in [16, 8192]; otherwise PAR_ERR_UNSUPPORTED.
+ * n_fft*zeropad must be a power of two in [16, 8192] (larger: par_stft_big_f32); otherwise PAR_ERR_UNSUPPORTED.
  */
 int64_t par_stft_frames(int64_t n, int n_fft, int hop);
 int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad,
                  const float* window, float* out, int mode, void* stream);
+
+/* The same transform for frames of more than 8192 points (n_fft*zeropad a power of two in (8192, 2^21]; the GUI offers
+ * FFT sizes up to 2^20, util/widgets.py:333-349): a four-step FFT in two passes over HBM.
+ *   scratch  device memory of par_stft_big_scratch_bytes(n, n_fft, hop, zeropad) bytes (caller-owned) */
+size_t par_stft_big_scratch_bytes(int64_t n, int n_fft, int hop, int zeropad);
+int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad,
+                     const float* window, float* out, int mode, void* scratch, size_t scratch_bytes, void* stream);
 
 /* ---- S6: ISTFT -----------------------------------------------------------------
  * Replaces util/fourier.py:314-437 (istft, center=True, win_length=n_fft) incl.

@@ -295,6 +295,140 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
   }
 }
 
+// ---- transforms above 8192 points: four-step FFT ----------------------------------------------------------
+// The GUI offers FFT sizes up to 2^20 (util/widgets.py:333-349).  A frame of M = n_fft*zeropad real points is an
+// H = M/2-point complex sequence; H = N1 N2 is transformed in two passes over HBM around the register/LDS core:
+//   pass A  N2 column transforms of N1 points (input index n2 + N2 n1), times W_H^(n2 k1), stored as A[k1][n2];
+//           the gather (reflect boundary), the window and the real->complex packing are fused into its loads
+//   pass B  N1 row transforms of N2 points, stored at k1 + N1 k2
+//   untangle to the H+1 real-FFT bins (complex, or |X| + 1e-7)
+// A workgroup owns C = 8 adjacent columns (rows): both its loads and its stores then move 64-byte runs (loads and
+// stores go through one LDS transposition each), and the C transforms run side by side in the core.
+struct BigTw {
+  float2* lo = nullptr;     // exp(-2 pi i m / H),        m = 0 .. kBigR-1
+  float2* hi = nullptr;     // exp(-2 pi i m kBigR / H),  m = 0 .. H/kBigR-1
+};
+constexpr int kBigR = 1024;
+constexpr int kBigC = 8;
+static std::map<std::pair<int, int>, BigTw> g_bigtw;
+
+static int get_big_twiddles(int device, int H, BigTw* out) {
+  std::lock_guard<std::mutex> lk(g_tw_mu);
+  auto key = std::make_pair(device, H);
+  auto it = g_bigtw.find(key);
+  if (it != g_bigtw.end()) {
+    *out = it->second;
+    return PAR_OK;
+  }
+  const int nh = H / kBigR > 1 ? H / kBigR : 1;
+  std::vector<float2> lo(kBigR), hi(nh);
+  for (int m = 0; m < kBigR; ++m) {
+    const double a = -2.0 * M_PI * (double)m / (double)H;
+    lo[m] = make_float2((float)cos(a), (float)sin(a));
+  }
+  for (int m = 0; m < nh; ++m) {
+    const double a = -2.0 * M_PI * (double)m * (double)kBigR / (double)H;
+    hi[m] = make_float2((float)cos(a), (float)sin(a));
+  }
+  BigTw t;
+  PAR_HIP_CHECK(hipMalloc(&t.lo, lo.size() * sizeof(float2)));
+  PAR_HIP_CHECK(hipMalloc(&t.hi, hi.size() * sizeof(float2)));
+  PAR_HIP_CHECK(hipMemcpy(t.lo, lo.data(), lo.size() * sizeof(float2), hipMemcpyHostToDevice));
+  PAR_HIP_CHECK(hipMemcpy(t.hi, hi.data(), hi.size() * sizeof(float2), hipMemcpyHostToDevice));
+  g_bigtw[key] = t;
+  *out = t;
+  return PAR_OK;
+}
+
+// PASS 0: columns of the packed windowed frame -> A;  PASS 1: rows of A -> Z.  grid (groups of kBigC transforms, frames)
+template <int LOGS, int PASS>
+__global__ __launch_bounds__((1 << LOGS) < 64 ? 64 : (1 << LOGS)) void k_bigfft(const float* __restrict__ x, int64_t n,
+                                                                             int64_t x_stride, int n_fft, int hop,
+                                                                             const float* __restrict__ window,
+                                                                             const float2* __restrict__ tw,
+                                                                             const float2* __restrict__ tlo,
+                                                                             const float2* __restrict__ thi,
+                                                                             float2* __restrict__ A, float2* __restrict__ Z,
+                                                                             int64_t f_first, int logN1, int logN2) {
+  constexpr int S = 1 << LOGS, T = S / 8;
+  constexpr int FrameLds = S + S / 8 + 8;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const int N1 = 1 << logN1, N2 = 1 << logN2;
+  const int64_t H = (int64_t)N1 * N2;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int g0 = blockIdx.x * kBigC;                       // first column (pass 0) / row (pass 1) of the group
+  const int64_t fb = blockIdx.y;                           // frame of this batch
+  float2* Ab = A + fb * H;
+  if (PASS == 0) {
+    const long long base = (long long)(f_first + fb) * hop - (n_fft >> 1);
+    for (int idx = tid; idx < kBigC * S; idx += nthreads) {
+      const int n1 = idx / kBigC, f = idx % kBigC;
+      const long long t0 = 2ll * ((long long)(g0 + f) + (long long)N2 * n1);      // first real sample of the packed pair
+      float2 z = make_float2(0.0f, 0.0f);
+      if (t0 < n_fft) z.x = window[t0] * x[reflect_index(base + t0, n) * x_stride];
+      if (t0 + 1 < n_fft) z.y = window[t0 + 1] * x[reflect_index(base + t0 + 1, n) * x_stride];
+      lds[f * FrameLds + lpad(n1)] = z;
+    }
+  } else {
+    for (int idx = tid; idx < kBigC * S; idx += nthreads) {
+      const int f = idx / S, n2 = idx % S;
+      lds[f * FrameLds + lpad(n2)] = Ab[(int64_t)(g0 + f) * N2 + n2];
+    }
+  }
+  __syncthreads();
+  // kBigC transforms side by side: thread -> (transform f, lane j); a short transform leaves threads idle
+  const int f = tid / T, j = tid - f * T;
+  const bool act = f < kBigC;
+  float2* X = lds + (act ? f : 0) * FrameLds;
+  float2 v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = act ? X[lpad(j + q * T)] : make_float2(0.0f, 0.0f);
+  __syncthreads();
+  if (T > kWave || act) fft_core<LOGS>(v, act ? X : lds + kBigC * FrameLds, j, tw);
+  __syncthreads();
+  if (PASS == 0) {
+    for (int idx = tid; idx < kBigC * S; idx += nthreads) {
+      const int k1 = idx / kBigC, ff = idx % kBigC;
+      const long long m = (long long)(g0 + ff) * k1;       // < H
+      const float2 w = cmul(thi[m / kBigR], tlo[m % kBigR]);
+      Ab[(int64_t)k1 * N2 + g0 + ff] = cmul(lds[ff * FrameLds + lpad(k1)], w);
+    }
+  } else {
+    float2* Zb = Z + fb * H;
+    for (int idx = tid; idx < kBigC * S; idx += nthreads) {
+      const int k2 = idx / kBigC, ff = idx % kBigC;
+      Zb[(int64_t)(g0 + ff) + (int64_t)N1 * k2] = lds[ff * FrameLds + lpad(k2)];
+    }
+  }
+}
+
+// real-FFT bins from the H-point spectrum of the packed frame: X[k] = (Z[k] + conj Z[H-k])/2 - i W_M^k (Z[k] - conj Z[H-k])/2
+__global__ __launch_bounds__(256) void k_big_untangle(const float2* __restrict__ Z, int64_t H, const float2* __restrict__ tlo,
+                                                      const float2* __restrict__ thi, float* __restrict__ out,
+                                                      int64_t f_first, int mode, float scale) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k > H / 2) return;
+  const int64_t fb = blockIdx.y, fr = f_first + fb, bins = H + 1;
+  const float2* Zb = Z + fb * H;
+  const float2 zk = Zb[k];
+  const float2 zc = cconj(Zb[(H - k) & (H - 1)]);
+  // W_M^k = exp(-2 pi i k / (2H)): the half-step table is the H-table of 2H points -> evaluate in float64
+  // (H/2 + 1 sincos per frame against H log H butterflies)
+  double sn, cs;
+  sincospi(-(double)k / (double)H, &sn, &cs);
+  const float2 pw = make_float2((float)cs, (float)sn);
+  const float2 ev = cadd(zk, zc);
+  const float2 t = cmul(pw, csub(zk, zc));
+  const float hs = 0.5f * scale;
+  auto emit = [&](int64_t kk, float re, float im) {
+    if (mode == 0) reinterpret_cast<float2*>(out)[fr * bins + kk] = make_float2(re, im);
+    else out[fr * bins + kk] = sqrtf(re * re + im * im) + 1e-7f;
+  };
+  emit(k, (ev.x + t.y) * hs, (ev.y - t.x) * hs);
+  if (k > 0 && k < H / 2) emit(H - k, (ev.x - t.y) * hs, (-ev.y - t.x) * hs);
+  if (k == 0) emit(H, (ev.x - t.y) * hs, (-ev.y - t.x) * hs);
+}
+
 // ISTFT stage 1: frame f -> window * irfft(spec[f] * sqrt(n_fft))   (util/fourier.py:359, :401)
 // irfft of H+1 bins via an H-point complex inverse FFT (conjugate trick on the forward core).
 template <int LOGH>
@@ -582,6 +716,70 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
   }
 #undef PAR_STFT_LAUNCH
   PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
+// Frames of more than 8192 points (up to 2^21): four-step transform through a caller-owned scratch of
+// par_stft_big_scratch_bytes() (two H-point complex arrays per frame of a batch; batches of up to 16 frames).
+size_t par_stft_big_scratch_bytes(int64_t n, int n_fft, int hop, int zeropad) {
+  const int64_t M = (int64_t)n_fft * zeropad;
+  if (M <= 8192 || M > (1ll << 21)) return 0;
+  int64_t frames = par_stft_frames(n, n_fft, hop);
+  if (frames > 16) frames = 16;
+  return (size_t)(2 * frames * (M / 2) * sizeof(float2));
+}
+
+int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad,
+                     const float* window, float* out, int mode, void* scratch, size_t scratch_bytes, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(x && window && out && scratch, PAR_ERR_ARG, "par_stft_big_f32: null pointer");
+  PAR_REQUIRE(n >= 1 && x_stride >= 1 && hop >= 1 && zeropad >= 1 && n_fft >= 2, PAR_ERR_ARG, "par_stft_big_f32: bad sizes");
+  PAR_REQUIRE(mode == 0 || mode == 1, PAR_ERR_ARG, "par_stft_big_f32: mode must be 0 (complex) or 1 (magnitude)");
+  const int64_t M64 = (int64_t)n_fft * zeropad;
+  PAR_REQUIRE(M64 > 8192 && M64 <= (1ll << 21) && (M64 & (M64 - 1)) == 0 && (n_fft % 2) == 0, PAR_ERR_UNSUPPORTED,
+              "par_stft_big_f32: n_fft*zeropad=%lld is not a power of two in (8192, 2^21]", (long long)M64);
+  PAR_REQUIRE(scratch_bytes >= par_stft_big_scratch_bytes(n, n_fft, hop, zeropad), PAR_ERR_WORKSPACE,
+              "par_stft_big_f32: scratch %zu < %zu", scratch_bytes, par_stft_big_scratch_bytes(n, n_fft, hop, zeropad));
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipStream_t s = as_stream(stream);
+  const int64_t H = M64 / 2;
+  const int L = ilog2((int)H), l1 = (L + 1) / 2, l2 = L - l1;          // N1 >= N2, both in [64, 1024]
+  Twiddles t1, t2;
+  BigTw bt;
+  int rc = get_twiddles(device, 2 << l1, &t1);
+  if (rc == PAR_OK) rc = get_twiddles(device, 2 << l2, &t2);
+  if (rc == PAR_OK) rc = get_big_twiddles(device, (int)H, &bt);
+  if (rc != PAR_OK) return rc;
+  const int64_t n_frames = par_stft_frames(n, n_fft, hop);
+  const float scale = (float)(1.0 / sqrt((double)n_fft));
+  float2* A = static_cast<float2*>(scratch);
+  for (int64_t f0 = 0; f0 < n_frames; f0 += 16) {
+    const int64_t nb = n_frames - f0 < 16 ? n_frames - f0 : 16;
+    float2* Z = A + nb * H;
+#define PAR_BIG_PASS(LS, PASS, NG, TW)                                                                                   \
+  hipLaunchKernelGGL((k_bigfft<LS, PASS>), dim3((unsigned)((NG) / kBigC), (unsigned)nb), dim3((1 << LS) < 64 ? 64 : (1 << LS)), \
+                     (size_t)(kBigC + 1) * ((1 << LS) + (1 << LS) / 8 + 8) * sizeof(float2), s, x, n, x_stride, n_fft, hop, \
+                     window, TW, bt.lo, bt.hi, A, Z, f0, l1, l2)
+    switch (l1) {
+      case 7: PAR_BIG_PASS(7, 0, 1 << l2, t1.w); break;
+      case 8: PAR_BIG_PASS(8, 0, 1 << l2, t1.w); break;
+      case 9: PAR_BIG_PASS(9, 0, 1 << l2, t1.w); break;
+      case 10: PAR_BIG_PASS(10, 0, 1 << l2, t1.w); break;
+      default: PAR_REQUIRE(false, PAR_ERR_UNSUPPORTED, "par_stft_big_f32: unsupported size");
+    }
+    switch (l2) {
+      case 6: PAR_BIG_PASS(6, 1, 1 << l1, t2.w); break;
+      case 7: PAR_BIG_PASS(7, 1, 1 << l1, t2.w); break;
+      case 8: PAR_BIG_PASS(8, 1, 1 << l1, t2.w); break;
+      case 9: PAR_BIG_PASS(9, 1, 1 << l1, t2.w); break;
+      case 10: PAR_BIG_PASS(10, 1, 1 << l1, t2.w); break;
+      default: PAR_REQUIRE(false, PAR_ERR_UNSUPPORTED, "par_stft_big_f32: unsupported size");
+    }
+#undef PAR_BIG_PASS
+    hipLaunchKernelGGL(k_big_untangle, dim3((unsigned)ceil_div(H / 2 + 1, 256), (unsigned)nb), dim3(256), 0, s, (const float2*)Z,
+                       H, bt.lo, bt.hi, out, f0, mode, scale);
+    PAR_HIP_CHECK(hipGetLastError());
+  }
   return PAR_OK;
 }
 

@@ -1316,3 +1316,24 @@ def test_config4_x256_tiles_one_launch(par):
         d = np.max(np.abs(got[k * n1 + edge:(k + 1) * n1 - edge] - want[edge:n1 - edge])) / scale
         worst = max(worst, d)
     assert worst < TOL, worst
+
+
+@pytest.mark.parametrize("n_fft,hop,zp", [(16384, 4096, 1), (65536, 16384, 1), (4096, 1024, 4), (32768, 5000, 2), (1048576, 262144, 1)])
+def test_stft_above_8192_four_step(par, n_fft, hop, zp):
+    """FFT sizes above 8192 (the GUI offers up to 2^20, util/widgets.py:333-349): the four-step transform against the C
+    oracle (float64 FFT of the same float32 frames), complex and magnitude, frame counts exact; strided input."""
+    from oracle import oracle_c as C
+    import scipy.signal
+    n = max(3 * n_fft + 12345, 400000)
+    x = inputs.noise(n, 21) + inputs.sine(n, 1234.5, 96000, 0.5)
+    win = scipy.signal.get_window("blackmanharris", n_fft).astype(np.float32)
+    want = C.stft(x, n_fft, hop, win, zp, mode=0, threads=8)
+    got = par.fourier.stft(x, n_fft, hop, "blackmanharris", zp)
+    assert got.shape == want.shape == (n_fft * zp // 2 + 1, n // hop + 1)
+    assert relerr(got, want) < TOL
+    mag = par.fourier.get_mag(x, n_fft, hop, "blackmanharris", zp)
+    assert relerr(mag, np.abs(want) + 1e-7) < TOL
+    st = np.stack((x, x[::-1]), axis=-1)
+    xt = par.torch.from_numpy(st).cuda()
+    got1 = par.fourier.stft(xt[:, 1], n_fft, hop, "blackmanharris", zp).cpu().numpy()
+    assert relerr(got1, C.stft(np.ascontiguousarray(st[:, 1]), n_fft, hop, win, zp, mode=0, threads=8)) < TOL
