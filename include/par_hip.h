@@ -269,6 +269,22 @@ int par_track_corr_f64(int device, const float* mag, int64_t n_frames, int bins,
                        const double* M, const double* wind, int n, double log_span, double log_mean, double* work,
                        double* freqs, int32_t* status, void* stream);
 
+/* X2: util/correlation.py:6-39 on the device.  a, b: float64 device signals (what butter_bandpass_filter hands to
+ * find_delay, pytapesynch_gui.py:128-131).
+ *   par_xcorr_f64       scipy.signal.correlate(a/|a|, b/|b|, 'full'): full[na + nb - 1] float64, through one complex
+ *                       float32 transform of a + i b (values carry ~1e-6 of the peak)
+ *   par_find_delay_f64  find_delay(a, b, ignore_phase) with the window already applied by the caller (the reference
+ *                       multiplies a and b in place): the peak of the 'same' correlation is located by the transform,
+ *                       the lags around it are re-evaluated as float64 dot products and parabolic() (:42-46) runs on
+ *                       those; *delay = peak - na//2 (host), *corr = its height.  A peak on the last lag is the
+ *                       reference's IndexError: PAR_ERR_INDEX.  Synchronises.
+ *   scratch             device bytes of par_xcorr_scratch_bytes(na, nb); na + nb - 1 <= 2^20 (else PAR_ERR_UNSUPPORTED) */
+size_t par_xcorr_scratch_bytes(int64_t na, int64_t nb);
+int par_xcorr_f64(int device, const double* a, int64_t na, const double* b, int64_t nb, void* scratch, size_t scratch_bytes,
+                  double* full, void* stream);
+int par_find_delay_f64(int device, const double* a, int64_t na, const double* b, int64_t nb, int ignore_phase, void* scratch,
+                       size_t scratch_bytes, double* delay, double* corr, void* stream);
+
 /* W3: sign-change indices of a (band-passed) float64 signal, ascending -- zero_crossings(a) =
  * np.where(np.bitwise_xor(a[1:] > 0, a[:-1] > 0))[0] (util/wow_detection.py:448-450), the full-rate pass of
  * ZeroCrossingTracker.trace (:340).

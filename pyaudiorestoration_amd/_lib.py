@@ -73,6 +73,9 @@ SIGNATURES = {
     "par_track_cog_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]),
     "par_stft_big_scratch_bytes": (ctypes.c_size_t, [c_i64, c_int, c_int, c_int]),
     "par_stft_big_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, ctypes.c_size_t, c_vp]),
+    "par_xcorr_scratch_bytes": (ctypes.c_size_t, [c_i64, c_i64]),
+    "par_xcorr_f64": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, ctypes.c_size_t, c_vp, c_vp]),
+    "par_find_delay_f64": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp, c_vp]),
     "par_track_corr_work_len": (c_i64, [c_i64, c_int]),
     "par_track_corr_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_int, c_int, c_i64, c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp,
                                    c_vp, c_vp]),

@@ -1,29 +1,16 @@
 """Correlation helpers with the call contracts of the reference's util/correlation.py (xcorr :6-13,
-find_delay :16-39, parabolic :42-46).  Host code: they only ever see window-sized vectors (CorrelationTracker,
-tape-sync markers); the implementation is this package's own (FFT correlation, batched form for the tracker).
+find_delay :16-39, parabolic :42-46), on the device: `par_xcorr_f64` / `par_find_delay_f64` (csrc/stft.hip) run the
+correlation through one complex four-step FFT of a + i b; find_delay re-evaluates the lags around the peak as
+float64 dot products before the parabolic refinement, so the delay the tape-sync tool reads is exact.
 """
+import ctypes
 import logging
 
 import numpy as np
+import torch
 from scipy.signal import get_window
 
-
-def _next_pow2(n):
-    return 1 << max(0, int(n) - 1).bit_length()
-
-
-def xcorr_rows(A, B):
-    """L2-normalised 'full' cross-correlation of matching rows of A and B (shape (rows, N) and (rows, M)):
-    out[r, j] = sum_n a[r, n + j - (M-1)] * b[r, n], j = 0 .. N+M-2, computed with one batched real FFT."""
-    A = np.atleast_2d(np.asarray(A, dtype=np.float64))
-    B = np.atleast_2d(np.asarray(B, dtype=np.float64))
-    A = A / np.sqrt(np.einsum("ij,ij->i", A, A))[:, None]
-    B = B / np.sqrt(np.einsum("ij,ij->i", B, B))[:, None]
-    n, m = A.shape[1], B.shape[1]
-    nfft = _next_pow2(n + m - 1)
-    circ = np.fft.irfft(np.fft.rfft(A, nfft, axis=1) * np.conj(np.fft.rfft(B, nfft, axis=1)), nfft, axis=1)
-    # lag l = j - (M-1): negative lags wrap to the end of the circular result
-    return np.concatenate((circ[:, nfft - (m - 1):] if m > 1 else circ[:, :0], circ[:, :n]), axis=1)
+from . import _dev, _lib
 
 
 def _centre(full, n, m, mode):
@@ -38,11 +25,32 @@ def _centre(full, n, m, mode):
     raise ValueError(f"unknown correlation mode {mode!r}")
 
 
+def _up(a, dev):
+    return a.to(device=f"cuda:{dev}", dtype=torch.float64) if isinstance(a, torch.Tensor) else \
+        _dev.to_dev(np.ascontiguousarray(a, dtype=np.float64), torch.float64, dev)
+
+
+def xcorr_dev(a_t, b_t, dev=None):
+    """'full' normalised cross-correlation of two 1-D float64 device tensors -> float64 device tensor."""
+    dev = _dev.device_index(dev if dev is not None else a_t.device)
+    L = _lib.lib()
+    na, nb = a_t.numel(), b_t.numel()
+    nbytes = int(L.par_xcorr_scratch_bytes(na, nb))
+    scratch = _dev.empty(max(nbytes, 1), torch.uint8, dev)
+    full = _dev.empty(na + nb - 1, torch.float64, dev)
+    _lib.check(L.par_xcorr_f64(dev, _dev.ptr(a_t), na, _dev.ptr(b_t), nb, _dev.ptr(scratch), nbytes, _dev.ptr(full),
+                               _dev.stream_ptr(dev)))
+    return full
+
+
 def xcorr(a, b, mode='full'):
     """Normalised cross-correlation in [-1, 1] of two 1-D signals (scipy.signal.correlate conventions)."""
-    a = np.asarray(a)
-    b = np.asarray(b)
-    return _centre(xcorr_rows(a[None, :], b[None, :])[0], len(a), len(b), mode)
+    dev = _dev.device_index(None)
+    a, b = np.asarray(a), np.asarray(b)
+    if a.ndim != 1 or b.ndim != 1 or len(a) < 1 or len(b) < 1:
+        raise ValueError("xcorr needs two non-empty 1-D signals")
+    full = xcorr_dev(_up(a, dev), _up(b, dev), dev).cpu().numpy()
+    return _centre(full, len(a), len(b), mode)
 
 
 def parabolic(f, x):
@@ -58,10 +66,16 @@ def find_delay(a, b, ignore_phase=False, window_name=None):
     Like the reference, a given window is applied to `a` and `b` IN PLACE."""
     for sig in ((a, b) if window_name else ()):
         sig *= get_window(window_name, len(sig))
-    res = xcorr(a, b, mode="same")
     if ignore_phase:
         logging.warning("Ignoring phase")
-    best = int(np.argmax(np.abs(res) if ignore_phase else res))
-    i_peak, corr = parabolic(res, best)
-    logging.debug(f"i_peak {i_peak}")
-    return i_peak - len(res) // 2, corr
+    dev = _dev.device_index(None)
+    L = _lib.lib()
+    a_t, b_t = _up(a, dev), _up(b, dev)
+    na, nb = a_t.numel(), b_t.numel()
+    nbytes = int(L.par_xcorr_scratch_bytes(na, nb))
+    scratch = _dev.empty(max(nbytes, 1), torch.uint8, dev)
+    delay, corr = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    _lib.check(L.par_find_delay_f64(dev, _dev.ptr(a_t), na, _dev.ptr(b_t), nb, int(bool(ignore_phase)), _dev.ptr(scratch), nbytes,
+                                    ctypes.byref(delay), ctypes.byref(corr), _dev.stream_ptr(dev)))
+    logging.debug(f"i_peak {delay.value + na // 2}")
+    return delay.value, corr.value

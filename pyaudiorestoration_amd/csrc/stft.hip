@@ -341,7 +341,7 @@ static int get_big_twiddles(int device, int H, BigTw* out) {
 }
 
 // PASS 0: columns of the packed windowed frame -> A;  PASS 1: rows of A -> Z.  grid (groups of kBigC transforms, frames)
-template <int LOGS, int PASS>
+template <int LOGS, int PASS, int SRC = 0>
 __global__ __launch_bounds__((1 << LOGS) < 64 ? 64 : (1 << LOGS)) void k_bigfft(const float* __restrict__ x, int64_t n,
                                                                              int64_t x_stride, int n_fft, int hop,
                                                                              const float* __restrict__ window,
@@ -359,7 +359,12 @@ __global__ __launch_bounds__((1 << LOGS) < 64 ? 64 : (1 << LOGS)) void k_bigfft(
   const int g0 = blockIdx.x * kBigC;                       // first column (pass 0) / row (pass 1) of the group
   const int64_t fb = blockIdx.y;                           // frame of this batch
   float2* Ab = A + fb * H;
-  if (PASS == 0) {
+  if (PASS == 0 && SRC == 1) {                             // plain complex input, transformed in place
+    for (int idx = tid; idx < kBigC * S; idx += nthreads) {
+      const int n1 = idx / kBigC, f = idx % kBigC;
+      lds[f * FrameLds + lpad(n1)] = Ab[(int64_t)(g0 + f) + (int64_t)N2 * n1];
+    }
+  } else if (PASS == 0) {
     const long long base = (long long)(f_first + fb) * hop - (n_fft >> 1);
     for (int idx = tid; idx < kBigC * S; idx += nthreads) {
       const int n1 = idx / kBigC, f = idx % kBigC;
@@ -427,6 +432,139 @@ __global__ __launch_bounds__(256) void k_big_untangle(const float2* __restrict__
   emit(k, (ev.x + t.y) * hs, (ev.y - t.x) * hs);
   if (k > 0 && k < H / 2) emit(H - k, (ev.x - t.y) * hs, (-ev.y - t.x) * hs);
   if (k == 0) emit(H, (ev.x - t.y) * hs, (-ev.y - t.x) * hs);
+}
+
+// H-point complex FFT (H a power of two in [8192, 2^20]) of `batch` arrays: A is overwritten, the spectrum lands in Z
+static int big_fft_c2c(int device, float2* A, float2* Z, int64_t H, int64_t batch, hipStream_t s) {
+  const int L = [&] { int l = 0; while ((1ll << l) < H) ++l; return l; }(), l1 = (L + 1) / 2, l2 = L - l1;
+  PAR_REQUIRE(H >= 8192 && H <= (1ll << 20) && (1ll << L) == H, PAR_ERR_UNSUPPORTED, "big_fft_c2c: H=%lld", (long long)H);
+  Twiddles t1, t2;
+  BigTw bt;
+  int rc = get_twiddles(device, 2 << l1, &t1);
+  if (rc == PAR_OK) rc = get_twiddles(device, 2 << l2, &t2);
+  if (rc == PAR_OK) rc = get_big_twiddles(device, (int)H, &bt);
+  if (rc != PAR_OK) return rc;
+#define PAR_BIG_C2C(LS, PASS, NG, TW)                                                                                     \
+  hipLaunchKernelGGL((k_bigfft<LS, PASS, 1>), dim3((unsigned)((NG) / kBigC), (unsigned)batch), dim3((1 << LS) < 64 ? 64 : (1 << LS)), \
+                     (size_t)(kBigC + 1) * ((1 << LS) + (1 << LS) / 8 + 8) * sizeof(float2), s, (const float*)nullptr, (int64_t)0, \
+                     (int64_t)1, 0, 1, (const float*)nullptr, TW, bt.lo, bt.hi, A, Z, (int64_t)0, l1, l2)
+  switch (l1) {
+    case 7: PAR_BIG_C2C(7, 0, 1 << l2, t1.w); break;
+    case 8: PAR_BIG_C2C(8, 0, 1 << l2, t1.w); break;
+    case 9: PAR_BIG_C2C(9, 0, 1 << l2, t1.w); break;
+    case 10: PAR_BIG_C2C(10, 0, 1 << l2, t1.w); break;
+    default: PAR_REQUIRE(false, PAR_ERR_UNSUPPORTED, "big_fft_c2c: unsupported size");
+  }
+  switch (l2) {
+    case 6: PAR_BIG_C2C(6, 1, 1 << l1, t2.w); break;
+    case 7: PAR_BIG_C2C(7, 1, 1 << l1, t2.w); break;
+    case 8: PAR_BIG_C2C(8, 1, 1 << l1, t2.w); break;
+    case 9: PAR_BIG_C2C(9, 1, 1 << l1, t2.w); break;
+    case 10: PAR_BIG_C2C(10, 1, 1 << l1, t2.w); break;
+    default: PAR_REQUIRE(false, PAR_ERR_UNSUPPORTED, "big_fft_c2c: unsupported size");
+  }
+#undef PAR_BIG_C2C
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
+// ---- X2: normalised cross-correlation and delay search (util/correlation.py:6-39) ---------------------------
+// scipy.signal.correlate(a/|a|, b/|b|, 'full') through ONE complex transform of z = a + i b (both zero-padded to
+// N >= len a + len b - 1): A_k = (Z_k + conj Z_{N-k})/2, B_k = (Z_k - conj Z_{N-k})/(2i), cross spectrum A conj(B),
+// inverse transform by the conjugate trick.  The float32 transform places the peak (error ~1e-6 of it); find_delay
+// then re-evaluates the few lags around it as float64 dot products, so the parabola through the peak -- the delay
+// the tape-sync tool uses -- is exact.
+__global__ __launch_bounds__(256) void k_xc_pack(const double* __restrict__ a, int64_t na, const double* __restrict__ b,
+                                                 int64_t nb, float2* __restrict__ Z, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  Z[i] = make_float2(i < na ? (float)a[i] : 0.0f, i < nb ? (float)b[i] : 0.0f);
+}
+// conj(A_k conj(B_k)) for the second (forward) transform
+__global__ __launch_bounds__(256) void k_xc_cross(const float2* __restrict__ Z, float2* __restrict__ C, int64_t N) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= N) return;
+  const float2 zk = Z[k], zc = cconj(Z[(N - k) & (N - 1)]);
+  const float2 A = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+  const float2 d = csub(zk, zc);                            // 2i B_k  ->  B_k = (d.y, -d.x)/2
+  const float2 B = make_float2(0.5f * d.y, -0.5f * d.x);
+  const float2 c = cmul(A, cconj(B));
+  C[k] = cconj(c);
+}
+// full[j] = circ[(j - (nb-1)) mod N] / (N |a| |b|), j = 0 .. na + nb - 2
+__global__ __launch_bounds__(256) void k_xc_unpack(const float2* __restrict__ Y, int64_t N, int64_t nb, int64_t n_full,
+                                                   const double* __restrict__ norms, double* __restrict__ full) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_full) return;
+  full[j] = (double)Y[(j - (nb - 1)) & (N - 1)].x / ((double)N * norms[0] * norms[1]);
+}
+// norms[0] = |a|, norms[1] = |b| (float64, one workgroup each)
+__global__ __launch_bounds__(1024) void k_xc_norms(const double* __restrict__ a, int64_t na, const double* __restrict__ b,
+                                                   int64_t nb, double* __restrict__ norms) {
+  __shared__ double part[16];
+  const double* v = blockIdx.x ? b : a;
+  const int64_t n = blockIdx.x ? nb : na;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) acc += v[i] * v[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += part[w];
+    norms[blockIdx.x] = sqrt(t);
+  }
+}
+// first index of the maximum of v[lo .. lo+n) (|v| when ignore_phase), one workgroup
+__global__ __launch_bounds__(1024) void k_xc_argmax(const double* __restrict__ v, int64_t n, int use_abs, long long* __restrict__ arg) {
+  __shared__ double bv[1024];
+  __shared__ long long bi[1024];
+  double best = -INFINITY;
+  long long at = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double x = use_abs ? fabs(v[i]) : v[i];
+    if (x > best) {
+      best = x;
+      at = i;
+    }
+  }
+  bv[threadIdx.x] = best;
+  bi[threadIdx.x] = at;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const double x = bv[threadIdx.x + o];
+      const long long j = bi[threadIdx.x + o];
+      if (x > bv[threadIdx.x] || (x == bv[threadIdx.x] && j < bi[threadIdx.x])) {
+        bv[threadIdx.x] = x;
+        bi[threadIdx.x] = j;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *arg = bi[0];
+}
+// exact 'same' correlation values at lags c0 .. c0+count-1 (one workgroup per lag, float64):
+// same[j] = sum_t a[t + j + (nb-1)//2 - (nb-1)] b[t] / (|a| |b|)
+__global__ __launch_bounds__(256) void k_xc_exact(const double* __restrict__ a, int64_t na, const double* __restrict__ b,
+                                                  int64_t nb, const double* __restrict__ norms, const long long* __restrict__ arg,
+                                                  int64_t rel0, double* __restrict__ vals) {
+  __shared__ double part[4];
+  const int64_t j = *arg + rel0 + blockIdx.x;
+  double acc = 0.0;
+  if (j >= 0 && j < na) {
+    const int64_t sh = j + (nb - 1) / 2 - (nb - 1);
+    for (int64_t t = threadIdx.x; t < nb; t += 256) {
+      const int64_t ia = t + sh;
+      if (ia >= 0 && ia < na) acc += a[ia] * b[t];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) vals[blockIdx.x] = (part[0] + part[1] + part[2] + part[3]) / (norms[0] * norms[1]);
 }
 
 // ISTFT stage 1: frame f -> window * irfft(spec[f] * sqrt(n_fft))   (util/fourier.py:359, :401)
@@ -780,6 +918,104 @@ int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, in
                        H, bt.lo, bt.hi, out, f0, mode, scale);
     PAR_HIP_CHECK(hipGetLastError());
   }
+  return PAR_OK;
+}
+
+// X2: xcorr(a, b, 'full') of two float64 device signals (util/correlation.py:6-13): full[na + nb - 1] float64 out.
+// scratch: par_xcorr_scratch_bytes(na, nb) device bytes.  The values carry the float32 transform's error (~1e-6 of the
+// peak); par_find_delay_f64 refines what the tape-sync tool needs exactly.
+static int64_t xc_fft_len(int64_t na, int64_t nb) {
+  int64_t N = 8192;
+  while (N < na + nb - 1) N <<= 1;
+  return N;
+}
+size_t par_xcorr_scratch_bytes(int64_t na, int64_t nb) {
+  if (na < 1 || nb < 1) return 0;
+  return (size_t)(2 * xc_fft_len(na, nb) * sizeof(float2) + 64 + (size_t)(na + nb + 16) * sizeof(double));
+}
+
+static int xcorr_full(int device, const double* a, int64_t na, const double* b, int64_t nb, void* scratch, double* full,
+                      double** norms_out, hipStream_t s) {
+  using namespace par;
+  const int64_t N = xc_fft_len(na, nb);
+  PAR_REQUIRE(N <= (1ll << 20), PAR_ERR_UNSUPPORTED, "xcorr: %lld + %lld samples need a transform of %lld points (limit 2^20)",
+              (long long)na, (long long)nb, (long long)N);
+  float2* Z = static_cast<float2*>(scratch);
+  float2* Y = Z + N;
+  double* norms = reinterpret_cast<double*>(Y + N);
+  hipLaunchKernelGGL(k_xc_norms, dim3(2), dim3(1024), 0, s, a, na, b, nb, norms);
+  hipLaunchKernelGGL(k_xc_pack, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, a, na, b, nb, Z, N);
+  int rc = big_fft_c2c(device, Z, Y, N, 1, s);                       // Y = FFT(a + i b)
+  if (rc != PAR_OK) return rc;
+  hipLaunchKernelGGL(k_xc_cross, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, (const float2*)Y, Z, N);
+  rc = big_fft_c2c(device, Z, Y, N, 1, s);                           // Y = conj(N * circular correlation)
+  if (rc != PAR_OK) return rc;
+  hipLaunchKernelGGL(k_xc_unpack, dim3((unsigned)ceil_div(na + nb - 1, 256)), dim3(256), 0, s, (const float2*)Y, N, nb,
+                     na + nb - 1, (const double*)norms, full);
+  PAR_HIP_CHECK(hipGetLastError());
+  *norms_out = norms;
+  return PAR_OK;
+}
+
+int par_xcorr_f64(int device, const double* a, int64_t na, const double* b, int64_t nb, void* scratch, size_t scratch_bytes,
+                  double* full, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(a && b && scratch && full && na >= 1 && nb >= 1, PAR_ERR_ARG, "par_xcorr_f64: bad args");
+  PAR_REQUIRE(scratch_bytes >= par_xcorr_scratch_bytes(na, nb), PAR_ERR_WORKSPACE, "par_xcorr_f64: scratch too small");
+  PAR_HIP_CHECK(hipSetDevice(device));
+  double* norms;
+  return xcorr_full(device, a, na, b, nb, scratch, full, &norms, as_stream(stream));
+}
+
+// find_delay(a, b, ignore_phase) of util/correlation.py:16-39 (windows are applied by the caller, in place, like the
+// reference): *delay = parabola-refined peak of the 'same' correlation minus len//2, *corr = its height.  The peak is
+// located by the float32 transform and the lags around it are re-evaluated as float64 dot products.  A peak on the last
+// lag is the reference's IndexError (PAR_ERR_INDEX).  Synchronises.
+int par_find_delay_f64(int device, const double* a, int64_t na, const double* b, int64_t nb, int ignore_phase, void* scratch,
+                       size_t scratch_bytes, double* delay, double* corr, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(a && b && scratch && delay && corr && na >= 3 && nb >= 1, PAR_ERR_ARG, "par_find_delay_f64: bad args");
+  PAR_REQUIRE(scratch_bytes >= par_xcorr_scratch_bytes(na, nb), PAR_ERR_WORKSPACE, "par_find_delay_f64: scratch too small");
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipStream_t s = as_stream(stream);
+  const int64_t N = xc_fft_len(na, nb);
+  double* full = reinterpret_cast<double*>(static_cast<char*>(scratch) + 2 * N * sizeof(float2) + 64);
+  double* norms;
+  int rc = xcorr_full(device, a, na, b, nb, scratch, full, &norms, s);
+  if (rc != PAR_OK) return rc;
+  long long* arg = reinterpret_cast<long long*>(norms + 2);
+  double* vals = full + (na + nb - 1);                                 // 7 values behind the correlation (scratch holds 16 spare)
+  const double* same = full + (nb - 1) / 2;                            // 'same': na values centred on the full output
+  hipLaunchKernelGGL(k_xc_argmax, dim3(1), dim3(1024), 0, s, same, na, ignore_phase, arg);
+  // exact values at arg-3 .. arg+3; the final peak is the best of arg-2 .. arg+2
+  hipLaunchKernelGGL(k_xc_exact, dim3(7), dim3(256), 0, s, a, na, b, nb, (const double*)norms, (const long long*)arg, (int64_t)-3,
+                     vals);
+  PAR_HIP_CHECK(hipGetLastError());
+  long long p0 = 0;
+  double v[7];
+  PAR_HIP_CHECK(hipMemcpyAsync(&p0, arg, sizeof(p0), hipMemcpyDeviceToHost, s));
+  PAR_HIP_CHECK(hipMemcpyAsync(v, vals, sizeof(v), hipMemcpyDeviceToHost, s));
+  PAR_HIP_CHECK(hipStreamSynchronize(s));
+  int best = 3;
+  for (int c = 1; c <= 5; ++c) {
+    const long long j = p0 - 3 + c;
+    if (j < 0 || j >= na) continue;
+    const double x = ignore_phase ? fabs(v[c]) : v[c], y = ignore_phase ? fabs(v[best]) : v[best];
+    if (x > y || (x == y && c < best)) best = c;
+  }
+  const long long peak = p0 - 3 + best;
+  PAR_REQUIRE(peak != na - 1, PAR_ERR_INDEX, "par_find_delay_f64: correlation peak on the last lag (index %lld is out of bounds "
+              "for axis 0 with size %lld in the reference's parabolic())", (long long)na, (long long)na);
+  double fm = v[best - 1], f0 = v[best], fp = v[best + 1];
+  if (peak == 0) {                                                     // f[-1]: numpy wraps to the last element
+    hipLaunchKernelGGL(k_xc_exact, dim3(1), dim3(256), 0, s, a, na, b, nb, (const double*)norms, (const long long*)arg,
+                       (int64_t)(na - 1 - p0), vals);
+    PAR_HIP_CHECK(hipMemcpyAsync(&fm, vals, sizeof(double), hipMemcpyDeviceToHost, s));
+    PAR_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  const double xv = 0.5 * (fm - fp) / (fm - 2.0 * f0 + fp) + (double)peak;
+  *corr = f0 - 0.25 * (fm - fp) * (xv - (double)peak);
+  *delay = xv - (double)(na / 2);
   return PAR_OK;
 }
 

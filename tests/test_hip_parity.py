@@ -1337,3 +1337,46 @@ def test_stft_above_8192_four_step(par, n_fft, hop, zp):
     xt = par.torch.from_numpy(st).cuda()
     got1 = par.fourier.stft(xt[:, 1], n_fft, hop, "blackmanharris", zp).cpu().numpy()
     assert relerr(got1, C.stft(np.ascontiguousarray(st[:, 1]), n_fft, hop, win, zp, mode=0, threads=8)) < TOL
+
+
+def test_correlation_on_the_device(par, golden):
+    """util/correlation.py on the device: xcorr through one complex four-step FFT (float32: 1e-6 of the peak),
+    find_delay with its peak neighbourhood re-evaluated in float64 (the reference-generated golden to 1e-9), window
+    applied in place like the reference, every scipy mode, tape-sync sized windows against scipy, ignore_phase, and
+    the reference's IndexError for a peak on the last lag."""
+    import scipy.signal
+    from pyaudiorestoration_amd import correlation as C
+    g = golden["correlation"]
+    aa = np.sin(np.arange(521) * 1.0)
+    bb = np.sin(np.arange(521) * 1.0 + 3)
+    keep = aa.copy()
+    assert np.allclose(C.find_delay(aa, bb, window_name="hann"), g["find_delay"], rtol=1e-9, atol=1e-9)
+    assert not np.array_equal(aa, keep)                                  # windowed in place, like the reference
+    a, b = inputs.noise(200, 40).astype(np.float64), inputs.noise(200, 41).astype(np.float64)
+    assert np.max(np.abs(C.xcorr(a, b, mode="same") - g["xcorr_same"])) < 2e-6
+    for n, m in ((7, 7), (64, 9), (9, 64), (33, 1), (5000, 3000)):
+        u, v = inputs.noise(n, n).astype(np.float64), inputs.noise(m, m + 1).astype(np.float64)
+        un, vn = u / np.linalg.norm(u), v / np.linalg.norm(v)
+        for mode in ("full", "same") + (("valid",) if n >= m else ()):
+            assert np.max(np.abs(C.xcorr(u, v, mode) - scipy.signal.correlate(un, vn, mode=mode))) < 2e-6, (n, m, mode)
+    # tape-sync sized: two band-limited takes, one delayed by a fractional number of samples, one inverted
+    sr, n = 44100, 300000
+    rng = np.random.default_rng(5)
+    src = scipy.signal.sosfiltfilt(scipy.signal.butter(3, [200 / (sr / 2), 3000 / (sr / 2)], btype="band", output="sos"),
+                                   rng.standard_normal(n + 4000))
+    t = np.arange(n)
+    ref = src[2000:2000 + n].copy()
+    other = np.interp(t + 2000 - 37.3, np.arange(len(src)), src)
+
+    def ref_find_delay(x, y, ignore_phase):
+        res = scipy.signal.correlate(x / np.linalg.norm(x), y / np.linalg.norm(y), mode="same", method="fft")
+        k = int(np.argmax(np.abs(res) if ignore_phase else res))
+        xv = 0.5 * (res[k - 1] - res[k + 1]) / (res[k - 1] - 2 * res[k] + res[k + 1]) + k
+        return xv - len(res) // 2, res[k] - 0.25 * (res[k - 1] - res[k + 1]) * (xv - k)
+    for y, ign in ((other, False), (-other, True)):
+        d, c = C.find_delay(ref.copy(), y.copy(), ignore_phase=ign)
+        wd, wc = ref_find_delay(ref, y, ign)
+        assert abs(d - wd) < 1e-6 and abs(c - wc) < 1e-9, (d, wd, c, wc)
+        assert abs(abs(d) - 37.3) < 0.05
+    with pytest.raises(IndexError):
+        C.find_delay(np.array([0.0, 0.0, 0.0, 1.0]), np.array([0.0, 1.0]))   # peak on the last lag: parabolic() reads f[x+1]
