@@ -20,6 +20,10 @@
 #include <map>
 #include <vector>
 
+#ifndef PAR_STFT_STORE
+#define PAR_STFT_STORE 0
+#endif
+
 namespace par {
 
 struct Twiddles {
@@ -275,11 +279,17 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
   fft_core<LOGH>(v, X, j, tw);
   if (!live) return;
   const float hs = 0.5f * scale;
+  // PAR_STFT_STORE (experiment switch): 0 streaming (nontemporal) stores straight from the registers; 1 plain stores;
+  // 3 one-wave-per-frame sizes stage the row in the wave's own LDS and write it with 16-byte aligned stores
+  constexpr bool kRowStage = (PAR_STFT_STORE == 3) && T == kWave;
+  float* Mg = reinterpret_cast<float*>(lds + G::Frames * G::FrameLds) + f * (bins + 3);      // this frame's row (mode 1)
   auto emit = [&](int k, float re, float im) {
     // The magnitude spectrogram is consumed sparsely (tracker bands): streaming stores (get_mag 0.39 -> 0.365 ms).
     // The complex one is re-read right away by the inpaint / ISTFT kernels: regular stores (streaming ones cost
     // 2 % on the config-4 chain).
     if (mode == 0) reinterpret_cast<float2*>(out)[fr * bins + k] = make_float2(re, im);
+    else if (kRowStage) Mg[k] = sqrtf(re * re + im * im) + 1e-7f;
+    else if (PAR_STFT_STORE == 1) out[fr * bins + k] = sqrtf(re * re + im * im) + 1e-7f;
     else __builtin_nontemporal_store(sqrtf(re * re + im * im) + 1e-7f, out + fr * bins + k);
   };
 #pragma unroll
@@ -292,6 +302,20 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
     const float2 t = cmul(pw[i], csub(zk, zc));         // W^k * (Z[k] - conj(Z[H-k]))
     emit(k, (ev.x + t.y) * hs, (ev.y - t.x) * hs);      // X[k]   = (ev - i*t)/2
     if (i < P) emit(H - k, (ev.x - t.y) * hs, (-ev.y - t.x) * hs);   // X[H-k] = (conj(ev) - i*conj(t))/2
+  }
+  if (kRowStage && mode == 1) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    const int64_t e0 = fr * bins, e1 = e0 + bins;
+    const int64_t a0 = (e0 + 3) & ~3ll, a1 = e1 & ~3ll;
+    for (int64_t e = a0 + 4 * j; e < a1; e += 4 * T) {
+      const float* m = Mg + (e - e0);
+      const vf4 q = {m[0], m[1], m[2], m[3]};
+      __builtin_nontemporal_store(q, reinterpret_cast<vf4*>(out + e));
+    }
+    if (j < a0 - e0) __builtin_nontemporal_store(Mg[j], out + e0 + j);
+    if (j < e1 - a1) __builtin_nontemporal_store(Mg[a1 - e0 + j], out + a1 + j);
   }
 }
 
@@ -837,8 +861,9 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
   const float scale = (float)(1.0 / sqrt((double)n_fft));
 #define PAR_STFT_LAUNCH(LH)                                                                                          \
   hipLaunchKernelGGL(k_stft<LH>, dim3((unsigned)(ceil_div(ceil_div(n_frames, FftGeom<LH>::Frames), 8) * 8)), dim3(FftGeom<LH>::Threads),  \
-                     (size_t)FftGeom<LH>::Frames * FftGeom<LH>::FrameLds * sizeof(float2), as_stream(stream), x, n,      \
-                     x_stride, n_fft, hop, window, tw.w, tw.post, out, n_frames, mode, scale)
+                     (size_t)FftGeom<LH>::Frames * FftGeom<LH>::FrameLds * sizeof(float2) +                              \
+                         (PAR_STFT_STORE == 3 ? (size_t)FftGeom<LH>::Frames * ((1 << LH) + 4) * sizeof(float) : 0),      \
+                     as_stream(stream), x, n, x_stride, n_fft, hop, window, tw.w, tw.post, out, n_frames, mode, scale)
   switch (ilog2(H)) {
     case 3: PAR_STFT_LAUNCH(3); break;
     case 4: PAR_STFT_LAUNCH(4); break;
