@@ -31,6 +31,7 @@ extern "C" {
 #define PAR_ERR_WORKSPACE 4      /* caller-provided workspace too small */
 #define PAR_ERR_EMPTY_BAND 5     /* a tracker band is empty: the reference raises ValueError (argmax of an empty slice) */
 #define PAR_ERR_INDEX 6          /* the reference indexes past the end of an array here and raises IndexError */
+#define PAR_ERR_SHAPE 7          /* the reference multiplies arrays of different lengths here and raises ValueError */
 
 /* ---- library / device ---------------------------------------------------------- */
 int par_version(void);
@@ -244,7 +245,9 @@ int par_synth_speed_curve_f64(int device, double* sampletimes, double* speeds, i
  *   mode 0   PeakTracker: band re-centred on freqs[i] every frame
  *   mode 1   PeakTrackTracker: band fixed on freqs[0]; tolerance halves for i > 2
  *   status   device int32 scratch (4 bytes).  A band whose widening reaches below bin 0 is an empty slice in the
- *            reference (its argmax raises ValueError): reported as PAR_ERR_EMPTY_BAND, never clamped.  Synchronises.
+ *            reference (its argmax raises ValueError): reported as PAR_ERR_EMPTY_BAND, never clamped; a peak on the last
+ *            bin is its IndexError (is_peak reads the bin above): PAR_ERR_INDEX; a Center-of-Gravity band past the last
+ *            bin is its broadcast ValueError: PAR_ERR_SHAPE.  Synchronises.
  */
 int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
                        double* freqs, int fft_size, double sr, double tolerance_oct, int mode, int32_t* status,

@@ -305,7 +305,8 @@ class _TrackGeometry:
     def peak(self, i):
         """util/wow_detection.py:119-139 (allow_window is never True in shipped code)."""
         col = self.spectrum[:, self.frame_0 + i]
-        b = self.NL + int(np.argmax(col[self.NL:self.NU]))
+        # the all-ones window is kept: a band widened past the last bin makes this product raise (ValueError)
+        b = self.NL + int(np.argmax(col[self.NL:self.NU] * np.ones(self.NU - self.NL)))
         if col[b - 1] < col[b] > col[b + 1]:
             b, _ = parabolic(col, b)
         return b / self.fft_size * self.sr

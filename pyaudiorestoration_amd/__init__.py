@@ -7,5 +7,7 @@ PyTorch-ROCm only owns device buffers and streams.  There is no CPU fallback: wi
 library or without a GPU every compute entry point raises.
 """
 from . import _lib  # noqa: F401
+from ._lib import ParError, ParUnsupported, ParIndexError, ParShapeError, ParEmptyBand  # noqa: F401
 
-__all__ = ["fourier", "resampling", "wow_detection", "filters", "correlation", "pipeline", "io_ops"]
+__all__ = ["fourier", "resampling", "wow_detection", "filters", "correlation", "pipeline", "io_ops",
+           "ParError", "ParUnsupported", "ParIndexError", "ParShapeError", "ParEmptyBand"]

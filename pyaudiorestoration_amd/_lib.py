@@ -100,6 +100,10 @@ class ParIndexError(ParError, IndexError):
     """The reference indexes past the end of an array at this point (status PAR_ERR_INDEX)."""
 
 
+class ParShapeError(ParError, ValueError):
+    """The reference multiplies arrays of different lengths at this point (status PAR_ERR_SHAPE)."""
+
+
 class ParEmptyBand(ParError, ValueError):
     """A tracker band is empty (status PAR_ERR_EMPTY_BAND); also a ValueError, which is what the reference's
     argmax of an empty slice raises."""
@@ -137,4 +141,4 @@ def last_error():
 def check(rc):
     if rc != 0:
         msg = last_error()
-        raise {3: ParUnsupported, 5: ParEmptyBand, 6: ParIndexError}.get(rc, ParError)(rc, msg)
+        raise {3: ParUnsupported, 5: ParEmptyBand, 6: ParIndexError, 7: ParShapeError}.get(rc, ParError)(rc, msg)

@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(kWave * kFillWaves) void k_pos_fill(const double* _
                                                                   double* __restrict__ pos) {
   __shared__ double buf[kFillWaves][kWave][kFillChunk + 1];
   __shared__ long long s_start[kFillWaves][kWave];
-  __shared__ int s_n[kFillWaves][kWave];
+  __shared__ long long s_n[kFillWaves][kWave];      // a sparse curve's segment can exceed 2^31 samples
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int64_t i = ((int64_t)blockIdx.x * kFillWaves + w) * kWave + lane;
   long long n = 0, start = 0;
@@ -1381,7 +1381,7 @@ __global__ __launch_bounds__(kWave * kFillWaves) void k_pos_fill(const double* _
     off = seg_off[i];
   }
   s_start[w][lane] = start;
-  s_n[w][lane] = (int)(n > 0x7fffffff ? 0x7fffffff : n);
+  s_n[w][lane] = n;
   long long nmax = n;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(kWave * kFillWaves) void k_pos_fill(const double* _
     for (int seg = 0; seg < kWave; seg += kWave / kFillChunk) {
       const int sg = seg + half;
       const long long k = k0 + col;
-      if (k < (long long)s_n[w][sg]) pos[s_start[w][sg] + k] = buf[w][sg][col];
+      if (k < s_n[w][sg]) pos[s_start[w][sg] + k] = buf[w][sg][col];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -12,6 +12,8 @@ namespace par {
 
 struct Band {
   int NL, NU;
+  bool past_end;       // NU reached past the last bin before the clip (a numpy slice clips silently; a product with a
+                       // full-length window does not)
 };
 
 __device__ __forceinline__ int freq_to_bin(double f, int fft_size, double sr, int bins) {
@@ -35,11 +37,16 @@ __device__ __forceinline__ Band band_limits(double freq, double tol, int fft_siz
   }
   // A band widened below bin 0 (both edges on bin 1: a frequency below the transform's resolution) is an EMPTY
   // numpy slice [-k:NU] in the reference, whose argmax raises; reported through `empty`, never silently clamped.
+  b.past_end = b.NU > bins;
   if (b.NU > bins) b.NU = bins;
   return b;
 }
 
-__device__ __forceinline__ double peak_freq(const float* __restrict__ col, Band b, int bins, int fft_size, double sr) {
+// status bits: 1 empty band (ValueError), 2 peak on the last bin: is_peak() reads fft_frame[peak_i + 1] (IndexError),
+// 4 band widened past the last bin: window(NU - NL) * spectrum[NL:NU] does not broadcast (ValueError); freq_2_bin caps
+// both edges at bins - 1 and min_bins is 4, so such a slice always keeps >= 3 bins against a window of >= 4
+__device__ __forceinline__ double peak_freq(const float* __restrict__ col, Band b, int bins, int fft_size, double sr,
+                                            int* __restrict__ status) {
   int arg = b.NL;
   float best = col[b.NL];
   for (int k = b.NL + 1; k < b.NU; ++k) {
@@ -50,7 +57,15 @@ __device__ __forceinline__ double peak_freq(const float* __restrict__ col, Band 
     }
   }
   double x = (double)arg;
-  const double fm = (double)col[(arg - 1 + bins) % bins], f0 = (double)col[arg], fp = (double)col[(arg + 1) % bins];
+  if (b.past_end) {
+    atomicOr(status, 4);
+    return x / (double)fft_size * sr;
+  }
+  if (arg == bins - 1) {
+    atomicOr(status, 2);
+    return x / (double)fft_size * sr;
+  }
+  const double fm = (double)col[(arg - 1 + bins) % bins], f0 = (double)col[arg], fp = (double)col[arg + 1];
   if (fm < f0 && f0 > fp) {
     // parabolic(): xv = 1/2*(f[x-1]-f[x+1]) / (f[x-1]-2f[x]+f[x+1]) + x
     x = 0.5 * (fm - fp) / (fm - 2.0 * f0 + fp) + x;
@@ -70,7 +85,7 @@ __global__ void k_track_peak(const float* __restrict__ mag, int bins, int64_t fr
   if (i >= count) return;
   const Band b = band_limits(freqs[i], tol, fft_size, sr, bins);     // PeakTracker: band follows the drawn trail
   if (empty_band(b, empty)) return;
-  freqs[i] = peak_freq(mag + (frame_0 + i) * bins, b, bins, fft_size, sr);
+  freqs[i] = peak_freq(mag + (frame_0 + i) * bins, b, bins, fft_size, sr, empty);
 }
 
 // PeakTrackTracker: band fixed on the first trail frequency (read back by the host entry point).
@@ -81,7 +96,7 @@ __global__ void k_track_peak_fixed(const float* __restrict__ mag, int bins, int6
   if (i >= count) return;
   const Band b = band_limits(centre, i > 2 ? tol / 2 : tol, fft_size, sr, bins);
   if (empty_band(b, empty)) return;
-  freqs[i] = peak_freq(mag + (frame_0 + i) * bins, b, bins, fft_size, sr);
+  freqs[i] = peak_freq(mag + (frame_0 + i) * bins, b, bins, fft_size, sr, empty);
 }
 
 // CenterOfGravity: the band of frame i+1 depends on the result of frame i -> one wave walks the frames,
@@ -94,6 +109,10 @@ __global__ __launch_bounds__(64) void k_track_cog(const float* __restrict__ mag,
   for (int64_t i = 0; i < count; ++i) {
     if (b.NL < 0 || b.NL >= b.NU) {                        // the reference's 0/0 centroid -> NaN -> int(round(nan)) raises
       if (lane == 0) atomicOr(empty, 1);
+      return;
+    }
+    if (b.past_end) {                                      // hanning(NU - NL) against a shorter slice: ValueError
+      if (lane == 0) atomicOr(empty, 4);
       return;
     }
     const float* col = mag + (frame_0 + i) * bins;
@@ -313,9 +332,12 @@ static int check_empty(int* d_flag, hipStream_t s, const char* who) {
   int h = 0;
   PAR_HIP_CHECK(hipMemcpyAsync(&h, d_flag, sizeof(h), hipMemcpyDeviceToHost, s));
   PAR_HIP_CHECK(hipStreamSynchronize(s));
-  PAR_REQUIRE(h == 0, PAR_ERR_EMPTY_BAND,
+  PAR_REQUIRE(!(h & 1), PAR_ERR_EMPTY_BAND,
               "%s: a tracking band is empty (frequency below the transform's resolution: the reference's slice "
               "[NL:NU] with NL < 0 is empty and its argmax raises)", who);
+  PAR_REQUIRE(!(h & 2), PAR_ERR_INDEX, "%s: the peak sits on the last bin (is_peak() reads fft_frame[peak_i + 1]: IndexError)", who);
+  PAR_REQUIRE(!(h & 4), PAR_ERR_SHAPE, "%s: the band reaches past the last bin (operands could not be broadcast together: "
+              "np.hanning(NU - NL) against the clipped slice)", who);
   return PAR_OK;
 }
 

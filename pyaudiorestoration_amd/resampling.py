@@ -200,6 +200,10 @@ def varispeed_batch_dev(items, NT, dev=None):
             # does not wait for the K_sinc running on the main stream
             with torch.cuda.stream(stream):
                 plan = speed_plan_dev(st_t, sp_t, len_in, dev, fused=True, work=work[slot], aux=aux[slot], stream=stream)
+            # allocated (or regrown) under the side stream, read by the K_sinc on the main stream: without this a
+            # block freed at generator teardown returns to the side stream's pool while that kernel still runs
+            plan.work.record_stream(main)
+            plan.aux.record_stream(main)
         work[slot], aux[slot] = plan.work, plan.aux        # keep (possibly grown) buffers for reuse
         return plan
 
@@ -375,6 +379,8 @@ def sinc_resample_dev(pos_t, sig_t, NT, out_t=None, sig_stride=1, len_in=None, o
         len_in = sig_t.numel() // sig_stride
     if out_t is None:
         out_t = _dev.empty(len_out * out_stride, torch.float32, dev)
+    if len_out == 0:
+        return out_t
     _lib.check(L.par_sinc_resample_f32(dev, _dev.ptr(pos_t), len_out, _dev.ptr(sig_t), sig_stride, len_in, int(NT),
                                        _dev.ptr(out_t), out_stride, _dev.stream_ptr(dev)))
     return out_t
@@ -396,7 +402,9 @@ def linear_resample_dev(pos_t, sig_t, out_t=None, sig_stride=1, len_in=None, out
 def sinc_wrapper(sample_at, signal, lowpass, NT):
     """Returns float32[len(sample_at)].  `lowpass` is ignored, as in the reference (dead argument)."""
     dev = _dev.device_index(None)
-    if len(sample_at) < 2:
+    if len(sample_at) == 0:                         # the reference's loop never runs: an empty float32 array
+        return np.empty(0, np.float32)
+    if len(sample_at) == 1:
         raise UnboundLocalError("local variable 'period_to' referenced before assignment")   # reference behaviour
     sample_at = np.asarray(sample_at, dtype=np.float64)
     if not np.isfinite(sample_at).all():            # the reference's int(round(p)) raises on these

@@ -227,6 +227,8 @@ def test_sinc_wrapper_mt_and_core_signatures(par, golden):
     assert relerr(out, g["bench_y"]) < TOL
     with pytest.raises(UnboundLocalError):
         par.resampling.sinc_wrapper(np.array([5.0]), bsig, 0, 32)
+    empty = par.resampling.sinc_wrapper(np.empty(0), bsig, 0, 32)       # the reference's loop never runs
+    assert empty.shape == (0,) and empty.dtype == np.float32
 
 
 @pytest.mark.parametrize("NT", [4, 32, 50])
@@ -455,6 +457,24 @@ def test_tracker_error_behaviour_matches_reference(par):
             O.TRACKERS[name](mag.cpu().numpy(), list(low), n_fft, hop, sr, 0.5)
         with pytest.raises(ValueError):
             par.wow.wow_detectors[name](mag, x[:, None], list(low), n_fft, hop, sr, 0.5, "Linear")
+    # the top of the spectrum: a band that ends ON the last bin with the peak there makes is_peak() read one bin past
+    # the end (IndexError); a band widened PAST the last bin no longer broadcasts against its window (ValueError)
+    ny = (0.5 * np.cos(np.pi * np.arange(60000))).astype(np.float32)
+    mag_ny = par.fourier.get_mag(par.torch.from_numpy(ny).cuda(), n_fft, hop, "blackmanharris", 1)
+    top = [(0.05, 95000.0), (0.25, 95000.0)]
+    ref = O.TRACKERS["Peak"](mag_ny.cpu().numpy(), list(top), n_fft, hop, sr, 0.5)
+    tr = par.wow.wow_detectors["Peak"](mag_ny, ny[:, None], list(top), n_fft, hop, sr, 0.5, "Linear")
+    assert relerr(tr.freqs, ref[1]) < 1e-6
+    with pytest.raises(IndexError):
+        O.TRACKERS["Peak Track"](mag_ny.cpu().numpy(), list(top), n_fft, hop, sr, 0.5)
+    with pytest.raises(IndexError):
+        par.wow.wow_detectors["Peak Track"](mag_ny, ny[:, None], list(top), n_fft, hop, sr, 0.5, "Linear")
+    past = [(0.05, 95900.0), (0.25, 95900.0)]
+    for name in ("Peak", "Peak Track", "Center of Gravity"):
+        with pytest.raises(ValueError):
+            O.TRACKERS[name](mag_ny.cpu().numpy(), list(past), n_fft, hop, sr, 0.01)
+        with pytest.raises(ValueError):
+            par.wow.wow_detectors[name](mag_ny, ny[:, None], list(past), n_fft, hop, sr, 0.01, "Linear")
     one_frame = [(0.1000, 4000.0), (0.1001, 4000.0)]
     tr = par.wow.wow_detectors["Peak"](mag, x[:, None], list(one_frame), n_fft, hop, sr, 0.5, "Linear")
     assert len(tr.freqs) == 0 and len(tr.times) == 0
