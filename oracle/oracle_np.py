@@ -306,7 +306,9 @@ class _TrackGeometry:
         """util/wow_detection.py:119-139 (allow_window is never True in shipped code)."""
         col = self.spectrum[:, self.frame_0 + i]
         # the all-ones window is kept: a band widened past the last bin makes this product raise (ValueError)
-        b = self.NL + int(np.argmax(col[self.NL:self.NU] * np.ones(self.NU - self.NL)))
+        # b stays a numpy int64 as in the reference: with float32 magnitudes (torch / pyfftw backends) the parabolic
+        # offset is then float32 arithmetic but "+ x" promotes to float64 (a Python int would keep float32)
+        b = self.NL + np.argmax(col[self.NL:self.NU] * np.ones(self.NU - self.NL))
         if col[b - 1] < col[b] > col[b + 1]:
             b, _ = parabolic(col, b)
         return b / self.fft_size * self.sr

@@ -20,6 +20,9 @@
 #include <map>
 #include <vector>
 
+#ifndef PAR_STFT_TW
+#define PAR_STFT_TW 0
+#endif
 #ifndef PAR_STFT_STORE
 #define PAR_STFT_STORE 0
 #endif
@@ -161,8 +164,17 @@ __device__ __forceinline__ void fft_core(float2 (&v)[8], float2* __restrict__ X,
     if (st > 0) {
       // one gathered twiddle load per stage; the other six are its powers (3 multiply levels, ~2 ulp)
       const float2 w1 = w1s[st];
+#if PAR_STFT_TW == 1          // accuracy experiment: all seven from the table (correctly rounded)
+      const int ti = (j & (Ns - 1)) * (H / (Ns * 8));
+      const float2 w2 = tw[2 * ti], w3 = tw[3 * ti], w4 = tw[4 * ti], w5 = tw[5 * ti], w6 = tw[6 * ti], w7 = tw[7 * ti];
+#elif PAR_STFT_TW == 2        // accuracy experiment: w1, w2, w4 from the table, the rest one multiply away
+      const int ti = (j & (Ns - 1)) * (H / (Ns * 8));
+      const float2 w2 = tw[2 * ti], w4 = tw[4 * ti];
+      const float2 w3 = cmul(w2, w1), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+#else
       const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
       const float2 w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+#endif
       v[1] = cmul(v[1], w1);
       v[2] = cmul(v[2], w2);
       v[3] = cmul(v[3], w3);

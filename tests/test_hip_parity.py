@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
+# End-to-end bound of the config-3 flow (STFT -> tracker -> curve -> positions -> resample).  The stage tests hold TOL;
+# the chain cannot: the reference's own STFT backends (torch.stft float32 first, numpy last -- util/fourier.py:67-75) move
+# its output by 1.4e-5 (numpy < 2 vs >= 2) to 1.1e-4 (torch on one x86 host; 8e-6 on another) on flutter_192.flac against
+# the numpy >= 2 run the fixtures hold (profiles/r02_p0_sensitivity.txt; tools/p0_sensitivity.py reproduces it).  This
+# build measures 3.7e-5 there.
+P0_BACKEND_SPREAD = 5e-5
+
+
 def relerr(a, b):
     a = np.asarray(a)
     b = np.asarray(b)
@@ -494,7 +502,16 @@ def test_pipeline_config3_flow(par, golden):
     assert r["speed_curve"].shape == g["curve"].shape and relerr(r["speed_curve"][:, 1], g["curve"][:, 1]) < 1e-7
     pos = r["positions"].cpu().numpy()
     assert len(pos) == len(g["pos"]) and np.max(np.abs(pos - g["pos"])) < 1e-4
-    assert relerr(r["output"].cpu().numpy()[:, 0], g["y"]) < 5e-5      # speed curve differs ~1e-7 -> positions ~1e-5
+    # End to end the flow is ill-conditioned (profiles/r02_p0_sensitivity.txt, DESIGN "P0"): positions are a running
+    # sum over the whole file, so the 5e-9 the tracked frequencies move when the magnitudes are float32 (as in the
+    # reference's own torch / pyfftw backends) instead of the numpy backend's float64 containers becomes 1e-5 samples,
+    # and where that moves a position across a half-integer the reference's interpolant (window centred on
+    # round(p), util/resampling.py:60-75) jumps.  TOL holds wherever both position sets round alike; the
+    # flips stay inside the spread of the reference's own backends (test_oracle_golden.py::test_config3_conditioning).
+    y = r["output"].cpu().numpy()[:, 0]
+    same = np.rint(pos) == np.rint(g["pos"])
+    assert relerr(y[same], g["y"][same]) < TOL and (~same).sum() <= 4
+    assert relerr(y, g["y"]) < P0_BACKEND_SPREAD
 
 
 # ------------------------------------------------------------- properties at bench-like sizes
@@ -758,7 +775,7 @@ def test_config1_and_config3_on_reference_samples(par, golden):
     assert r["positions"].numel() == int(g["c3_len_pos"])
     assert np.max(np.abs(r["positions"].cpu().numpy()[::1009] - g["c3_pos_grid"])) < 1e-3     # 1e-10 curve difference x 8e5 samples
     y = r["output"].cpu().numpy()[:, 0]
-    assert relerr(y[g["c3_sel"]], g["c3_y_sel"]) < 5e-5       # curve differs ~1e-7 -> positions ~1e-5
+    assert relerr(y[g["c3_sel"]], g["c3_y_sel"]) < P0_BACKEND_SPREAD    # 8e-9 on the curve x 8e5 samples: see P0_BACKEND_SPREAD
     # with the reference's exact curve the positions are bit-identical and the output within tolerance
     t = par.torch
     curve = g["c3_curve"]
@@ -1172,7 +1189,7 @@ def test_headless_cli_respeed_and_resample(par, golden, tmp_path):
     assert cli.main(["respeed", "--trail", "0.2,4000,4.0,4000", "--quality", "32", f]) == 0
     y, sr, ch = io_ops.read_file(str(tmp_path / "tape_res.wav"))
     assert sr == 192000 and ch == 1 and len(y) == int(g["c3_len_pos"])
-    assert relerr(y[g["c3_sel"], 0], g["c3_y_sel"]) < 5e-5
+    assert relerr(y[g["c3_sel"], 0], g["c3_y_sel"]) < P0_BACKEND_SPREAD
     curve = np.load(str(tmp_path / "tape_speed.npy"))
     assert relerr(curve[:, 1], g["c3_curve"][:, 1]) < 1e-7
     json.dump(g["c3_curve"].tolist(), open(str(tmp_path / "c.json"), "w"))

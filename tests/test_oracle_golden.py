@@ -177,6 +177,36 @@ def test_pipeline(golden):
     assert relerr(y, g["y"]) < 3e-7
 
 
+def test_config3_conditioning(golden):
+    """Why the END-TO-END config-3 bound is not the per-stage 1e-5 (tests/test_hip_parity.py::P0_BACKEND_SPREAD): the
+    flow amplifies.  (a) The reference's interpolant centres its window on round(p) (util/resampling.py:60-75), so a
+    position moved by 1e-5 samples across a half-integer changes the output by more than 1e-5 of peak, and even
+    without a flip the output follows the position with slope ~0.5/sample.  (b) Positions are a running sum over the
+    file: the same flow on the float64 transform numpy < 2 computes (rfft upcasts) instead of numpy >= 2's float32
+    moves the tracked frequencies by ~1e-9 and the positions by ~1000 times that.  tools/p0_sensitivity.py prints
+    the full table, torch.stft backend and flutter_192.flac included (profiles/r02_p0_sensitivity.txt)."""
+    import scipy.signal
+    g = golden["pipeline"]
+    sr, n, n_fft, hop = (int(v) for v in g["cfg"])
+    x = inputs.pilot(n, sr)
+    y0 = O.sinc_resample(g["pos"], x, 32)
+    y1 = O.sinc_resample(g["pos"] + 1e-5, x, 32)
+    e = np.abs(y1 - y0) / np.max(np.abs(y0))
+    flips = np.rint(g["pos"] + 1e-5) != np.rint(g["pos"])
+    assert flips.sum() >= 1 and e[flips].max() > 1e-5 and e[~flips].max() < 1e-5
+    assert 2e-6 < np.median(e) < 1e-5                                 # slope: ~0.37 of peak per sample at the median
+    win = scipy.signal.get_window("blackmanharris", n_fft).astype(np.float32)
+    xp = np.pad(x, n_fft // 2, mode="reflect")
+    idx = np.arange((len(xp) - n_fft) // hop + 1)[:, None] * hop + np.arange(n_fft)[None, :]
+    frames = (win[None, :] * xp[idx]).astype(np.float32)
+    mag64 = np.abs(np.fft.rfft(frames.astype(np.float64), axis=1).T / np.sqrt(n_fft)) + 1e-7
+    t, f = O.track_peak(mag64, [(0.05, 4000.0), (1.45, 4000.0)], n_fft, hop, sr, 0.5)
+    curve = O.master_speed_curve([(t, O.trace_to_speed(f))], n / sr, sr, hop, bands=(0, 20))
+    pos, _ = O.speed_to_pos(curve[:, 0] * sr, curve[:, 1], n)
+    df, dp = relerr(f, g["track_freqs"]), np.max(np.abs(pos - g["pos"]))
+    assert 1e-10 < df < 1e-8 and len(pos) == len(g["pos"]) and dp > 300 * df
+
+
 def test_linear_and_lag(golden):
     g = golden["linear_lag"]
     sig = inputs.noise(5000, 50)

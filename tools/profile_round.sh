@@ -15,4 +15,5 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT" -o write -- python bench.py 
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d "$OUT" -o sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/sq.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM -d "$OUT" -o lds -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/lds.log" 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d "$OUT" -o grbm -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/grbm.log" 2>&1
-cat "$OUT/bench_default.json"
+python bench.py --config5 --steps 1 --warmup 1 > "$OUT/bench_config5_n1.json" 2> "$OUT/bench_config5_n1.err"
+cat "$OUT/bench_default.json" "$OUT/bench_config5_n1.json"

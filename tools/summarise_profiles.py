@@ -2,7 +2,8 @@
 """Turn the rocprofv3 sqlite outputs of tools/profile_round.sh into the committed text summaries:
      python tools/summarise_profiles.py gpurun_out/r01 r01
 writes profiles/<tag>_kernel_stats.txt, profiles/<tag>_pmc.txt, profiles/<tag>_bench_default.json and
-profiles/pmc_traffic.json (HBM bytes per output sample of K_sinc, used by bench.py's roofline.traffic)."""
+profiles/pmc_traffic.json (HBM bytes per output sample of K_sinc, used by bench.py's roofline.traffic) and
+profiles/pmc_valu.json (VALU lane-instructions per output sample of K_sinc, used by bench.py's roofline_valu)."""
 import json
 import os
 import sqlite3
@@ -33,10 +34,11 @@ for db in ("fetch", "write", "sq", "lds", "grbm"):
     if not os.path.exists(path):
         continue
     for (k, n), (cnt, a) in sorted(counters(db + "_results.db", "par::").items()):
-        if any(s in k for s in ("k_sinc", "k_pos_fill", "k_seg_sum", "k_stft")):
+        names = ("k_sinc", "k_pos_fill", "k_seg_sum", "k_block_rec2", "k_block_rec", "k_tile_seg", "k_stft", "k_istft")
+        if any(s in k for s in names):
             lines.append(f"{k[:60]:60s} {n:24s} n={cnt:3d} avg={a:18.1f}")
-            short = "k_sinc" if "k_sinc" in k else ("k_pos_fill" if "k_pos_fill" in k else ("k_seg_sum" if "k_seg_sum" in k else "k_stft"))
-            if short == "k_sinc" and ", 2>" in k:
+            short = next(s for s in names if s in k)
+            if short == "k_sinc" and ("k_sinc_fused<2" in k or ", 2>" in k):
                 short = "k_sinc_stereo"                       # the config-5 secondary line, not the timed workload
             vals[(short, n)] = a
 open(os.path.join(prof, f"{tag}_pmc.txt"), "w").write("\n".join(lines) + "\n")
@@ -53,4 +55,20 @@ if fetch and write:
          "source": f"profiles/{tag}_pmc.txt"}
     json.dump(t, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     print(t)
+valu = vals.get(("k_sinc", "SQ_INSTS_VALU"))
+if valu:
+    n = bench["roofline"]["samples_per_launch"]
+    fma = 58.76
+    try:                                                      # tools/ubench.hip's measured v_fma_f32 stream, if this round re-ran it
+        for ln in open(os.path.join(prof, f"{tag}_ubench_gfx950.txt")):
+            if ln.startswith("fma_stream_Tlaneops"):
+                fma = float(ln.split()[1])
+    except OSError:
+        pass
+    v = {"kernel": bench["roofline"].get("kernel", "k_sinc"), "samples_per_launch": n, "SQ_INSTS_VALU_per_launch": valu,
+         "valu_lane_instr_per_output": valu * 64 / n, "fma_stream_Tlaneops": fma,
+         "note": "SQ_INSTS_VALU counts wave64 instructions; x64 lanes / output samples of the launch",
+         "source": f"profiles/{tag}_pmc.txt"}
+    json.dump(v, open(os.path.join(prof, "pmc_valu.json"), "w"), indent=1)
+    print(v)
 print(stats[:1500])
