@@ -45,6 +45,9 @@
 #ifndef PAR_SINC_EXP
 #define PAR_SINC_EXP 0
 #endif
+#ifndef PAR_SINC_HOT
+#define PAR_SINC_HOT 1          // experiment knob: 0 = every wave takes the general (masked, strided) path
+#endif
 #ifndef PAR_SINC_WAVES
 #define PAR_SINC_WAVES 6      // waves per SIMD the fused kernel is built for (register budget 512 / this)
 #endif
@@ -852,42 +855,21 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc_pos(const double* __rest
                     });
 }
 
-// FUSED form: there is no position array in HBM.  The plan leaves a 32-byte record per block of 8 outputs (BlockRec:
-// the block's positions as a quadratic in u) and a header per tile (anchor, first and last window centre), both at
-// addresses that follow from the output index alone.  A workgroup therefore issues ALL its loads up front -- the
-// records of its outputs, the header, then the signal span the header names -- instead of walking
-// tile map -> segment -> checkpoint -> positions -> span (five dependent HBM round trips per tile, which 6 waves per
-// SIMD could not cover: measured, phases were additive).  Per output the placement is ~20 float32 / integer
-// instructions; outputs within the reference's own rounding of a half-integer position, and blocks the record model
-// does not cover, are redone through place_fast / place_exact, so every window centre rint(p) is the reference's.
-// Every WAVE is on its own: it owns 64 kOut consecutive outputs of the tile, places them, stages just their input span
-// into its own quarter of the workgroup's LDS and runs the tap loops -- no workgroup barrier anywhere (measured with
-// the per-phase wave clock, tools/phase_clock.py: with one span per workgroup a wave spent 28 % of its life waiting at
-// the barrier for the slowest of its three siblings).  The halo (2 NT + margin samples per 64 kOut outputs) is fetched
-// by neighbouring waves too; they sit on the same CU, so the repeats are L1/L2 hits.
 // LDS floats per wave and channel: room for the span of 64 NS/NCH outputs at speeds up to ~3.7 plus the halo
 __host__ __device__ constexpr int fused_capw(int NS, int NCH) { return (kWave * NS / NCH) * 4 >= 1024 ? 1024 : (NS / NCH == 2 ? 640 : 448); }
-template <int NCH, int NTC, int NS>
-__global__ __launch_bounds__(kSincBlock, PAR_SINC_WAVES) void k_sinc_fused(int64_t len_out, const float* __restrict__ sig,
-                                                                  const float* __restrict__ sig1, int64_t sig_stride,
-                                                                  int64_t len_in, int NT, const float4* __restrict__ tab,
-                                                                  TapModes tmd, float* __restrict__ out,
-                                                                  float* __restrict__ out1, int64_t out_stride,
-                                                                  FusedArgs fa) {
-  // NS (output, channel) slots per lane: a wave owns kWaveOut = 64 NS / NCH consecutive outputs and its own piece of LDS;
-  // workgroups are 4 waves whatever NS is (the plan's tiles, 1024 outputs, hold a whole number of waves)
+// One wave's share of the fused kernel.  HOT: a full wave (all kWaveOut outputs exist) on unit-stride signal and output --
+// the case every wave but a file's last one is in: no validity masks, no index clamps, stride-free addresses, and the
+// span goes to LDS by direct loads.
+template <int NCH, int NTC, int NS, bool HOT>
+__device__ __forceinline__ void fused_wave(const int64_t len_out, const float* __restrict__ sig, const float* __restrict__ sig1,
+                                           const int64_t sig_stride, const int64_t len_in, const int NT,
+                                           const float4* __restrict__ tab, const TapModes tmd, float* __restrict__ out,
+                                           float* __restrict__ out1, const int64_t out_stride, const FusedArgs& fa,
+                                           float* __restrict__ tile, const int l, const int64_t jw, const int nrem) {
   constexpr int kOut = NS / NCH;                    // outputs per lane
   constexpr int kWaveOut = kWave * kOut;            // outputs per wave: 256 / 128 / 64
-  constexpr int kWaves = kSincBlock / kWave;
   constexpr int capw = fused_capw(NS, NCH);         // floats of one channel's span a wave may stage
-  static_assert(NCH == 1 || NCH == 2, "mono or stereo");
-  static_assert(kSincTile % kWaveOut == 0, "tiles hold whole waves");
-  extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int t = threadIdx.x;
-  const int l = t & (kWave - 1);
-  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  float* tile = lds_all + wv * (capw * NCH);        // this wave's span: channel 0, then channel 1 `capw` floats on
-  const int64_t jw = ((int64_t)blockIdx.x * kWaves + wv) * kWaveOut;   // the wave's outputs: jw + l + 64 r, r < kOut
   const int64_t T = jw / kSincTile;
   PAR_PHASE_BEGIN();
 #ifdef PAR_SINC_PRIO
@@ -895,14 +877,13 @@ __global__ __launch_bounds__(kSincBlock, PAR_SINC_WAVES) void k_sinc_fused(int64
 #endif
   // 1. records of this lane's outputs: block (jw >> 3) + (l >> 3) + 8 r, u = l & 7 for every r.  Unconditional 16-byte
   // loads off a wave-uniform base (indices past the file's last block are clamped to it)
-  const int nrem = (int)(len_out - jw < (int64_t)kWaveOut ? (len_out - jw > 0 ? len_out - jw : 0) : kWaveOut);   // valid outputs of the wave
   const int gmax = nrem > 0 ? (nrem - 1) >> 3 : 0;
   const uint4* rp = reinterpret_cast<const uint4*>(fa.rec + (jw >> 3));
   uint4 ra[kOut];
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
     const int gr = (l >> 3) + 8 * r;
-    ra[r] = rp[gr < gmax ? gr : gmax];
+    ra[r] = rp[HOT ? gr : (gr < gmax ? gr : gmax)];
   }
   // 2. tile header: the anchor all window centres are relative to
   const TileHdr hd = fa.hdr[T];
@@ -922,7 +903,7 @@ __global__ __launch_bounds__(kSincBlock, PAR_SINC_WAVES) void k_sinc_fused(int64
   float F[kOut], e1[kOut];
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
-    valid[r] = l + kWave * r < nrem;
+    valid[r] = HOT || l + kWave * r < nrem;
     second[r] = (unsigned)u > (ra[r].w & 7u);            // u >= ustar, ustar - 1 in bits 0-2
     anysecond = anysecond || second[r];
     I[r] = ra[r].x;
@@ -935,7 +916,7 @@ __global__ __launch_bounds__(kSincBlock, PAR_SINC_WAVES) void k_sinc_fused(int64
     for (int r = 0; r < kOut; ++r) {
       if (second[r]) {
         const int gr = (l >> 3) + 8 * r;
-        const uint4 q = rp2[gr < gmax ? gr : gmax];
+        const uint4 q = rp2[HOT ? gr : (gr < gmax ? gr : gmax)];
         I[r] = q.x;
         F[r] = __uint_as_float(q.y);
         e1[r] = __uint_as_float(q.z);
@@ -1005,19 +986,41 @@ __global__ __launch_bounds__(kSincBlock, PAR_SINC_WAVES) void k_sinc_fused(int64
   // the tap loops run in chunks of kChunk and may touch up to kChunk-1 taps beyond +-(NT-1); those carry an
   // exactly-zero weight but must read finite data: stage a kChunk margin
   const int margin = NT + kChunk + 1;
-  const unsigned long long vmask = __ballot(valid[0]);
-  const int lastl = vmask ? 63 - __builtin_clzll(vmask) : 0;
+  const unsigned long long vmask = HOT ? ~0ull : __ballot(valid[0]);
+  const int lastl = HOT ? kWave - 1 : (vmask ? 63 - __builtin_clzll(vmask) : 0);
   const int mn = __builtin_amdgcn_readlane(cmin, 0);
   const int mx = __builtin_amdgcn_readlane(cmax, lastl);
   const long long span = (long long)mx - (long long)mn + 2ll * margin;     // <= capw for the LDS path
   const bool usable = !__any(wild) && vmask != 0 && span <= capw && span > 0;
   const long long lo = anchor + mn - margin;                               // signal index of tile[0]
   const int nspan = usable ? (int)span : 0;
-  for (int q = l; q < nspan; q += kWave) {
-    const long long g = lo + q;
-    const bool inside = g >= 0 && g < (long long)len_in;
-    tile[q] = (inside && !(PAR_SINC_EXP & 16)) ? sig[g * sig_stride] : 0.0f;
-    if (NCH == 2) tile[capw + q] = (inside && !(PAR_SINC_EXP & 16)) ? sig1[g * sig_stride] : 0.0f;
+  // HOT (full wave, unit strides) and the span, rounded up to whole 64-sample rows, inside the signal: the rows go from
+  // HBM straight into LDS (global_load_lds_dword: LDS address = M0 base + instruction offset + 4 lane, the same offset
+  // advances the global address) -- one address per lane, no VGPR round trip, no address or bounds arithmetic per row
+  bool dma = false;
+  if constexpr (HOT && !(PAR_SINC_EXP & 16)) {
+    dma = lo >= 0 && lo + (long long)((nspan + kWave - 1) & ~(kWave - 1)) <= (long long)len_in;
+    if (dma) {
+      static_for<NCH>([&](auto chi) {
+        constexpr int ch = decltype(chi)::value;
+        const float* gp = (ch ? sig1 : sig) + lo + l;
+        static_for<capw / kWave>([&](auto qi) {
+          constexpr int q = decltype(qi)::value;
+          if (q * kWave < nspan)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)(tile + ch * capw), 4, q * kWave * 4, 0);
+        });
+      });
+      __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the rows are in LDS
+    }
+  }
+  if (!dma) {
+    for (int q = l; q < nspan; q += kWave) {
+      const long long g = lo + q;
+      const bool inside = g >= 0 && g < (long long)len_in;
+      tile[q] = (inside && !(PAR_SINC_EXP & 16)) ? sig[g * sig_stride] : 0.0f;
+      if (NCH == 2) tile[capw + q] = (inside && !(PAR_SINC_EXP & 16)) ? sig1[g * sig_stride] : 0.0f;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the wave's own LDS writes before its LDS reads
   __builtin_amdgcn_wave_barrier();
@@ -1066,8 +1069,9 @@ __global__ __launch_bounds__(kSincBlock, PAR_SINC_WAVES) void k_sinc_fused(int64
 #endif
   PAR_PHASE_MARK(4);                 // taps
   // 6. stores
-  float* const op0 = out + (jw + l) * out_stride;
-  float* const op1 = NCH == 2 ? out1 + (jw + l) * out_stride : nullptr;
+  const int64_t ostr = HOT ? 1 : out_stride;
+  float* const op0 = out + (jw + l) * ostr;
+  float* const op1 = NCH == 2 ? out1 + (jw + l) * ostr : nullptr;
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
     if (!valid[r]) continue;
@@ -1083,10 +1087,51 @@ __global__ __launch_bounds__(kSincBlock, PAR_SINC_WAVES) void k_sinc_fused(int64
       float v = res[r * NCH + ch];
       if (!fastlane[r]) v = sinc_one_f64(e.p, e.dp, ch ? sig1 : sig, sig_stride, len_in, NT);
       if ((PAR_SINC_EXP & 32) && v != 12345.678f) continue;
-      (ch ? op1 : op0)[(int64_t)(r * kWave) * out_stride] = v;
+      (ch ? op1 : op0)[(int64_t)(r * kWave) * ostr] = v;
     }
   }
   PAR_PHASE_MARK(5);                 // stores issued
+}
+
+// FUSED form: there is no position array in HBM.  The plan leaves a 32-byte record per block of 8 outputs (BlockRec:
+// the block's positions as a quadratic in u) and a header per tile (anchor, first and last window centre), both at
+// addresses that follow from the output index alone.  A workgroup therefore issues ALL its loads up front -- the
+// records of its outputs, the header, then the signal span the header names -- instead of walking
+// tile map -> segment -> checkpoint -> positions -> span (five dependent HBM round trips per tile, which 6 waves per
+// SIMD could not cover: measured, phases were additive).  Per output the placement is ~20 float32 / integer
+// instructions; outputs within the reference's own rounding of a half-integer position, and blocks the record model
+// does not cover, are redone through place_fast / place_exact, so every window centre rint(p) is the reference's.
+// Every WAVE is on its own: it owns 64 kOut consecutive outputs of the tile, places them, stages just their input span
+// into its own quarter of the workgroup's LDS and runs the tap loops -- no workgroup barrier anywhere (measured with
+// the per-phase wave clock, tools/phase_clock.py: with one span per workgroup a wave spent 28 % of its life waiting at
+// the barrier for the slowest of its three siblings).  The halo (2 NT + margin samples per 64 kOut outputs) is fetched
+// by neighbouring waves too; they sit on the same CU, so the repeats are L1/L2 hits.
+template <int NCH, int NTC, int NS>
+__global__ __launch_bounds__(kSincBlock, PAR_SINC_WAVES) void k_sinc_fused(int64_t len_out, const float* __restrict__ sig,
+                                                                  const float* __restrict__ sig1, int64_t sig_stride,
+                                                                  int64_t len_in, int NT, const float4* __restrict__ tab,
+                                                                  TapModes tmd, float* __restrict__ out,
+                                                                  float* __restrict__ out1, int64_t out_stride,
+                                                                  FusedArgs fa) {
+  // NS (output, channel) slots per lane: a wave owns kWaveOut = 64 NS / NCH consecutive outputs and its own piece of LDS;
+  // workgroups are 4 waves whatever NS is (the plan's tiles, 1024 outputs, hold a whole number of waves)
+  constexpr int kOut = NS / NCH;                    // outputs per lane
+  constexpr int kWaveOut = kWave * kOut;            // outputs per wave: 256 / 128 / 64
+  constexpr int kWaves = kSincBlock / kWave;
+  constexpr int capw = fused_capw(NS, NCH);         // floats of one channel's span a wave may stage
+  static_assert(NCH == 1 || NCH == 2, "mono or stereo");
+  static_assert(kSincTile % kWaveOut == 0, "tiles hold whole waves");
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  const int t = threadIdx.x;
+  const int l = t & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  float* tile = lds_all + wv * (capw * NCH);        // this wave's span: channel 0, then channel 1 `capw` floats on
+  const int64_t jw = ((int64_t)blockIdx.x * kWaves + wv) * kWaveOut;   // the wave's outputs: jw + l + 64 r, r < kOut
+  const int nrem = (int)(len_out - jw < (int64_t)kWaveOut ? (len_out - jw > 0 ? len_out - jw : 0) : kWaveOut);   // valid outputs of the wave
+  if (PAR_SINC_HOT && nrem == kWaveOut && sig_stride == 1 && out_stride == 1)
+    fused_wave<NCH, NTC, NS, true>(len_out, sig, sig1, sig_stride, len_in, NT, tab, tmd, out, out1, out_stride, fa, tile, l, jw, nrem);
+  else
+    fused_wave<NCH, NTC, NS, false>(len_out, sig, sig1, sig_stride, len_in, NT, tab, tmd, out, out1, out_stride, fa, tile, l, jw, nrem);
 }
 
 // ---- host side: per-(device, NT) tap tables -------------------------------------------------------
