@@ -93,9 +93,23 @@ class WorkQueue:
     def __init__(self, ctx, order, tag):
         self.ctx, self.order, self.key, self._next = ctx, list(order), f"par_queue_{tag}", 0
         if ctx.dist and WorkQueue._store is None:
-            port = int(os.environ.get("MASTER_PORT", "29533")) + 1
-            WorkQueue._store = ctx.dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, ctx.world,
-                                                 is_master=(ctx.rank == 0), wait_for_workers=True)
+            # rank 0 binds the first free port above the rendezvous port and tells the others through the gloo group
+            addr, base = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29533"))
+            port, store = 0, None
+            if ctx.rank == 0:
+                for cand in range(base + 1, base + 33):
+                    try:
+                        store = ctx.dist.TCPStore(addr, cand, ctx.world, is_master=True, wait_for_workers=False)
+                        port = cand
+                        break
+                    except (RuntimeError, OSError):
+                        continue
+            port = int(ctx.reduce_max(port))
+            if port == 0:
+                raise RuntimeError(f"WorkQueue: no free port in {base + 1}..{base + 32} for the queue's TCP store")
+            if ctx.rank != 0:
+                store = ctx.dist.TCPStore(addr, port, ctx.world, is_master=False)
+            WorkQueue._store = store
 
     def pull(self):
         """Next item, or None when the queue is empty."""

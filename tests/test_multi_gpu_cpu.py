@@ -21,6 +21,14 @@ def test_shard_items_partition_is_disjoint_and_complete():
 
 
 def test_world2_gloo_timing_and_reduction():
+    import socket
+    blocker = socket.socket()                     # the port right above the rendezvous port is taken: the queue's
+    blocker.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)     # store must move on to the next free one
+    try:
+        blocker.bind(("127.0.0.1", 29542))
+        blocker.listen(1)
+    except OSError:
+        pass
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "tests", "_dist_worker.py")]
@@ -32,6 +40,7 @@ def test_world2_gloo_timing_and_reduction():
     assert r["dt"] >= 0.055            # MAX over ranks: the slow rank (3 x 20 ms) sets the time
     # shared work queue: 40 items pulled exactly once in total, the faster rank took more of them
     assert r["q_total"] == 40 and r["q_sum"] == sum(range(40)) and 1 <= r["q_min"] < 20
+    blocker.close()
 
 
 def test_work_queue_single_process():

@@ -19,6 +19,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 t_end = time.time() + budget
 case = worst = refused = 0
+worst_f = 0.0
 why = {}
 paths = [0, 0, 0]            # plans that ran on the device / went to the serial host plan / took host-made lengths only
 worst_cfg = None
@@ -83,7 +84,11 @@ while time.time() < t_end:
     errs = [float(np.max(np.abs(out_a - ref)) / scale)]
     if plan.fused_ok:
         out_f = R.varispeed_fused_dev(plan, sig_t, NT).cpu().numpy()
-        assert np.array_equal(out_f, out_a), (case, "fused != position-array", n, NT, seg, style)
+        # record-placed outputs: same window centres as the position-array form, shift to ~1e-7 of a sample
+        ef = float(np.max(np.abs(out_f - out_a)) / scale)
+        assert ef < (2e-6 if NT <= 64 else 4e-6), (case, "fused vs position-array", ef, n, NT, seg, style)   # float32 sums of 2 NT taps
+        errs.append(float(np.max(np.abs(out_f - ref)) / scale))
+        worst_f = max(worst_f, ef)
         # stereo form: both channels in one launch == one mono launch each (to float32 rounding)
         sig2_t = torch.flip(sig_t, dims=(0,)).contiguous()
         o0 = torch.empty(plan.len_out, dtype=torch.float32, device="cuda")
@@ -97,5 +102,6 @@ while time.time() < t_end:
         worst, worst_cfg = max(errs), (case, n, NT, seg, style)
     assert max(errs) < 1e-5, (case, errs, n, NT, seg, style)       # the north-star tolerance, relative to the OUTPUT peak
     case += 1
-print(f"fuzz ok: {case} cases ({refused} refused by both the oracle and the device), worst relative error {worst:.2e} at {worst_cfg}; "
+print(f"fuzz ok: {case} cases ({refused} refused by both the oracle and the device), worst relative error {worst:.2e} at {worst_cfg}, "
+      f"worst fused-vs-position-array difference {worst_f:.2e}; "
       f"plan path device/serial-host/host-lengths = {paths[0]}/{paths[1]}/{paths[2]}, device flag words behind the host paths: {why}")
