@@ -234,12 +234,16 @@ struct FftGeom {
   static constexpr int FrameLds = H + H / 8 + 8;                // padded float2 slots per frame
 };
 
-template <int LOGH>
-__global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __restrict__ x, int64_t n, int64_t x_stride,
+// MODE 0: complex spectrum, 1: magnitude |X| + 1e-7.  UNIT: the signal is contiguous (x_stride == 1): no 64-bit stride
+// multiply per sample and the two samples of a packed point arrive in one 8-byte load.
+template <int LOGH, int MODE, bool UNIT>
+__global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __restrict__ x, int64_t n, int64_t x_stride_arg,
                                                                   int n_fft, int hop, const float* __restrict__ window,
                                                                   const float2* __restrict__ tw,
                                                                   const float2* __restrict__ post, float* __restrict__ out,
-                                                                  int64_t n_frames, int mode, float scale) {
+                                                                  int64_t n_frames, float scale) {
+  const int64_t x_stride = UNIT ? 1 : x_stride_arg;
+  constexpr int mode = MODE;
   using G = FftGeom<LOGH>;
   constexpr int H = G::H, T = G::T;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -295,25 +299,41 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
   // 3 one-wave-per-frame sizes stage the row in the wave's own LDS and write it with 16-byte aligned stores
   constexpr bool kRowStage = (PAR_STFT_STORE == 3) && T == kWave;
   float* Mg = reinterpret_cast<float*>(lds + G::Frames * G::FrameLds) + f * (bins + 3);      // this frame's row (mode 1)
+  // (re, im) arrive UNSCALED (twice the bin, before the 1/sqrt(n_fft)): the complex form scales both parts, the magnitude
+  // form scales once behind the square root (|hs z| = hs |z|: two multiplies per bin saved)
   auto emit = [&](int k, float re, float im) {
     // The magnitude spectrogram is consumed sparsely (tracker bands): streaming stores (get_mag 0.39 -> 0.365 ms).
     // The complex one is re-read right away by the inpaint / ISTFT kernels: regular stores (streaming ones cost
     // 2 % on the config-4 chain).
-    if (mode == 0) reinterpret_cast<float2*>(out)[fr * bins + k] = make_float2(re, im);
-    else if (kRowStage) Mg[k] = sqrtf(re * re + im * im) + 1e-7f;
-    else if (PAR_STFT_STORE == 1) out[fr * bins + k] = sqrtf(re * re + im * im) + 1e-7f;
-    else __builtin_nontemporal_store(sqrtf(re * re + im * im) + 1e-7f, out + fr * bins + k);
+    if constexpr (mode == 0) {
+      reinterpret_cast<float2*>(out)[fr * bins + k] = make_float2(re * hs, im * hs);
+    } else {
+      const float mag = fmaf(sqrtf(fmaf(re, re, im * im)), hs, 1e-7f);
+      if (kRowStage) Mg[k] = mag;
+      else if (PAR_STFT_STORE == 1) out[fr * bins + k] = mag;
+      else __builtin_nontemporal_store(mag, out + fr * bins + k);
+    }
   };
+  // LDS slots of the pair (k, H - k), k = j + i T: with T a multiple of 8 the padding is linear in i, so both are one
+  // base per lane plus an immediate (the wrap H - 0 -> 0 only exists for lane 0's first pair)
+  constexpr bool kLinearPad = (T % 8) == 0;
+  constexpr int kPadStep = T + T / 8;
+  const int lp_k0 = lpad(j), lp_m0 = lpad(H - j);
 #pragma unroll
   for (int i = 0; i <= P; ++i) {
     const int k = (i < P) ? j + i * T : H / 2;
     if (i == P && j != 0) break;
-    const float2 zk = X[lpad(k)];
-    const float2 zc = cconj(X[lpad((H - k) & (H - 1))]);
+    int sk = lpad(k), sm = lpad((H - k) & (H - 1));
+    if (kLinearPad && i < P) {
+      sk = lp_k0 + i * kPadStep;
+      sm = (i == 0 && j == 0) ? 0 : lp_m0 - i * kPadStep;
+    }
+    const float2 zk = X[sk];
+    const float2 zc = cconj(X[sm]);
     const float2 ev = cadd(zk, zc);                     // Z[k] + conj(Z[H-k])
     const float2 t = cmul(pw[i], csub(zk, zc));         // W^k * (Z[k] - conj(Z[H-k]))
-    emit(k, (ev.x + t.y) * hs, (ev.y - t.x) * hs);      // X[k]   = (ev - i*t)/2
-    if (i < P) emit(H - k, (ev.x - t.y) * hs, (-ev.y - t.x) * hs);   // X[H-k] = (conj(ev) - i*conj(t))/2
+    emit(k, ev.x + t.y, ev.y - t.x);                    // X[k]   = (ev - i*t)/2 * scale
+    if (i < P) emit(H - k, ev.x - t.y, -ev.y - t.x);    // X[H-k] = (conj(ev) - i*conj(t))/2 * scale
   }
   if (kRowStage && mode == 1) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -871,11 +891,18 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
   if (rc != PAR_OK) return rc;
   const int64_t n_frames = par_stft_frames(n, n_fft, hop);
   const float scale = (float)(1.0 / sqrt((double)n_fft));
-#define PAR_STFT_LAUNCH(LH)                                                                                          \
-  hipLaunchKernelGGL(k_stft<LH>, dim3((unsigned)(ceil_div(ceil_div(n_frames, FftGeom<LH>::Frames), 8) * 8)), dim3(FftGeom<LH>::Threads),  \
+#define PAR_STFT_LAUNCH_MU(LH, MD, UN)                                                                              \
+  hipLaunchKernelGGL((k_stft<LH, MD, UN>), dim3((unsigned)(ceil_div(ceil_div(n_frames, FftGeom<LH>::Frames), 8) * 8)), dim3(FftGeom<LH>::Threads),  \
                      (size_t)FftGeom<LH>::Frames * FftGeom<LH>::FrameLds * sizeof(float2) +                              \
                          (PAR_STFT_STORE == 3 ? (size_t)FftGeom<LH>::Frames * ((1 << LH) + 4) * sizeof(float) : 0),      \
-                     as_stream(stream), x, n, x_stride, n_fft, hop, window, tw.w, tw.post, out, n_frames, mode, scale)
+                     as_stream(stream), x, n, x_stride, n_fft, hop, window, tw.w, tw.post, out, n_frames, scale)
+#define PAR_STFT_LAUNCH(LH)                                                                                          \
+  do {                                                                                                               \
+    if (mode == 1 && x_stride == 1) PAR_STFT_LAUNCH_MU(LH, 1, true);                                                 \
+    else if (mode == 1) PAR_STFT_LAUNCH_MU(LH, 1, false);                                                            \
+    else if (x_stride == 1) PAR_STFT_LAUNCH_MU(LH, 0, true);                                                         \
+    else PAR_STFT_LAUNCH_MU(LH, 0, false);                                                                           \
+  } while (0)
   switch (ilog2(H)) {
     case 3: PAR_STFT_LAUNCH(3); break;
     case 4: PAR_STFT_LAUNCH(4); break;
@@ -890,6 +917,7 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
     default: PAR_REQUIRE(false, PAR_ERR_UNSUPPORTED, "par_stft_f32: unsupported size");
   }
 #undef PAR_STFT_LAUNCH
+#undef PAR_STFT_LAUNCH_MU
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }
