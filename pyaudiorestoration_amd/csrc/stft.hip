@@ -308,7 +308,8 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
     if constexpr (mode == 0) {
       reinterpret_cast<float2*>(out)[fr * bins + k] = make_float2(re * hs, im * hs);
     } else {
-      const float mag = fmaf(sqrtf(fmaf(re, re, im * im)), hs, 1e-7f);
+      // v_sqrt_f32 itself (1 ulp): the correctly rounded sqrtf costs 16 instructions per bin, mostly compares and selects
+      const float mag = fmaf(__builtin_amdgcn_sqrtf(fmaf(re, re, im * im)), hs, 1e-7f);
       if (kRowStage) Mg[k] = mag;
       else if (PAR_STFT_STORE == 1) out[fr * bins + k] = mag;
       else __builtin_nontemporal_store(mag, out + fr * bins + k);
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(256) void k_big_untangle(const float2* __restrict__
   const float hs = 0.5f * scale;
   auto emit = [&](int64_t kk, float re, float im) {
     if (mode == 0) reinterpret_cast<float2*>(out)[fr * bins + kk] = make_float2(re, im);
-    else out[fr * bins + kk] = sqrtf(re * re + im * im) + 1e-7f;
+    else out[fr * bins + kk] = __builtin_amdgcn_sqrtf(re * re + im * im) + 1e-7f;
   };
   emit(k, (ev.x + t.y) * hs, (ev.y - t.x) * hs);
   if (k > 0 && k < H / 2) emit(H - k, (ev.x - t.y) * hs, (-ev.y - t.x) * hs);
