@@ -366,9 +366,12 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-template <int NT, int R>
+// LS: LDS stride of a sample.  1: one channel per LDS array; 2: the wave's span holds interleaved stereo samples and the R = 2
+// slots of a call are the two channels of ONE output (c[1] == c[0] + 1): their taps are adjacent words of one base.
+template <int NT, int R, int LS = 1>
 __device__ __forceinline__ void taps_unity_ct(const float* __restrict__ tile, const int (&c)[R], const float (&s)[R],
                                               const int nt_rt, float (&res)[R]) {
+  static_assert(LS == 1 || (LS == 2 && R == 2), "interleaved spans: the two channel slots of one output");
   using T = TapTab<NT>;
   float q[R], e0[R], e1[R], e2[R], d0[R], d1[R], d2[R];
   lds_cfloat* base[R];
@@ -377,7 +380,7 @@ __device__ __forceinline__ void taps_unity_ct(const float* __restrict__ tile, co
   for (int r = 0; r < R; ++r) {
     q[r] = s[r] * s[r];
     e0[r] = e1[r] = e2[r] = d0[r] = d1[r] = d2[r] = 0.0f;
-    base[r] = tl + c[r] - NT;                // tap +n at [NT + n], tap -n at [NT - n]: immediates
+    base[r] = (LS == 2 && r == 1) ? base[0] + 1 : tl + c[r] - NT * LS;    // tap +n at [(NT + n) LS], tap -n at [(NT - n) LS]: immediates
   }
   // One basic block per chunk of kChunk taps: the (always true, but opaque to the compiler) test on the run-time NT keeps
   // the instruction selector from interleaving the whole unrolled sequence -- left as ONE block it runs loads and
@@ -402,7 +405,7 @@ __device__ __forceinline__ void taps_unity_ct(const float* __restrict__ tile, co
         // sample there still poisons the sum as 0 * NaN), tap +NT is not
         e0[r] = fmaf(base[r][0], 0.0f, e0[r]);
       } else {
-        const float sp = base[r][NT + n], sm = base[r][NT - n];
+        const float sp = base[r][(NT + n) * LS], sm = base[r][(NT - n) * LS];
         const float D = sp - sm, E = sp + sm;
         if constexpr (mode == kRcp) {
 #pragma clang fp contract(off)
@@ -445,10 +448,11 @@ __device__ __forceinline__ void taps_unity_ct(const float* __restrict__ tile, co
   }
 }
 
-template <int NT, int R>
+template <int NT, int R, int LS = 1>
 __device__ __forceinline__ void taps_general_ct(const float* __restrict__ tile, const int (&c)[R], const float (&s)[R],
                                                 const float (&fc)[R], const float (&dd)[R], const int nt_rt,
                                                 float (&res)[R]) {
+  static_assert(LS == 1 || (LS == 2 && R == 2), "interleaved spans: the two channel slots of one output");
   using T = TapTab<NT>;
   float q[R], U[R], Up[R], V[R], Vp[R], c2[R], M0[R], M1[R], M2[R], P0[R], P1[R], P2[R], centre[R];
   lds_cfloat* base[R];
@@ -474,7 +478,7 @@ __device__ __forceinline__ void taps_general_ct(const float* __restrict__ tile, 
     q[r] = s[r] * s[r];
     centre[r] = tile[c[r]] * (Up[r] * fast_rcp(s[r] * b0));
     M0[r] = M1[r] = M2[r] = P0[r] = P1[r] = P2[r] = 0.0f;
-    base[r] = tl + c[r] - NT;
+    base[r] = (LS == 2 && r == 1) ? base[0] + 1 : tl + c[r] - NT * LS;
   }
   static_for<(NT + kChunk - 1) / kChunk>([&](auto cidx) {
    constexpr int n0 = decltype(cidx)::value * kChunk + 1;
@@ -495,7 +499,7 @@ __device__ __forceinline__ void taps_general_ct(const float* __restrict__ tile, 
       if constexpr (n == NT) {
         M0[r] = fmaf(base[r][0] * V[r], 0.0f, M0[r]);             // tap -NT: weight 0, poison kept (see taps_unity_ct)
       } else {
-        const float sp = base[r][NT + n], sm = base[r][NT - n];
+        const float sp = base[r][(NT + n) * LS], sm = base[r][(NT - n) * LS];
         const float G = sp * U[r], H = sm * V[r];
         const float t1 = G - H, t2 = G + H;
         if constexpr (mode == kRcp) {
@@ -669,7 +673,7 @@ __device__ __forceinline__ void place_fast(const FusedArgs& fa, long long i, lon
 // The tap loops of one lane: NS (output, channel) slots, two at a time where the loops carry 6-10 live values per slot
 // (one pass over four spilled 48 B/lane = as much HBM write traffic as the output).  `all_unity`: fc == 1 for every lane
 // of the wave.
-template <int NTC, int NS>
+template <int NTC, int NS, int LS = 1>
 __device__ __forceinline__ void run_taps(const float* __restrict__ tile, const int (&cs)[NS], const float (&ss)[NS],
                                          const float (&fcs)[NS], const float (&dds)[NS], const bool all_unity,
                                          const int NT, const float4* __restrict__ tab, const TapModes tmd,
@@ -687,11 +691,11 @@ __device__ __forceinline__ void run_taps(const float* __restrict__ tile, const i
     const float sa[2] = {ss[2 * h], ss[2 * h + 1]};
     float ra[2];
     if (all_unity) {
-      if constexpr (NTC > 0) taps_unity_ct<NTC, 2>(tile, ca, sa, NT, ra);
+      if constexpr (NTC > 0) taps_unity_ct<NTC, 2, LS>(tile, ca, sa, NT, ra);
     } else {
       const float fa_[2] = {fcs[2 * h], fcs[2 * h + 1]};
       const float da[2] = {dds[2 * h], dds[2 * h + 1]};
-      if constexpr (NTC > 0) taps_general_ct<NTC, 2>(tile, ca, sa, fa_, da, NT, ra);
+      if constexpr (NTC > 0) taps_general_ct<NTC, 2, LS>(tile, ca, sa, fa_, da, NT, ra);
       else taps_general<2>(tile, ca, sa, fa_, da, NT, tab, tmd, ra);
     }
     res[2 * h] = ra[0];
@@ -869,6 +873,10 @@ __device__ __forceinline__ void fused_wave(const int64_t len_out, const float* _
   constexpr int kOut = NS / NCH;                    // outputs per lane
   constexpr int kWaveOut = kWave * kOut;            // outputs per wave: 256 / 128 / 64
   constexpr int capw = fused_capw(NS, NCH);         // floats of one channel's span a wave may stage
+  // HOT stereo = an interleaved file (sig1 == sig + 1, stride 2, same for the output): the span is staged as it lies in
+  // memory, sample i of channel ch at LDS word 2 i + ch, and the two channel slots of an output read adjacent words
+  constexpr int LS = (HOT && NCH == 2) ? 2 : 1;     // LDS words per sample
+  constexpr int CHO = LS == 2 ? 1 : capw;           // LDS offset of channel 1
   const int t = threadIdx.x;
   const int64_t T = jw / kSincTile;
   PAR_PHASE_BEGIN();
@@ -999,16 +1007,19 @@ __device__ __forceinline__ void fused_wave(const int64_t len_out, const float* _
   // advances the global address) -- one address per lane, no VGPR round trip, no address or bounds arithmetic per row
   bool dma = false;
   if constexpr (HOT && !(PAR_SINC_EXP & 16)) {
-    dma = lo >= 0 && lo + (long long)((nspan + kWave - 1) & ~(kWave - 1)) <= (long long)len_in;
+    const int nwords = nspan * LS;                  // float words of the span as it lies in memory (interleaved: 2 per sample)
+    dma = lo >= 0 && (lo * LS + (long long)((nwords + kWave - 1) & ~(kWave - 1))) <= (long long)len_in * LS;
     if (dma) {
-      static_for<NCH>([&](auto chi) {
-        constexpr int ch = decltype(chi)::value;
-        const float* gp = (ch ? sig1 : sig) + lo + l;
-        static_for<capw / kWave>([&](auto qi) {
-          constexpr int q = decltype(qi)::value;
-          if (q * kWave < nspan)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)(tile + ch * capw), 4, q * kWave * 4, 0);
+      const float* gp = sig + lo * LS + l;
+      // the instruction offset (13 bits, signed) advances the global and the LDS address alike: 16 rows per base
+      static_for<(capw * NCH / kWave + 15) / 16>([&](auto bi) {
+        constexpr int b = decltype(bi)::value;
+        static_for<16>([&](auto qi) {
+          constexpr int q = b * 16 + decltype(qi)::value;
+          if (q < capw * NCH / kWave && q * kWave < nwords)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + b * 16 * kWave),
+                                             (__attribute__((address_space(3))) void*)(tile + b * 16 * kWave), 4,
+                                             (q - b * 16) * kWave * 4, 0);
         });
       });
       __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the rows are in LDS
@@ -1018,8 +1029,8 @@ __device__ __forceinline__ void fused_wave(const int64_t len_out, const float* _
     for (int q = l; q < nspan; q += kWave) {
       const long long g = lo + q;
       const bool inside = g >= 0 && g < (long long)len_in;
-      tile[q] = (inside && !(PAR_SINC_EXP & 16)) ? sig[g * sig_stride] : 0.0f;
-      if (NCH == 2) tile[capw + q] = (inside && !(PAR_SINC_EXP & 16)) ? sig1[g * sig_stride] : 0.0f;
+      tile[q * LS] = (inside && !(PAR_SINC_EXP & 16)) ? sig[g * sig_stride] : 0.0f;
+      if (NCH == 2) tile[q * LS + CHO] = (inside && !(PAR_SINC_EXP & 16)) ? sig1[g * sig_stride] : 0.0f;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the wave's own LDS writes before its LDS reads
@@ -1044,7 +1055,7 @@ __device__ __forceinline__ void fused_wave(const int64_t len_out, const float* _
   float ss[NS], fcs[NS], dds[NS], res[NS];
 #pragma unroll
   for (int sl = 0; sl < NS; ++sl) {
-    cs[sl] = c[sl / NCH] + (sl % NCH) * capw;
+    cs[sl] = c[sl / NCH] * LS + (sl % NCH) * CHO;
     ss[sl] = s[sl / NCH];
     fcs[sl] = fc[sl / NCH];
     dds[sl] = dd[sl / NCH];
@@ -1053,7 +1064,7 @@ __device__ __forceinline__ void fused_wave(const int64_t len_out, const float* _
 #ifdef PAR_SINC_PRIO
   __builtin_amdgcn_s_setprio(0);
 #endif
-  if (!(PAR_SINC_EXP & 1) && __any(anyfast)) run_taps<NTC, NS>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res);
+  if (!(PAR_SINC_EXP & 1) && __any(anyfast)) run_taps<NTC, NS, LS>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res);
 #ifdef PAR_SINC_PRIO
   __builtin_amdgcn_s_setprio(PAR_SINC_PRIO_OUT);
 #endif
@@ -1062,14 +1073,14 @@ __device__ __forceinline__ void fused_wave(const int64_t len_out, const float* _
     float res2[NS];
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) ss[sl] += 1e-3f * res[sl];
-    if (__any(anyfast)) run_taps<NTC, NS>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res2);
+    if (__any(anyfast)) run_taps<NTC, NS, LS>(tile, cs, ss, fcs, dds, __all(unity), NT, tab, tmd, res2);
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) res[sl] += 1e-9f * res2[sl];
   }
 #endif
   PAR_PHASE_MARK(4);                 // taps
   // 6. stores
-  const int64_t ostr = HOT ? 1 : out_stride;
+  const int64_t ostr = HOT ? (int64_t)LS : out_stride;
   float* const op0 = out + (jw + l) * ostr;
   float* const op1 = NCH == 2 ? out1 + (jw + l) * ostr : nullptr;
 #pragma unroll
@@ -1082,12 +1093,21 @@ __device__ __forceinline__ void fused_wave(const int64_t len_out, const float* _
       while (i + 1 < fa.nseg && fa.seg_start[i + 1] <= j) ++i;
       e = place_exact(fa.speeds, fa.seg_start, fa.seg_off, fa.ck, i, j, len_out);
     }
+    float vch[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      float v = res[r * NCH + ch];
-      if (!fastlane[r]) v = sinc_one_f64(e.p, e.dp, ch ? sig1 : sig, sig_stride, len_in, NT);
-      if ((PAR_SINC_EXP & 32) && v != 12345.678f) continue;
-      (ch ? op1 : op0)[(int64_t)(r * kWave) * ostr] = v;
+      vch[ch] = res[r * NCH + ch];
+      if (!fastlane[r]) vch[ch] = sinc_one_f64(e.p, e.dp, ch ? sig1 : sig, sig_stride, len_in, NT);
+    }
+    if constexpr (LS == 2) {           // interleaved output: both channels of the output in one 8-byte store
+      if (!((PAR_SINC_EXP & 32) && vch[0] != 12345.678f))
+        *reinterpret_cast<float2*>(op0 + (int64_t)(r * kWave) * 2) = make_float2(vch[0], vch[NCH - 1]);
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        if ((PAR_SINC_EXP & 32) && vch[ch] != 12345.678f) continue;
+        (ch ? op1 : op0)[(int64_t)(r * kWave) * ostr] = vch[ch];
+      }
     }
   }
   PAR_PHASE_MARK(5);                 // stores issued
@@ -1128,7 +1148,11 @@ __global__ __launch_bounds__(kSincBlock, PAR_SINC_WAVES) void k_sinc_fused(int64
   float* tile = lds_all + wv * (capw * NCH);        // this wave's span: channel 0, then channel 1 `capw` floats on
   const int64_t jw = ((int64_t)blockIdx.x * kWaves + wv) * kWaveOut;   // the wave's outputs: jw + l + 64 r, r < kOut
   const int nrem = (int)(len_out - jw < (int64_t)kWaveOut ? (len_out - jw > 0 ? len_out - jw : 0) : kWaveOut);   // valid outputs of the wave
-  if (PAR_SINC_HOT && nrem == kWaveOut && sig_stride == 1 && out_stride == 1)
+  // hot waves: full, and either mono on unit strides or an interleaved stereo file (8-byte aligned output pairs)
+  const bool hot_layout = NCH == 1 ? (sig_stride == 1 && out_stride == 1)
+                                   : (NTC > 0 && sig_stride == 2 && out_stride == 2 && sig1 == sig + 1 && out1 == out + 1 &&
+                                      (reinterpret_cast<uintptr_t>(out) & 7) == 0);
+  if (PAR_SINC_HOT && nrem == kWaveOut && hot_layout)
     fused_wave<NCH, NTC, NS, true>(len_out, sig, sig1, sig_stride, len_in, NT, tab, tmd, out, out1, out_stride, fa, tile, l, jw, nrem);
   else
     fused_wave<NCH, NTC, NS, false>(len_out, sig, sig1, sig_stride, len_in, NT, tab, tmd, out, out1, out_stride, fa, tile, l, jw, nrem);

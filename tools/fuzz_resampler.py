@@ -98,6 +98,14 @@ while time.time() < t_end:
         sc = max(float(np.max(np.abs(out_f))), float(np.max(np.abs(m1))), 1e-30)
         es = max(float(np.max(np.abs(o0.cpu().numpy() - out_f))), float(np.max(np.abs(o1.cpu().numpy() - m1)))) / sc
         assert es < 5e-6, (case, "stereo != mono", es, n, NT, seg, style)
+        # the same two channels as ONE interleaved file (the layout the full-wave fast path of the stereo kernel takes)
+        inter = torch.stack((sig_t, sig2_t), dim=1).contiguous()
+        oi = torch.empty((plan.len_out, 2), dtype=torch.float32, device="cuda")
+        R.varispeed_fused_stereo_dev(plan, inter.reshape(-1)[0:], inter.reshape(-1)[1:], NT, oi.reshape(-1)[0:], oi.reshape(-1)[1:],
+                                     sig_stride=2, len_in=n, out_stride=2)
+        oin = oi.cpu().numpy()
+        ei = max(float(np.max(np.abs(oin[:, 0] - out_f))), float(np.max(np.abs(oin[:, 1] - m1)))) / sc
+        assert ei < 5e-6, (case, "interleaved stereo != mono", ei, n, NT, seg, style)
     if max(errs) > worst:
         worst, worst_cfg = max(errs), (case, n, NT, seg, style)
     assert max(errs) < 1e-5, (case, errs, n, NT, seg, style)       # the north-star tolerance, relative to the OUTPUT peak
