@@ -135,7 +135,9 @@ int par_speed_to_pos_plan(int device, const double* sampletimes, const double* s
 /* Same as par_speed_to_pos_plan; force_host != 0 runs the serial host evaluation of the two
  * order-dependent chains (the exact fallback the device scans defer to when they flag a near-tie),
  * *path_used (optional) reports 0 = device scans, 1 = serial host path, 2 = segment lengths redone on the host after a
- * near-tie (O(m)) with everything else on the device. */
+ * near-tie (O(m)) with everything else on the device.  force_host == 2 (fused form, tests only) additionally injects
+ * the failure the exact chunked cumsum reports when its verification does not close: the plan stays valid, *fused_ok
+ * must come back 0. */
 int par_speed_to_pos_plan_ex(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
                              void* work, size_t work_bytes, int64_t* len_out, int* trimmed, int force_host,
                              int* path_used, void* stream);

@@ -923,6 +923,9 @@ __global__ __launch_bounds__(256) void k_long_final(const double* __restrict__ s
   if (c.j == c.J - 1) S[c.i] = x;
 }
 
+// force_host == 2 (tests): a checkpoint verification failure as the chunked long-segment cumsum would report it
+__global__ void k_inject_verify_fault(PlanHeader* __restrict__ h) { atomicOr(&h->flags, kFlagVerify); }
+
 // after k_tile_seg: publish checkpoint validity in the header (device side, so the host needs one read-back)
 __global__ void k_publish_ck(PlanHeader* __restrict__ h, int64_t ck_len) {
   h->ck_len = ck_len;
@@ -1771,11 +1774,13 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
       hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(std::max<int64_t>(nseg, max_tiles), 256)), dim3(256), 0, s,
                          speeds, pv.seg_start, pv.seg_off, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len),
                          reinterpret_cast<SegFast*>(ck + ck_len + max_tiles), fused_aux_view(aux, max_out, m).tile_st, pv.hdr);
+      if (force_host == 2) hipLaunchKernelGGL(k_inject_verify_fault, dim3(1), dim3(1), 0, s, pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
       launch_block_rec(speeds, pv, nseg, aux, max_out, m, s);
       PAR_HIP_CHECK(hipGetLastError());
       PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
       PAR_HIP_CHECK(hipStreamSynchronize(s));
+      g_last_plan_flags |= h.flags;
     }
   } else {
     // the reference writes each segment into its end_guess-sized buffer BEFORE testing the trim (:127-129)

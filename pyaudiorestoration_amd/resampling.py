@@ -47,7 +47,9 @@ def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_h
                    max_out=None, work=None, aux=None, stream=None):
     """Planning stage.  fused=True also stores per-segment cumsum checkpoints (every 8th step) so that
     varispeed_resample_dev can regenerate positions inside K_sinc instead of reading a position array.
-    work / aux: caller-owned uint8 device buffers to (re)use; stream: torch stream to plan on (default: current)."""
+    work / aux: caller-owned uint8 device buffers to (re)use; stream: torch stream to plan on (default: current).
+    force_host_chain: True/1 = serial host evaluation of the two chains; 2 (tests) = that plus an injected checkpoint
+    verification failure, after which fused_ok must be False."""
     dev = _dev.device_index(dev if dev is not None else sampletimes_t.device)
     L = _lib.lib()
     m = sampletimes_t.numel()
@@ -70,7 +72,7 @@ def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_h
         _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m,
                                                  int(num_imput_samples), _dev.ptr(work), work.numel(), _dev.ptr(aux),
                                                  aux.numel(), max_out, ctypes.byref(len_out), ctypes.byref(trimmed),
-                                                 1 if force_host_chain else 0, ctypes.byref(path), ctypes.byref(ok),
+                                                 int(force_host_chain), ctypes.byref(path), ctypes.byref(ok),
                                                  s_ptr))
         return SpeedPlan(speeds_t, m, work, len_out.value, bool(trimmed.value), path.value, dev, aux, bool(ok.value),
                          max_out)

@@ -785,6 +785,28 @@ def test_config1_and_config3_on_reference_samples(par, golden):
     assert len(y2) == int(g["c3_len_pos"]) and relerr(y2[g["c3_sel"]], g["c3_y_sel"]) < TOL
 
 
+def test_unverified_checkpoints_are_never_published(par):
+    """a plan whose exact chunked cumsum failed its own verification goes to the serial host path, which
+    re-runs the same checkpoint pass; the checkpoints must then NOT be published as valid (the fused resampler would
+    regenerate positions from them) -- callers fall back to the position array, whose plan stays good."""
+    from oracle import oracle_c as C
+    t = par.torch
+    R = par.resampling
+    n = 200000
+    st, sp = np.linspace(0, n, 700), 1.0 + 0.02 * np.sin(np.arange(700) * 0.07)
+    st_t, sp_t = t.from_numpy(st).cuda(), t.from_numpy(sp).cuda()
+    sig = inputs.noise(n, 3)
+    good = R.speed_plan_dev(st_t, sp_t, n, fused=True, force_host_chain=1)
+    assert good.fused_ok and good.path == 1
+    bad = R.speed_plan_dev(st_t, sp_t, n, fused=True, force_host_chain=2)
+    assert not bad.fused_ok and bad.path == 1 and bad.len_out == good.len_out
+    pos, _ = C.speed_to_pos(st, sp, n)
+    item = (st_t, sp_t, t.from_numpy(sig).cuda())
+    want = C.sinc(pos, sig, 32)
+    for plan in (good, bad):                      # the batch driver's per-item launch: the bad plan takes the position array
+        assert relerr(R._resample_item(plan, item, 32, 0).cpu().numpy(), want) < TOL
+
+
 def test_fused_extreme_curves_and_channels(par):
     """Fused path under stress: fast curves whose tiles overflow the LDS stage (float64 slow path),
     slow curves (many outputs per input), stereo strided views, tiny NT and NT = 100."""
