@@ -886,12 +886,20 @@ __device__ __forceinline__ void fused_wave(const int64_t len_out, const float* _
   // 1. records of this lane's outputs: block (jw >> 3) + (l >> 3) + 8 r, u = l & 7 for every r.  Unconditional 16-byte
   // loads off a wave-uniform base (indices past the file's last block are clamped to it)
   const int gmax = nrem > 0 ? (nrem - 1) >> 3 : 0;
-  const uint4* rp = reinterpret_cast<const uint4*>(fa.rec + (jw >> 3));
+  const uint4* rp = reinterpret_cast<const uint4*>(fa.rec + (jw >> 3) * kRecStride);
   uint4 ra[kOut];
+#if PAR_REC_BOTH
+  uint4 rb[kOut];                   // the block's second piece (garbage unless a segment starts inside the block)
+  const uint4* rp2 = PAR_REC_INTERLEAVE == 1 ? rp + 1 : reinterpret_cast<const uint4*>(fa.rec2 + (jw >> 3));
+#endif
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
     const int gr = (l >> 3) + 8 * r;
-    ra[r] = rp[HOT ? gr : (gr < gmax ? gr : gmax)];
+    const int gi = (HOT ? gr : (gr < gmax ? gr : gmax)) * kRecStride;
+    ra[r] = rp[gi];
+#if PAR_REC_BOTH
+    rb[r] = rp2[gi];
+#endif
   }
   // 2. tile header: the anchor all window centres are relative to
   const TileHdr hd = fa.hdr[T];
@@ -918,6 +926,14 @@ __device__ __forceinline__ void fused_wave(const int64_t len_out, const float* _
     F[r] = __uint_as_float(ra[r].y);
     e1[r] = __uint_as_float(ra[r].z);
   }
+#if PAR_REC_BOTH
+#pragma unroll
+  for (int r = 0; r < kOut; ++r) {   // a segment starts inside the lane's block at or before u: its second piece
+    I[r] = second[r] ? rb[r].x : I[r];
+    F[r] = second[r] ? __uint_as_float(rb[r].y) : F[r];
+    e1[r] = second[r] ? __uint_as_float(rb[r].z) : e1[r];
+  }
+#else
   if (__any(anysecond)) {            // a segment starts inside some lane's block: those lanes take its second piece
     const uint4* rp2 = reinterpret_cast<const uint4*>(fa.rec2 + (jw >> 3));
 #pragma unroll
@@ -931,6 +947,7 @@ __device__ __forceinline__ void fused_wave(const int64_t len_out, const float* _
       }
     }
   }
+#endif
 #pragma unroll
   for (int r = 0; r < kOut; ++r) {
     const unsigned m = ra[r].w;

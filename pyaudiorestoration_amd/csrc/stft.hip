@@ -810,19 +810,41 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) __attribute__((amdgpu_waves
   const int64_t ola_len = (int64_t)n_fft + (int64_t)hop * (n_frames - 1);
   const int out_len = out_frames * hop;
   const int64_t TT0 = (int64_t)blockIdx.x * out_len;                  // overlap-add coordinate of the first owned sample
-  for (int p = tid; p < out_len; p += G::Threads) {
+  // Window-sumsquare envelope.  Away from the two ends of the signal every frame that can cover a sample exists, and the
+  // envelope depends on the sample's phase TT mod hop alone: one table of hop sums per workgroup (same order of terms
+  // as the general loop below: frames ascending = window offsets descending) replaces two 64-bit divisions and a
+  // 16-term loop PER SAMPLE (they were a third of the kernel's instructions at 512/32).
+  float* env_tab = wl + n_fft;          // kTab: behind the window (pl is dead now); else behind the staged window in the frame slots
+  const bool use_tab = kTab || n_fft + hop <= 2 * G::Frames * G::FrameLds;
+  if (use_tab) {
+    for (int ph = tid; ph < hop; ph += G::Threads) {
+      float env = 0.0f;
+      for (int o = ph + ((n_fft - 1 - ph) / hop) * hop; o >= 0; o -= hop) env += wl[o] * wl[o];
+      env_tab[ph] = env;
+    }
+    __syncthreads();
+  }
+  const int64_t interior_lo = n_fft - 1, interior_hi = (int64_t)hop * (n_frames - 1);     // all covering frames exist in [lo, hi]
+  const int step_ph = G::Threads % hop;
+  int ph = tid % hop;                                                  // TT0 is a multiple of hop: phase of TT = phase of p
+  for (int p = tid; p < out_len; p += G::Threads, ph = ph + step_ph >= hop ? ph + step_ph - hop : ph + step_ph) {
     const int64_t TT = TT0 + p, t = TT - skip;
     if (t < 0) continue;
     if (t >= y_len) break;
     float a = 0.0f;
     if (TT < ola_len) {
-      int64_t e_hi = TT / hop;
-      if (e_hi > n_frames - 1) e_hi = n_frames - 1;
-      const int64_t e_lo = (TT - n_fft + 1 <= 0) ? 0 : (TT - n_fft + hop) / hop;
-      float env = 0.0f;
-      for (int64_t e = e_lo; e <= e_hi; ++e) {
-        const float w = wl[TT - e * hop];
-        env += w * w;
+      float env;
+      if (use_tab && TT >= interior_lo && TT <= interior_hi) {
+        env = env_tab[ph];
+      } else {
+        int64_t e_hi = TT / hop;
+        if (e_hi > n_frames - 1) e_hi = n_frames - 1;
+        const int64_t e_lo = (TT - n_fft + 1 <= 0) ? 0 : (TT - n_fft + hop) / hop;
+        env = 0.0f;
+        for (int64_t e = e_lo; e <= e_hi; ++e) {
+          const float w = wl[TT - e * hop];
+          env += w * w;
+        }
       }
       a = acc[p + (s - 1) * hop];
       if (env > 1.17549435e-38f) a /= env;                           // > tiny(float32)  (:414-415)
