@@ -1169,6 +1169,9 @@ __global__ __launch_bounds__(kSincBlock, PAR_SINC_WAVES) void k_sinc_fused(int64
   const bool hot_layout = NCH == 1 ? (sig_stride == 1 && out_stride == 1)
                                    : (NTC > 0 && sig_stride == 2 && out_stride == 2 && sig1 == sig + 1 && out1 == out + 1 &&
                                       (reinterpret_cast<uintptr_t>(out) & 7) == 0);
+#ifdef PAR_SINC_PRIO_ALL
+  __builtin_amdgcn_s_setprio(PAR_SINC_PRIO_ALL);   // experiment: the whole kernel above the plan kernels that share its SIMDs
+#endif
   if (PAR_SINC_HOT && nrem == kWaveOut && hot_layout)
     fused_wave<NCH, NTC, NS, true>(len_out, sig, sig1, sig_stride, len_in, NT, tab, tmd, out, out1, out_stride, fa, tile, l, jw, nrem);
   else
