@@ -65,7 +65,10 @@ def find_delay(a, b, ignore_phase=False, window_name=None):
     """Delay in samples (fractional) between 1-D signals a and b, and the correlation there.
     Like the reference, a given window is applied to `a` and `b` IN PLACE."""
     for sig in ((a, b) if window_name else ()):
-        sig *= get_window(window_name, len(sig))
+        if isinstance(sig, torch.Tensor):          # device-resident signals (pipeline.correlate_sources): windowed in HBM
+            sig.mul_(torch.from_numpy(get_window(window_name, sig.numel())).to(device=sig.device, dtype=sig.dtype))
+        else:
+            sig *= get_window(window_name, len(sig))
     if ignore_phase:
         logging.warning("Ignoring phase")
     dev = _dev.device_index(None)

@@ -265,6 +265,22 @@ def lag_curve_from_markers(markers, duration, sr, hop, smoothing=3, bands=(0, 99
     return np.stack((times, filters.butter_bandpass_filter(lag_at(times), lo, hi, marker_sr, order=3)), axis=-1)
 
 
+def correlate_sources(ref_sig, src_sig, sr, lower, upper, ignore_phase=False, window_name=None, speed=1.0):
+    """Delay (seconds) and correlation between two signal windows, as the tape-sync tool measures them
+    (pytapesynch_gui.py:108-133 behind its widget lookups): both windows band-passed (order-3 zero-phase Butterworth,
+    K_sosfiltfilt), then find_delay -- filter outputs stay in HBM and feed the correlation there.  `speed`: the rough
+    speed difference the caller resampled `src_sig` by (its match_speed branch uses resampy, not part of this
+    package); the delay is corrected for it like the reference does.  The inputs are not modified."""
+    from . import correlation, filters
+    a_t = filters.bandpass_dev(ref_sig, lower, upper, sr, order=3)
+    b_t = filters.bandpass_dev(src_sig, lower, upper, sr, order=3)
+    if window_name:                                  # find_delay windows in place: never the caller's own buffers
+        a_t = a_t.clone() if a_t is ref_sig else a_t
+        b_t = b_t.clone() if b_t is src_sig else b_t
+    sample_delay, corr = correlation.find_delay(a_t, b_t, ignore_phase=ignore_phase, window_name=window_name)
+    return sample_delay / sr * speed, corr
+
+
 def tapesync(project, source=None, out_suffix=None, device=None):
     """Run a saved pytapesynch project headless: `project` is the path of a .tapesync JSON (util/widgets.py:
     1224-1233 writes it: fft_size, fft_overlap, markers, source, resampling_mode, sinc_quality, smoothing,

@@ -1398,6 +1398,27 @@ def test_stft_above_8192_four_step(par, n_fft, hop, zp):
     assert relerr(got1, C.stft(np.ascontiguousarray(st[:, 1]), n_fft, hop, win, zp, mode=0, threads=8)) < TOL
 
 
+def test_correlate_sources_flow(par):
+    """pytapesynch_gui.py:108-133: band-pass both windows, then find_delay -- against the oracle's filter + find_delay
+    (each pinned to the reference's goldens on its own), with and without a window / phase."""
+    from oracle import oracle_np as O
+    from pyaudiorestoration_amd import pipeline
+    sr, n = 48000, 24000
+    rng = np.random.default_rng(11)
+    base = np.convolve(rng.standard_normal(n + 400), np.hanning(9) / 4, mode="same")
+    ref = base[200:200 + n].copy()
+    src = 0.8 * np.interp(np.arange(n) + 200 - 37.3, np.arange(len(base)), base) + 0.01 * rng.standard_normal(n)
+    for window_name, ignore_phase in ((None, False), ("hann", False), ("hann", True)):
+        want_d, want_c = O.find_delay(O.butter_bandpass_filter(ref.copy(), 300.0, 6000.0, sr, order=3),
+                                      O.butter_bandpass_filter(src.copy(), 300.0, 6000.0, sr, order=3),
+                                      ignore_phase=ignore_phase, window_name=window_name)
+        keep = ref.copy()
+        got_d, got_c = pipeline.correlate_sources(ref, src, sr, 300.0, 6000.0, ignore_phase, window_name)
+        assert abs(got_d * sr - want_d) < 1e-5 and abs(got_c - want_c) < 1e-8, (window_name, got_d * sr, want_d, got_c, want_c)
+        assert np.array_equal(ref, keep)
+    assert abs(abs(got_d * sr) - 37.3) < 0.1
+
+
 def test_correlation_on_the_device(par, golden):
     """util/correlation.py on the device: xcorr through one complex four-step FFT (float32: 1e-6 of the peak),
     find_delay with its peak neighbourhood re-evaluated in float64 (the reference-generated golden to 1e-9), window
