@@ -269,6 +269,12 @@ int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, 
  *   log_span = log2 f[NU-1] - log2 f[NL], log_mean = log2((fL + fU)/2): the reference's final scaling
  *   work     device f64 [par_track_corr_work_len(count, n)];  freqs  device f64 [count] out
  *   status   device int32 scratch.  A peak on the last lag is the reference's IndexError: PAR_ERR_INDEX.  Synchronises. */
+/* PartialsTracker's librosa.piptrack (util/wow_detection.py:361-387; third-party routine, restated from librosa 0.10's
+ * published source, parity unpinned): thresholded local maxima of every magnitude column inside [fmin, fmax), refined by
+ * a parabola.  mag: device f32 [n_frames][bins] as par_stft_f32 mode 1 writes it; S = (mag - offset) * scale gives the
+ * |stft| librosa works on (offset 1e-7, scale sqrt(n_fft)).  pitches / mags: device f32 [n_frames][bins] out. */
+int par_piptrack_f32(int device, const float* mag, int64_t n_frames, int bins, float scale, float offset, int fft_size,
+                     double sr, double fmin, double fmax, float threshold, float* pitches, float* mags, void* stream);
 int64_t par_track_corr_work_len(int64_t count, int n);
 int par_track_corr_f64(int device, const float* mag, int64_t n_frames, int bins, int NL, int NU, int64_t count,
                        const double* M, const double* wind, int n, double log_span, double log_mean, double* work,

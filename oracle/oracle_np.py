@@ -416,6 +416,34 @@ TRACKERS = {
 
 # ------------------------------------------------- P0: headless pyrespeeder data flow
 
+def piptrack(S, sr, n_fft, fmin=150.0, fmax=4000.0, threshold=0.1):
+    """librosa.piptrack(S=...) restated from librosa 0.10's published source (core/pitch.py): the routine PartialsTracker
+    calls (util/wow_detection.py:361-387).  librosa is a third-party dependency that is neither vendored in the reference
+    nor installed here (requirements.txt names it without a version): PARITY UNPINNED -- no golden vector exists; the
+    restatement is checked by hand-computed cases in tests/test_oracle_golden.py.  S: magnitudes (bins, frames)."""
+    S = np.abs(np.asarray(S))
+    fmin = np.maximum(fmin, 0)
+    fmax = np.minimum(fmax, float(sr) / 2)
+    fft_freqs = np.fft.rfftfreq(n_fft, 1.0 / sr)
+    avg = np.gradient(S, axis=-2)
+    a = S[2:] + S[:-2] - 2 * S[1:-1]                       # _parabolic_interpolation along the frequency axis
+    b = (S[2:] - S[:-2]) / 2
+    shift = np.zeros_like(S)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inner = np.where(np.abs(b) < np.abs(a), -b / a, 0)
+    shift[1:-1] = inner
+    dskew = 0.5 * avg * shift
+    pitches, mags = np.zeros_like(S), np.zeros_like(S)
+    freq_mask = ((fmin <= fft_freqs) & (fft_freqs < fmax))[:, None]
+    ref_value = threshold * np.max(S, axis=-2)[None, :]
+    x = S * (S > ref_value)
+    xp = np.pad(x, ((1, 1), (0, 0)), mode="edge")          # util.localmax: strictly above the left, at least the right neighbour
+    idx = np.nonzero(freq_mask & (x > xp[:-2]) & (x >= xp[2:]))
+    pitches[idx] = (idx[0] + shift[idx]) * float(sr) / n_fft
+    mags[idx] = S[idx] + dskew[idx]
+    return pitches, mags
+
+
 def trace_to_speed(freqs):
     """util/markers.py:197-199 (TraceLine, offset 0): log2 speed centred on 0."""
     s = np.log2(freqs)

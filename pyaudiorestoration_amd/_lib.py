@@ -16,6 +16,7 @@ c_int = ctypes.c_int
 c_vp = ctypes.c_void_p
 c_dbl = ctypes.c_double
 c_sz = ctypes.c_size_t
+c_float = ctypes.c_float
 c_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); mirrors include/par_hip.h one to one
@@ -76,6 +77,7 @@ SIGNATURES = {
     "par_xcorr_scratch_bytes": (ctypes.c_size_t, [c_i64, c_i64]),
     "par_xcorr_f64": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "par_find_delay_f64": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp, c_vp]),
+    "par_piptrack_f32": (c_int, [c_int, c_vp, c_i64, c_int, c_float, c_float, c_int, c_dbl, c_dbl, c_dbl, c_float, c_vp, c_vp, c_vp]),
     "par_track_corr_work_len": (c_i64, [c_i64, c_int]),
     "par_track_corr_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_int, c_int, c_i64, c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp,
                                    c_vp, c_vp]),

@@ -295,6 +295,53 @@ __global__ __launch_bounds__(256) void k_zc_write(const double* __restrict__ x, 
   }
 }
 
+// PartialsTracker (util/wow_detection.py:361-387) calls librosa.piptrack, a third-party routine that is not part of the
+// reference checkout (librosa is unpinned in requirements.txt; restated from its published 0.10 source, parity unpinned):
+// per frame, every local maximum of the thresholded magnitude column inside [fmin, fmax) becomes a pitch
+//   (k + shift) sr / n_fft,  shift = -b/a,  a = S[k+1] + S[k-1] - 2 S[k],  b = (S[k+1] - S[k-1]) / 2   (0 unless |b| < |a|)
+// with magnitude S[k] + b shift / 2; everything else is 0.  Threshold = `threshold` x the column maximum; local maximum:
+// x[k] > x[k-1] and x[k] >= x[k+1] on the edge-padded, thresholded column.  One wave per frame; S = (mag - offset) * scale
+// undoes get_mag's + 1e-7 and 1/sqrt(n_fft) so the magnitudes are librosa's |stft|.
+__global__ __launch_bounds__(256) void k_piptrack(const float* __restrict__ mag, int bins, int64_t n_frames, float scale,
+                                                  float offset, int fft_size, double sr, double fmin, double fmax,
+                                                  float threshold, float* __restrict__ pitches, float* __restrict__ mags) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t fr = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  if (fr >= n_frames) return;
+  const float* row = mag + fr * bins;
+  float m = -INFINITY;
+  for (int k = lane; k < bins; k += kWave) {
+    const float x = (row[k] - offset) * scale;
+    m = x > m ? x : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float t = __shfl_xor(m, o, kWave);
+    m = t > m ? t : m;
+  }
+  const float ref = threshold * m;
+  for (int k = lane; k < bins; k += kWave) {
+    const float x = (row[k] - offset) * scale;
+    const float xm = k > 0 ? (row[k - 1] - offset) * scale : x;
+    const float xp = k + 1 < bins ? (row[k + 1] - offset) * scale : x;
+    const float t = x > ref ? x : 0.0f, tm = xm > ref ? xm : 0.0f, tp = xp > ref ? xp : 0.0f;
+    const double f = (double)k * sr / (double)fft_size;
+    float pitch = 0.0f, magv = 0.0f;
+    if (t > tm && t >= tp && fmin <= f && f < fmax) {
+      float shift = 0.0f, avg = 0.0f;
+      if (k > 0 && k + 1 < bins) {
+        const float a = xp + xm - 2.0f * x, b = (xp - xm) / 2.0f;
+        shift = fabsf(b) < fabsf(a) ? -b / a : 0.0f;
+        avg = b;
+      }
+      pitch = (float)(((double)k + (double)shift) * sr / (double)fft_size);
+      magv = x + 0.5f * avg * shift;
+    }
+    pitches[fr * bins + k] = pitch;
+    mags[fr * bins + k] = magv;
+  }
+}
+
 }  // namespace par
 
 extern "C" {
@@ -415,6 +462,22 @@ int par_track_corr_f64(int device, const float* mag, int64_t n_frames, int bins,
   PAR_HIP_CHECK(hipStreamSynchronize(s));
   PAR_REQUIRE(!(h & 2), PAR_ERR_INDEX, "par_track_corr_f64: correlation peak on the last lag (index %d is out of bounds for "
               "axis 0 with size %d in the reference's parabolic())", n, n);
+  return PAR_OK;
+}
+
+// librosa.piptrack on a frame-major magnitude spectrogram (see k_piptrack); pitches / mags: [n_frames][bins] float32.
+int par_piptrack_f32(int device, const float* mag, int64_t n_frames, int bins, float scale, float offset, int fft_size,
+                     double sr, double fmin, double fmax, float threshold, float* pitches, float* mags, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(mag && pitches && mags, PAR_ERR_ARG, "par_piptrack_f32: null pointer");
+  PAR_REQUIRE(n_frames >= 0 && bins >= 2 && fft_size >= 2 && sr > 0, PAR_ERR_ARG, "par_piptrack_f32: bad sizes");
+  if (n_frames == 0) return PAR_OK;
+  PAR_HIP_CHECK(hipSetDevice(device));
+  fmin = fmin > 0.0 ? fmin : 0.0;
+  fmax = fmax < sr / 2 ? fmax : sr / 2;
+  hipLaunchKernelGGL(k_piptrack, dim3((unsigned)ceil_div(n_frames, 4)), dim3(256), 0, as_stream(stream), mag, bins, n_frames, scale,
+                     offset, fft_size, sr, fmin, fmax, threshold, pitches, mags);
+  PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }
 

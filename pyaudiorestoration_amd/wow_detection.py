@@ -204,12 +204,40 @@ class ZeroCrossingTracker(Track):
         self.freqs[:] = crossing_periods_to_freqs(crossings, self.sr, self.times[0], self.times)
 
 
+def piptrack_dev(mag_t, fft_size, sr, fmin, fmax, threshold=0.1, scale=None, offset=1e-7, dev=None):
+    """librosa.piptrack on a device magnitude spectrogram as fourier.get_mag returns it ((bins, frames) view of the
+    frame-major buffer): (pitches, magnitudes), both (bins, frames) float32 device tensors.  `scale` / `offset` undo
+    get_mag's 1/sqrt(n_fft) and + 1e-7 (defaults), so the magnitudes are those of librosa's own |stft|."""
+    dev = _dev.device_index(dev if dev is not None else mag_t.device)
+    fm = mag_t.T                                            # frame-major [frames][bins]
+    if not fm.is_contiguous():
+        fm = fm.contiguous()
+    frames, bins = fm.shape
+    pitches = _dev.empty((frames, bins), torch.float32, dev)
+    mags = _dev.empty((frames, bins), torch.float32, dev)
+    _lib.check(_lib.lib().par_piptrack_f32(dev, _dev.ptr(fm), frames, bins, float(np.sqrt(fft_size) if scale is None else scale),
+                                           float(offset), int(fft_size), float(sr), float(fmin), float(fmax), float(threshold),
+                                           _dev.ptr(pitches), _dev.ptr(mags), _dev.stream_ptr(dev)))
+    return pitches.T, mags.T
+
+
 class PartialsTracker(Track):
+    """util/wow_detection.py:361-387: the reference computes librosa.piptrack(y=signal[:, 0], fmin=min(trail),
+    fmax=max(trail), threshold=0.15) and SHOWS the pitch map in a matplotlib window -- it never writes self.freqs, so the
+    traced line is the drawn trail.  Here the map is computed on the device (K_stft with librosa's Hann window, then
+    par_piptrack_f32) and kept as .pitches / .magnitudes ((bins, frames) device tensors); no window is opened.  The frames
+    at the two ends differ from librosa >= 0.10's: its STFT pads with zeros, K_stft reflects like the reference's own."""
     name = 'Partials'
 
     def trace(self):
-        raise NotImplementedError("PartialsTracker needs librosa.piptrack and an interactive matplotlib window "
-                                  "(reference util/wow_detection.py:361-387); not part of the HIP hot path")
+        if len(self.freqs) == 0:
+            raise ValueError("zero-size array to reduction operation minimum which has no identity")   # np.min(self.freqs)
+        fl, fu = float(np.min(self.freqs)), float(np.max(self.freqs))
+        dev = _dev.device_index(self.spectrum.device if isinstance(self.spectrum, torch.Tensor) else None)
+        sig = np.ascontiguousarray(np.asarray(self.signal)[:, 0], dtype=np.float32)
+        mag = fourier.get_mag(_dev.to_dev(sig, torch.float32, dev), self.fft_size, self.hop, "hann", 1)
+        self.pitches, self.magnitudes = piptrack_dev(mag, self.fft_size, self.sr, fl, fu, threshold=0.15, dev=dev)
+        logging.info("Partials: pitch / magnitude maps are in .pitches / .magnitudes; the interactive plot is not shown")
 
 
 class FreehandTracker(Track):

@@ -1398,6 +1398,34 @@ def test_stft_above_8192_four_step(par, n_fft, hop, zp):
     assert relerr(got1, C.stft(np.ascontiguousarray(st[:, 1]), n_fft, hop, win, zp, mode=0, threads=8)) < TOL
 
 
+def test_partials_tracker_piptrack(par):
+    """PartialsTracker (util/wow_detection.py:361-387): the device piptrack against the oracle's restatement of librosa's
+    algorithm on the SAME magnitudes (parity of the restatement itself is unpinned: librosa is not in the reference
+    checkout), and the tracker's contract -- freqs stay the drawn trail, the maps land in .pitches / .magnitudes."""
+    from oracle import oracle_np as O
+    sr, n, n_fft, hop = 48000, 72000, 1024, 256
+    x = inputs.pilot(n, sr)
+    t = par.torch
+    mag = par.fourier.get_mag(t.from_numpy(x).cuda(), n_fft, hop, "hann", 1)
+    S = (mag.cpu().numpy().astype(np.float64) - 1e-7) * np.sqrt(n_fft)
+    for fmin, fmax, thr in ((3000.0, 5000.0, 0.15), (0.0, sr, 0.01), (150.0, 4000.0, 0.5)):
+        p_t, m_t = par.wow.piptrack_dev(mag, n_fft, sr, fmin, fmax, thr)
+        want_p, want_m = O.piptrack(S.astype(np.float32), sr, n_fft, fmin, fmax, thr)
+        got_p, got_m = p_t.cpu().numpy(), m_t.cpu().numpy()
+        # the device rebuilds S from mag in float32: a bin within one rounding of the threshold or of a tie may flip
+        same = (got_p != 0) == (want_p != 0)
+        assert same.mean() > 0.9999, (fmin, fmax, thr, same.mean())
+        assert np.max(np.abs(got_p - want_p)[same]) < 0.05 and np.max(np.abs(got_m - want_m)[same]) < 1e-4 * want_m.max()
+    trail = [(0.2, 3950.0), (1.3, 4080.0)]
+    tr = par.wow.wow_detectors["Partials"](mag, x[:, None], list(trail), n_fft, hop, sr, 0.5, "Linear")
+    base = par.wow.wow_detectors["Freehand Draw"](mag, x[:, None], list(trail), n_fft, hop, sr, 0.5, "Linear")
+    assert np.array_equal(tr.freqs, base.freqs) and np.array_equal(tr.times, base.times)
+    assert tuple(tr.pitches.shape) == tuple(mag.shape)
+    pk = tr.pitches.cpu().numpy()
+    hits = pk[:, 40:-40]                                      # the pilot's 4 kHz line, flutter included
+    assert ((hits > 3900) & (hits < 4100)).sum(axis=0).min() == 1
+
+
 def test_correlate_sources_flow(par):
     """pytapesynch_gui.py:108-133: band-pass both windows, then find_delay -- against the oracle's filter + find_delay
     (each pinned to the reference's goldens on its own), with and without a window / phase."""

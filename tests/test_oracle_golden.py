@@ -207,6 +207,25 @@ def test_config3_conditioning(golden):
     assert 1e-10 < df < 1e-8 and len(pos) == len(g["pos"]) and dp > 300 * df
 
 
+def test_piptrack_restatement_by_hand():
+    """oracle piptrack (librosa's published algorithm, parity unpinned) on columns whose answer is computable by hand:
+    a parabola sampled at integers has its vertex recovered exactly; thresholding, the frequency mask, the one-sided local
+    maximum rule (x[k] > x[k-1] and x[k] >= x[k+1]) and the never-selected edge bins."""
+    sr, n_fft = 8000, 16                        # bins 0..8, 500 Hz apart
+    k = np.arange(9.0)
+    col0 = np.maximum(0.0, 10.0 - 2.0 * (k - 3.3) ** 2)               # vertex at bin 3.3 (1650 Hz), height 10
+    col1 = np.array([5.0, 1.0, 4.0, 4.0, 1.0, 0.2, 0.3, 0.2, 9.0])    # plateau over bins 2-3
+    col2 = np.zeros(9)
+    S = np.stack((col0, col1, col2), axis=1)
+    p, m = O.piptrack(S, sr, n_fft, fmin=400.0, fmax=3900.0, threshold=0.15)
+    assert p.shape == S.shape and np.count_nonzero(p[:, 0]) == 1
+    assert abs(p[3, 0] - 3.3 * 500.0) < 1e-9 and abs(m[3, 0] - 10.0) < 1e-9
+    # column 1: bin 0 (left edge) and bin 8 (right edge, = sr/2, outside fmax) never count; the plateau's first bin wins
+    # (4 > 1 on the left, 4 >= 4 on the right), its second does not (4 > 4 fails); bin 6 (0.3) is under the threshold 1.35
+    assert list(np.nonzero(p[:, 1])[0]) == [2] and p[2, 1] == (2 + 0.5) * 500.0 and m[2, 1] == 4.0 + 0.5 * 1.5 * 0.5
+    assert not p[:, 2].any() and not m[:, 2].any()
+
+
 def test_linear_and_lag(golden):
     g = golden["linear_lag"]
     sig = inputs.noise(5000, 50)
