@@ -269,9 +269,10 @@ def config5_batch(a, ctx):
                                "the next file's plan runs on a side stream under K_sinc"},
             "roofline": {"bound": "hbm", "achieved": round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / world, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / world / HBM_PEAK_GBS, 5),
-                         "traffic": None, "kernel": "k_sinc_fused<2> (whole step, per GPU)",
-                         "note": "per-GPU whole-step rate x 8 algorithmic B per channel-sample; the per-kernel roofline with HIP-event "
-                                 "timing and PMC traffic is the N = 1 line's"},
+                         "traffic": None, "kernel": "k_sinc_fused<2> (whole step, per GPU)", "limited_by": "valu",
+                         "note": "per-GPU whole-step rate x 8 algorithmic B per channel-sample against the HBM roof the contract "
+                                 "names; what limits the kernel is VALU issue (the N = 1 line carries the per-kernel HIP-event "
+                                 "timing, PMC traffic and the VALU roofline)"},
         }
         print(json.dumps(res), flush=True)
     ctx.close()
@@ -442,14 +443,14 @@ def main():
                        "step": ("plan (device scans, cumsum checkpoints, block records) + fused K_sinc (outputs placed from 16-byte block records, no position array)" if fused else "plan (device scans) + K_pos fill (float64 position array) + K_sinc") + "; inputs resident in HBM"
                                + ("; batch pipelining: the plan of file k+1 runs on a side stream under K_sinc of file k (every step = one full plan + one full K_sinc)" if overlap else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": "k_sinc",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": "k_sinc", "limited_by": "valu",
                          "kernel_ms": round(k_ms, 4), "launches_per_step": n_launch // len(sinc_ms),
                          "samples_per_launch": int(samples_per_launch),
                          "note": "achieved = 8 algorithmic B/output sample (4 B in + 4 B out) / HIP-event K_sinc time; "
                                  "traffic = PMC HBM bytes/sample (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json) at this "
                                  "run's rate" + (": signal + output + 1 B/sample cumsum checkpoints + tile halos"
                                                  if fused else " incl. the 8 B float64 position read") +
-                                 "; HBM is NOT what limits this kernel (64 taps per output against 8 B): see roofline_valu"},
+                                 "; `bound` names the roof this object measures against (the contract's HBM roof on algorithmic bytes); the kernel is LIMITED BY VALU issue (64 taps per output against 8 B): roofline_valu is the roof it sits under; FETCH_SIZE x2 calibrated for this kernel's access patterns in profiles/r02_fetch_calibration.txt"},
         }
         if overlap:
             k_alone = min(alone)
