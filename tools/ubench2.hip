@@ -124,6 +124,10 @@ K_CVT(k_cvt_f64_f32, T_CVT_F64_F32, double, float)
 #define T_ADD_VV2(i) "v_add_f32 %" #i ", %9, %10\n"
 #define T_SUB_VV(i) "v_sub_f32 %" #i ", %" #i ", %9\n"
 #define T_PKFMA(i) "v_pk_fma_f32 %" #i ", %" #i ", %9, %10\n"
+#define T_PKFMA_S(i) "v_pk_fma_f32 %" #i ", %9, s[20:21], %" #i "\n"
+#define T_PKFMA_ACC(i) "v_pk_fma_f32 %" #i ", %9, %10, %" #i "\n"
+#define T_PKADD_SEL(i) "v_pk_add_f32 %" #i ", %9, %9 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n"
+#define T_PKMUL(i) "v_pk_mul_f32 %" #i ", %" #i ", %9\n"
 #define T_CNDM_S(i) "v_cndmask_b32 %" #i ", %" #i ", %9, s[20:21]\n"
 #define T_MOV_DPP(i) "v_mov_b32_dpp %" #i ", %9 row_shr:1 row_mask:0xf bank_mask:0xf\n"
 #define T_ADD_DPP(i) "v_add_f32_dpp %" #i ", %9, %" #i " row_shr:1 row_mask:0xf bank_mask:0xf\n"
@@ -156,6 +160,29 @@ __global__ void k_pkfma2(float* out, float a) {
   float s = 0; for (int i = 0; i < 8; ++i) s += v[i].x + v[i].y;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+
+// packed f32 forms the K_sinc tap loops could use: accumulate (e, d) += (E, D) * (A, nA) with the constant pair in SGPRs,
+// or in VGPRs; (E, D) = (sp + sm, sp - sm) from one register pair by op_sel / neg modifiers; packed multiply
+#define K_PK(NAME, T)                                                                                                   \
+  __global__ void NAME(float* out, float a) {                                                                            \
+    typedef float f2 __attribute__((ext_vector_type(2)));                                                               \
+    f2 v[8];                                                                                                             \
+    const f2 b = {a * 1.5f + threadIdx.x, a}, c = {a, a * 0.5f};                                                         \
+    for (int i = 0; i < 8; ++i) v[i] = (f2){threadIdx.x * 1e-3f + i + a, 1.0f * i};                                      \
+    for (int it = 0; it < ITERS; ++it) {                                                                                 \
+      asm volatile("s_mov_b32 s20, 0x3f800100\ns_mov_b32 s21, 0x3f7fff00\n" T(0) T(1) T(2) T(3) T(4) T(5) T(6) T(7)      \
+                   : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])       \
+                   : "s"(a), "v"(b), "v"(c)                                                                               \
+                   : "s20", "s21");                                                                                       \
+    }                                                                                                                    \
+    float s = 0;                                                                                                         \
+    for (int i = 0; i < 8; ++i) s += v[i].x + v[i].y;                                                                    \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                                      \
+  }
+K_PK(k_pkfma_sgpr, T_PKFMA_S)
+K_PK(k_pkfma_acc, T_PKFMA_ACC)
+K_PK(k_pkadd_sel, T_PKADD_SEL)
+K_PK(k_pkmul, T_PKMUL)
 
 // pure LDS reads at lane-consecutive addresses (conflict-free), results discarded by the hardware wait only
 template <int KIND>
@@ -249,7 +276,7 @@ int main(int argc, char** argv) {
   RUN32(k_mul24); RUN32(k_cmp32); RUN32(k_rnd32); RUN32(k_cvti32f32); RUN32(k_rcp32);
   RUN32(k_fma_vsv); RUN32(k_fma_svv); RUN32(k_fmac_sv); RUN32(k_fma_vvv); RUN32(k_fma_ssv); RUN32(k_fma_vss); RUN32(k_fma_neg);
   RUN32(k_fmaak); RUN32(k_fmamk); RUN32(k_mul_sv); RUN32(k_add_vv2); RUN32(k_sub_vv); RUN32(k_cndm_s); RUN32(k_mov_dpp); RUN32(k_add_dpp);
-  RUN32(k_pkfma2);
+  RUN32(k_pkfma2); RUN32(k_pkfma_sgpr); RUN32(k_pkfma_acc); RUN32(k_pkadd_sel); RUN32(k_pkmul);
   RUN64(k_fma64); RUN64(k_add64); RUN64(k_mul64); RUN64(k_rnd64); RUN64(k_rcp64); RUN64(k_lshladd64); RUN64(k_cmp64);
   RUN64(k_cvt_f64_i32); RUN64(k_cvt_i32_f64); RUN64(k_cvt_f32_f64); RUN64(k_cvt_f64_f32);
   report("ds_read_b32", time_ms([&] { hipLaunchKernelGGL(k_ldsread<0>, blocks, threads, 0, 0, (float*)out); }), ITERS * 8.0);
