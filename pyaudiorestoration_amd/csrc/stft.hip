@@ -748,14 +748,19 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) __attribute__((amdgpu_waves
       wq[q] = *reinterpret_cast<const float2*>(window + 2 * (j + q * T));
     }
   }
+  // A frame outside [0, n_frames) is transformed like any other and dropped at the overlap-add (`live` below): its rows
+  // only have to be readable, so the row index is clamped instead of selecting zeros element by element (32 v_cndmask per
+  // round).  Whatever the clamped row holds -- NaNs included -- never reaches the accumulator.
   auto fetch = [&](int r) {
-    const int64_t fr = F0 + r + u * s;
-    const bool live = r < s && fr >= 0 && fr < n_frames;
+    if (r >= s) return;
+    int64_t fr = F0 + r + u * s;
+    fr = fr < 0 ? 0 : (fr >= n_frames ? n_frames - 1 : fr);
+    const float2* row = spec + fr * bins;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int k = j + q * T;
-      pa[q] = live ? spec[fr * bins + k] : make_float2(0.0f, 0.0f);
-      pb[q] = live ? spec[fr * bins + (H - k)] : make_float2(0.0f, 0.0f);
+      pa[q] = row[k];
+      pb[q] = row[H - k];
     }
   };
   if (!kTab) fetch(0);                       // large transforms run at 2 waves per SIMD either way: keep their register
