@@ -1090,6 +1090,7 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
   for (int q = 1; q < kTileStarts; ++q) si += jr >= Sr[q];
   long long i = iT + si;
   long long k;                                                // step index of the block's first output in its segment
+  double kd;                                                  // the same as a double (from 32 bits where the table serves)
   int rem;                                                    // outputs of segment i from jb on (>= 1), clamped to 9
   long long slot0;                                            // checkpoint slot of the segment's step 0
   if (si < kTileStarts - 1 && Sr[0] > -0x40000000) {
@@ -1102,6 +1103,7 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
       }
     }
     k = jr - sr;
+    kd = (double)(jr - sr);
     const int d = nr - jr;
     rem = d < 9 ? d : 9;
     slot0 = ck_slot0(j0 + sr, i);
@@ -1113,6 +1115,7 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
     }
     const long long start = seg_start[i], d = seg_start[i + 1] - jb;
     k = jb - start;
+    kd = (double)k;
     rem = d < 9 ? (int)d : 9;
     slot0 = ck_slot0(start, i);
   }
@@ -1126,12 +1129,13 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
   const int uk = (int)(k & 7);
   static_assert(kCk == 8, "k >> 3");
   const double ckv = b ? ck[slot0 + b] : 0.0;
-  const BlockPoly q0 = block_poly(sf.foff, sf.step, sp0, (double)k, uk, ckv, sf.fast != 0);
+  const BlockPoly q0 = block_poly(sf.foff, sf.step, sp0, kd, uk, ckv, sf.fast != 0);
   const double r0 = rint(q0.a0);
-  const long long I0 = sf.A + (long long)r0;
+  const long long I0 = sf.A + (long long)(int)r0;             // |a0| >= 1e9 saturates: such a block is flagged (range0) and never placed from I
   const bool range0 = fabs(q0.a0) < 1.0e9 && sf.A > -(1ll << 61) && sf.A < (1ll << 61);
   const unsigned ustar = rem < 8 ? (unsigned)rem : 8u;
-  const long long ul = len_out - 1 - jb;                      // the file's last output reuses the previous period: slow path
+  // the file's last output reuses the previous period: slow path.  Only the last tile can hold it (wave-uniform test)
+  const long long ul = j0 + kSincTileOutputs >= len_out ? len_out - 1 - jb : -1;
   const unsigned slow0 = !(sf.fast == 2 && range0 && fabs(q0.a1m1) <= 0.03125) || (ul >= 0 && ul < (long long)ustar);
   unsigned slow1 = 0u, end1 = 0u;
   if (ustar < 8) {                                            // a segment starts at u = ustar (its piece: k_block_rec2)
@@ -1158,23 +1162,8 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
     hd->anchor = anchor;
     hd->iT = i;
     hd->mn_rel = (int)(I0 - anchor);
+    hd->c_last = 0;                                            // (unused: K_sinc takes its span from its own placements)
     hd->flags = range0 ? 0 : 1;
-  }
-  const long long jt = (j0 + kSincTileOutputs < len_out ? j0 + kSincTileOutputs : len_out) - 1;
-  if (jt >= jb && jt < jb + 8) {
-    const int ut = (int)(jt - jb);
-    double pl;
-    long long Al = sf.A;
-    if ((unsigned)ut < ustar) {
-      const double u = (double)ut;
-      pl = q0.a0 + u * (1.0 + q0.a1m1) + u * u * q0.a2;
-    } else {                                                  // in the next segment: its step ut - ustar
-      const BlockPoly b1 = block_poly(s1.foff, s1.step, sp1, 0.0, 0, 0.0, true);
-      const double u = (double)(ut - (int)ustar);
-      pl = b1.a0 + u * (1.0 + b1.a1m1) + u * u * b1.a2;
-      Al = s1.A;
-    }
-    hdr[T].c_last = Al + (long long)rint(pl);
   }
   }
 }
