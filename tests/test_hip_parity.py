@@ -1398,6 +1398,27 @@ def test_stft_above_8192_four_step(par, n_fft, hop, zp):
     assert relerr(got1, C.stft(np.ascontiguousarray(st[:, 1]), n_fft, hop, win, zp, mode=0, threads=8)) < TOL
 
 
+def test_two_rank_config5_bench_flow(par):
+    """bench.py --gpus 2 end to end on this box (both ranks share GPU 0): gloo rendezvous, the shared work queue, the
+    stereo batch pipeline and the reductions -- the flow the driver launches on 2/4/8 GPUs -- with a small archive."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29677")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29677", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--files", "12", "--ring", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["files"] == 12
+    assert r["config"]["channel_samples_per_step"] > 12 * 2 * 115_000_000 and r["value"] > 1000.0
+    lo, hi = r["config"]["files_per_rank_min_max"]
+    assert 0 <= lo <= hi <= 12
+
+
 def test_partials_tracker_piptrack(par):
     """PartialsTracker (util/wow_detection.py:361-387): the device piptrack against the oracle's restatement of librosa's
     algorithm on the SAME magnitudes (parity of the restatement itself is unpinned: librosa is not in the reference
