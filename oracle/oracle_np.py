@@ -9,6 +9,9 @@ Parity status: PINNED.  Every function below is checked in
 real reference (``oracle/gen_golden.py``, run in the build container where
 ``/root/reference`` exists; numpy 2.2.6 + scipy 1.15.3 are the de-facto pin of the
 reference's un-versioned third-party arithmetic).
+ONE EXCEPTION, parity UNPINNED: ``piptrack`` restates librosa's published algorithm
+(the reference's PartialsTracker calls librosa, which is neither in the reference
+checkout nor installed here); it is checked by hand-computed cases only.
 
 Each function cites the reference lines it restates (paths relative to the
 reference checkout).  Third-party arithmetic the reference itself delegates to
