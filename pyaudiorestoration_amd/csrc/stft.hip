@@ -955,9 +955,14 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
 size_t par_stft_big_scratch_bytes(int64_t n, int n_fft, int hop, int zeropad) {
   const int64_t M = (int64_t)n_fft * zeropad;
   if (M <= 8192 || M > (1ll << 21)) return 0;
+  // frames per batch: as many as fit 1 GiB of scratch (at least 16, at most what one grid dimension takes): 16-frame
+  // batches made the 16384-point transform launch-bound (880 batches of three small launches: 16 ms for a 10-minute file)
   int64_t frames = par_stft_frames(n, n_fft, hop);
-  if (frames > 16) frames = 16;
-  return (size_t)(2 * frames * (M / 2) * sizeof(float2));
+  const int64_t per_frame = 2 * (M / 2) * (int64_t)sizeof(float2);
+  int64_t cap = (1ll << 30) / per_frame;
+  cap = cap < 16 ? 16 : (cap > 32768 ? 32768 : cap);
+  if (frames > cap) frames = cap;
+  return (size_t)(frames * per_frame);
 }
 
 int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad,
@@ -984,8 +989,10 @@ int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, in
   const int64_t n_frames = par_stft_frames(n, n_fft, hop);
   const float scale = (float)(1.0 / sqrt((double)n_fft));
   float2* A = static_cast<float2*>(scratch);
-  for (int64_t f0 = 0; f0 < n_frames; f0 += 16) {
-    const int64_t nb = n_frames - f0 < 16 ? n_frames - f0 : 16;
+  int64_t batch = (int64_t)(scratch_bytes / (size_t)(2 * H * (int64_t)sizeof(float2)));     // frames the scratch holds
+  batch = batch > 32768 ? 32768 : batch;
+  for (int64_t f0 = 0; f0 < n_frames; f0 += batch) {
+    const int64_t nb = n_frames - f0 < batch ? n_frames - f0 : batch;
     float2* Z = A + nb * H;
 #define PAR_BIG_PASS(LS, PASS, NG, TW)                                                                                   \
   hipLaunchKernelGGL((k_bigfft<LS, PASS>), dim3((unsigned)((NG) / kBigC), (unsigned)nb), dim3((1 << LS) < 64 ? 64 : (1 << LS)), \
