@@ -72,6 +72,43 @@ __global__ void k_sos_chain(const double* __restrict__ r, int64_t nblk, double p
   }
 }
 
+// The chain over ~L/256 block boundaries is itself cut in two levels (a 10^8-sample signal has 4 10^5 blocks: one
+// thread walking them all took 40 % of the filter's time): super-blocks of kFiltSuper blocks are chained from a zero
+// state in parallel (k_sos_super_zero), one thread chains the few super-block boundaries with Q = P^kFiltSuper
+// (k_sos_chain on the super-block records), and every super-block then re-walks its own blocks from its true state
+// (k_sos_super_run).  Same affine maps, composed in a different order: float64 re-association only.
+constexpr int kFiltSuper = 256;
+__global__ void k_sos_super_zero(const double* __restrict__ r, int64_t nblk, double p00, double p01, double p10, double p11,
+                                 int64_t nsup, double* __restrict__ R) {
+  const int64_t B = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (B >= nsup) return;
+  const int64_t b0 = B * kFiltSuper, b1 = b0 + kFiltSuper < nblk ? b0 + kFiltSuper : nblk;
+  double z0 = 0.0, z1 = 0.0;
+  for (int64_t b = b0; b < b1; ++b) {
+    const double n0 = p00 * z0 + p01 * z1 + r[2 * b];
+    const double n1 = p10 * z0 + p11 * z1 + r[2 * b + 1];
+    z0 = n0;
+    z1 = n1;
+  }
+  R[2 * B] = z0;
+  R[2 * B + 1] = z1;
+}
+__global__ void k_sos_super_run(const double* __restrict__ r, int64_t nblk, double p00, double p01, double p10, double p11,
+                                int64_t nsup, const double* __restrict__ S, double* __restrict__ s) {
+  const int64_t B = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (B >= nsup) return;
+  const int64_t b0 = B * kFiltSuper, b1 = b0 + kFiltSuper < nblk ? b0 + kFiltSuper : nblk;
+  double z0 = S[2 * B], z1 = S[2 * B + 1];
+  for (int64_t b = b0; b < b1; ++b) {
+    s[2 * b] = z0;
+    s[2 * b + 1] = z1;
+    const double n0 = p00 * z0 + p01 * z1 + r[2 * b];
+    const double n1 = p10 * z0 + p11 * z1 + r[2 * b + 1];
+    z0 = n0;
+    z1 = n1;
+  }
+}
+
 __global__ void k_sos_block_run(const double* __restrict__ u, int64_t L, int reverse, Biquad q, int64_t nblk,
                                 const double* __restrict__ s, double* __restrict__ y) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,7 +138,8 @@ extern "C" {
 int64_t par_sosfiltfilt_work_len(int64_t n, int64_t padlen) {
   const int64_t L = n + 2 * padlen;
   const int64_t nblk = (L + par::kFiltBlock - 1) / par::kFiltBlock;
-  return 2 * L + 4 * nblk + 8;
+  const int64_t nsup = (nblk + par::kFiltSuper - 1) / par::kFiltSuper;
+  return 2 * L + 4 * nblk + 4 * nsup + 8;
 }
 
 int par_sosfiltfilt_f64(int device, const double* sos, const double* zi, int n_sections, const double* x, int64_t n,
@@ -119,8 +157,11 @@ int par_sosfiltfilt_f64(int device, const double* sos, const double* zi, int n_s
   const int64_t nblk = ceil_div(L, kFiltBlock);
   double* bufA = work;
   double* bufB = work + L;
+  const int64_t nsup = ceil_div(nblk, kFiltSuper);
   double* r = work + 2 * L;
   double* s = r + 2 * nblk;
+  double* Rs = s + 2 * nblk + 2;          // [2 nsup] zero-state end states of the super-blocks (behind the two latch slots)
+  double* Ss = Rs + 2 * nsup;             // [2 nsup] true start states of the super-blocks
   hipLaunchKernelGGL(k_odd_ext, dim3((unsigned)ceil_div(L, 256)), dim3(256), 0, st, x, n, padlen, bufA);
   double* cur = bufA;
   double* nxt = bufB;
@@ -150,8 +191,29 @@ int par_sosfiltfilt_f64(int device, const double* sos, const double* zi, int n_s
         PAR_HIP_CHECK(hipMemcpyAsync(latch, cur + (dir ? L - 1 : 0), sizeof(double), hipMemcpyDeviceToDevice, st));
       }
       hipLaunchKernelGGL(k_sos_block_zero, dim3((unsigned)ceil_div(nblk, 64)), dim3(64), 0, st, cur, L, dir, q, nblk, r);
-      hipLaunchKernelGGL(k_sos_chain, dim3(1), dim3(1), 0, st, r, nblk, p00, p01, p10, p11, zi[2 * sec], zi[2 * sec + 1],
-                         latch, s);
+      if (nsup <= 4) {
+        hipLaunchKernelGGL(k_sos_chain, dim3(1), dim3(1), 0, st, r, nblk, p00, p01, p10, p11, zi[2 * sec], zi[2 * sec + 1],
+                           latch, s);
+      } else {
+        // Q = P^kFiltSuper
+        double q00 = 1, q01 = 0, q10 = 0, q11 = 1, b00 = p00, b01 = p01, b10 = p10, b11 = p11;
+        for (int e = kFiltSuper; e > 0; e >>= 1) {
+          if (e & 1) {
+            const double t00 = q00 * b00 + q01 * b10, t01 = q00 * b01 + q01 * b11;
+            const double t10 = q10 * b00 + q11 * b10, t11 = q10 * b01 + q11 * b11;
+            q00 = t00; q01 = t01; q10 = t10; q11 = t11;
+          }
+          const double s00 = b00 * b00 + b01 * b10, s01 = b00 * b01 + b01 * b11;
+          const double s10 = b10 * b00 + b11 * b10, s11 = b10 * b01 + b11 * b11;
+          b00 = s00; b01 = s01; b10 = s10; b11 = s11;
+        }
+        hipLaunchKernelGGL(k_sos_super_zero, dim3((unsigned)ceil_div(nsup, 64)), dim3(64), 0, st, (const double*)r, nblk, p00, p01,
+                           p10, p11, nsup, Rs);
+        hipLaunchKernelGGL(k_sos_chain, dim3(1), dim3(1), 0, st, (const double*)Rs, nsup, q00, q01, q10, q11, zi[2 * sec],
+                           zi[2 * sec + 1], latch, Ss);
+        hipLaunchKernelGGL(k_sos_super_run, dim3((unsigned)ceil_div(nsup, 64)), dim3(64), 0, st, (const double*)r, nblk, p00, p01,
+                           p10, p11, nsup, (const double*)Ss, s);
+      }
       hipLaunchKernelGGL(k_sos_block_run, dim3((unsigned)ceil_div(nblk, 64)), dim3(64), 0, st, cur, L, dir, q, nblk, s, nxt);
       double* t = cur;
       cur = nxt;
