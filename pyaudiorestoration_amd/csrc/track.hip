@@ -104,8 +104,16 @@ __global__ void k_track_peak_fixed(const float* __restrict__ mag, int bins, int6
 __global__ __launch_bounds__(64) void k_track_cog(const float* __restrict__ mag, int bins, int64_t frame_0, int64_t count,
                                                    double* __restrict__ freqs, int fft_size, double sr, double tol,
                                                    int* __restrict__ empty) {
+  // Frame i + 1's band follows from frame i's result: the frames are walked by one wave.  What the walk can hide it
+  // hides: the band moves by whole bins and rarely, so the Hann weights and log2 of the bin frequencies are kept per
+  // lane while (NL, NU) stay put, and frame i + 1's magnitudes are fetched with frame i's band before frame i is
+  // reduced (a changed band refetches).  Bands wider than one wave's 64 lanes take the plain loop.
   const int lane = threadIdx.x;
   Band b = band_limits(freqs[0], tol, fft_size, sr, bins);
+  int cNL = -1, cNU = -1;                  // the band the cached per-lane terms belong to
+  double cw = 0.0, clog = 0.0;             // np.hanning(L)[lane], log2(frequency of bin NL + lane)
+  float pre = 0.0f;                        // magnitude of bin pNL + lane of the frame about to be reduced
+  int pNL = -1, pNU = -1;
   for (int64_t i = 0; i < count; ++i) {
     if (b.NL < 0 || b.NL >= b.NU) {                        // the reference's 0/0 centroid -> NaN -> int(round(nan)) raises
       if (lane == 0) atomicOr(empty, 1);
@@ -118,13 +126,32 @@ __global__ __launch_bounds__(64) void k_track_cog(const float* __restrict__ mag,
     const float* col = mag + (frame_0 + i) * bins;
     const int L = b.NU - b.NL;
     double num = 0.0, den = 0.0;
-    for (int k = lane; k < L; k += kWave) {
-      // np.hanning(L)[k] = 0.5 - 0.5*cos(2*pi*k/(L-1));  hanning(1) == [1.]
-      const double w = (L == 1) ? 1.0 : 0.5 - 0.5 * cos(2.0 * M_PI * (double)k / (double)(L - 1));
-      const double wm = w * (double)col[b.NL + k];
-      const double fr = (double)(b.NL + k) / (double)fft_size * sr;
-      num += wm * log2(fr);
-      den += wm;
+    if (L <= kWave) {
+      if (b.NL != cNL || b.NU != cNU) {
+        // np.hanning(L)[k] = 0.5 - 0.5*cos(2*pi*k/(L-1));  hanning(1) == [1.]
+        cw = lane < L ? ((L == 1) ? 1.0 : 0.5 - 0.5 * cos(2.0 * M_PI * (double)lane / (double)(L - 1))) : 0.0;
+        clog = lane < L ? log2((double)(b.NL + lane) / (double)fft_size * sr) : 0.0;
+        cNL = b.NL;
+        cNU = b.NU;
+      }
+      float m = (pNL == b.NL && pNU == b.NU) ? pre : (lane < L ? col[b.NL + lane] : 0.0f);
+      if (i + 1 < count) {                                 // next frame, this band: in flight under the reduction below
+        pre = lane < L ? col[bins + b.NL + lane] : 0.0f;
+        pNL = b.NL;
+        pNU = b.NU;
+      }
+      const double wm = cw * (double)m;
+      num = wm * clog;
+      den = wm;
+    } else {
+      pNL = -1;
+      for (int k = lane; k < L; k += kWave) {
+        const double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)k / (double)(L - 1));
+        const double wm = w * (double)col[b.NL + k];
+        const double fr = (double)(b.NL + k) / (double)fft_size * sr;
+        num += wm * log2(fr);
+        den += wm;
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
