@@ -34,6 +34,20 @@ class SpeedPlan:
         self.aux, self.fused_ok, self.max_out = aux, fused_ok, max_out
 
 
+def _max_out_for_bytes(L, nbytes, m):
+    """Largest output bound whose fused aux layout fits nbytes (par_fused_aux_bytes is monotone in max_out)."""
+    lo, hi = 0, max(int(nbytes) // 2, 1)               # > 2 bytes of aux per output: hi never fits... unless tiny
+    if int(L.par_fused_aux_bytes(hi, m)) <= nbytes:
+        return hi
+    while hi - lo > 1024:
+        mid = (lo + hi) // 2
+        if int(L.par_fused_aux_bytes(mid, m)) <= nbytes:
+            lo = mid
+        else:
+            hi = mid
+    return lo
+
+
 def fused_max_out(sampletimes_t, speeds_t):
     """Output bound used to size the fused plan's checkpoint buffer: the reference's own end_guess
     (util/resampling.py:108, int(mean(speeds) * span * 1.01)) plus the longest segment.  Buffer sizing only,
@@ -63,19 +77,32 @@ def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_h
     trimmed = ctypes.c_int(0)
     path = ctypes.c_int(0)
     if fused:
+        def plan_with(max_out_, aux_):
+            ok = ctypes.c_int(0)
+            _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m,
+                                                     int(num_imput_samples), _dev.ptr(work), work.numel(), _dev.ptr(aux_),
+                                                     aux_.numel(), max_out_, ctypes.byref(len_out), ctypes.byref(trimmed),
+                                                     int(force_host_chain), ctypes.byref(path), ctypes.byref(ok),
+                                                     s_ptr))
+            return SpeedPlan(speeds_t, m, work, len_out.value, bool(trimmed.value), path.value, dev, aux_, bool(ok.value),
+                             max_out_)
+
+        if max_out is None and aux is not None:
+            # A batch hands the previous item's buffer back: size the plan to what that buffer holds instead of running
+            # three device reductions with host read-backs for the bound (under a concurrent K_sinc each of them waits
+            # ~0.5 ms for a free CU: they, not the kernels, set the pace of a batch of 10-minute files).  A buffer that
+            # turns out too small makes the plan refuse the fused form: only then the bound is computed and the plan redone.
+            cap = _max_out_for_bytes(L, aux.numel(), m)
+            if cap > 0:
+                plan = plan_with(cap, aux)
+                if plan.fused_ok:
+                    return plan
         if max_out is None:
             max_out = fused_max_out(sampletimes_t, speeds_t)
         aux_bytes = int(L.par_fused_aux_bytes(max_out, m))
         if aux is None or aux.numel() < aux_bytes:
             aux = _dev.empty(aux_bytes, torch.uint8, dev)
-        ok = ctypes.c_int(0)
-        _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m,
-                                                 int(num_imput_samples), _dev.ptr(work), work.numel(), _dev.ptr(aux),
-                                                 aux.numel(), max_out, ctypes.byref(len_out), ctypes.byref(trimmed),
-                                                 int(force_host_chain), ctypes.byref(path), ctypes.byref(ok),
-                                                 s_ptr))
-        return SpeedPlan(speeds_t, m, work, len_out.value, bool(trimmed.value), path.value, dev, aux, bool(ok.value),
-                         max_out)
+        return plan_with(max_out, aux)
     _lib.check(L.par_speed_to_pos_plan_ex(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m, int(num_imput_samples),
                                           _dev.ptr(work), work.numel(), ctypes.byref(len_out), ctypes.byref(trimmed),
                                           1 if force_host_chain else 0, ctypes.byref(path), s_ptr))
