@@ -1033,8 +1033,7 @@ __device__ __forceinline__ BlockPoly block_poly(double foff, double step, double
 // every wave of k_block_rec)
 __global__ __launch_bounds__(256) void k_block_rec2(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
                                                     int64_t nseg, const SegFast* __restrict__ seg_fast,
-                                                    BlockRec2* __restrict__ rec2, BlockRec* __restrict__ rec_base,
-                                                    const PlanHeader* __restrict__ h) {
+                                                    BlockRec2* __restrict__ rec2, const PlanHeader* __restrict__ h) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 1 || i >= nseg || !h->ck_valid) return;
   const long long start = seg_start[i];
@@ -1050,8 +1049,7 @@ __global__ __launch_bounds__(256) void k_block_rec2(const double* __restrict__ s
   o2.F2 = (float)(a0 - r1);
   o2.e1b = (float)(b1.a1m1 - 2.0 * b1.a2 * u);
   o2.pad = 0u;
-  if (PAR_REC_INTERLEAVE == 1) reinterpret_cast<BlockRec2*>(rec_base)[(start >> 3) * 2 + 1] = o2;
-  else rec2[start >> 3] = o2;
+  rec2[start >> 3] = o2;
 }
 
 __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
@@ -1153,7 +1151,7 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
   o.e1 = (float)q0.a1m1;
   o.e2m = (__float_as_uint((float)q0.a2) & ~kRecFlagBits) | (ustar - 1u) | ((unsigned)(rem == 8) << 3) | (end1 << 4) |
           (slow0 << 5) | (slow1 << 6);
-  rec[g * kRecStride] = o;
+  rec[g] = o;
   // tile header: the block that opens the tile writes anchor / first centre, the one that holds the tile's last output
   // writes the last centre (approximate placements are fine here: K_sinc stages one sample of slack on either side)
   if (jr == 0) {
@@ -1657,7 +1655,7 @@ static void launch_block_rec(const double* speeds, const par::PlanView& pv, int6
                      (const double*)a.ck, (const int64_t*)a.tile_seg, (const long long*)a.tile_st, (const SegFast*)a.seg_fast,
                      a.hdr, a.rec, (const PlanHeader*)pv.hdr);
   hipLaunchKernelGGL(k_block_rec2, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, s, speeds, pv.seg_start, nseg,
-                     (const SegFast*)a.seg_fast, a.rec2, a.rec, (const PlanHeader*)pv.hdr);
+                     (const SegFast*)a.seg_fast, a.rec2, (const PlanHeader*)pv.hdr);
 }
 
 // Shared implementation.  aux (optional, device): cumsum checkpoints for the fused resampler.

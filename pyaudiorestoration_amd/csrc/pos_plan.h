@@ -182,16 +182,10 @@ struct BlockRec2 {
   unsigned pad;
 };
 static_assert(sizeof(BlockRec2) == 16, "BlockRec2 is one 16-byte word");
-// Experiment switch, measured on one box (K_sinc alone / pipelined step, ms): 0 = two arrays, second pieces fetched only by
-// the lanes that need them, behind the first records (6.05 / 7.20); 1 = a block's two records share one 32-byte slot, both
-// loaded up front (5.94 / 7.93: the plan's 16-byte stores at a 32-byte stride are partial-granule writes and its tail
-// lands on the critical path); 2 = two arrays, both loaded up front (5.69 vs 5.82 alone, 6.90 vs 6.88 pipelined: the step is
-// bound by the VALU work of K_sinc plus the plan, shorter latency chains do not show; +2 B/sample of reads)
-#ifndef PAR_REC_INTERLEAVE
-#define PAR_REC_INTERLEAVE 0
-#endif
-#define PAR_REC_BOTH (PAR_REC_INTERLEAVE != 0)
-constexpr int kRecStride = PAR_REC_INTERLEAVE == 1 ? 2 : 1;     // 16-byte words between the records of consecutive blocks
+// (Measured and not kept, one box, K_sinc alone / pipelined step in ms: both records of a block in one 32-byte slot and
+// loaded up front 5.94 / 7.93 against 6.05 / 7.20 -- the plan's 16-byte stores at a 32-byte stride are partial-granule
+// writes and its tail lands on the critical path; two arrays, both loaded up front 5.69 / 6.90 against 5.82 / 6.88 -- the step
+// is bound by the VALU work of K_sinc plus the plan, a shorter load chain does not show.)
 // Tile header: everything K_sinc needs before it can stage a tile's input span, in ONE scalar load.
 struct TileHdr {
   long long anchor;         // even integer next to the tile's first position
