@@ -289,7 +289,8 @@ int par_track_corr_f64(int device, const float* mag, int64_t n_frames, int bins,
  *                       the lags around it are re-evaluated as float64 dot products and parabolic() (:42-46) runs on
  *                       those; *delay = peak - na//2 (host), *corr = its height.  A peak on the last lag is the
  *                       reference's IndexError: PAR_ERR_INDEX.  Synchronises.
- *   scratch             device bytes of par_xcorr_scratch_bytes(na, nb); na + nb - 1 <= 2^20 (else PAR_ERR_UNSUPPORTED) */
+ *   scratch             device bytes of par_xcorr_scratch_bytes(na, nb).  na + nb - 1 <= 2^20: one transform; longer signals
+ *                       (up to 2^25 samples each, else PAR_ERR_UNSUPPORTED) are correlated in pairs of 2^19-sample sections */
 size_t par_xcorr_scratch_bytes(int64_t na, int64_t nb);
 int par_xcorr_f64(int device, const double* a, int64_t na, const double* b, int64_t nb, void* scratch, size_t scratch_bytes,
                   double* full, void* stream);

@@ -555,6 +555,13 @@ __global__ __launch_bounds__(256) void k_xc_unpack(const float2* __restrict__ Y,
   if (j >= n_full) return;
   full[j] = (double)Y[(j - (nb - 1)) & (N - 1)].x / ((double)N * norms[0] * norms[1]);
 }
+// sectioned form: full[j] += circ[(j - (nbq-1)) mod N] / (N |a| |b|) for the n_local lags of one section pair
+__global__ __launch_bounds__(256) void k_xc_unpack_acc(const float2* __restrict__ Y, int64_t N, int64_t nbq, int64_t n_local,
+                                                       const double* __restrict__ norms, double* __restrict__ full) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_local) return;
+  full[j] += (double)Y[(j - (nbq - 1)) & (N - 1)].x / ((double)N * norms[0] * norms[1]);
+}
 // norms[0] = |a|, norms[1] = |b| (float64, one workgroup each)
 __global__ __launch_bounds__(1024) void k_xc_norms(const double* __restrict__ a, int64_t na, const double* __restrict__ b,
                                                    int64_t nb, double* __restrict__ norms) {
@@ -1024,9 +1031,12 @@ int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, in
 // X2: xcorr(a, b, 'full') of two float64 device signals (util/correlation.py:6-13): full[na + nb - 1] float64 out.
 // scratch: par_xcorr_scratch_bytes(na, nb) device bytes.  The values carry the float32 transform's error (~1e-6 of the
 // peak); par_find_delay_f64 refines what the tape-sync tool needs exactly.
+constexpr int64_t kXcMaxFft = 1ll << 20;         // the four-step transform's largest size
+constexpr int64_t kXcSection = kXcMaxFft / 2;    // longer signals are correlated section pair by section pair
+constexpr int64_t kXcMaxLen = 1ll << 25;         // per signal (4096 section pairs of two 2^20-point transforms each)
 static int64_t xc_fft_len(int64_t na, int64_t nb) {
   int64_t N = 8192;
-  while (N < na + nb - 1) N <<= 1;
+  while (N < na + nb - 1 && N < kXcMaxFft) N <<= 1;
   return N;
 }
 size_t par_xcorr_scratch_bytes(int64_t na, int64_t nb) {
@@ -1038,12 +1048,37 @@ static int xcorr_full(int device, const double* a, int64_t na, const double* b, 
                       double** norms_out, hipStream_t s) {
   using namespace par;
   const int64_t N = xc_fft_len(na, nb);
-  PAR_REQUIRE(N <= (1ll << 20), PAR_ERR_UNSUPPORTED, "xcorr: %lld + %lld samples need a transform of %lld points (limit 2^20)",
-              (long long)na, (long long)nb, (long long)N);
+  PAR_REQUIRE(na <= kXcMaxLen && nb <= kXcMaxLen, PAR_ERR_UNSUPPORTED, "xcorr: %lld / %lld samples (limit 2^25 per signal)",
+              (long long)na, (long long)nb);
   float2* Z = static_cast<float2*>(scratch);
   float2* Y = Z + N;
   double* norms = reinterpret_cast<double*>(Y + N);
   hipLaunchKernelGGL(k_xc_norms, dim3(2), dim3(1024), 0, s, a, na, b, nb, norms);
+  if (na + nb - 1 > N) {
+    // Windows of more than ~2.7 s at 192 kHz: correlation is bilinear, so the signals are cut into sections of 2^19
+    // samples and every pair (p, q) adds its 2^20-point correlation into full at the lag offset p - q sections.  The
+    // float32 transforms only have to FIND the peak; par_find_delay_f64 re-evaluates the lags around it exactly.
+    PAR_HIP_CHECK(hipMemsetAsync(full, 0, (size_t)(na + nb - 1) * sizeof(double), s));
+    for (int64_t pa = 0; pa < na; pa += kXcSection) {
+      const int64_t la = na - pa < kXcSection ? na - pa : kXcSection;
+      for (int64_t qb = 0; qb < nb; qb += kXcSection) {
+        const int64_t lb = nb - qb < kXcSection ? nb - qb : kXcSection;
+        hipLaunchKernelGGL(k_xc_pack, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, a + pa, la, b + qb, lb, Z, N);
+        int rc = big_fft_c2c(device, Z, Y, N, 1, s);
+        if (rc != PAR_OK) return rc;
+        hipLaunchKernelGGL(k_xc_cross, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, (const float2*)Y, Z, N);
+        rc = big_fft_c2c(device, Z, Y, N, 1, s);
+        if (rc != PAR_OK) return rc;
+        // local index jl = lag + lb - 1; global index = lag + (pa - qb) + nb - 1
+        const int64_t joff = pa - qb + nb - lb;
+        hipLaunchKernelGGL(k_xc_unpack_acc, dim3((unsigned)ceil_div(la + lb - 1, 256)), dim3(256), 0, s, (const float2*)Y, N, lb,
+                           la + lb - 1, (const double*)norms, full + joff);
+      }
+    }
+    PAR_HIP_CHECK(hipGetLastError());
+    *norms_out = norms;
+    return PAR_OK;
+  }
   hipLaunchKernelGGL(k_xc_pack, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, s, a, na, b, nb, Z, N);
   int rc = big_fft_c2c(device, Z, Y, N, 1, s);                       // Y = FFT(a + i b)
   if (rc != PAR_OK) return rc;

@@ -48,13 +48,14 @@ def same_resample(fused, via_pos):
 def par():
     import torch
     assert torch.cuda.is_available(), "GPU tests need a GPU"
-    from pyaudiorestoration_amd import _lib, fourier, resampling, wow_detection, filters, pipeline
+    from pyaudiorestoration_amd import _lib, correlation, fourier, resampling, wow_detection, filters, pipeline
     assert _lib.lib().par_device_count() >= 1
 
     class P:
         pass
     p = P()
     p.fourier, p.resampling, p.wow, p.filters, p.pipeline, p.torch = fourier, resampling, wow_detection, filters, pipeline, torch
+    p.correlation = correlation
     return p
 
 
@@ -1450,6 +1451,26 @@ def test_partials_tracker_piptrack(par):
     pk = tr.pitches.cpu().numpy()
     hits = pk[:, 40:-40]                                      # the pilot's 4 kHz line, flutter included
     assert ((hits > 3900) & (hits < 4100)).sum(axis=0).min() == 1
+
+
+def test_correlation_of_long_windows(par):
+    """Windows longer than one 2^20-point transform can hold (2.7 s at 192 kHz) are correlated section pair by section
+    pair: full correlation against scipy's FFT method, delay and height against the oracle's find_delay."""
+    import scipy.signal
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(21)
+    na, nb = 1_300_000, 1_100_000
+    base = np.convolve(rng.standard_normal(na + 5000), np.hanning(15) / 7, mode="same")
+    a = base[2500:2500 + na].copy()
+    b = 0.7 * np.interp(np.arange(nb) + 2500 - 811.4, np.arange(len(base)), base) + 0.02 * rng.standard_normal(nb)
+    full = par.correlation.xcorr(a, b, mode="full")
+    an, bn = a / np.linalg.norm(a), b / np.linalg.norm(b)
+    want = scipy.signal.correlate(an, bn, mode="full", method="fft")
+    assert full.shape == want.shape and np.max(np.abs(full - want)) < 5e-6
+    m = 1_050_000                                           # equal lengths: the delay is then the plain lag
+    got = par.correlation.find_delay(a[:m].copy(), b[:m].copy())
+    ref = O.find_delay(a[:m].copy(), b[:m].copy())
+    assert abs(got[0] - ref[0]) < 1e-5 and abs(got[1] - ref[1]) < 1e-8 and abs(abs(got[0]) - 811.4) < 0.2, (got, ref)
 
 
 def test_correlate_sources_flow(par):
