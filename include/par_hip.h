@@ -57,7 +57,7 @@ int par_stream_sync(int device, void* stream);
  *   out      device, FRAME-MAJOR: mode 0 -> complex64 [frames][bins] interleaved re,im
  *                                 mode 1 -> float32   [frames][bins]
  *            bins = n_fft*zeropad/2+1, frames = par_stft_frames(n, n_fft, hop)
- * n_fft*zeropad must be a power of two in [16, 8192] (larger: par_stft_big_f32); otherwise PAR_ERR_UNSUPPORTED.
+ * n_fft*zeropad must be a power of two in [16, 16384] (larger: par_stft_big_f32); otherwise PAR_ERR_UNSUPPORTED.
  */
 int64_t par_stft_frames(int64_t n, int n_fft, int hop);
 int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad,

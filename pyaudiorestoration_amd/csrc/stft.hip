@@ -917,8 +917,8 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
   PAR_REQUIRE(n >= 1 && x_stride >= 1 && hop >= 1 && zeropad >= 1 && n_fft >= 2, PAR_ERR_ARG, "par_stft_f32: bad sizes");
   PAR_REQUIRE(mode == 0 || mode == 1, PAR_ERR_ARG, "par_stft_f32: mode must be 0 (complex) or 1 (magnitude)");
   const int64_t M64 = (int64_t)n_fft * zeropad;
-  PAR_REQUIRE(M64 >= 16 && M64 <= 8192 && (M64 & (M64 - 1)) == 0 && (n_fft % 2) == 0, PAR_ERR_UNSUPPORTED,
-              "par_stft_f32: n_fft*zeropad=%lld is not a power of two in [16, 8192]", (long long)M64);
+  PAR_REQUIRE(M64 >= 16 && M64 <= 16384 && (M64 & (M64 - 1)) == 0 && (n_fft % 2) == 0, PAR_ERR_UNSUPPORTED,
+              "par_stft_f32: n_fft*zeropad=%lld is not a power of two in [16, 16384]", (long long)M64);
   const int M = (int)M64, H = M / 2;
   PAR_HIP_CHECK(hipSetDevice(device));
   Twiddles tw;
@@ -949,6 +949,21 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
     case 10: PAR_STFT_LAUNCH(10); break;
     case 11: PAR_STFT_LAUNCH(11); break;
     case 12: PAR_STFT_LAUNCH(12); break;
+    case 13: {
+      // 16384 points (the GUI's 4096 x zero-padding 4): one 1024-lane workgroup per frame, 72 KB of the CU's 160 KB of LDS
+      // (above the 64 KB a kernel gets by default: raised per kernel once)
+      constexpr int kLds13 = FftGeom<13>::Frames * FftGeom<13>::FrameLds * (int)sizeof(float2) + (PAR_STFT_STORE == 3 ? (8192 + 4) * 4 : 0);
+      static bool raised = false;
+      if (!raised) {
+        PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft<13, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds13));
+        PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft<13, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds13));
+        PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft<13, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds13));
+        PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft<13, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds13));
+        raised = true;
+      }
+      PAR_STFT_LAUNCH(13);
+      break;
+    }
     default: PAR_REQUIRE(false, PAR_ERR_UNSUPPORTED, "par_stft_f32: unsupported size");
   }
 #undef PAR_STFT_LAUNCH
