@@ -1383,9 +1383,11 @@ def test_config4_x256_tiles_one_launch(par):
     assert worst < TOL, worst
 
 
-@pytest.mark.parametrize("n_fft,hop,zp", [(16384, 4096, 1), (65536, 16384, 1), (4096, 1024, 4), (32768, 5000, 2), (1048576, 262144, 1)])
+@pytest.mark.parametrize("n_fft,hop,zp", [(16384, 4096, 1), (65536, 16384, 1), (4096, 1024, 4), (32768, 5000, 2), (1048576, 262144, 1),
+                                           (32768, 8192, 1), (8192, 3000, 4)])
 def test_stft_above_8192_four_step(par, n_fft, hop, zp):
-    """FFT sizes above 8192 (the GUI offers up to 2^20, util/widgets.py:333-349): the four-step transform against the C
+    """FFT sizes above 8192 (the GUI offers up to 2^20, util/widgets.py:333-349): the 16384-point single-workgroup kernel and
+    the four-step transform (from 32768 points on) against the C
     oracle (float64 FFT of the same float32 frames), complex and magnitude, frame counts exact; strided input."""
     from oracle import oracle_c as C
     import scipy.signal
