@@ -199,9 +199,23 @@ def stereo_secondary(dev, sr=192000, seconds=600.0, nt=32):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
+    # the same file as a batch of 48 through the library's batch driver (next file's plan on a side stream under K_sinc):
+    # what one GPU does in the N > 1 / --config5 mode
+    from pyaudiorestoration_amd import resampling
+    del out, work, aux
+    items = [(st, sp, sig)] * 48
+    for _ in resampling.varispeed_batch_dev(items[:3], nt, dev=dev):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in resampling.varispeed_batch_dev(items, nt, dev=dev):
+        pass
+    torch.cuda.synchronize()
+    dtb = (time.perf_counter() - t0) / len(items)
     return {"workload": f"config 5 work item: {seconds:g}-s {sr} Hz stereo file, interleaved; 1 plan + 1 stereo fused K_sinc launch",
             "channel_samples_out": 2 * len_out.value, "ms_per_file": round(dt * 1e3, 3),
-            "Msamples/s": round(2 * len_out.value / dt / 1e6, 1)}
+            "Msamples/s": round(2 * len_out.value / dt / 1e6, 1),
+            "batched_ms_per_file": round(dtb * 1e3, 3), "batched_Msamples/s": round(2 * len_out.value / dtb / 1e6, 1)}
 
 
 def config5_batch(a, ctx):
