@@ -397,98 +397,202 @@ static int get_big_twiddles(int device, int H, BigTw* out) {
   return PAR_OK;
 }
 
-// PASS 0: columns of the packed windowed frame -> A;  PASS 1: rows of A -> Z.  grid (groups of kBigC transforms, frames)
+// PASS 0: columns of the packed windowed frame -> A;  PASS 1: rows of A -> Z.
+// grid: round_up(groups * n_batch, 8) workgroups in ONE dimension, group = kBigC adjacent transforms of one frame.  The
+// hardware deals workgroups round-robin to the 8 XCDs, so neighbouring column groups -- whose 64-byte runs are the two
+// halves of the same 128-byte lines, on the load and on the store side -- used to meet in eight different L2s and reach
+// HBM as scattered half-line accesses (1.4 GB moved in 0.79 ms).  xcd_contiguous_block() hands every XCD a contiguous
+// range of (frame, group) pairs instead, so the halves merge in one L2.
+__host__ __device__ constexpr int64_t round_up8(int64_t v) { return (v + 7) & ~7ll; }
 template <int LOGS, int PASS, int SRC = 0>
-__global__ __launch_bounds__((1 << LOGS) < 64 ? 64 : (1 << LOGS)) void k_bigfft(const float* __restrict__ x, int64_t n,
-                                                                             int64_t x_stride, int n_fft, int hop,
-                                                                             const float* __restrict__ window,
-                                                                             const float2* __restrict__ tw,
-                                                                             const float2* __restrict__ tlo,
-                                                                             const float2* __restrict__ thi,
-                                                                             float2* __restrict__ A, float2* __restrict__ Z,
-                                                                             int64_t f_first, int logN1, int logN2) {
+__global__ __launch_bounds__(1 << LOGS) void k_bigfft(const float* __restrict__ x, int64_t n, int64_t x_stride, int n_fft, int hop,
+                                                      const float* __restrict__ window, const float2* __restrict__ tw,
+                                                      const float2* __restrict__ tlo, const float2* __restrict__ thi,
+                                                      float2* __restrict__ A, float2* __restrict__ Z, int64_t f_first,
+                                                      int logN1, int logN2, int64_t n_batch) {
+  static_assert(LOGS >= 6 && LOGS <= 10, "one lane per 8 points, kBigC transforms side by side: blockDim.x == 1 << LOGS");
   constexpr int S = 1 << LOGS, T = S / 8;
   constexpr int FrameLds = S + S / 8 + 8;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   const int N1 = 1 << logN1, N2 = 1 << logN2;
   const int64_t H = (int64_t)N1 * N2;
-  const int tid = threadIdx.x, nthreads = blockDim.x;
-  const int g0 = blockIdx.x * kBigC;                       // first column (pass 0) / row (pass 1) of the group
-  const int64_t fb = blockIdx.y;                           // frame of this batch
+  const int tid = threadIdx.x;
+  const int groups = (PASS == 0 ? N2 : N1) / kBigC;
+  const int64_t w = xcd_contiguous_block(groups * n_batch);
+  if (w >= groups * n_batch) return;
+  const int64_t fb = w / groups;                           // frame of this batch
+  const int g0 = (int)(w - fb * groups) * kBigC;           // first column (pass 0) / row (pass 1) of the group
   float2* Ab = A + fb * H;
+  // every loop below runs kBigC times with compile-time bounds: all of a thread's loads are in flight together
   if (PASS == 0 && SRC == 1) {                             // plain complex input, transformed in place
-    for (int idx = tid; idx < kBigC * S; idx += nthreads) {
-      const int n1 = idx / kBigC, f = idx % kBigC;
+#pragma unroll
+    for (int it = 0; it < kBigC; ++it) {
+      const int idx = tid + it * S, n1 = idx / kBigC, f = idx % kBigC;
       lds[f * FrameLds + lpad(n1)] = Ab[(int64_t)(g0 + f) + (int64_t)N2 * n1];
     }
   } else if (PASS == 0) {
     const long long base = (long long)(f_first + fb) * hop - (n_fft >> 1);
-    for (int idx = tid; idx < kBigC * S; idx += nthreads) {
-      const int n1 = idx / kBigC, f = idx % kBigC;
-      const long long t0 = 2ll * ((long long)(g0 + f) + (long long)N2 * n1);      // first real sample of the packed pair
-      float2 z = make_float2(0.0f, 0.0f);
-      if (t0 < n_fft) z.x = window[t0] * x[reflect_index(base + t0, n) * x_stride];
-      if (t0 + 1 < n_fft) z.y = window[t0 + 1] * x[reflect_index(base + t0 + 1, n) * x_stride];
-      lds[f * FrameLds + lpad(n1)] = z;
+    // a frame that lies inside the signal (all but the first and last few) indexes it directly; the reflect fold is a
+    // 64-bit modulo per sample
+    if (base >= 0 && base + n_fft <= (long long)n) {
+      const float* xs = x + base * x_stride;
+      // contiguous signal, frame starting on an 8-byte boundary (even hop and n_fft / 2): the two samples of a packed
+      // point arrive in one load
+      const bool paired = x_stride == 1 && (reinterpret_cast<uintptr_t>(xs) & 7) == 0;
+      float2 z[kBigC];
+#pragma unroll
+      for (int it = 0; it < kBigC; ++it) {
+        const int idx = tid + it * S, n1 = idx / kBigC, f = idx % kBigC;
+        const int t0 = 2 * (g0 + f + N2 * n1);             // first real sample of the packed pair (< n_fft * zeropad <= 2^21)
+        z[it] = make_float2(0.0f, 0.0f);
+        if (t0 + 1 < n_fft) {
+          const float2 wv = *reinterpret_cast<const float2*>(window + t0);
+          const float2 xv = paired ? *reinterpret_cast<const float2*>(xs + t0)
+                                   : make_float2(xs[(int64_t)t0 * x_stride], xs[(int64_t)(t0 + 1) * x_stride]);
+          z[it].x = wv.x * xv.x;
+          z[it].y = wv.y * xv.y;
+        } else if (t0 < n_fft) {
+          z[it].x = window[t0] * xs[(int64_t)t0 * x_stride];
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < kBigC; ++it) {
+        const int idx = tid + it * S, n1 = idx / kBigC, f = idx % kBigC;
+        lds[f * FrameLds + lpad(n1)] = z[it];
+      }
+    } else {
+      for (int it = 0; it < kBigC; ++it) {
+        const int idx = tid + it * S, n1 = idx / kBigC, f = idx % kBigC;
+        const long long t0 = 2ll * ((long long)(g0 + f) + (long long)N2 * n1);
+        float2 z = make_float2(0.0f, 0.0f);
+        if (t0 < n_fft) z.x = window[t0] * x[reflect_index(base + t0, n) * x_stride];
+        if (t0 + 1 < n_fft) z.y = window[t0 + 1] * x[reflect_index(base + t0 + 1, n) * x_stride];
+        lds[f * FrameLds + lpad(n1)] = z;
+      }
     }
   } else {
-    for (int idx = tid; idx < kBigC * S; idx += nthreads) {
-      const int f = idx / S, n2 = idx % S;
-      lds[f * FrameLds + lpad(n2)] = Ab[(int64_t)(g0 + f) * N2 + n2];
-    }
+#pragma unroll
+    for (int f = 0; f < kBigC; ++f) lds[f * FrameLds + lpad(tid)] = Ab[(int64_t)(g0 + f) * N2 + tid];
   }
   __syncthreads();
-  // kBigC transforms side by side: thread -> (transform f, lane j); a short transform leaves threads idle
+  // kBigC transforms side by side: thread -> (transform f, lane j)
   const int f = tid / T, j = tid - f * T;
-  const bool act = f < kBigC;
-  float2* X = lds + (act ? f : 0) * FrameLds;
+  float2* X = lds + f * FrameLds;
   float2 v[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) v[q] = act ? X[lpad(j + q * T)] : make_float2(0.0f, 0.0f);
-  __syncthreads();
-  if (T > kWave || act) fft_core<LOGS>(v, act ? X : lds + kBigC * FrameLds, j, tw);
+  for (int q = 0; q < 8; ++q) v[q] = X[lpad(j + q * T)];
+  fft_core<LOGS>(v, X, j, tw);
   __syncthreads();
   if (PASS == 0) {
-    for (int idx = tid; idx < kBigC * S; idx += nthreads) {
-      const int k1 = idx / kBigC, ff = idx % kBigC;
-      const long long m = (long long)(g0 + ff) * k1;       // < H
-      const float2 w = cmul(thi[m / kBigR], tlo[m % kBigR]);
-      Ab[(int64_t)k1 * N2 + g0 + ff] = cmul(lds[ff * FrameLds + lpad(k1)], w);
+    float2 wv[kBigC];
+#pragma unroll
+    for (int it = 0; it < kBigC; ++it) {
+      const int idx = tid + it * S, k1 = idx / kBigC, ff = idx % kBigC;
+      const unsigned m = (unsigned)(g0 + ff) * (unsigned)k1;       // < H <= 2^20
+      wv[it] = cmul(thi[m / kBigR], tlo[m % kBigR]);
+    }
+#pragma unroll
+    for (int it = 0; it < kBigC; ++it) {
+      const int idx = tid + it * S, k1 = idx / kBigC, ff = idx % kBigC;
+      Ab[(int64_t)k1 * N2 + g0 + ff] = cmul(lds[ff * FrameLds + lpad(k1)], wv[it]);
     }
   } else {
     float2* Zb = Z + fb * H;
-    for (int idx = tid; idx < kBigC * S; idx += nthreads) {
-      const int k2 = idx / kBigC, ff = idx % kBigC;
+#pragma unroll
+    for (int it = 0; it < kBigC; ++it) {
+      const int idx = tid + it * S, k2 = idx / kBigC, ff = idx % kBigC;
       Zb[(int64_t)(g0 + ff) + (int64_t)N1 * k2] = lds[ff * FrameLds + lpad(k2)];
     }
   }
 }
 
-// real-FFT bins from the H-point spectrum of the packed frame: X[k] = (Z[k] + conj Z[H-k])/2 - i W_M^k (Z[k] - conj Z[H-k])/2
-__global__ __launch_bounds__(256) void k_big_untangle(const float2* __restrict__ Z, int64_t H, const float2* __restrict__ tlo,
-                                                      const float2* __restrict__ thi, float* __restrict__ out,
-                                                      int64_t f_first, int mode, float scale) {
-  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (k > H / 2) return;
-  const int64_t fb = blockIdx.y, fr = f_first + fb, bins = H + 1;
-  const float2* Zb = Z + fb * H;
-  const float2 zk = Zb[k];
-  const float2 zc = cconj(Zb[(H - k) & (H - 1)]);
-  // W_M^k = exp(-2 pi i k / (2H)): the half-step table is the H-table of 2H points -> evaluate in float64
-  // (H/2 + 1 sincos per frame against H log H butterflies)
-  double sn, cs;
-  sincospi(-(double)k / (double)H, &sn, &cs);
-  const float2 pw = make_float2((float)cs, (float)sn);
-  const float2 ev = cadd(zk, zc);
-  const float2 t = cmul(pw, csub(zk, zc));
+// Row pass of the STFT, fused with the untangle to the H+1 real-FFT bins
+//   X[k] = (Z[k] + conj Z[H-k])/2 - i W_2H^k (Z[k] - conj Z[H-k])/2,      k = k1 + N1 k2,  H - k = (N1 - k1) + N1 (N2 - 1 - k2):
+// a bin's partner lives in row N1 - k1, so a workgroup transforms the kBigC rows k1 = 8m+1 .. 8m+8 AND their partners
+// N1-8m-8 .. N1-8m-1 (two rounds through the core, all 16 spectra staying in LDS) and writes both output runs itself:
+// the H-point spectrum Z never travels to HBM (it used to be written, then read back by a separate untangle kernel:
+// 2 x 8 H bytes per frame of the pass's 3 x 8 H).  Row N1/2 pairs with itself and rides on both sides of the last
+// regular group; row 0 pairs with itself under k2 -> (N2 - k2) mod N2 and has the extra group blockIdx.x == N1/16.
+// tlo2/thi2: the two-level table of the 2H-point circle.  MODE 0: complex bins, 1: |X| + 1e-7.
+template <int LOGS, int MODE>
+__global__ __launch_bounds__(1 << LOGS) void k_bigfft_rows_out(const float2* __restrict__ A, const float2* __restrict__ tw,
+                                                               const float2* __restrict__ tlo2, const float2* __restrict__ thi2,
+                                                               float* __restrict__ out, int64_t f_first, int logN1, float scale,
+                                                               int64_t n_batch) {
+  static_assert(LOGS >= 6 && LOGS <= 10, "one lane per 8 points, 8 transforms per round");
+  constexpr int S = 1 << LOGS, T = S / 8, N2 = S;
+  constexpr int FrameLds = S + S / 8 + 8;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const int N1 = 1 << logN1;
+  const int64_t H = (int64_t)N1 * N2, bins = H + 1;
+  const int tid = threadIdx.x;                               // blockDim.x == S
+  // one grid dimension, XCD-contiguous like k_bigfft: neighbouring groups write neighbouring 32/64-byte runs
+  const int groups = N1 / (2 * kBigC) + 1;
+  const int64_t w = xcd_contiguous_block(groups * n_batch);
+  if (w >= groups * n_batch) return;
+  const int64_t fb = w / groups, fr = f_first + fb;
+  const float2* Ab = A + fb * H;
+  const int m = (int)(w - fb * groups);
+  const bool row0 = m == N1 / 16;
+  const int p0 = 8 * m + 1, q0 = N1 - 8 * m - 8;             // first row of the group, first row of its partners
+  if (row0) {
+    lds[lpad(tid)] = Ab[tid];
+#pragma unroll
+    for (int f = 1; f < kBigC; ++f) lds[f * FrameLds + lpad(tid)] = make_float2(0.0f, 0.0f);
+  } else {
+#pragma unroll
+    for (int f = 0; f < 2 * kBigC; ++f) {
+      const int row = f < kBigC ? p0 + f : q0 + (f - kBigC);
+      lds[f * FrameLds + lpad(tid)] = Ab[(int64_t)row * N2 + tid];
+    }
+  }
+  __syncthreads();
+  const int f = tid / T, j = tid - f * T;
+  for (int round = 0; round < (row0 ? 1 : 2); ++round) {
+    float2* X = lds + (round * kBigC + f) * FrameLds;
+    float2 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = X[lpad(j + q * T)];
+    fft_core<LOGS>(v, X, j, tw);
+  }
+  __syncthreads();
   const float hs = 0.5f * scale;
   auto emit = [&](int64_t kk, float re, float im) {
-    if (mode == 0) reinterpret_cast<float2*>(out)[fr * bins + kk] = make_float2(re, im);
-    else out[fr * bins + kk] = __builtin_amdgcn_sqrtf(re * re + im * im) + 1e-7f;
+    // plain stores: a group's runs are 32 (magnitudes) or 64 bytes long and complete their 128-byte lines only together with
+    // the neighbouring groups' -- in L2.  Streaming (nontemporal) stores, right for K_stft's whole rows, sent every run to
+    // HBM on its own: 0.85 ms for this kernel against 0.32 ms (0.25 ms with the stores removed altogether).
+    if constexpr (MODE == 0) reinterpret_cast<float2*>(out)[fr * bins + kk] = make_float2(re * hs, im * hs);
+    else out[fr * bins + kk] = fmaf(__builtin_amdgcn_sqrtf(fmaf(re, re, im * im)), hs, 1e-7f);
   };
-  emit(k, (ev.x + t.y) * hs, (ev.y - t.x) * hs);
-  if (k > 0 && k < H / 2) emit(H - k, (ev.x - t.y) * hs, (-ev.y - t.x) * hs);
-  if (k == 0) emit(H, (ev.x - t.y) * hs, (-ev.y - t.x) * hs);
+  auto half_step = [&](int64_t k) { return cmul(thi2[(uint64_t)k / kBigR], tlo2[(uint64_t)k % kBigR]); };
+  if (row0) {
+    if (tid <= N2 / 2) {
+      const int k2 = tid;
+      const int64_t k = (int64_t)N1 * k2;
+      const float2 zk = lds[lpad(k2)];
+      const float2 zc = cconj(lds[lpad((N2 - k2) & (N2 - 1))]);
+      const float2 ev = cadd(zk, zc);
+      const float2 t = cmul(half_step(k), csub(zk, zc));
+      emit(k, ev.x + t.y, ev.y - t.x);
+      if (k2 > 0 && k2 < N2 / 2) emit(H - k, ev.x - t.y, -ev.y - t.x);
+      if (k2 == 0) emit(H, ev.x - t.y, -ev.y - t.x);
+    }
+    return;
+  }
+#pragma unroll
+  for (int it = 0; it < kBigC; ++it) {
+    const int idx = tid + it * S;
+    const int k2 = idx / kBigC, i = idx % kBigC;
+    const int k1 = p0 + i;
+    if (k1 == N1 / 2 && k2 >= N2 / 2) continue;              // the self-paired row: each pair once
+    const int64_t k = k1 + (int64_t)N1 * k2;
+    const float2 zk = lds[i * FrameLds + lpad(k2)];
+    const float2 zc = cconj(lds[(2 * kBigC - 1 - i) * FrameLds + lpad(N2 - 1 - k2)]);
+    const float2 ev = cadd(zk, zc);
+    const float2 t = cmul(half_step(k), csub(zk, zc));
+    emit(k, ev.x + t.y, ev.y - t.x);
+    emit(H - k, ev.x - t.y, -ev.y - t.x);
+  }
 }
 
 // H-point complex FFT (H a power of two in [8192, 2^20]) of `batch` arrays: A is overwritten, the spectrum lands in Z
@@ -502,9 +606,9 @@ static int big_fft_c2c(int device, float2* A, float2* Z, int64_t H, int64_t batc
   if (rc == PAR_OK) rc = get_big_twiddles(device, (int)H, &bt);
   if (rc != PAR_OK) return rc;
 #define PAR_BIG_C2C(LS, PASS, NG, TW)                                                                                     \
-  hipLaunchKernelGGL((k_bigfft<LS, PASS, 1>), dim3((unsigned)((NG) / kBigC), (unsigned)batch), dim3((1 << LS) < 64 ? 64 : (1 << LS)), \
-                     (size_t)(kBigC + 1) * ((1 << LS) + (1 << LS) / 8 + 8) * sizeof(float2), s, (const float*)nullptr, (int64_t)0, \
-                     (int64_t)1, 0, 1, (const float*)nullptr, TW, bt.lo, bt.hi, A, Z, (int64_t)0, l1, l2)
+  hipLaunchKernelGGL((k_bigfft<LS, PASS, 1>), dim3((unsigned)round_up8((int64_t)((NG) / kBigC) * batch)), dim3(1 << LS),   \
+                     (size_t)kBigC * ((1 << LS) + (1 << LS) / 8 + 8) * sizeof(float2), s, (const float*)nullptr, (int64_t)0, \
+                     (int64_t)1, 0, 1, (const float*)nullptr, TW, bt.lo, bt.hi, A, Z, (int64_t)0, l1, l2, batch)
   switch (l1) {
     case 7: PAR_BIG_C2C(7, 0, 1 << l2, t1.w); break;
     case 8: PAR_BIG_C2C(8, 0, 1 << l2, t1.w); break;
@@ -1006,38 +1110,60 @@ int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, in
   BigTw bt;
   int rc = get_twiddles(device, 2 << l1, &t1);
   if (rc == PAR_OK) rc = get_twiddles(device, 2 << l2, &t2);
+  BigTw bt2;                                                              // the untangle step's half-step circle
   if (rc == PAR_OK) rc = get_big_twiddles(device, (int)H, &bt);
+  if (rc == PAR_OK) rc = get_big_twiddles(device, (int)(2 * H), &bt2);
   if (rc != PAR_OK) return rc;
   const int64_t n_frames = par_stft_frames(n, n_fft, hop);
   const float scale = (float)(1.0 / sqrt((double)n_fft));
   float2* A = static_cast<float2*>(scratch);
-  int64_t batch = (int64_t)(scratch_bytes / (size_t)(2 * H * (int64_t)sizeof(float2)));     // frames the scratch holds
+  // frames the scratch holds: one H-point array per frame (the row pass writes the bins itself; the scratch size still
+  // counts two, so a caller's buffer takes twice the frames it was sized for)
+  int64_t batch = (int64_t)(scratch_bytes / (size_t)(H * (int64_t)sizeof(float2)));
   batch = batch > 32768 ? 32768 : batch;
   for (int64_t f0 = 0; f0 < n_frames; f0 += batch) {
     const int64_t nb = n_frames - f0 < batch ? n_frames - f0 : batch;
-    float2* Z = A + nb * H;
-#define PAR_BIG_PASS(LS, PASS, NG, TW)                                                                                   \
-  hipLaunchKernelGGL((k_bigfft<LS, PASS>), dim3((unsigned)((NG) / kBigC), (unsigned)nb), dim3((1 << LS) < 64 ? 64 : (1 << LS)), \
-                     (size_t)(kBigC + 1) * ((1 << LS) + (1 << LS) / 8 + 8) * sizeof(float2), s, x, n, x_stride, n_fft, hop, \
-                     window, TW, bt.lo, bt.hi, A, Z, f0, l1, l2)
+#define PAR_BIG_COLS(LS, NG, TW)                                                                                         \
+  hipLaunchKernelGGL((k_bigfft<LS, 0>), dim3((unsigned)round_up8((int64_t)((NG) / kBigC) * nb)), dim3(1 << LS),           \
+                     (size_t)kBigC * ((1 << LS) + (1 << LS) / 8 + 8) * sizeof(float2), s, x, n, x_stride, n_fft, hop,     \
+                     window, TW, bt.lo, bt.hi, A, (float2*)nullptr, f0, l1, l2, nb)
     switch (l1) {
-      case 7: PAR_BIG_PASS(7, 0, 1 << l2, t1.w); break;
-      case 8: PAR_BIG_PASS(8, 0, 1 << l2, t1.w); break;
-      case 9: PAR_BIG_PASS(9, 0, 1 << l2, t1.w); break;
-      case 10: PAR_BIG_PASS(10, 0, 1 << l2, t1.w); break;
+      case 7: PAR_BIG_COLS(7, 1 << l2, t1.w); break;
+      case 8: PAR_BIG_COLS(8, 1 << l2, t1.w); break;
+      case 9: PAR_BIG_COLS(9, 1 << l2, t1.w); break;
+      case 10: PAR_BIG_COLS(10, 1 << l2, t1.w); break;
       default: PAR_REQUIRE(false, PAR_ERR_UNSUPPORTED, "par_stft_big_f32: unsupported size");
     }
+#undef PAR_BIG_COLS
+    // rows + untangle: 16 padded spectra in LDS (148 KB at 1024 points: above the 64 KB default, raised per kernel once)
+#define PAR_BIG_ROWS(LS)                                                                                                 \
+  {                                                                                                                      \
+    constexpr int kLds = 2 * kBigC * ((1 << LS) + (1 << LS) / 8 + 8) * (int)sizeof(float2);                              \
+    static bool raised = false;                                                                                          \
+    if (!raised && kLds > 65536) {                                                                                       \
+      PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigfft_rows_out<LS, 0>),                        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds));                              \
+      PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigfft_rows_out<LS, 1>),                        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds));                              \
+      raised = true;                                                                                                     \
+    }                                                                                                                    \
+    const dim3 grid((unsigned)round_up8((int64_t)((1 << l1) / (2 * kBigC) + 1) * nb));                                   \
+    if (mode == 0)                                                                                                       \
+      hipLaunchKernelGGL((k_bigfft_rows_out<LS, 0>), grid, dim3(1 << LS), kLds, s, (const float2*)A, t2.w, bt2.lo, bt2.hi, out, \
+                         f0, l1, scale, nb);                                                                               \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((k_bigfft_rows_out<LS, 1>), grid, dim3(1 << LS), kLds, s, (const float2*)A, t2.w, bt2.lo, bt2.hi, out, \
+                         f0, l1, scale, nb);                                                                               \
+  }
     switch (l2) {
-      case 6: PAR_BIG_PASS(6, 1, 1 << l1, t2.w); break;
-      case 7: PAR_BIG_PASS(7, 1, 1 << l1, t2.w); break;
-      case 8: PAR_BIG_PASS(8, 1, 1 << l1, t2.w); break;
-      case 9: PAR_BIG_PASS(9, 1, 1 << l1, t2.w); break;
-      case 10: PAR_BIG_PASS(10, 1, 1 << l1, t2.w); break;
+      case 6: PAR_BIG_ROWS(6); break;
+      case 7: PAR_BIG_ROWS(7); break;
+      case 8: PAR_BIG_ROWS(8); break;
+      case 9: PAR_BIG_ROWS(9); break;
+      case 10: PAR_BIG_ROWS(10); break;
       default: PAR_REQUIRE(false, PAR_ERR_UNSUPPORTED, "par_stft_big_f32: unsupported size");
     }
-#undef PAR_BIG_PASS
-    hipLaunchKernelGGL(k_big_untangle, dim3((unsigned)ceil_div(H / 2 + 1, 256), (unsigned)nb), dim3(256), 0, s, (const float2*)Z,
-                       H, bt.lo, bt.hi, out, f0, mode, scale);
+#undef PAR_BIG_ROWS
     PAR_HIP_CHECK(hipGetLastError());
   }
   return PAR_OK;
