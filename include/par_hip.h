@@ -64,7 +64,8 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
                  const float* window, float* out, int mode, void* stream);
 
 /* The same transform for frames of more than 8192 points (n_fft*zeropad a power of two in (8192, 2^21]; the GUI offers
- * FFT sizes up to 2^20, util/widgets.py:333-349): a four-step FFT in two passes over HBM.
+ * FFT sizes up to 2^20, util/widgets.py:333-349): a four-step FFT in two passes over HBM (columns, then rows fused with
+ * the real-transform untangle: only one H-point array per frame is ever stored).
  *   scratch  device memory of par_stft_big_scratch_bytes(n, n_fft, hop, zeropad) bytes (caller-owned) */
 size_t par_stft_big_scratch_bytes(int64_t n, int n_fft, int hop, int zeropad);
 int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad,

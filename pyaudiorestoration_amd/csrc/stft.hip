@@ -439,21 +439,33 @@ __global__ __launch_bounds__(1 << LOGS) void k_bigfft(const float* __restrict__ 
       // contiguous signal, frame starting on an 8-byte boundary (even hop and n_fft / 2): the two samples of a packed
       // point arrive in one load
       const bool paired = x_stride == 1 && (reinterpret_cast<uintptr_t>(xs) & 7) == 0;
-      float2 z[kBigC];
+      // branch-free: n_fft is even, so a packed pair lies entirely inside the frame or entirely in the zero padding; a
+      // padded pair loads the frame's last pair instead and is zeroed afterwards (a branch per pair made every load wait
+      // for the one before it)
+      float2 z[kBigC], wv[kBigC];
+      int t0[kBigC];
 #pragma unroll
       for (int it = 0; it < kBigC; ++it) {
         const int idx = tid + it * S, n1 = idx / kBigC, f = idx % kBigC;
-        const int t0 = 2 * (g0 + f + N2 * n1);             // first real sample of the packed pair (< n_fft * zeropad <= 2^21)
-        z[it] = make_float2(0.0f, 0.0f);
-        if (t0 + 1 < n_fft) {
-          const float2 wv = *reinterpret_cast<const float2*>(window + t0);
-          const float2 xv = paired ? *reinterpret_cast<const float2*>(xs + t0)
-                                   : make_float2(xs[(int64_t)t0 * x_stride], xs[(int64_t)(t0 + 1) * x_stride]);
-          z[it].x = wv.x * xv.x;
-          z[it].y = wv.y * xv.y;
-        } else if (t0 < n_fft) {
-          z[it].x = window[t0] * xs[(int64_t)t0 * x_stride];
+        t0[it] = 2 * (g0 + f + N2 * n1);                   // first real sample of the packed pair (< n_fft * zeropad <= 2^21)
+        const int tc = t0[it] < n_fft ? t0[it] : n_fft - 2;
+        wv[it] = *reinterpret_cast<const float2*>(window + tc);
+        t0[it] = t0[it] < n_fft ? tc : -1;
+      }
+      if (paired) {
+#pragma unroll
+        for (int it = 0; it < kBigC; ++it) z[it] = *reinterpret_cast<const float2*>(xs + (t0[it] < 0 ? n_fft - 2 : t0[it]));
+      } else {
+#pragma unroll
+        for (int it = 0; it < kBigC; ++it) {
+          const int64_t tc = t0[it] < 0 ? n_fft - 2 : t0[it];
+          z[it] = make_float2(xs[tc * x_stride], xs[(tc + 1) * x_stride]);
         }
+      }
+#pragma unroll
+      for (int it = 0; it < kBigC; ++it) {
+        z[it].x = t0[it] < 0 ? 0.0f : wv[it].x * z[it].x;
+        z[it].y = t0[it] < 0 ? 0.0f : wv[it].y * z[it].y;
       }
 #pragma unroll
       for (int it = 0; it < kBigC; ++it) {
