@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun):
-#   tools/profile_round.sh r01         -> gpurun_out/r01/*  (copy the summaries into profiles/ afterwards
-#                                         with tools/summarise_profiles.py)
+#   tools/profile_round.sh r01         -> gpurun_out/r01/summary/*  (tools/summarise_profiles.py run on the box;
+#                                         copy them into profiles/)
 # Counters are collected in separate passes with --kernel-trace only (never with sys/hip/hsa traces).
 set -u
 TAG=${1:-r01}
@@ -16,4 +16,10 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACT
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM -d "$OUT" -o lds -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/lds.log" 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d "$OUT" -o grbm -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/grbm.log" 2>&1
 python bench.py --config5 --steps 1 --warmup 1 > "$OUT/bench_config5_n1.json" 2> "$OUT/bench_config5_n1.err"
+# summarise on the box and keep only the summaries: the six sqlite files outgrew the 64 MiB that gpurun copies back
+python tools/summarise_profiles.py "$OUT" "$TAG" > "$OUT/summarise.log" 2>&1
+mkdir -p "$OUT/summary"
+cp profiles/${TAG}_kernel_stats.txt profiles/${TAG}_pmc.txt profiles/${TAG}_bench_default.json profiles/pmc_traffic.json profiles/pmc_valu.json "$OUT/summary/"
+cp "$OUT/bench_config5_n1.json" "$OUT/summary/${TAG}_bench_config5_n1.json"
+rm -f "$OUT"/*_results.db
 cat "$OUT/bench_default.json" "$OUT/bench_config5_n1.json"
