@@ -18,6 +18,7 @@
 #include "par_common.h"
 #include <math.h>
 #include <map>
+#include <set>
 #include <vector>
 
 #ifndef PAR_STFT_TW
@@ -34,6 +35,18 @@ struct Twiddles {
   float2* post = nullptr; // exp(-2*pi*i*k/M), k = 0..H            (real-FFT untangling)
 };
 static std::mutex g_tw_mu;
+
+// Dynamic LDS above the 64 KB a kernel gets by default is raised per (kernel, device) once: the attribute belongs to the
+// function object of the CURRENT device.
+static int raise_dynamic_lds(const void* fn, int bytes, int device) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  std::lock_guard<std::mutex> lk(mu);
+  if (bytes <= 65536 || done.count({fn, device})) return PAR_OK;
+  PAR_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({fn, device});
+  return PAR_OK;
+}
 static std::map<std::pair<int, int>, Twiddles> g_tw;
 
 static int get_twiddles(int device, int M, Twiddles* out) {
@@ -618,6 +631,9 @@ static int big_fft_c2c(int device, float2* A, float2* Z, int64_t H, int64_t batc
   if (rc == PAR_OK) rc = get_big_twiddles(device, (int)H, &bt);
   if (rc != PAR_OK) return rc;
 #define PAR_BIG_C2C(LS, PASS, NG, TW)                                                                                     \
+  if (int rc_lds = raise_dynamic_lds(reinterpret_cast<const void*>(&k_bigfft<LS, PASS, 1>),                               \
+                                     kBigC * ((1 << LS) + (1 << LS) / 8 + 8) * (int)sizeof(float2), device))              \
+    return rc_lds;                                                                                                        \
   hipLaunchKernelGGL((k_bigfft<LS, PASS, 1>), dim3((unsigned)round_up8((int64_t)((NG) / kBigC) * batch)), dim3(1 << LS),   \
                      (size_t)kBigC * ((1 << LS) + (1 << LS) / 8 + 8) * sizeof(float2), s, (const float*)nullptr, (int64_t)0, \
                      (int64_t)1, 0, 1, (const float*)nullptr, TW, bt.lo, bt.hi, A, Z, (int64_t)0, l1, l2, batch)
@@ -1069,13 +1085,10 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
       // 16384 points (the GUI's 4096 x zero-padding 4): one 1024-lane workgroup per frame, 72 KB of the CU's 160 KB of LDS
       // (above the 64 KB a kernel gets by default: raised per kernel once)
       constexpr int kLds13 = FftGeom<13>::Frames * FftGeom<13>::FrameLds * (int)sizeof(float2) + (PAR_STFT_STORE == 3 ? (8192 + 4) * 4 : 0);
-      static bool raised = false;
-      if (!raised) {
-        PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft<13, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds13));
-        PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft<13, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds13));
-        PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft<13, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds13));
-        PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft<13, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds13));
-        raised = true;
+      for (const void* fn : {reinterpret_cast<const void*>(&k_stft<13, 0, true>), reinterpret_cast<const void*>(&k_stft<13, 0, false>),
+                             reinterpret_cast<const void*>(&k_stft<13, 1, true>), reinterpret_cast<const void*>(&k_stft<13, 1, false>)}) {
+        const int rc = raise_dynamic_lds(fn, kLds13, device);
+        if (rc != PAR_OK) return rc;
       }
       PAR_STFT_LAUNCH(13);
       break;
@@ -1136,6 +1149,9 @@ int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, in
   for (int64_t f0 = 0; f0 < n_frames; f0 += batch) {
     const int64_t nb = n_frames - f0 < batch ? n_frames - f0 : batch;
 #define PAR_BIG_COLS(LS, NG, TW)                                                                                         \
+  if (int rc_lds = raise_dynamic_lds(reinterpret_cast<const void*>(&k_bigfft<LS, 0>),                                    \
+                                     kBigC * ((1 << LS) + (1 << LS) / 8 + 8) * (int)sizeof(float2), device))             \
+    return rc_lds;                                                                                                       \
   hipLaunchKernelGGL((k_bigfft<LS, 0>), dim3((unsigned)round_up8((int64_t)((NG) / kBigC) * nb)), dim3(1 << LS),           \
                      (size_t)kBigC * ((1 << LS) + (1 << LS) / 8 + 8) * sizeof(float2), s, x, n, x_stride, n_fft, hop,     \
                      window, TW, bt.lo, bt.hi, A, (float2*)nullptr, f0, l1, l2, nb)
@@ -1147,18 +1163,13 @@ int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, in
       default: PAR_REQUIRE(false, PAR_ERR_UNSUPPORTED, "par_stft_big_f32: unsupported size");
     }
 #undef PAR_BIG_COLS
-    // rows + untangle: 16 padded spectra in LDS (148 KB at 1024 points: above the 64 KB default, raised per kernel once)
+    // rows + untangle: 16 padded spectra in LDS (148 KB at 1024 points: above the 64 KB default)
 #define PAR_BIG_ROWS(LS)                                                                                                 \
   {                                                                                                                      \
     constexpr int kLds = 2 * kBigC * ((1 << LS) + (1 << LS) / 8 + 8) * (int)sizeof(float2);                              \
-    static bool raised = false;                                                                                          \
-    if (!raised && kLds > 65536) {                                                                                       \
-      PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigfft_rows_out<LS, 0>),                        \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds));                              \
-      PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigfft_rows_out<LS, 1>),                        \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds));                              \
-      raised = true;                                                                                                     \
-    }                                                                                                                    \
+    int rc_lds = raise_dynamic_lds(reinterpret_cast<const void*>(&k_bigfft_rows_out<LS, 0>), kLds, device);              \
+    if (rc_lds == PAR_OK) rc_lds = raise_dynamic_lds(reinterpret_cast<const void*>(&k_bigfft_rows_out<LS, 1>), kLds, device); \
+    if (rc_lds != PAR_OK) return rc_lds;                                                                                 \
     const dim3 grid((unsigned)round_up8((int64_t)((1 << l1) / (2 * kBigC) + 1) * nb));                                   \
     if (mode == 0)                                                                                                       \
       hipLaunchKernelGGL((k_bigfft_rows_out<LS, 0>), grid, dim3(1 << LS), kLds, s, (const float2*)A, t2.w, bt2.lo, bt2.hi, out, \

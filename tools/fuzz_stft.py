@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised fuzz of K_stft / K_istft against the numpy oracle (run on the GPU box): every power-of-two transform
-size, arbitrary hops (1 .. 2 n_fft), zero-padding factors, window names, strided (channel-of-interleaved) input,
+size up to 8192 points plus (15 % of the cases) the 16384-point kernel and the four-step path up to 2^18 points, arbitrary
+hops (1 .. 2 n_fft, odd ones included), zero-padding factors, window names, strided (channel-of-interleaved) input,
 signals shorter than a frame; complex and magnitude modes; ISTFT round trips incl. explicit lengths."""
 import os
 import sys
@@ -28,13 +29,18 @@ def relerr(a, b):
 
 while time.time() < t_end:
     rng = np.random.default_rng(seed0 + case)
-    n_fft = int(2 ** rng.integers(4, 14))
+    big = rng.random() < 0.15                          # the 16384-point kernel and the four-step path (up to 2^18 here)
+    n_fft = int(2 ** rng.integers(13, 18)) if big else int(2 ** rng.integers(4, 14))
     zp = int(rng.choice([1, 1, 1, 2, 4]))
-    while n_fft * zp > 8192:
+    while n_fft * zp > (1 << 18 if big else 8192):
         zp //= 2
-    hop = int(rng.choice([1, 3, n_fft // 8, n_fft // 4, n_fft // 2, n_fft, n_fft + 7, 2 * n_fft]))
+    if big:
+        hop = int(rng.choice([n_fft // 8, n_fft // 4, n_fft // 2, n_fft, n_fft + 7, 2 * n_fft, 5000, 4097]))
+        n = int(rng.choice([n_fft // 2 + 2, n_fft, n_fft + 1, 3 * n_fft + 17, 5 * n_fft + 5]))
+    else:
+        hop = int(rng.choice([1, 3, n_fft // 8, n_fft // 4, n_fft // 2, n_fft, n_fft + 7, 2 * n_fft]))
+        n = int(rng.choice([n_fft // 2 + 2, n_fft, n_fft + 1, 3 * n_fft + 17, 20 * n_fft + 5, 50000]))
     hop = max(1, hop)
-    n = int(rng.choice([n_fft // 2 + 2, n_fft, n_fft + 1, 3 * n_fft + 17, 20 * n_fft + 5, 50000]))
     if hop <= 3:
         n = min(n, 4000)                               # keep the oracle's frame matrix small
     win = str(rng.choice(["hann", "blackmanharris", "hamming", "boxcar"]))
@@ -51,7 +57,7 @@ while time.time() < t_end:
     e3 = relerr(mag, np.abs(want) + 1e-7)
     assert got.shape == want.shape == got_t.shape == mag.shape, (case, n_fft, hop, zp, n)
     errs = [e1, e2, e3]
-    if zp == 1:
+    if zp == 1 and n_fft <= 8192:
         S = want.astype(np.complex64)
         for length in (n, None):
             y_want = O.istft(S, hop, win, length)
