@@ -270,7 +270,16 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
   // interior frames (the vast majority) index the signal directly; only frames that overhang an end of
   // the signal pay for the reflect fold (a 64-bit modulo per sample)
   const bool interior = live && base >= 0 && base + n_fft <= (long long)n;
-  if (interior) {
+  if (interior && n_fft == 2 * H) {
+    // no zero padding (the usual case): every packed pair lies inside the frame, no compare per pair
+    const float* xs = x + base * x_stride;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int t0 = 2 * (j + q * T);
+      const float2 w = *reinterpret_cast<const float2*>(window + t0);
+      v[q] = make_float2(w.x * xs[(int64_t)t0 * x_stride], w.y * xs[(int64_t)(t0 + 1) * x_stride]);
+    }
+  } else if (interior) {
     const float* xs = x + base * x_stride;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
