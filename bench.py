@@ -215,7 +215,10 @@ def stereo_secondary(dev, sr=192000, seconds=600.0, nt=32):
     return {"workload": f"config 5 work item: {seconds:g}-s {sr} Hz stereo file, interleaved; 1 plan + 1 stereo fused K_sinc launch",
             "channel_samples_out": 2 * len_out.value, "ms_per_file": round(dt * 1e3, 3),
             "Msamples/s": round(2 * len_out.value / dt / 1e6, 1),
-            "batched_ms_per_file": round(dtb * 1e3, 3), "batched_Msamples/s": round(2 * len_out.value / dtb / 1e6, 1)}
+            "batched_ms_per_file": round(dtb * 1e3, 3), "batched_Msamples/s": round(2 * len_out.value / dtb / 1e6, 1),
+            "note": "batched_Msamples/s is the 1-GPU point of the --gpus N > 1 curve: those runs time the config-5 archive (this "
+                    "work item x 512, files pulled from a shared queue), not the mono file of this line's `value`; the whole "
+                    "archive on one GPU: python bench.py --config5 (profiles/r02_bench_config5_n1.json)"}
 
 
 def config5_batch(a, ctx):
@@ -278,6 +281,10 @@ def config5_batch(a, ctx):
                                    f"curve per file (0.55 Hz, hop 256, phase 0.7 + file index), {2 * a.nt}-tap Hann sinc; one step = the "
                                    "whole archive, files pulled by the ranks from a shared host-side queue (no collective, no RCCL)",
                        "files": files, "channel_samples_per_step": int(total), "files_per_rank_min_max": [int(files_min), int(files_max)],
+                       "value_per_gpu": round(value / world, 3),
+                       "n1_same_workload": "the --gpus 1 line times the mono 60-min file of BASELINE configs[1]; the 1-GPU point "
+                                           "of THIS workload is that line's secondary_config5.batched_Msamples/s, or "
+                                           "`python bench.py --config5` (profiles/r02_bench_config5_n1.json: 129 G)",
                        "NT": a.nt, "resident": f"ring of {a.ring} synthetic stereo files per GPU + all {files} speed curves",
                        "step": "per file: plan (device scans, cumsum checkpoints, block records) + ONE stereo fused K_sinc launch; "
                                "the next file's plan runs on a side stream under K_sinc"},
