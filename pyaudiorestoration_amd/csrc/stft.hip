@@ -1111,14 +1111,14 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
 }
 
 // Frames of more than 8192 points (up to 2^21): four-step transform through a caller-owned scratch of
-// par_stft_big_scratch_bytes() (two H-point complex arrays per frame of a batch; batches of up to 16 frames).
+// par_stft_big_scratch_bytes() (one H-point complex array per frame of a batch; a batch fills up to 1 GiB).
 size_t par_stft_big_scratch_bytes(int64_t n, int n_fft, int hop, int zeropad) {
   const int64_t M = (int64_t)n_fft * zeropad;
   if (M <= 8192 || M > (1ll << 21)) return 0;
   // frames per batch: as many as fit 1 GiB of scratch (at least 16, at most what one grid dimension takes): 16-frame
   // batches made the 16384-point transform launch-bound (880 batches of three small launches: 16 ms for a 10-minute file)
   int64_t frames = par_stft_frames(n, n_fft, hop);
-  const int64_t per_frame = 2 * (M / 2) * (int64_t)sizeof(float2);
+  const int64_t per_frame = (M / 2) * (int64_t)sizeof(float2);       // A[k1][n2]; the row pass writes the bins itself
   int64_t cap = (1ll << 30) / per_frame;
   cap = cap < 16 ? 16 : (cap > 32768 ? 32768 : cap);
   if (frames > cap) frames = cap;
@@ -1151,8 +1151,7 @@ int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, in
   const int64_t n_frames = par_stft_frames(n, n_fft, hop);
   const float scale = (float)(1.0 / sqrt((double)n_fft));
   float2* A = static_cast<float2*>(scratch);
-  // frames the scratch holds: one H-point array per frame (the row pass writes the bins itself; the scratch size still
-  // counts two, so a caller's buffer takes twice the frames it was sized for)
+  // frames the scratch holds: one H-point array per frame
   int64_t batch = (int64_t)(scratch_bytes / (size_t)(H * (int64_t)sizeof(float2)));
   batch = batch > 32768 ? 32768 : batch;
   for (int64_t f0 = 0; f0 < n_frames; f0 += batch) {

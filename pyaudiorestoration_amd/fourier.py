@@ -54,7 +54,7 @@ def stft_dev(x_t, n_fft, step, window_t, zeropad=1, mode=0, x_stride=1, n=None, 
     bins = (n_fft * zeropad) // 2 + 1
     frames = int(L.par_stft_frames(n, n_fft, step))
     out = _dev.empty((frames, bins), torch.complex64 if mode == 0 else torch.float32, dev)
-    if n_fft * zeropad > 16384:           # four-step transform through a scratch of two complex frames per batch slot
+    if n_fft * zeropad > 16384:           # four-step transform through a scratch of one complex H-point array per frame of a batch
         nbytes = int(L.par_stft_big_scratch_bytes(n, n_fft, step, zeropad))
         scratch = _dev.empty(max(nbytes, 1), torch.uint8, dev)
         _lib.check(L.par_stft_big_f32(dev, _dev.ptr(x_t), n, x_stride, n_fft, step, zeropad, _dev.ptr(window_t), _dev.ptr(out),
