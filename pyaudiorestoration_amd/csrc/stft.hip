@@ -332,8 +332,11 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
     } else {
       // v_sqrt_f32 itself (1 ulp): the correctly rounded sqrtf costs 16 instructions per bin, mostly compares and selects
       const float mag = fmaf(__builtin_amdgcn_sqrtf(fmaf(re, re, im * im)), hs, 1e-7f);
+      // streaming stores pay when a frame's lanes write runs of at least 64 bytes (T >= 16: n_fft >= 256); shorter runs only
+      // complete their lines together with the neighbouring frames', in L2, and went to HBM piecemeal as streaming stores
+      // (n_fft = 64, hop 16 on 57.6 M samples: 0.81 ms streaming, 0.39 ms plain; n_fft = 256: 0.26 against 0.31)
       if (kRowStage) Mg[k] = mag;
-      else if (PAR_STFT_STORE == 1) out[fr * bins + k] = mag;
+      else if (PAR_STFT_STORE == 1 || T < 16) out[fr * bins + k] = mag;
       else __builtin_nontemporal_store(mag, out + fr * bins + k);
     }
   };

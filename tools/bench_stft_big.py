@@ -14,7 +14,7 @@ from pyaudiorestoration_amd import _dev, _lib, fourier
 n = 96000 * 600
 x = torch.empty(n, dtype=torch.float32, device="cuda")
 _lib.check(_lib.lib().par_synth_signal_f32(0, _dev.ptr(x), 0, n, 96000.0, 0x5EED, _dev.stream_ptr(0)))
-for n_fft in (256, 1024, 4096, 8192, 16384, 65536, 262144, 1048576):
+for n_fft in (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 262144, 1048576):
     hop = n_fft // 4
     win = torch.from_numpy(scipy.signal.get_window("blackmanharris", n_fft).astype(np.float32)).cuda()
     fourier.stft_dev(x, n_fft, hop, win, 1, 1)
