@@ -1032,7 +1032,17 @@ static inline size_t istft_fused_lds_any(int n_fft, int hop) {
   }
   return (size_t)-1;
 }
-static inline bool istft_is_fused(int n_fft, int hop) { return hop >= 1 && istft_fused_lds_any(n_fft, hop) <= 64 * 1024; }
+// Largest n_fft that takes the fused kernel.  A workgroup re-transforms s - 1 = n_fft/hop - 1 frames of its neighbour; with
+// 8 or 4 frames side by side (n_fft <= 1024) that is 13-23 % extra work for never storing the frames, at 2048 (2 frames)
+// the two forms are within 9 %, and a 4096-point frame fills the workgroup alone: s frames transformed per hop of
+// output (tools/bench_istft_sweep.py, 23 M samples: 4096 at hop n/4, n/8, n/16 took 0.78 / 2.44 / 8.65 ms fused against
+// 0.37 / 0.68 / 1.27 ms through the frame array).
+#ifndef PAR_ISTFT_FUSE_MAX
+#define PAR_ISTFT_FUSE_MAX 2048
+#endif
+static inline bool istft_is_fused(int n_fft, int hop) {
+  return hop >= 1 && n_fft <= PAR_ISTFT_FUSE_MAX && istft_fused_lds_any(n_fft, hop) <= 64 * 1024;
+}
 
 }  // namespace par
 

@@ -158,7 +158,8 @@ def test_istft_size_matrix_vs_oracle(par, n_fft, hop):
         assert got.shape == want.shape and relerr(got, want) < TOL, (n_fft, hop, length)
     from pyaudiorestoration_amd import _lib
     L = _lib.lib()
-    assert (L.par_istft_scratch_floats(10, n_fft, hop) != 0) == (hop == 5000 or n_fft == 8192)   # only these spans exceed 64 KB of LDS
+    # the frame array is needed where the overlap-add span exceeds 64 KB of LDS or a frame fills the workgroup alone
+    assert (L.par_istft_scratch_floats(10, n_fft, hop) != 0) == (hop == 5000 or n_fft >= 4096)
 
 
 def test_istft_single_frame_without_length_is_empty(par):
