@@ -27,7 +27,7 @@ def _centre(full, n, m, mode):
 
 def _up(a, dev):
     return a.to(device=f"cuda:{dev}", dtype=torch.float64) if isinstance(a, torch.Tensor) else \
-        _dev.to_dev(np.ascontiguousarray(a, dtype=np.float64), torch.float64, dev)
+        _dev.to_dev(a, torch.float64, dev)                  # float32 signals cross PCIe as they are and widen in HBM
 
 
 def xcorr_dev(a_t, b_t, dev=None):

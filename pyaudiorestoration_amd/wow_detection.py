@@ -111,7 +111,7 @@ def zero_crossings_dev(x_t, dev=None):
 def zero_crossings(a):
     """Host-array convenience form of zero_crossings_dev (same name as the reference's helper)."""
     dev = _dev.device_index(None)
-    return zero_crossings_dev(_dev.to_dev(np.asarray(a, dtype=np.float64), torch.float64, dev), dev).cpu().numpy()
+    return zero_crossings_dev(_dev.to_dev(a, torch.float64, dev), dev).cpu().numpy()
 
 
 # ------------------------------------------------------------------------------------------ trackers
