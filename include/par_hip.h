@@ -77,8 +77,9 @@ int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, in
  *   spec     device complex64 [n_frames][bins] frame-major (bins = n_fft/2+1)
  *   window   device f32[n_fft]  (get_window(name, n_fft, fftbins=True))
  *   frames   device f32 scratch of par_istft_scratch_floats(n_frames, n_fft, hop) floats; that is 0 (pass NULL)
- *            when the frames are overlap-added in LDS and never stored (the overlap-add span of one workgroup
- *            fits 64 KB: every shipped size), else [n_frames][n_fft]
+ *            when the frames are overlap-added in LDS and never stored (n_fft <= 2048 and the overlap-add span of
+ *            one workgroup fits 64 KB), else [n_frames][n_fft] (n_fft >= 4096: a frame fills the workgroup alone and the
+ *            fused form would re-transform n_fft/hop frames per hop of output)
  *   y        device f32[y_len]; y[t] = ola[t + skip] / sumsq[t + skip] (0 beyond the ola length),
  *            skip = n_fft/2 and y_len = `length` reproduce fix_length(y[n_fft//2:], length) (:430-435).
  */
