@@ -42,7 +42,13 @@ __global__ void k_odd_ext(const double* __restrict__ x, int64_t n, int64_t pad, 
 // load touches 64 cache lines.  The wave therefore moves its 64 x kFiltBlock samples through LDS in tiles of
 // kFiltTile columns: global accesses run along the blocks (two 256-byte runs per instruction), the recurrence reads its
 // own row (row pitch kFiltTile + 1: conflict-free).  The block kernels went from 0.7 to ~3 TB/s of useful traffic.
-constexpr int kFiltTile = 32;
+#ifndef PAR_FILT_TILE
+#define PAR_FILT_TILE 32
+#endif
+#ifndef PAR_FILT_TILED_MIN
+#define PAR_FILT_TILED_MIN (1ll << 25)
+#endif
+constexpr int kFiltTile = PAR_FILT_TILE;
 template <bool WRITE>
 __device__ __forceinline__ void sos_wave_blocks(const double* __restrict__ u, int64_t L, int reverse, const Biquad& q,
                                                 int64_t nblk, double& z0, double& z1, double* __restrict__ y,
@@ -260,7 +266,7 @@ int par_sosfiltfilt_f64(int device, const double* sos, const double* zi, int n_s
         PAR_HIP_CHECK(hipMemcpyAsync(latch, cur + (dir ? L - 1 : 0), sizeof(double), hipMemcpyDeviceToDevice, st));
       }
       // LDS-tiled block kernels pay off from ~3 10^7 samples on (10^8: 27 -> 9 ms; 10^7: 1.6 -> 2.2 ms, measured)
-      const bool tiled = L >= (1ll << 25);
+      const bool tiled = L >= PAR_FILT_TILED_MIN;
       if (tiled) hipLaunchKernelGGL(k_sos_block_zero, dim3((unsigned)ceil_div(nblk, 64)), dim3(64), 0, st, cur, L, dir, q, nblk, r);
       else hipLaunchKernelGGL(k_sos_block_zero_direct, dim3((unsigned)ceil_div(nblk, 64)), dim3(64), 0, st, cur, L, dir, q, nblk, r);
       if (nsup <= 4) {
