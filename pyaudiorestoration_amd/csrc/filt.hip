@@ -42,11 +42,17 @@ __global__ void k_odd_ext(const double* __restrict__ x, int64_t n, int64_t pad, 
 // load touches 64 cache lines.  The wave therefore moves its 64 x kFiltBlock samples through LDS in tiles of
 // kFiltTile columns: global accesses run along the blocks (two 256-byte runs per instruction), the recurrence reads its
 // own row (row pitch kFiltTile + 1: conflict-free).  The block kernels went from 0.7 to ~3 TB/s of useful traffic.
+// Tile width and the length from which the tiled form is used were set by tools/ab_filt.sh (order-3 band-pass, ms):
+//            16M   24M   30M   40M   60M   80M  100M
+//   direct  1.97  3.45  4.52
+//   tile 32 2.27  2.93  3.30  5.17  6.12  8.19  9.13    (8.4 KB more LDS per wave: 9 waves per CU, a full round of the GPU
+//   tile 16 2.26  3.11  3.42  3.83  4.88  7.18  8.37     is 37.7 M samples and 40 M took two)
+//   tile  8 2.19  3.08  3.46  3.93  5.40  6.82  8.54
 #ifndef PAR_FILT_TILE
-#define PAR_FILT_TILE 32
+#define PAR_FILT_TILE 16
 #endif
 #ifndef PAR_FILT_TILED_MIN
-#define PAR_FILT_TILED_MIN (1ll << 25)
+#define PAR_FILT_TILED_MIN 20000000ll
 #endif
 constexpr int kFiltTile = PAR_FILT_TILE;
 template <bool WRITE>

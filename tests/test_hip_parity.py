@@ -428,7 +428,7 @@ def test_filters_golden(par, golden):
         f(x[:10], 0, 20, 172.0, order=3)
     big = inputs.noise(1350000, 3).astype(np.float64)           # C2-sized speed curve
     assert relerr(f(big, 0, 20, 375.0, order=3), scipy.signal.sosfiltfilt(scipy.signal.butter(3, 20 / 187.5, btype="low", output="sos"), big)) < 1e-9
-    # a whole-file filter (dropouts_gui.py:314-321 band-passes entire recordings): from 2^25 samples on the block kernels
+    # a whole-file filter (dropouts_gui.py:314-321 band-passes entire recordings): from 2e7 samples on the block kernels
     # go through LDS tiles and the block boundaries through the two-level chain
     huge = np.random.default_rng(9).standard_normal((1 << 25) + 777)
     want = scipy.signal.sosfiltfilt(scipy.signal.butter(3, [300 / 24000, 6000 / 24000], btype="band", output="sos"), huge)
