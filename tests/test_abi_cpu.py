@@ -43,6 +43,18 @@ def test_pure_host_entry_points_and_argument_errors():
     assert rc == 3 and "power of two" in _lib.last_error()      # PAR_ERR_UNSUPPORTED -> caller falls through
     with pytest.raises(_lib.ParUnsupported):
         _lib.check(rc)
+    # scratch sizing (host arithmetic): the fused ISTFT needs no frame array up to 2048 points when its overlap-add span fits
+    # LDS; 4096 and 8192 points and over-long hops go through [n_frames][n_fft]
+    assert L.par_istft_scratch_floats(100, 512, 32) == 0 and L.par_istft_scratch_floats(100, 2048, 512) == 0
+    assert L.par_istft_scratch_floats(100, 4096, 1024) == 100 * 4096 and L.par_istft_scratch_floats(100, 8192, 2048) == 100 * 8192
+    assert L.par_istft_scratch_floats(100, 128, 5000) == 100 * 128
+    # four-step STFT: one H-point complex array per frame of a batch, at most 1 GiB (and at least 16 frames)
+    assert L.par_stft_big_scratch_bytes(1000, 1024, 256, 1) == 0                      # single-workgroup sizes need none
+    n = 57_600_000
+    frames = L.par_stft_frames(n, 65536, 16384)
+    assert L.par_stft_big_scratch_bytes(n, 65536, 16384, 1) == frames * 32768 * 8      # 3516 frames fit the cap
+    assert L.par_stft_big_scratch_bytes(n, 32768, 64, 1) == (1 << 30)                  # capped: 8192 frames of 128 KiB
+    assert L.par_stft_big_scratch_bytes(n * 40, 1 << 20, 4096, 2) == 128 * (1 << 20) * 8
 
 
 def test_no_cpu_fallback_without_gpu():
