@@ -1411,6 +1411,37 @@ def test_stft_above_8192_four_step(par, n_fft, hop, zp):
         assert relerr(got2, np.abs(C.stft(np.ascontiguousarray(x[1:]), n_fft, hop, win, zp, mode=0, threads=8)) + 1e-7) < TOL
 
 
+@pytest.mark.parametrize("n_fft,hop,zp", [(16384, 4096, 1), (4096, 1000, 4), (16384, 16391, 1)])
+def test_four_step_entry_point_at_its_smallest_size(par, n_fft, hop, zp):
+    """par_stft_big_f32 accepts n_fft*zeropad = 16384 (fourier.stft sends that size to the single-workgroup kernel, so only a
+    direct C-ABI caller reaches the 128 x 64 split: 64-point row pass, one wave per workgroup): complex and magnitude
+    against the C oracle."""
+    import scipy.signal
+    from oracle import oracle_c as C
+    from pyaudiorestoration_amd import _dev, _lib
+    torch = par.torch
+    L = _lib.lib()
+    n = 150001
+    x = inputs.noise(n, 5) + inputs.sine(n, 997.0, 96000, 0.7)
+    win = scipy.signal.get_window("hann", n_fft).astype(np.float32)
+    want = C.stft(x, n_fft, hop, win, zp, mode=0, threads=8)
+    xt, wt = torch.from_numpy(x).cuda(), torch.from_numpy(win).cuda()
+    frames, bins = int(L.par_stft_frames(n, n_fft, hop)), n_fft * zp // 2 + 1
+    assert want.shape == (bins, frames)
+    nbytes = int(L.par_stft_big_scratch_bytes(n, n_fft, hop, zp))
+    assert nbytes == min(frames, (1 << 30) // (8192 * 8)) * 8192 * 8
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    for mode, dtype in ((0, torch.complex64), (1, torch.float32)):
+        out = torch.empty((frames, bins), dtype=dtype, device="cuda")
+        _lib.check(L.par_stft_big_f32(0, _dev.ptr(xt), n, 1, n_fft, hop, zp, _dev.ptr(wt), _dev.ptr(out), mode, _dev.ptr(scratch), nbytes,
+                                      _dev.stream_ptr(0)))
+        got = out.T.cpu().numpy()
+        assert relerr(got, want if mode == 0 else np.abs(want) + 1e-7) < TOL, (mode, relerr(got, want if mode == 0 else np.abs(want) + 1e-7))
+    # a scratch one byte short is refused, not overrun
+    rc = L.par_stft_big_f32(0, _dev.ptr(xt), n, 1, n_fft, hop, zp, _dev.ptr(wt), _dev.ptr(out), 1, _dev.ptr(scratch), nbytes - 1, _dev.stream_ptr(0))
+    assert rc != 0
+
+
 def test_two_rank_config5_bench_flow(par):
     """bench.py --gpus 2 end to end on this box (both ranks share GPU 0): gloo rendezvous, the shared work queue, the
     stereo batch pipeline and the reductions -- the flow the driver launches on 2/4/8 GPUs -- with a small archive."""
