@@ -1385,7 +1385,7 @@ def test_config4_x256_tiles_one_launch(par):
 
 
 @pytest.mark.parametrize("n_fft,hop,zp", [(16384, 4096, 1), (65536, 16384, 1), (4096, 1024, 4), (32768, 5000, 2), (1048576, 262144, 1),
-                                           (32768, 8192, 1), (8192, 3000, 4)])
+                                           (32768, 8192, 1), (8192, 3000, 4), (1048576, 524288, 2), (131072, 40000, 4)])
 def test_stft_above_8192_four_step(par, n_fft, hop, zp):
     """FFT sizes above 8192 (the GUI offers up to 2^20, util/widgets.py:333-349): the 16384-point single-workgroup kernel and
     the four-step transform (from 32768 points on) against the C
