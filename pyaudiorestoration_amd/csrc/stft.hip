@@ -1152,7 +1152,9 @@ int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, in
   PAR_HIP_CHECK(hipSetDevice(device));
   hipStream_t s = as_stream(stream);
   const int64_t H = M64 / 2;
-  const int L = ilog2((int)H), l1 = (L + 1) / 2, l2 = L - l1;          // N1 >= N2, both in [64, 1024]
+  // N1 >= N2, both in [64, 1024]: the balanced split, except 2^15 = 512 x 64 -- both pure radix-8 sizes (five radix-8 stages
+  // instead of 256 x 128's four plus a radix-4 and a radix-2 stage) -- and 2^14 = 256 x 64 (one remainder stage instead of two)
+  const int L = ilog2((int)H), l1 = L == 15 ? 9 : (L == 14 ? 8 : (L + 1) / 2), l2 = L - l1;
   Twiddles t1, t2;
   BigTw bt;
   int rc = get_twiddles(device, 2 << l1, &t1);
