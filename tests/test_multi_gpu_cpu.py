@@ -43,6 +43,19 @@ def test_world2_gloo_timing_and_reduction():
     blocker.close()
 
 
+def test_world8_gloo_queue_and_reductions():
+    """The driver's largest launch shape (8 ranks of one node) over gloo on the CPU: rendezvous, the TCPStore work queue,
+    MAX-over-ranks timing and the sum reductions."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "tests", "_dist_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["world"] == 8 and r["total"] == 1024 and r["per_rank"] == 128 and r["first_sum"] == sum(range(8))
+    assert r["q_total"] == 40 and r["q_sum"] == sum(range(40))          # every item pulled exactly once across the 8 ranks
+
+
 def test_work_queue_single_process():
     ctx = multi_gpu.RankContext()
     assert list(multi_gpu.WorkQueue(ctx, [5, 3, 9], "solo")) == [5, 3, 9]
