@@ -10,7 +10,11 @@ speed curve -> segment plan -> float64 positions (K_pos) -> Hann-windowed sinc i
 N > 1 (or --config5): BASELINE config 5 -- the 512-file archive (192 kHz stereo, 10 min each) as ONE step,
 shared out over the ranks through a host-side work queue (files/channels are independent in the reference,
 util/resampling.py:168,225): one process per GPU, no data-path collective, no RCCL (gloo barrier + MAX/SUM of
-time and sample counts).  Strong scaling: the batch is fixed, `value` = aggregate channel-samples/s.
+time and sample counts).  Strong scaling: the batch is fixed, `value` = aggregate channel-samples/s; the line also
+carries the SAME workload on one GPU measured in the same run (n1_same_workload_value, speedup_vs_n1, efficiency)
+and the host-gather leg (value_e2e: every output copied to pinned host memory).
+`python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run, gloo, 127.0.0.1);
+under the driver's `python -m torch.distributed.run ... bench.py --gpus N` it joins the ranks it was given.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event-timed
 K_sinc launches vs the 8 TB/s HBM peak, 8 algorithmic bytes per output sample) and `cpu_baseline`
@@ -221,13 +225,88 @@ def stereo_secondary(dev, sr=192000, seconds=600.0, nt=32):
                     "archive on one GPU: python bench.py --config5 (profiles/r02_bench_config5_n1.json)"}
 
 
+def _launch_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks ourselves (one
+    process per GPU, gloo rendezvous on the loopback interface) by re-executing this file under torch.distributed.run,
+    and pass rank 0's JSON line through.  Fewer than N visible devices is an error, not a fold onto what there is."""
+    import socket
+    import subprocess
+    if not (a.dry_run or os.environ.get("PAR_OVERSUBSCRIBE") == "1"):
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < a.gpus:
+            sys.exit(f"bench.py: --gpus {a.gpus} but {have} GPU(s) visible; refusing to fold ranks onto fewer devices "
+                     "(PAR_OVERSUBSCRIBE=1 shares devices on purpose)")
+    with socket.socket() as sk:                          # a free rendezvous port (the queue's store binds above it)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    if a.dry_run:
+        env["PAR_OVERSUBSCRIBE"] = "1"                   # no GPU work in a dry run: the device count is irrelevant
+    return subprocess.call(cmd, env=env)
+
+
+def config5_dry_run(a, ctx):
+    """--dry-run: the launch, rendezvous, work queue, same-workload base, reductions and the JSON line of the config-5
+    mode with the GPU work replaced by a sleep per file -- what the CPU tests drive (no HIP call, `value` means nothing)."""
+    from pyaudiorestoration_amd import multi_gpu
+    per_file = 2 * 115_200_000
+    done = {"files": 0}
+    step_no = [0]
+
+    def run_files(file_iter):
+        k = 0
+        for _ in file_iter:
+            time.sleep(0.002)
+            k += 1
+        return k
+
+    def step():
+        q = multi_gpu.WorkQueue(ctx, range(a.files), f"d{step_no[0]}")
+        step_no[0] += 1
+        done["files"] = run_files(q)
+
+    for _ in range(a.warmup):
+        step()
+    ctx.barrier()
+    n1 = None
+    if ctx.rank == 0:
+        t0 = time.perf_counter()
+        k = run_files(range(min(a.files, a.n1_files)))
+        n1 = k * per_file / (time.perf_counter() - t0) / 1e6
+    dt = ctx.timed(step, a.steps)
+    total = ctx.reduce_sum(done["files"]) * per_file
+    if ctx.rank == 0:
+        value = total * a.steps / dt / 1e6
+        print(json.dumps({"metric": "Msamples/sec resampled (192 kHz varispeed)", "value": round(value, 3), "unit": "Msamples/s",
+                          "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dry_run": True,
+                          "data": "none (dry run: a sleep per file)", "config": {"workload": "config 5 flow, dry run", "files": a.files,
+                                                                                 "channel_samples_per_step": int(total)},
+                          "n1_same_workload_value": round(n1, 3), "speedup_vs_n1": round(value / n1, 3),
+                          "efficiency": round(value / n1 / ctx.world, 4)}), flush=True)
+    ctx.close()
+
+
 def config5_batch(a, ctx):
     """BASELINE config 5 as the timed workload (N > 1, or --config5): 512 stereo 10-min files at 192 kHz, one step =
-    the whole archive.  Every rank pulls files from the shared longest-first queue (multi_gpu.WorkQueue: a host-side
-    fetch-add, no collective) and runs them through resampling.varispeed_batch_dev: one plan per file (each file has
-    its own speed curve: phase 0.7 + file index) and ONE stereo K_sinc launch, the next file's plan on a
-    side stream under it.  Inputs resident in HBM before the timed region: a ring of `--ring` synthetic stereo files
-    per GPU (the archive itself is 472 GB; signal content does not change the work) and all 512 speed curves."""
+    the whole archive.  Every rank pulls files (four per request) from the shared longest-first queue
+    (multi_gpu.WorkQueue: a host-side fetch-add, no collective) and runs them through resampling.varispeed_batch_dev: one
+    plan per file (each file has its own speed curve: phase 0.7 + file index) and ONE stereo K_sinc launch,
+    the next file's plan on a side stream under it.  Inputs resident in HBM before the timed region: a ring of `--ring`
+    synthetic stereo files per GPU (the archive itself is 472 GB; signal content does not change the work) and the
+    speed curves (7.2 MB per file, all of them on every rank: any rank may pull any file).
+
+    Besides `value` (results left in HBM, like the N = 1 line) the line carries
+    * the same workload on ONE GPU, measured in this run: rank 0 alone over `--n1-files` files of the archive while the
+      other ranks wait -> n1_same_workload_value, speedup_vs_n1, efficiency;
+    * the end-to-end leg (north_star: "results gathered on the host"; SURVEY 8e: kernel-only and end-to-end scaling
+      reported separately): the same archive with every output copied into a pinned host ring per rank
+      (resampling.varispeed_batch_gather) -> value_e2e, with its own one-GPU base."""
     import torch
     from pyaudiorestoration_amd import _dev, _lib, multi_gpu, resampling
     world, rank, dev = ctx.world, ctx.rank, ctx.local
@@ -252,24 +331,48 @@ def config5_batch(a, ctx):
     done = {"samples": 0, "files": 0}
     step_no = [0]
 
-    def step():
-        q = multi_gpu.WorkQueue(ctx, range(files), f"s{step_no[0]}")
-        step_no[0] += 1
-
+    def run_files(file_iter, gather):
+        """One GPU's loop over the files it is handed -> (channel-samples, files)."""
         def produce():
-            for k, f in enumerate(q):
+            for k, f in enumerate(file_iter):
                 yield curves[f, 0], curves[f, 1], ring[k % a.ring]
         n_s = n_f = 0
-        for _, out, plan in resampling.varispeed_batch_dev(produce(), a.nt, dev):
+        driver = resampling.varispeed_batch_gather if gather else resampling.varispeed_batch_dev
+        for _, out, plan in driver(produce(), a.nt, dev):
             n_s += 2 * plan.len_out
             n_f += 1
-        done["samples"], done["files"] = n_s, n_f
+        torch.cuda.synchronize(dev)
+        return n_s, n_f
+
+    def step(gather=False):
+        q = multi_gpu.WorkQueue(ctx, range(files), f"s{step_no[0]}")
+        step_no[0] += 1
+        done["samples"], done["files"] = run_files(q, gather)
+
+    def solo(n_files, gather):
+        """Rank 0 alone over the first n_files files (the others idle at the barrier that follows): the one-GPU rate of
+        THIS workload, taken in THIS run on THIS node."""
+        rate = 0.0
+        if rank == 0:
+            run_files(range(min(3, n_files)), gather)
+            t0 = time.perf_counter()
+            n_s, _ = run_files(range(n_files), gather)
+            rate = n_s / (time.perf_counter() - t0) / 1e6
+        ctx.barrier()
+        return rate
 
     for _ in range(a.warmup):
         step()
+    n1 = solo(min(files, a.n1_files), False)
     dt = ctx.timed(step, a.steps)
     total = ctx.reduce_sum(done["samples"])            # channel-samples of one step, all ranks
     files_max, files_min = ctx.reduce_max(done["files"]), -ctx.reduce_max(-done["files"])
+    e2e = None
+    if not a.no_e2e:
+        n1_e2e = solo(min(files, a.n1_e2e_files), True)
+        dt_e = ctx.timed(lambda: step(True), 1)
+        total_e = ctx.reduce_sum(done["samples"])
+        e2e = (total_e / dt_e / 1e6, n1_e2e, dt_e)
     if rank == 0:
         value = total * a.steps / dt / 1e6
         res = {
@@ -277,15 +380,20 @@ def config5_batch(a, ctx):
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 taps / f64 positions",
             "data": "synthetic",
+            "n1_same_workload_value": round(n1, 3), "speedup_vs_n1": round(value / n1, 3),
+            "efficiency": round(value / n1 / world, 4), "distinct_devices": ctx.distinct_devices,
             "config": {"workload": f"config 5: {files}-file archive, {seconds:g}-s {sr} Hz stereo float32 each, +-1% sinusoidal speed "
                                    f"curve per file (0.55 Hz, hop 256, phase 0.7 + file index), {2 * a.nt}-tap Hann sinc; one step = the "
                                    "whole archive, files pulled by the ranks from a shared host-side queue (no collective, no RCCL)",
                        "files": files, "channel_samples_per_step": int(total), "files_per_rank_min_max": [int(files_min), int(files_max)],
                        "value_per_gpu": round(value / world, 3),
-                       "n1_same_workload": "the --gpus 1 line times the mono 60-min file of BASELINE configs[1]; the 1-GPU point "
-                                           "of THIS workload is that line's secondary_config5.batched_Msamples/s, or "
-                                           "`python bench.py --config5` (profiles/r02_bench_config5_n1.json: 129 G)",
+                       "n1_same_workload": f"n1_same_workload_value = rank 0 alone over {min(files, a.n1_files)} files of this archive, "
+                                           "same code path, measured in this run before the timed region (the other ranks idle); "
+                                           "speedup_vs_n1 = value / that, efficiency = speedup / n_gpus.  The `--gpus 1` line without "
+                                           "--config5 times a different workload (the mono 60-min file of BASELINE configs[1]): do "
+                                           "not build a curve from it",
                        "NT": a.nt, "resident": f"ring of {a.ring} synthetic stereo files per GPU + all {files} speed curves",
+                       "queue": "one TCP-store fetch-add per 4 files",
                        "step": "per file: plan (device scans, cumsum checkpoints, block records) + ONE stereo fused K_sinc launch; "
                                "the next file's plan runs on a side stream under K_sinc"},
             "roofline": {"bound": "hbm", "achieved": round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / world, 2), "peak": HBM_PEAK_GBS,
@@ -295,6 +403,17 @@ def config5_batch(a, ctx):
                                  "names; what limits the kernel is VALU issue (the N = 1 line carries the per-kernel HIP-event "
                                  "timing, PMC traffic and the VALU roofline)"},
         }
+        if e2e is not None:
+            v_e, n1_e, dt_e = e2e
+            res["value_e2e"] = round(v_e, 3)
+            res["e2e"] = {"value_e2e": round(v_e, 3), "unit": "Msamples/s", "s_per_step": round(dt_e, 3), "steps": 1,
+                          "n1_same_workload_value": round(n1_e, 3), "speedup_vs_n1": round(v_e / n1_e, 3),
+                          "efficiency": round(v_e / n1_e / world, 4),
+                          "GB_per_s_to_host_per_gpu": round(v_e * 1e6 * 4 / 1e9 / world, 2),
+                          "what": "the same archive, every output copied to a ring of 3 pinned host buffers per rank on a "
+                                  "separate stream under the next files' kernels (inputs stay resident in HBM); the bus (one "
+                                  "0.92 GB D2H per file), not the kernels, sets this rate; one-GPU base = rank 0 alone over "
+                                  f"{min(files, a.n1_e2e_files)} files"}
         print(json.dumps(res), flush=True)
     ctx.close()
 
@@ -302,8 +421,9 @@ def config5_batch(a, ctx):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 150 mono files ~ 1 s of timed region at N = 1; 2 archive passes in the config-5 mode)")
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--seconds", type=float, default=3600.0, help="file duration (default: the 60-min config)")
     ap.add_argument("--sr", type=int, default=192000)
     ap.add_argument("--nt", type=int, default=32)
@@ -315,7 +435,24 @@ def main():
     ap.add_argument("--config5", action="store_true", help="time the 512-file stereo archive (default when --gpus > 1)")
     ap.add_argument("--files", type=int, default=512, help="files of the config-5 archive")
     ap.add_argument("--ring", type=int, default=6, help="resident synthetic stereo files per GPU in the config-5 mode")
+    ap.add_argument("--n1-files", type=int, default=64, help="files of the one-GPU same-workload base (config-5 mode)")
+    ap.add_argument("--n1-e2e-files", type=int, default=24, help="files of the one-GPU base of the host-gather leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-gather leg of the config-5 mode")
+    ap.add_argument("--dry-run", action="store_true", help="config-5 flow with a sleep per file instead of GPU work (CPU tests)")
     a = ap.parse_args()
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if a.gpus > 1 and env_world == 0:
+        sys.exit(_launch_ranks(a))                     # start the N ranks ourselves; rank 0 of the child run prints the line
+    if env_world and a.gpus != env_world:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={env_world} ranks")
+    batch_mode = a.gpus > 1 or a.config5 or a.dry_run
+    if a.steps is None:
+        a.steps = 2 if batch_mode else 150
+    if a.warmup is None:
+        a.warmup = 1 if batch_mode else 3
+    if a.dry_run:
+        from pyaudiorestoration_amd import multi_gpu
+        return config5_dry_run(a, multi_gpu.RankContext())
 
     import torch
     from pyaudiorestoration_amd import _dev, _lib, multi_gpu

@@ -7,6 +7,8 @@
 // frame's band is a contiguous run.  Band/bin arithmetic is float64 like the reference.
 #include "par_common.h"
 #include <math.h>
+#include <mutex>
+#include <set>
 
 namespace par {
 
@@ -194,20 +196,32 @@ __global__ __launch_bounds__(256) void k_corr_resample(const float* __restrict__
   }
 }
 
+// One workgroup per frame pair.  No `same` array: a thread keeps the running (value, first index) maximum of the lags it
+// evaluates, the workgroup reduces those pairs (ties -> the smaller lag, np.argmax's first occurrence), and the two
+// neighbours of the winner are evaluated once more by the same expression (bit-identical to what the owner of that lag
+// computed).  LDS_AB: the two frames sit in dynamic LDS (2 n doubles, raised above 64 KB by the host wrapper up to
+// n = 8192); wider bands read them from HBM/L2.
+template <bool LDS_AB>
 __global__ __launch_bounds__(256) void k_corr_peak(const double* __restrict__ R, int n, double* __restrict__ changes,
                                                    int* __restrict__ status) {
-  extern __shared__ double sh[];                           // a[n], b[n], same[n]
-  double* a = sh;
-  double* b = sh + n;
-  double* same = sh + 2 * n;
+  extern __shared__ double sh[];                           // a[n], b[n] when LDS_AB
   __shared__ double red[2][4];
+  __shared__ double best_v[4];
+  __shared__ int best_j[4];
   const int64_t i = blockIdx.x;
+  const double* ga = R + i * n;
+  const double* gb = R + (i + 1) * n;
+  const double* a = LDS_AB ? sh : ga;
+  const double* b = LDS_AB ? sh + n : gb;
   double na = 0.0, nbv = 0.0;
   for (int g = threadIdx.x; g < n; g += blockDim.x) {
-    a[g] = R[i * n + g];
-    b[g] = R[(i + 1) * n + g];
-    na += a[g] * a[g];
-    nbv += b[g] * b[g];
+    const double av = ga[g], bv = gb[g];
+    if (LDS_AB) {
+      sh[g] = av;
+      sh[n + g] = bv;
+    }
+    na += av * av;
+    nbv += bv * bv;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -221,25 +235,57 @@ __global__ __launch_bounds__(256) void k_corr_peak(const double* __restrict__ R,
   __syncthreads();
   const double inv = 1.0 / (sqrt(red[0][0] + red[0][1] + red[0][2] + red[0][3]) * sqrt(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
   const int half = n / 2;
-  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+  auto same_at = [&](int j) {
     double acc = 0.0;
     const int lo = half - j > 0 ? half - j : 0;            // m + j - half >= 0
     const int hi = n + half - j < n ? n + half - j : n;    // m + j - half < n
     for (int m = lo; m < hi; ++m) acc += a[m + j - half] * b[m];
-    same[j] = acc * inv;
+    return acc * inv;
+  };
+  double bv = -INFINITY;
+  int bj = 0x7fffffff;
+  bool seen_nan = false;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const double v = same_at(j);
+    if (v != v && !seen_nan) {                             // np.argmax returns the first NaN
+      seen_nan = true;
+      bv = v;
+      bj = j;
+    }
+    if (!seen_nan && v > bv) {                             // ascending j per thread: strict > keeps the first occurrence
+      bv = v;
+      bj = j;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(bv, o, kWave);
+    const int oj = __shfl_xor(bj, o, kWave);
+    const bool mine_nan = bv != bv, other_nan = ov != ov;
+    const bool take = (other_nan && (!mine_nan || oj < bj)) || (!mine_nan && !other_nan && (ov > bv || (ov == bv && oj < bj)));
+    if (take) {
+      bv = ov;
+      bj = oj;
+    }
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    best_v[threadIdx.x / kWave] = bv;
+    best_j[threadIdx.x / kWave] = bj;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int arg = 0;
-    double best = same[0];
-    for (int j = 1; j < n; ++j) {
-      if (same[j] > best) {                                // first occurrence of the maximum (np.argmax)
-        best = same[j];
-        arg = j;
+    for (int w = 1; w < (int)(blockDim.x / kWave); ++w) {
+      const double ov = best_v[w];
+      const int oj = best_j[w];
+      const bool mine_nan = bv != bv, other_nan = ov != ov;
+      if ((other_nan && (!mine_nan || oj < bj)) || (!mine_nan && !other_nan && (ov > bv || (ov == bv && oj < bj)))) {
+        bv = ov;
+        bj = oj;
       }
     }
+    const int arg = bj < n ? bj : 0;
     if (arg == n - 1) atomicOr(status, 2);                 // parabolic() reads f[x + 1]: IndexError in the reference
-    const double fm = same[arg == 0 ? n - 1 : arg - 1], f0 = same[arg], fp = same[arg == n - 1 ? arg : arg + 1];
+    const double fm = same_at(arg == 0 ? n - 1 : arg - 1), f0 = same_at(arg), fp = same_at(arg == n - 1 ? arg : arg + 1);
     const double refined = 0.5 * (fm - fp) / (fm - 2.0 * f0 + fp) + (double)arg;
     changes[i] = (double)half - refined;
   }
@@ -468,20 +514,44 @@ int par_track_corr_f64(int device, const float* mag, int64_t n_frames, int bins,
                        double* freqs, int32_t* status, void* stream) {
   using namespace par;
   PAR_REQUIRE(mag && M && wind && work && freqs && status, PAR_ERR_ARG, "par_track_corr_f64: null pointer");
-  PAR_REQUIRE(NL >= 0 && NU > NL && NU <= bins && count >= 0 && count <= n_frames && n == 4 * (NU - NL) && n <= 4096,
-              PAR_ERR_ARG, "par_track_corr_f64: bad band / grid (NL=%d NU=%d bins=%d n=%d count=%lld)", NL, NU, bins, n,
-              (long long)count);
+  // NU may reach past the last bin: the reference's slices [NL:NU] clip to the spectrum while its grid keeps
+  // 4 (NU - NL) points (util/wow_detection.py:404-406), so the band has nb = min(NU, bins) - NL values and M is [n][nb]
+  const int nb = (NU < bins ? NU : bins) - NL;
+  PAR_REQUIRE(NL >= 0 && nb >= 3 && count >= 0 && count <= n_frames && n == 4 * (NU - NL), PAR_ERR_ARG,
+              "par_track_corr_f64: bad band / grid (NL=%d NU=%d bins=%d n=%d count=%lld)", NL, NU, bins, n, (long long)count);
   PAR_HIP_CHECK(hipSetDevice(device));
   hipStream_t s = as_stream(stream);
   PAR_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), s));
   if (count == 0) return PAR_OK;
-  const int nb = NU - NL;
   double* R = work;
   double* changes = work + (count + 1) * (int64_t)n;
-  hipLaunchKernelGGL(k_corr_resample, dim3((unsigned)(count + 1)), dim3(256), nb * sizeof(double), s, mag, bins, NL, nb, count,
-                     M, wind, n, R);
-  hipLaunchKernelGGL(k_corr_peak, dim3((unsigned)count), dim3(256), 3 * n * sizeof(double), s, (const double*)R, n, changes,
-                     status);
+  const size_t band_lds = (size_t)nb * sizeof(double);
+  PAR_REQUIRE(band_lds <= 131072, PAR_ERR_UNSUPPORTED, "par_track_corr_f64: band of %d bins (limit 16384)", nb);
+  if (band_lds > 65536) {
+    static std::mutex mu;
+    static std::set<int> done;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done.count(device)) {
+      PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_corr_resample), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+      done.insert(device);
+    }
+  }
+  hipLaunchKernelGGL(k_corr_resample, dim3((unsigned)(count + 1)), dim3(256), band_lds, s, mag, bins, NL, nb, count, M, wind, n, R);
+  const size_t ab_lds = 2 * (size_t)n * sizeof(double);
+  if (ab_lds <= 131072) {                                  // n <= 8192: both frames in LDS (up to 128 of the CU's 160 KB)
+    if (ab_lds > 65536) {
+      static std::mutex mu;
+      static std::set<int> done;
+      std::lock_guard<std::mutex> lk(mu);
+      if (!done.count(device)) {                           // the attribute belongs to the function object of the CURRENT device
+        PAR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_corr_peak<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        done.insert(device);
+      }
+    }
+    hipLaunchKernelGGL(k_corr_peak<true>, dim3((unsigned)count), dim3(256), ab_lds, s, (const double*)R, n, changes, status);
+  } else {
+    hipLaunchKernelGGL(k_corr_peak<false>, dim3((unsigned)count), dim3(256), 0, s, (const double*)R, n, changes, status);
+  }
   hipLaunchKernelGGL(k_corr_finish, dim3(1), dim3(1), 0, s, (const double*)changes, count, n, log_span, log_mean, freqs);
   PAR_HIP_CHECK(hipGetLastError());
   int h = 0;

@@ -34,6 +34,7 @@ class RankContext:
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
         self.device = "cpu"
+        self.distinct_devices = 1 if torch.cuda.is_available() else 0
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -41,8 +42,16 @@ class RankContext:
             if backend is None:
                 backend = os.environ.get("PAR_DIST_BACKEND") or "gloo"      # host-side coordination only
             dist.init_process_group(backend)
+            self.distinct_devices = 0
             if torch.cuda.is_available():
-                self.local %= torch.cuda.device_count()    # more ranks than GPUs: exercise the flow on what there is
+                n_dev = torch.cuda.device_count()
+                local_world = int(os.environ.get("LOCAL_WORLD_SIZE", self.world))
+                if local_world > n_dev and os.environ.get("PAR_OVERSUBSCRIBE") != "1":
+                    # one rank per GPU is the contract: folding ranks onto fewer devices would still print n_gpus = world
+                    raise RuntimeError(f"{local_world} ranks on this node but only {n_dev} GPU(s) visible; set "
+                                       "PAR_OVERSUBSCRIBE=1 to share devices on purpose (flow tests on a 1-GPU box)")
+                self.distinct_devices = min(local_world, n_dev)
+                self.local %= n_dev
                 torch.cuda.set_device(self.local)
                 self.device = f"cuda:{self.local}"
             self.reduce_device = "cpu"
@@ -86,12 +95,15 @@ class RankContext:
 
 class WorkQueue:
     """Shared longest-first queue of work items for the ranks of one node: every rank pulls the next
-    item with ONE fetch-add on a key of a c10d TCP store -- host-side, no collective, no GPU traffic.  `order` is the
-    item list, longest first (equal-sized items: any order); `tag` separates queues (one per benchmark step)."""
+    `grab` items with ONE fetch-add on a key of a c10d TCP store -- host-side, no collective, no GPU traffic.  `order`
+    is the item list, longest first (equal-sized items: any order); `tag` separates queues (one per benchmark step).
+    grab = 4: a rank asks rank 0's store thread once per four files (8 ranks x 1.8 ms per file would otherwise be
+    ~4400 requests/s); the tail imbalance is at most grab - 1 items per rank."""
     _store = None
 
-    def __init__(self, ctx, order, tag):
+    def __init__(self, ctx, order, tag, grab=4):
         self.ctx, self.order, self.key, self._next = ctx, list(order), f"par_queue_{tag}", 0
+        self.grab, self._have = max(1, int(grab)), []
         if ctx.dist and WorkQueue._store is None:
             # rank 0 binds the first free port above the rendezvous port and tells the others through the gloo group
             addr, base = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29533"))
@@ -113,11 +125,15 @@ class WorkQueue:
 
     def pull(self):
         """Next item, or None when the queue is empty."""
-        if self.ctx.dist:
-            k = WorkQueue._store.add(self.key, 1) - 1
-        else:
-            k, self._next = self._next, self._next + 1
-        return self.order[k] if k < len(self.order) else None
+        if not self._have:
+            if self.ctx.dist:
+                k = WorkQueue._store.add(self.key, self.grab) - self.grab
+            else:
+                k, self._next = self._next, self._next + self.grab
+            self._have = list(range(k, min(k + self.grab, len(self.order))))
+            if not self._have:
+                return None
+        return self.order[self._have.pop(0)]
 
     def __iter__(self):
         while True:

@@ -95,7 +95,9 @@ def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_h
             cap = _max_out_for_bytes(L, aux.numel(), m)
             if cap > 0:
                 plan = plan_with(cap, aux)
-                if plan.fused_ok:
+                # k_tile_seg's spare tiles and the checkpoint slack let a curve a little LONGER than cap still come
+                # back with valid checkpoints; K_sinc requires len_out <= max_out, so such a plan is redone below
+                if plan.fused_ok and plan.len_out <= cap:
                     return plan
         if max_out is None:
             max_out = fused_max_out(sampletimes_t, speeds_t)
@@ -341,6 +343,46 @@ def varispeed_batch_host(items, NT, dev=None):
     if pending is not None:
         pending[2].synchronize()
         yield pending[0], pending[1]
+
+
+def varispeed_batch_gather(items, NT, dev=None, slots=3):
+    """varispeed_batch_dev with the results GATHERED ON THE HOST (north_star; SURVEY 8e "results D2H into pinned host
+    buffers"): inputs are device-resident work items as in varispeed_batch_dev, every output goes back over the bus into
+    a ring of `slots` pinned buffers on its own stream while the next files' plans and K_sinc launches run.  This is the
+    per-GPU loop of the end-to-end leg of the multi-GPU benchmark: the bus (one 0.92 GB D2H per 10-min stereo file), not
+    the kernels, sets its pace.
+
+    Yields (index, host_view, plan) in order; host_view is a PINNED float32 CPU tensor shaped like the device output,
+    valid until `slots - 1` more items have been taken (the ring wraps)."""
+    dev = _dev.device_index(dev)
+    main = torch.cuda.current_stream(dev)
+    down = torch.cuda.Stream(device=dev)
+    ring = _pinned_ring.setdefault(("gather", dev), [None] * slots)
+    while len(ring) < slots:
+        ring.append(None)
+    landed = [None] * slots                              # event: the D2H into slot s is complete
+    pending = []                                         # (index, view, plan, event), oldest first
+    for k, out_t, plan in varispeed_batch_dev(items, NT, dev):
+        slot = k % slots
+        if ring[slot] is None or ring[slot].numel() < out_t.numel():
+            ring[slot] = torch.empty(int(out_t.numel() * 1.03) + 4096, dtype=torch.float32).pin_memory()
+        view = ring[slot][:out_t.numel()].view(out_t.shape)
+        done = torch.cuda.Event()
+        done.record(main)
+        down.wait_event(done)
+        with torch.cuda.stream(down):
+            view.copy_(out_t, non_blocking=True)
+            landed[slot] = torch.cuda.Event()
+            landed[slot].record(down)
+        out_t.record_stream(down)
+        pending.append((k, view, plan, landed[slot]))
+        if len(pending) >= slots - 1:                    # keep slots - 1 copies in flight behind the compute
+            i, v, p, ev = pending.pop(0)
+            ev.synchronize()
+            yield i, v, p
+    for i, v, p, ev in pending:
+        ev.synchronize()
+        yield i, v, p
 
 
 def varispeed_resample_dev(plan, sig_t, NT, out_t=None, pos_t=None, sig_stride=1, len_in=None, out_stride=1, n_chunks=0):

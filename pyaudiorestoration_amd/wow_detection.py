@@ -244,12 +244,14 @@ class FreehandTracker(Track):
     name = 'Freehand Draw'     # returns the interpolated trail itself
 
 
-def correlation_spline_matrix(log_freqs):
+def correlation_spline_matrix(log_freqs, n_grid=None):
     """The quadratic interpolating spline of `interp1d(log_freqs, y, kind='quadratic')` evaluated on the reference's
     4x oversampled uniform grid, as a matrix: grid values = M @ band values (the spline is linear in y and its
-    abscissae are the same for every frame, so scipy's own construction is applied once, to the identity)."""
+    abscissae are the same for every frame, so scipy's own construction is applied once, to the identity).
+    n_grid: grid points when they are not 4 per band value (a band clipped at the last bin keeps the grid of the
+    unclipped one, util/wow_detection.py:404-408)."""
     nb = len(log_freqs)
-    grid = np.linspace(log_freqs[0], log_freqs[-1], 4 * nb)
+    grid = np.linspace(log_freqs[0], log_freqs[-1], 4 * nb if n_grid is None else n_grid)
     return np.ascontiguousarray(make_interp_spline(log_freqs, np.eye(nb), k=2, axis=0, check_finite=False)(grid))
 
 
@@ -270,7 +272,7 @@ class CorrelationTracker(Track):
         n = 4 * (self.NU - self.NL)
         dev, mag = self._device_spectrum()
         L = _lib.lib()
-        M_t = _dev.to_dev(correlation_spline_matrix(log_f), torch.float64, dev)
+        M_t = _dev.to_dev(correlation_spline_matrix(log_f, n), torch.float64, dev)
         w_t = _dev.to_dev(np.hanning(n), torch.float64, dev)
         work = _dev.empty(int(L.par_track_corr_work_len(count, n)), torch.float64, dev)
         f_t = _dev.empty(count, torch.float64, dev)

@@ -39,7 +39,7 @@ def test_world2_gloo_timing_and_reduction():
     assert r["world"] == 2 and r["total"] == 1024 and r["per_rank"] == 512 and r["first_sum"] == 1
     assert r["dt"] >= 0.055            # MAX over ranks: the slow rank (3 x 20 ms) sets the time
     # shared work queue: 40 items pulled exactly once in total, the faster rank took more of them
-    assert r["q_total"] == 40 and r["q_sum"] == sum(range(40)) and 1 <= r["q_min"] < 20
+    assert r["q_total"] == 40 and r["q_sum"] == sum(range(40)) and 1 <= r["q_min"] <= 20
     blocker.close()
 
 
@@ -59,3 +59,34 @@ def test_world8_gloo_queue_and_reductions():
 def test_work_queue_single_process():
     ctx = multi_gpu.RankContext()
     assert list(multi_gpu.WorkQueue(ctx, [5, 3, 9], "solo")) == [5, 3, 9]
+
+
+def test_bench_gpus2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher: the flag is honoured, two ranks are started,
+    rank 0 prints one line with n_gpus == 2 and the same-workload one-GPU base.  --dry-run replaces the GPU work with a
+    sleep per file so the whole flow (self-launch, rendezvous, four-files-per-request queue, reductions) runs here."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--files", "42", "--steps", "2",
+           "--warmup", "1", "--n1-files", "20"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                     # ONE line, from rank 0
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["dry_run"] is True and r["steps"] == 2 and r["warmup"] == 1
+    assert r["config"]["channel_samples_per_step"] == 42 * 2 * 115_200_000      # every file exactly once per step
+    assert {"n1_same_workload_value", "speedup_vs_n1", "efficiency"} <= set(r)
+    assert 1.2 < r["speedup_vs_n1"] < 2.3
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                         capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode != 0 and "WORLD_SIZE=4" in out.stderr
+
+
+def test_work_queue_grabs_four_items_per_request():
+    ctx = multi_gpu.RankContext()
+    q = multi_gpu.WorkQueue(ctx, list(range(10, 21)), "solo4")
+    assert q.grab == 4 and list(q) == list(range(10, 21)) and q._next == 16    # 3 requests served items, the 4th came back empty
