@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(256) void k_block_rec2(const double* __restrict__ s
   o2.I2 = (int)(unsigned)(unsigned long long)(s1.A + (long long)r1);
   o2.F2 = (float)(a0 - r1);
   o2.e1b = (float)(b1.a1m1 - 2.0 * b1.a2 * u);
-  o2.pad = 0u;
+  o2.e2b = (float)b1.a2;
   rec2[start >> 3] = o2;
 }
 
@@ -1139,10 +1139,11 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
   if (ustar < 8) {                                            // a segment starts at u = ustar (its piece: k_block_rec2)
     const int need = 8 - (int)ustar;                          // outputs of the block that fall to segment i + 1
     end1 = s1.n == need;
-    // the record keeps ONE curvature term (e2 ~ -step/(2 speed^2)): the second piece rides on the first one's when the
-    // two agree to 1e-8 over u^2 <= 49; its first-order term must be inside the float32 budget like the first piece's
+    // the second piece has its own curvature term (BlockRec2::e2b; r02 let it ride on the first piece's, which the
+    // benchmark's own curve missed at 72 % of its segment boundaries: 63 % of K_sinc's waves then ran the float64 redo
+    // path for a handful of lanes, tools/rec_stats.py); its first-order term must be inside the float32 budget
     slow1 = !(i + 1 < nseg && s1.fast == 2 && s1.n >= need && s1.A > -(1ll << 61) && s1.A < (1ll << 61) && sp1 >= 0.971 &&
-              sp1 <= 1.031 && fabs(s1.step - sf.step) * 24.5 <= 1.0e-8 * sp1 * sp1) ||
+              sp1 <= 1.031) ||
             (ul >= (long long)ustar && ul < 8);
   }
   BlockRec o;

@@ -168,7 +168,7 @@ static_assert(sizeof(SegFast) == 32, "SegFast is loaded as two 16-byte words");
 //             |p| out of range, the file's last output): its outputs are placed by place_fast / place_exact instead
 // The last output of a segment matters because its period to the next position is the PREVIOUS increment (the next
 // segment starts at this ramp's end speed); u = ustar - 1 is always such an output.
-// The second piece (I2, F2, e1b; it shares e2) lives in a parallel array that only boundary blocks touch.
+// The second piece (I2, F2, e1b, e2b) lives in a parallel array that only boundary blocks touch.
 struct BlockRec {
   int I;
   float F, e1;
@@ -178,8 +178,7 @@ static_assert(sizeof(BlockRec) == 16, "BlockRec is one 16-byte word");
 constexpr unsigned kRecFlagBits = 0x7fu;
 struct BlockRec2 {
   int I2;
-  float F2, e1b;
-  unsigned pad;
+  float F2, e1b, e2b;       // the second piece's own quadratic (same variable u as the first piece's)
 };
 static_assert(sizeof(BlockRec2) == 16, "BlockRec2 is one 16-byte word");
 // (Measured and not kept, one box, K_sinc alone / pipelined step in ms: both records of a block in one 32-byte slot and
