@@ -941,9 +941,9 @@ __global__ void k_publish_ck(PlanHeader* __restrict__ h, int64_t ck_len) {
 // segment up (upper bound over seg_start: a tile per thread, not a segment per thread -- one segment can cover
 // 10^5..10^6 tiles).
 __global__ void k_tile_seg(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
-                           const double* __restrict__ seg_off, int64_t nseg, int64_t ck_len, int64_t max_tiles,
-                           int64_t* __restrict__ tile_seg, SegFast* __restrict__ seg_fast, long long* __restrict__ tile_st,
-                           PlanHeader* __restrict__ h) {
+                           const double* __restrict__ seg_off, int64_t nseg, const double* __restrict__ ck, int64_t ck_len,
+                           int64_t max_tiles, int64_t* __restrict__ tile_seg, SegFast* __restrict__ seg_fast,
+                           long long* __restrict__ tile_st, TileHdr* __restrict__ hdr, PlanHeader* __restrict__ h) {
   const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const long long len_out = h->len_out;                // written by k_trim / the host path earlier on this stream
   const long long n_tiles = (len_out + kSincTileOutputs - 1) / kSincTileOutputs;
@@ -969,8 +969,10 @@ __global__ void k_tile_seg(const double* __restrict__ sp, const int64_t* __restr
     const double smin = s0 < s1 ? s0 : s1, smax = s0 < s1 ? s1 : s0;
     f.fast = off_ok && n >= 2 && n < 0x7fffffffll && smin >= 0.0625 && smax <= 64.0 &&
              fabs(f.step) <= 6.0e-4 * smin * sqrt(sqrt(smin));
-    // level 2 (BlockRec): over 8 steps the reciprocal increments are linear up to 42 step^2 / smin^3 < 2e-8 samples
-    if (f.fast && fabs(f.step) <= 2.18e-5 * smin * sqrt(smin)) f.fast = 2;
+    // level 2 (BlockRec with the cubic term): over the 32 centred steps of a block (|d| <= 16, up to 33 with the steps behind
+    // the checkpoint) the quartic term of the reciprocal sum, z^3 d^4 / 4 with z = step / speed, stays < 1e-8 samples
+    // level 3 (the block quadratic alone): the cubic term z^2 d^3 / 3 <= 1365 z^2 stays < 1e-8
+    if (f.fast && fabs(f.step) <= 5.0e-5 * smin) f.fast = fabs(f.step) <= 2.7e-6 * smin ? 3 : 2;
     seg_fast[x] = f;
   }
   if (x > n_tiles || len_out <= 0) return;
@@ -983,21 +985,41 @@ __global__ void k_tile_seg(const double* __restrict__ sp, const int64_t* __restr
   }
   if (lo < nseg) {
     tile_seg[x] = lo;
-    // boundaries the tile's blocks may meet, for k_block_rec's lookup: one 48-byte scalar load per wave there
+    // boundaries the tile's blocks may meet, for k_block_rec's lookup
     for (int q = 0; q < kTileStarts; ++q) tile_st[x * kTileStarts + q] = lo + q <= nseg ? seg_start[lo + q] : LLONG_MAX;
+    // tile header: the anchor every window centre of the tile is relative to -- an even integer within ~8 samples of the
+    // tile's first position (the checkpoint below it; block records keep a 16-bit offset from it)
+    if (x < n_tiles) {
+      const long long start = seg_start[lo], k = sample - start, b = k >> 3;
+      static_assert(kCk == 8, "k >> 3");
+      const double off = seg_off[lo];
+      const bool off_ok = fabs(off) < 4.0e18;
+      const double ro = off_ok ? rint(off) : 0.0;
+      const long long slot = ck_slot0(start, lo) + b;
+      const double ckv = (b && slot < ck_len) ? ck[slot] : 0.0;
+      const double rel = (off_ok ? off - ro : 0.0) + ckv;
+      const bool ok = off_ok && fabs(rel) < 1.0e15 && ro > -0x1p61 && ro < 0x1p61;
+      TileHdr hd;
+      hd.anchor = ok ? ((long long)ro + (long long)rint(rel)) & ~1ll : 0ll;
+      hd.c_last = 0;
+      hd.iT = lo;
+      hd.mn_rel = 0;
+      hd.flags = ok ? 0 : 1;
+      hdr[x] = hd;
+    }
   }
 }
 
-// ---- block records and tile headers of the fused resampler (BlockRec / TileHdr, pos_plan.h) -----------------------
-// One lane per block of 8 consecutive outputs: finds the block's segment (the tile map, then a short walk), takes the
-// cumsum checkpoint below the block's first output, adds the closed-form sum of the <= 7 reciprocals in between, and
-// expands the 8 positions of the block as a quadratic in u around the block centre.  A block that contains a segment
-// boundary gets a second piece for the segment that starts inside it.  Positions are kept relative to rint(seg_off), so
-// every float64 operand is small and the polynomial constant is accurate to ~1e-12.  ONE reciprocal per piece: the
-// speed at the midpoint of the steps behind the checkpoint is at most 7.5 steps from the block centre, so its
-// reciprocal follows from the centre's by a 2-term series in x = r step d (|x| < 2e-4 where the model applies).
+// ---- block records of the fused resampler (BlockRec, pos_plan.h) ---------------------------------------------------
+// One lane per block of kRec = 32 consecutive outputs: finds the block's segment (the tile's boundary table, then a
+// bisection), takes the cumsum checkpoint below the block's first output, adds the closed-form sum of the <= 7
+// reciprocals in between, and expands the 32 positions of the block as a polynomial in the centred u' = u - 16.  A block
+// that contains a segment boundary gets a second piece for the segment that starts inside it (k_block_rec2).  Positions
+// are kept relative to rint(seg_off), so every float64 operand is small and the polynomial constant is accurate to
+// ~1e-12.  ONE reciprocal per piece: every speed the piece needs is at most 24 steps from the block centre, so its
+// reciprocal follows from the centre's by a short series in z d (|z d| < 1.3e-3 where the model applies).
 struct BlockPoly {
-  double a0;       // position of output u = 0 relative to rint(seg_off) of the piece's segment
+  double a0;       // position of the centre output (u' = 0) relative to rint(seg_off) of the piece's segment
   double a1m1;     // first-order coefficient - 1
   double a2;
 };
@@ -1006,74 +1028,78 @@ __device__ __forceinline__ double recip_nr(double b) {       // 1/b to ~1e-15 re
   x = __builtin_fma(x, __builtin_fma(-b, x, 1.0), x);
   return __builtin_fma(x, __builtin_fma(-b, x, 1.0), x);
 }
-// k = step index of the block's output u = 0 in its segment; uk = steps between the checkpoint and k; ckv = checkpoint
+// p(u') = base + sum_{d = d0}^{u'} r(d),  r(d) = 1 / (sc + step d) = rc (1 - z d + z^2 d^2 - ..),  rc = 1/sc, z = rc step:
+//   sum 1 = u' - d0 + 1,  sum d = (u'^2 + u' - d0^2 + d0) / 2,  sum d^2 = (2 u'^3 + 3 u'^2 + u') / 6 - S2(d0 - 1)
+// The pure cubic part rc z^2 u'^3 / 3 is what K_sinc adds itself where the record says `cubic` (it derives the
+// coefficient from e2); its quadratic, linear and constant companions are folded in here.
+__device__ __forceinline__ BlockPoly piece_poly(double base, double rc, double z, int d0) {
+  const double rp = -(rc * z), cz = rc * z * z, dd0 = (double)d0;
+  const double s2m = (dd0 - 1.0) * dd0 * (2.0 * dd0 - 1.0) * (1.0 / 6.0);
+  BlockPoly q;
+  q.a0 = ((base + rc * (1.0 - dd0)) + 0.5 * rp * (dd0 - dd0 * dd0)) - cz * s2m;
+  q.a1m1 = ((rc - 1.0) + 0.5 * rp) + cz * (1.0 / 6.0);
+  q.a2 = 0.5 * rp + 0.5 * cz;
+  return q;
+}
+// first piece of a block: k = step index of the block's output u = 0 in its segment; uk = steps between the checkpoint
+// and k; ckv = checkpoint (cumsum before step k - uk)
 __device__ __forceinline__ BlockPoly block_poly(double foff, double step, double s0, double k, int uk, double ckv, bool fast) {
-  const double rc = recip_nr(__builtin_fma(step, k + 3.5, s0));   // reciprocal speed at the block centre
+  const double rc = recip_nr(__builtin_fma(step, k + 16.0, s0));    // reciprocal speed at the block centre
   const double z = rc * step;
-  const double rp = -(rc * z);                                      // its change per step
   double cprev = ckv;                                               // cumsum before step k
   if (uk) {
-    if (fast) {                                                     // uk steps centred (uk + 1)/2 + 3.5 before the block centre
-      const double x = z * (-0.5 * (double)(uk + 1) - 3.5);
-      const double r = rc * __builtin_fma(x, x - 1.0, 1.0);        // 1/(b + step d) = rc (1 - x + x^2 ..)
+    if (fast) {                                                     // uk steps centred (uk + 1)/2 + 16 before the block centre
+      const double x = z * (-0.5 * (double)(uk + 1) - 16.0);
+      const double r = rc * __builtin_fma(x, __builtin_fma(x, -x, x) - 1.0, 1.0);   // rc (1 - x + x^2 - x^3)
       cprev += r * (double)uk * __builtin_fma(z * z, (double)(uk * uk - 1) * (1.0 / 12.0), 1.0);
     } else {
       for (int v = 0; v < uk; ++v) cprev += recip_nr(__builtin_fma(step, k - (double)(uk - v), s0));
     }
   }
-  const double alpha = __builtin_fma(-3.5, rp, rc);
-  BlockPoly q;
-  q.a0 = (foff + cprev) + alpha;                                    // sum_{v=k}^{k+u} r_v = (u+1) alpha + rp u(u+1)/2
-  q.a1m1 = (alpha - 1.0) + 0.5 * rp;
-  q.a2 = 0.5 * rp;
-  return q;
+  return piece_poly(foff + cprev, rc, z, -16);
 }
+__device__ __forceinline__ bool irel_ok(long long rel) { return rel > -32000 && rel < 32000; }
 
 // second piece of the blocks that contain a segment start: one lane per SEGMENT (m lanes instead of a divergent branch in
-// every wave of k_block_rec)
+// every wave of k_block_rec).  Runs after k_block_rec: a piece outside the 16-bit offset range flags its block slow1.
 __global__ __launch_bounds__(256) void k_block_rec2(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
                                                     int64_t nseg, const SegFast* __restrict__ seg_fast,
+                                                    const TileHdr* __restrict__ hdr, BlockRec* __restrict__ rec,
                                                     BlockRec2* __restrict__ rec2, const PlanHeader* __restrict__ h) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 1 || i >= nseg || !h->ck_valid) return;
   const long long start = seg_start[i];
-  const int us = (int)(start & 7);
+  const int us = (int)(start & (kRec - 1));
   if (us == 0 || start >= h->len_out) return;
   const SegFast s1 = seg_fast[i];
-  const BlockPoly b1 = block_poly(s1.foff, s1.step, sp[i], 0.0, 0, 0.0, true);
-  const double u = (double)us;
-  const double a0 = (b1.a0 - (1.0 + b1.a1m1) * u) + b1.a2 * u * u;   // polynomial in u' = u - ustar, rewritten in u
-  const double r1 = rint(a0);
+  // the cumsum restarts at 0 with the segment's step 0 = the block's u = us, i.e. d0 = us - 16 steps from the centre
+  const double rc = recip_nr(__builtin_fma(s1.step, (double)(16 - us), sp[i]));
+  const BlockPoly b1 = piece_poly(s1.foff, rc, rc * s1.step, us - 16);
+  const double r1 = rint(b1.a0);
+  const long long rel = s1.A + (long long)r1 - hdr[start / kSincTileOutputs].anchor;
   BlockRec2 o2;
-  o2.I2 = (int)(unsigned)(unsigned long long)(s1.A + (long long)r1);
-  o2.F2 = (float)(a0 - r1);
-  o2.e1b = (float)(b1.a1m1 - 2.0 * b1.a2 * u);
-  o2.e2b = (float)b1.a2;
-  rec2[start >> 3] = o2;
+  o2.w0 = (unsigned)((int)rel << 16);
+  o2.F = (float)(b1.a0 - r1);
+  o2.e1 = (float)b1.a1m1;
+  o2.e2 = (float)b1.a2;
+  rec2[start >> kRecShift] = o2;
+  if (!(fabs(b1.a0) < 1.0e9 && irel_ok(rel))) atomicOr(&rec[start >> kRecShift].w0, kRecSlow1);
 }
 
 __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
                                                    int64_t nseg, const double* __restrict__ ck,
                                                    const int64_t* __restrict__ tile_seg, const long long* __restrict__ tile_st,
-                                                   const SegFast* __restrict__ seg_fast, TileHdr* __restrict__ hdr,
+                                                   const SegFast* __restrict__ seg_fast, const TileHdr* __restrict__ hdr,
                                                    BlockRec* __restrict__ rec, const PlanHeader* __restrict__ h) {
-  // One wave per tile, two blocks per lane (lane and lane + 64): the scalar loads and the two dependent memory round
-  // trips are paid once per 128 blocks, and the second block's loads fly under the first one's arithmetic.
   const long long len_out = h->len_out;
   if (!h->ck_valid) return;
-  const long long gbase = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kBlocksPerTile + (threadIdx.x & 63);
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-  const long long g = gbase + 64 * half;
-  const long long jb = g * kCk;
-  if (jb >= len_out) continue;
-  // A wave's blocks lie in ONE tile.  The tile's first segment and the starts of the six segments from it on arrive
-  // by scalar loads and everything below is 32-bit arithmetic relative to the tile's first output; the lane counts the
-  // boundaries at or below its block.  Tiles with more segments (shorter than ~170 outputs) bisect the rest in memory.
-  const unsigned g0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)g);
-  const unsigned g1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)g >> 32));
-  const long long gw = (long long)(((unsigned long long)g1 << 32) | g0);      // the wave's first block
-  const long long T = gw / kBlocksPerTile;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long jb = g * kRec;
+  if (jb >= len_out) return;
+  // The tile's first segment and the starts of the six segments from it on: everything below is 32-bit arithmetic
+  // relative to the tile's first output; the lane counts the boundaries at or below its block.  Tiles with more segments
+  // (shorter than ~170 outputs) bisect the rest in memory.  (Lanes of one tile read the same table: two tiles per wave.)
+  const long long T = g / kBlocksPerTile;
   const long long j0 = T * kSincTileOutputs;
   const long long iT = tile_seg[T];
   int Sr[kTileStarts];                                        // segment starts relative to j0 (first one may be negative)
@@ -1082,14 +1108,14 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
     const long long d = tile_st[T * kTileStarts + q] - j0;
     Sr[q] = d < -0x40000000ll ? -0x40000000 : (d > 0x40000000ll ? 0x40000000 : (int)d);
   }
-  const int jr = (int)(jb - j0);                              // 0 .. 1016
+  const int jr = (int)(jb - j0);                              // 0 .. 992
   int si = 0;
 #pragma unroll
   for (int q = 1; q < kTileStarts; ++q) si += jr >= Sr[q];
   long long i = iT + si;
   long long k;                                                // step index of the block's first output in its segment
   double kd;                                                  // the same as a double (from 32 bits where the table serves)
-  int rem;                                                    // outputs of segment i from jb on (>= 1), clamped to 9
+  int rem;                                                    // outputs of segment i from jb on (>= 1), clamped to kRec + 1
   long long slot0;                                            // checkpoint slot of the segment's step 0
   if (si < kTileStarts - 1 && Sr[0] > -0x40000000) {
     int sr = Sr[0], nr = Sr[1];
@@ -1103,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
     k = jr - sr;
     kd = (double)(jr - sr);
     const int d = nr - jr;
-    rem = d < 9 ? d : 9;
+    rem = d < kRec + 1 ? d : kRec + 1;
     slot0 = ck_slot0(j0 + sr, i);
   } else {                                                    // beyond the table (or a segment of > 10^9 outputs)
     long long hi = tile_seg[T + 1];                           // entry [n_tiles] is the segment of the last output
@@ -1114,7 +1140,7 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
     const long long start = seg_start[i], d = seg_start[i + 1] - jb;
     k = jb - start;
     kd = (double)k;
-    rem = d < 9 ? (int)d : 9;
+    rem = d < kRec + 1 ? (int)d : kRec + 1;
     slot0 = ck_slot0(start, i);
   }
   // everything the block needs, in one round of independent loads (the next segment's record speculatively: boundary
@@ -1123,48 +1149,38 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
   const SegFast sf = seg_fast[i];
   const SegFast s1 = seg_fast[i1];
   const double sp0 = sp[i], sp1 = sp[i1];
+  const TileHdr hd = hdr[T];
   const long long b = k >> 3;
   const int uk = (int)(k & 7);
   static_assert(kCk == 8, "k >> 3");
   const double ckv = b ? ck[slot0 + b] : 0.0;
   const BlockPoly q0 = block_poly(sf.foff, sf.step, sp0, kd, uk, ckv, sf.fast != 0);
   const double r0 = rint(q0.a0);
-  const long long I0 = sf.A + (long long)(int)r0;             // |a0| >= 1e9 saturates: such a block is flagged (range0) and never placed from I
-  const bool range0 = fabs(q0.a0) < 1.0e9 && sf.A > -(1ll << 61) && sf.A < (1ll << 61);
-  const unsigned ustar = rem < 8 ? (unsigned)rem : 8u;
-  // the file's last output reuses the previous period: slow path.  Only the last tile can hold it (wave-uniform test)
+  const long long rel0 = sf.A + (long long)(int)r0 - hd.anchor;   // |a0| >= 1e9 saturates: such a block is flagged and never placed from Irel
+  const bool range0 = fabs(q0.a0) < 1.0e9 && sf.A > -(1ll << 61) && sf.A < (1ll << 61) && irel_ok(rel0) && !(hd.flags & 1);
+  const unsigned ustar = rem < kRec ? (unsigned)rem : (unsigned)kRec;
+  // the file's last output reuses the previous period: slow path
   const long long ul = j0 + kSincTileOutputs >= len_out ? len_out - 1 - jb : -1;
-  const unsigned slow0 = !(sf.fast == 2 && range0 && fabs(q0.a1m1) <= 0.03125) || (ul >= 0 && ul < (long long)ustar);
-  unsigned slow1 = 0u, end1 = 0u;
-  if (ustar < 8) {                                            // a segment starts at u = ustar (its piece: k_block_rec2)
-    const int need = 8 - (int)ustar;                          // outputs of the block that fall to segment i + 1
+  const unsigned slow0 = !(sf.fast >= 2 && range0 && fabs(q0.a1m1) <= 0.03125) || (ul >= 0 && ul < (long long)ustar);
+  unsigned slow1 = 0u, end1 = 0u, cubic = sf.fast == 2;
+  if (ustar < (unsigned)kRec) {                               // a segment starts at u = ustar (its piece: k_block_rec2)
+    const int need = kRec - (int)ustar;                       // outputs of the block that fall to segment i + 1
     end1 = s1.n == need;
-    // the second piece has its own curvature term (BlockRec2::e2b; r02 let it ride on the first piece's, which the
-    // benchmark's own curve missed at 72 % of its segment boundaries: 63 % of K_sinc's waves then ran the float64 redo
-    // path for a handful of lanes, tools/rec_stats.py); its first-order term must be inside the float32 budget
-    slow1 = !(i + 1 < nseg && s1.fast == 2 && s1.n >= need && s1.A > -(1ll << 61) && s1.A < (1ll << 61) && sp1 >= 0.971 &&
+    // the second piece has its own polynomial (r02 let its curvature ride on the first piece's, which the benchmark's
+    // own curve missed at 72 % of its segment boundaries: 63 % of K_sinc's waves then ran the float64 redo path for a
+    // handful of lanes, tools/rec_stats.py); its first-order term must be inside the float32 budget like the first's
+    slow1 = !(i + 1 < nseg && s1.fast >= 2 && s1.n >= need && s1.A > -(1ll << 61) && s1.A < (1ll << 61) && sp1 >= 0.971 &&
               sp1 <= 1.031) ||
-            (ul >= (long long)ustar && ul < 8);
+            (ul >= (long long)ustar && ul < kRec);
+    cubic |= s1.fast == 2;
   }
   BlockRec o;
-  o.I = (int)(unsigned)(unsigned long long)I0;
+  o.w0 = ((unsigned)((int)rel0 << 16)) | (ustar - 1u) | (((ustar < (unsigned)kRec) || rem == kRec) ? kRecE0 : 0u) |
+         (end1 ? kRecE1 : 0u) | (slow0 ? kRecSlow0 : 0u) | (slow1 ? kRecSlow1 : 0u) | (cubic ? kRecCubic : 0u);
   o.F = (float)(q0.a0 - r0);
   o.e1 = (float)q0.a1m1;
-  o.e2m = (__float_as_uint((float)q0.a2) & ~kRecFlagBits) | (ustar - 1u) | ((unsigned)(rem == 8) << 3) | (end1 << 4) |
-          (slow0 << 5) | (slow1 << 6);
+  o.e2 = (float)q0.a2;
   rec[g] = o;
-  // tile header: the block that opens the tile writes anchor / first centre, the one that holds the tile's last output
-  // writes the last centre (approximate placements are fine here: K_sinc stages one sample of slack on either side)
-  if (jr == 0) {
-    TileHdr* hd = hdr + T;
-    const long long anchor = I0 & ~1ll;
-    hd->anchor = anchor;
-    hd->iT = i;
-    hd->mn_rel = (int)(I0 - anchor);
-    hd->c_last = 0;                                            // (unused: K_sinc takes its span from its own placements)
-    hd->flags = range0 ? 0 : 1;
-  }
-  }
 }
 
 __device__ __forceinline__ void mark_direct(long long i, long long* direct, PlanHeader* h) {
@@ -1652,11 +1668,11 @@ static void launch_block_rec(const double* speeds, const par::PlanView& pv, int6
   using namespace par;
   const FusedAux a = fused_aux_view(aux, max_out, m);
   const int64_t blocks = (int64_t)fused_blocks(max_out);
-  hipLaunchKernelGGL(k_block_rec, dim3((unsigned)ceil_div(blocks, 512)), dim3(256), 0, s, speeds, pv.seg_start, nseg,
+  hipLaunchKernelGGL(k_block_rec, dim3((unsigned)ceil_div(blocks, 256)), dim3(256), 0, s, speeds, pv.seg_start, nseg,
                      (const double*)a.ck, (const int64_t*)a.tile_seg, (const long long*)a.tile_st, (const SegFast*)a.seg_fast,
-                     a.hdr, a.rec, (const PlanHeader*)pv.hdr);
+                     (const TileHdr*)a.hdr, a.rec, (const PlanHeader*)pv.hdr);
   hipLaunchKernelGGL(k_block_rec2, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, s, speeds, pv.seg_start, nseg,
-                     (const SegFast*)a.seg_fast, a.rec2, (const PlanHeader*)pv.hdr);
+                     (const SegFast*)a.seg_fast, (const TileHdr*)a.hdr, a.rec, a.rec2, (const PlanHeader*)pv.hdr);
 }
 
 // Shared implementation.  aux (optional, device): cumsum checkpoints for the fused resampler.
@@ -1726,8 +1742,9 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
                        (const double*)ck, ck_len, pv.hdr);
     if (aux) {
       hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(std::max<int64_t>(nseg, max_tiles), 256)), dim3(256), 0, s,
-                         speeds, pv.seg_start, pv.seg_off, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len),
-                         reinterpret_cast<SegFast*>(ck + ck_len + max_tiles), fused_aux_view(aux, max_out, m).tile_st, pv.hdr);
+                         speeds, pv.seg_start, pv.seg_off, nseg, (const double*)ck, ck_len, max_tiles,
+                         reinterpret_cast<int64_t*>(ck + ck_len), reinterpret_cast<SegFast*>(ck + ck_len + max_tiles),
+                         fused_aux_view(aux, max_out, m).tile_st, fused_aux_view(aux, max_out, m).hdr, pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
       launch_block_rec(speeds, pv, nseg, aux, max_out, m, s);
     }
@@ -1762,8 +1779,9 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
       rc = launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s);
       if (rc != PAR_OK) return rc;
       hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(std::max<int64_t>(nseg, max_tiles), 256)), dim3(256), 0, s,
-                         speeds, pv.seg_start, pv.seg_off, nseg, ck_len, max_tiles, reinterpret_cast<int64_t*>(ck + ck_len),
-                         reinterpret_cast<SegFast*>(ck + ck_len + max_tiles), fused_aux_view(aux, max_out, m).tile_st, pv.hdr);
+                         speeds, pv.seg_start, pv.seg_off, nseg, (const double*)ck, ck_len, max_tiles,
+                         reinterpret_cast<int64_t*>(ck + ck_len), reinterpret_cast<SegFast*>(ck + ck_len + max_tiles),
+                         fused_aux_view(aux, max_out, m).tile_st, fused_aux_view(aux, max_out, m).hdr, pv.hdr);
       if (force_host == 2) hipLaunchKernelGGL(k_inject_verify_fault, dim3(1), dim3(1), 0, s, pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
       launch_block_rec(speeds, pv, nseg, aux, max_out, m, s);

@@ -152,49 +152,51 @@ struct SegFast {
   double step;              // (s1 - s0) / (n - 1): ramp increment per output
   int n;                    // outputs in the segment
   int fast;                 // 1: closed-form placement valid (ramp gentle enough, speeds in range, n < 2^31)
-                            // 2: also the per-block quadratic (BlockRec): the cubic term of 8 steps stays < 2e-8
+                            // 2: also the per-block polynomial (BlockRec) WITH the cubic term K_sinc derives from e2
+                            // 3: the block quadratic alone is good to 1e-8 samples
 };
 static_assert(sizeof(SegFast) == 32, "SegFast is loaded as two 16-byte words");
-// Block record of a fused plan: one per 8 consecutive outputs (absolute index j = 8 g + u).  Within the block the
-// positions are a quadratic in u (the speed ramp is linear, so the reciprocal increments are linear to second order):
-//     p_u = I + F + u (1 + e1) + u^2 e2            u = 0..7
-// with I the integer part (low 32 bits of the absolute value: differences to the tile anchor are exact in int32
-// arithmetic) and |F| <= 1/2.  16 bytes per 8 outputs: K_sinc reads nothing else per output -- no segment lookup, no
-// float64.  The low 7 mantissa bits of e2 (a term of at most ~5e-4 samples, so 2^-17 of it is nothing) carry
-//   bits 0-2  ustar - 1: outputs u >= ustar belong to the NEXT segment and use the block's second piece (ustar = 8: none)
-//   bit  3    end0: (ustar = 8 only) the segment ends with the block's last output
-//   bit  4    end1: the second piece's segment ends with the block's last output
-//   bit  5/6  slow0 / slow1: that piece is not covered by the model (steep ramp, speed far from 1, very short segments,
+// Block record of a fused plan: one per kRec = 32 consecutive outputs (absolute index j = 32 g + u).  Within the block the
+// positions are a polynomial in the CENTRED variable u' = u - 16 (the speed ramp is linear, so the reciprocal increments
+// are linear to second order):
+//     p = anchor_T + Irel + F + u' (1 + e1) + u'^2 e2 [+ u'^3 e3]          u' = -16 .. 15
+// with Irel the integer part of the centre output's position relative to the tile's anchor (16 bits: a tile spans ~10^3
+// input samples where the model applies) and |F| <= 1/2.  Centred, |u' e1| <= 1/2 where the model applies (|e1| <= 1/32),
+// so the float32 evaluation stays within ~1.2e-7 of the float64 polynomial.  e3 = (4/3) e2^2 / (1 + e1) follows from e2
+// (both come from the one ramp slope) and is only evaluated where the record says so (`cubic`: steeper ramps, e.g.
+// flutter at low sample rates); the plan folds the quadratic and linear parts of the cubic sum into e2 and e1.
+// 16 bytes per 32 outputs (r02: per 8): K_sinc reads nothing else per output -- no segment lookup, no float64.
+// Word 0: Irel in the high 16 bits (signed), flags in the low 16:
+//   bits 0-4  ustar - 1: outputs u >= ustar belong to the NEXT segment and use the block's second piece (ustar = 32: none)
+//   bit  5    E0: output u = ustar - 1 is the last one of its segment (always so in a boundary block; in an interior block
+//             only when the segment ends with the block)
+//   bit  6    E1: the second piece's segment ends with the block's last output
+//   bit  7/8  slow0 / slow1: that piece is not covered by the model (steep ramp, speed far from 1, very short segments,
 //             |p| out of range, the file's last output): its outputs are placed by place_fast / place_exact instead
+//   bit  9    cubic: evaluate the e3 term (either piece)
 // The last output of a segment matters because its period to the next position is the PREVIOUS increment (the next
-// segment starts at this ramp's end speed); u = ustar - 1 is always such an output.
-// The second piece (I2, F2, e1b, e2b) lives in a parallel array that only boundary blocks touch.
+// segment starts at this ramp's end speed).
+// The second piece (same layout, its own polynomial in the same u') lives in a parallel array that only boundary
+// blocks touch; its word 0 carries only Irel.
+constexpr int kRec = 32;
+constexpr int kRecShift = 5;
 struct BlockRec {
-  int I;
-  float F, e1;
-  unsigned e2m;             // float e2 with the flags in its low 7 bits
+  unsigned w0;              // Irel << 16 | flags
+  float F, e1, e2;
 };
 static_assert(sizeof(BlockRec) == 16, "BlockRec is one 16-byte word");
-constexpr unsigned kRecFlagBits = 0x7fu;
-struct BlockRec2 {
-  int I2;
-  float F2, e1b, e2b;       // the second piece's own quadratic (same variable u as the first piece's)
-};
-static_assert(sizeof(BlockRec2) == 16, "BlockRec2 is one 16-byte word");
-// (Measured and not kept, one box, K_sinc alone / pipelined step in ms: both records of a block in one 32-byte slot and
-// loaded up front 5.94 / 7.93 against 6.05 / 7.20 -- the plan's 16-byte stores at a 32-byte stride are partial-granule
-// writes and its tail lands on the critical path; two arrays, both loaded up front 5.69 / 6.90 against 5.82 / 6.88 -- the step
-// is bound by the VALU work of K_sinc plus the plan, a shorter load chain does not show.)
+constexpr unsigned kRecE0 = 1u << 5, kRecE1 = 1u << 6, kRecSlow0 = 1u << 7, kRecSlow1 = 1u << 8, kRecCubic = 1u << 9;
+typedef BlockRec BlockRec2;
 // Tile header: everything K_sinc needs before it can stage a tile's input span, in ONE scalar load.
 struct TileHdr {
-  long long anchor;         // even integer next to the tile's first position
-  long long c_last;         // rint(position) of the tile's last output (absolute)
+  long long anchor;         // even integer within a few samples of the tile's first position (written by k_tile_seg)
+  long long c_last;         // (unused)
   long long iT;             // segment of the tile's first output
-  int mn_rel;               // rint(first position) - anchor
-  int flags;                // 1: positions out of the int32 range around the anchor (tile takes the float64 path)
+  int mn_rel;               // (unused)
+  int flags;                // 1: positions out of range (tile takes the float64 path)
 };
 static_assert(sizeof(TileHdr) == 32, "TileHdr is one s_load_dwordx8");
-constexpr int kBlocksPerTile = (int)(kSincTileOutputs / kCk);
+constexpr int kBlocksPerTile = (int)(kSincTileOutputs / kRec);
 constexpr int kTileStarts = 6;     // seg_start of the tile's first segment and the five behind it (k_block_rec's lookup)
 // aux buffer of a fused plan: [ck_len checkpoints (f64)] [tile map (int64)] [m SegFast] [tiles TileHdr] [blocks BlockRec]
 // [blocks BlockRec2 (sparse)] [tiles x kTileStarts int64]

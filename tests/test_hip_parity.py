@@ -836,6 +836,53 @@ def test_unverified_checkpoints_are_never_published(par):
         assert relerr(R._resample_item(plan, item, 32, 0).cpu().numpy(), want) < TOL
 
 
+def _block_record_stats(par, plan):
+    """Flag words of a fused plan's block records, decoded on the host (layout: csrc/pos_plan.h fused_aux_view, kRec = 32)."""
+    a = plan.aux.cpu().numpy()
+    ck_len, tiles = plan.max_out // 8 + plan.m + 16, plan.max_out // 1024 + 4
+    off = (ck_len + tiles) * 8 + plan.m * 32 + tiles * 32
+    nblk = (plan.len_out + 31) // 32
+    w = a[off:off + tiles * 32 * 16].view(np.uint32).reshape(-1, 4)[:nblk, 0]
+    boundary = (w & 31) + 1 < 32
+    return {"blocks": nblk, "boundary": int(boundary.sum()), "slow0": int(((w >> 7) & 1).sum()),
+            "slow1": int((((w >> 8) & 1) & boundary).sum()), "cubic": int(((w >> 9) & 1).sum())}
+
+
+def test_block_records_cover_benchmark_and_flutter_curves(par):
+    """r03 block records (32 outputs, centred polynomial, second piece with its own curvature, cubic term where the ramp
+    needs it): on the benchmark curve NO block leaves the model (r02 flagged 72 % of its boundary blocks slow and sent
+    63 % of K_sinc's waves through the float64 redo path); a flutter curve at 44.1 kHz sits in the cubic regime and is
+    still placed from records; a violent one leaves the model block by block and takes the float64 placement -- the
+    output equals the position-array path's in all three."""
+    t = par.torch
+    cases = []
+    sr, dur = 192000, 8.0
+    sc = inputs.bench_speed_curve(dur, sr)
+    cases.append(("bench", sc[:, 0] * sr, np.ascontiguousarray(sc[:, 1]), int(sr * dur), 32))
+    n = 44100 * 12
+    st = np.linspace(0, n, n // 256)
+    tt = st / 44100.0
+    cases.append(("flutter", st, 1 + 0.003 * np.sin(2 * np.pi * 20.0 * tt + 0.3) + 0.002 * np.sin(2 * np.pi * 3.1 * tt), n, 32))
+    cases.append(("violent", st, 1 + 0.03 * np.sin(2 * np.pi * 60.0 * tt + 0.3), n, 50))
+    for name, st, sp, n_in, NT in cases:
+        sig_t = t.from_numpy(inputs.noise(n_in, 7)).cuda()
+        st_t, sp_t = t.from_numpy(np.ascontiguousarray(st)).cuda(), t.from_numpy(np.ascontiguousarray(sp)).cuda()
+        plan = par.resampling.speed_plan_dev(st_t, sp_t, n_in, fused=True)
+        assert plan.fused_ok, name
+        stats = _block_record_stats(par, plan)
+        if name == "bench":
+            assert stats["slow0"] + stats["slow1"] <= 2 and stats["cubic"] == 0, stats     # the block of the file's last output
+            assert stats["boundary"] > 0.1 * stats["blocks"]
+        elif name == "flutter":
+            assert stats["cubic"] > 0.5 * stats["blocks"] and stats["slow0"] + stats["slow1"] <= 2, stats
+        else:
+            assert stats["slow0"] > 0.2 * stats["blocks"], stats
+        fused = par.resampling.varispeed_fused_dev(plan, sig_t, NT)
+        pos_t = par.resampling.speed_to_pos_dev(st_t, sp_t, n_in)
+        via_pos = par.resampling.sinc_resample_dev(pos_t, sig_t, NT)
+        assert same_resample(fused, via_pos), (name, float((fused - via_pos).abs().max() / via_pos.abs().max()))
+
+
 def test_fused_extreme_curves_and_channels(par):
     """Fused path under stress: fast curves whose tiles overflow the LDS stage (float64 slow path),
     slow curves (many outputs per input), stereo strided views, tiny NT and NT = 100."""

@@ -35,7 +35,7 @@ while time.time() < t_end:
         st = st + float(rng.choice([-1000.0, 0.37, 12345.678, 2.0 ** 20 - 3, 2.0 ** 24 - 100]))
     elif grid == 2:                                           # uneven spacing
         st = np.concatenate(([0.0], np.cumsum(rng.uniform(0.3, 1.7, m - 1)))) * (n / max(m - 1, 1))
-    style = int(rng.integers(0, 7))
+    style = int(rng.integers(0, 8))
     if style == 0:
         sp = 1.0 + 0.01 * np.sin(np.arange(m) * 0.05 + rng.uniform(0, 6))
     elif style == 1:
@@ -49,6 +49,9 @@ while time.time() < t_end:
         sp = 1.0 + 0.2 * np.sign(np.sin(np.arange(m) * 0.3))
     elif style == 5:
         sp = rng.choice([0.02, 0.1, 7.0, 40.0]) * rng.uniform(0.9, 1.1, m)     # very slow / very fast tape
+    elif style == 7:
+        # flutter: ramps steep enough for the cubic term of the block records (r03), up to ones that leave the model
+        sp = 1.0 + float(rng.choice([0.003, 0.01, 0.03])) * np.sin(np.arange(m) * float(rng.choice([0.2, 0.5, 1.0])) + rng.uniform(0, 6))
     else:
         sp = np.where(rng.random(m) < 0.5, 2.0 / seg, 1.0) * rng.uniform(0.99, 1.01, m)   # segments of ~2 samples
     sig = rng.standard_normal(n).astype(np.float32)

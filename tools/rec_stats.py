@@ -30,18 +30,17 @@ _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(st), _dev.ptr(sp), m, n, 
 torch.cuda.synchronize()
 a = aux.cpu().numpy()
 ck_len, tiles = cap // 8 + m + 16, cap // 1024 + 4
-blocks = tiles * 128
+blocks = tiles * 32                                     # kRec = 32 outputs per record
 off = (ck_len + tiles) * 8 + m * 32 + tiles * 32
 rec = a[off:off + blocks * 16].view(np.uint32).reshape(blocks, 4)
-nblk = (lo.value + 7) // 8
-w = rec[:nblk, 3]
-ustar = (w & 7) + 1
-slow0, slow1, end0, end1 = (w >> 5) & 1, (w >> 6) & 1, (w >> 3) & 1, (w >> 4) & 1
-boundary = ustar < 8
-print(f"{lo.value} outputs, {nblk} blocks, ok={ok.value}")
+nblk = (lo.value + 31) // 32
+w = rec[:nblk, 0]
+ustar = (w & 31) + 1
+e0, e1, slow0, slow1, cubic = (w >> 5) & 1, (w >> 6) & 1, (w >> 7) & 1, (w >> 8) & 1, (w >> 9) & 1
+boundary = ustar < 32
+print(f"{lo.value} outputs, {nblk} blocks of 32, ok={ok.value}")
 print(f"boundary blocks {boundary.sum()} ({boundary.mean():.4%}), slow0 {slow0.sum()}, slow1 among boundary {slow1[boundary].sum()} "
-      f"({slow1[boundary].mean():.2%}), end0 {end0.sum()}, end1 {end1.sum()}")
-# waves of 256 outputs (32 blocks) that contain a slow piece
-wv = nblk // 32
-anyslow = ((slow0[:wv * 32] | (slow1[:wv * 32] & boundary[:wv * 32])).reshape(wv, 32).max(axis=1))
+      f"({slow1[boundary].mean():.2%}), E0 {e0.sum()}, E1 {e1.sum()}, cubic {cubic.sum()}")
+wv = nblk // 8                                          # waves of 256 outputs = 8 blocks
+anyslow = ((slow0[:wv * 8] | (slow1[:wv * 8] & boundary[:wv * 8])).reshape(wv, 8).max(axis=1))
 print(f"waves with a slow piece: {anyslow.sum()} of {wv} ({anyslow.mean():.2%})")
