@@ -583,11 +583,15 @@ def main():
         samples_per_launch = len_out.value * len(sinc_ms) / n_launch
         achieved = ALGO_BYTES_PER_SAMPLE * samples_per_launch / (k_ms * 1e-3) / 1e9
         # HBM traffic from the committed PMC passes (tools/profile_round.sh): bytes/sample x this run's rate
-        traffic = None
+        traffic, traffic_src = None, None
+        from pyaudiorestoration_amd import build as _build
+        digest = _build.source_digest()                 # the kernel sources this run was built from
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if ("fused" in tr.get("kernel", "")) == bool(fused):          # the committed PMC pass measured this form
                 traffic = round(tr["hbm_bytes_per_sample"] * samples_per_launch / (k_ms * 1e-3) / 1e9, 2)
+                traffic_src = {"file": "profiles/pmc_traffic.json", "from": tr.get("source"), "source_digest": tr.get("source_digest"),
+                               "running_digest": digest, "stale": tr.get("source_digest") != digest}
         except Exception:
             pass
         res = {
@@ -601,12 +605,14 @@ def main():
                        "step": ("plan (device scans, cumsum checkpoints, block records) + fused K_sinc (outputs placed from 16-byte block records, no position array)" if fused else "plan (device scans) + K_pos fill (float64 position array) + K_sinc") + "; inputs resident in HBM"
                                + ("; batch pipelining: the plan of file k+1 runs on a side stream under K_sinc of file k (every step = one full plan + one full K_sinc)" if overlap else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel": "k_sinc", "limited_by": "valu",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "source": traffic_src,
+                         "kernel": "k_sinc", "limited_by": "valu",
                          "kernel_ms": round(k_ms, 4), "launches_per_step": n_launch // len(sinc_ms),
                          "samples_per_launch": int(samples_per_launch),
                          "note": "achieved = 8 algorithmic B/output sample (4 B in + 4 B out) / HIP-event K_sinc time; "
-                                 "traffic = PMC HBM bytes/sample (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json) at this "
-                                 "run's rate" + (": signal + output + 1 B/sample cumsum checkpoints + tile halos"
+                                 "traffic = PMC HBM bytes/sample (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json: a separate "
+                                 "rocprofv3 --pmc pass, stamped with the digest of the kernel sources it ran; `source.stale` says "
+                                 "whether that is the code running now) at this run's rate" + (": signal + output + 1 B/sample cumsum checkpoints + tile halos"
                                                  if fused else " incl. the 8 B float64 position read") +
                                  "; `bound` names the roof this object measures against (the contract's HBM roof on algorithmic bytes); the kernel is LIMITED BY VALU issue (64 taps per output against 8 B): roofline_valu is the roof it sits under; FETCH_SIZE x2 calibrated for this kernel's access patterns in profiles/r02_fetch_calibration.txt"},
         }
@@ -630,7 +636,8 @@ def main():
                                     "ceiling_measured_fma_stream_Tlaneops": vp.get("fma_stream_Tlaneops", 58.76),
                                     "frac_of_spec": round(ach / 78.64, 4),
                                     "frac_of_measured": round(ach / vp.get("fma_stream_Tlaneops", 58.76), 4),
-                                    "source": vp.get("source", "profiles/")}
+                                    "source": vp.get("source", "profiles/"), "source_digest": vp.get("source_digest"),
+                                    "running_digest": digest, "stale": vp.get("source_digest") != digest}
         except Exception:
             pass
         if world == 1:

@@ -256,6 +256,18 @@ int par_synth_speed_curve_f64(int device, double* sampletimes, double* speeds, i
 int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
                        double* freqs, int fft_size, double sr, double tolerance_oct, int mode, int32_t* status,
                        void* stream);
+/* The same two trackers with the band magnitudes RE-EVALUATED FROM THE SIGNAL in float64 (r03): the reference's numpy
+ * backend (util/fourier.py:136-157) hands Track.get_peak (util/wow_detection.py:119-134) float64 containers, and the
+ * config-3 chain amplifies the float32 noise of a spectrogram into 3.7e-5 of the output peak.  Per frame only the band
+ * [NL, NU) and the two neighbours of its peak are needed: a windowed direct DFT of the reference's own float32 frame
+ * (reflect pad n_fft/2, sample x window rounded to float32: segment_array :160-166; zero-extended to n_fft * zeropad;
+ * / sqrt(n_fft); + 1e-7 as to_mag :23-29 adds).
+ *   x        device f32 signal channel, element stride x_stride, n samples;  window  device f32[n_fft]
+ *   bins = n_fft * zeropad / 2 + 1, n_frames <= n / hop + 1; freqs / mode / status as par_track_peak_f64.
+ * A band wider than 2048 bins: PAR_ERR_UNSUPPORTED (use par_track_peak_f64 on the spectrogram).  Synchronises. */
+int par_track_peak_refined_f64(int device, const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad,
+                               const float* window, int bins, int64_t n_frames, int64_t frame_0, int64_t count, double* freqs,
+                               double sr, double tolerance_oct, int mode, int32_t* status, void* stream);
 /* CenterOfGravity.trace (util/wow_detection.py:256-291): sequential band adaptation. */
 int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
                       double* freqs, int fft_size, double sr, double tolerance_oct, int32_t* status, void* stream);

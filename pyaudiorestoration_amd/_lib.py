@@ -69,6 +69,8 @@ SIGNATURES = {
     "par_synth_signal_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_dbl, c_u64, c_vp]),
     "par_synth_speed_curve_f64": (c_int, [c_int, c_vp, c_vp, c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_vp]),
     "par_track_peak_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_int, c_vp, c_vp]),
+    "par_track_peak_refined_f64": (c_int, [c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_int, c_i64, c_i64, c_i64, c_vp,
+                                           c_dbl, c_dbl, c_int, c_vp, c_vp]),
     "par_sosfiltfilt_work_len": (c_i64, [c_i64, c_i64]),
     "par_sosfiltfilt_f64": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "par_track_cog_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]),

@@ -28,6 +28,17 @@ def _headers():
     return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
 
 
+def source_digest():
+    """sha256 (first 16 hex digits) over the kernel sources and headers: stamps the committed PMC summaries
+    (tools/summarise_profiles.py) so that bench.py can tell whether they were measured on the code that is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(sources() + glob.glob(os.path.join(CSRC, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True

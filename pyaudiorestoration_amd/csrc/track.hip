@@ -101,6 +101,102 @@ __global__ void k_track_peak_fixed(const float* __restrict__ mag, int bins, int6
   freqs[i] = peak_freq(mag + (frame_0 + i) * bins, b, bins, fft_size, sr, empty);
 }
 
+// Peak / Peak Track on band magnitudes re-evaluated from the SIGNAL in float64 (r03).  The reference's numpy backend hands
+// its trackers float64 containers (util/fourier.py:136-157: float32 frames -> pocketfft -> / np.float64(sqrt(n_fft)));
+// K_stft's magnitudes are float32 and a few 1e-8 relative noisier than one float32 rounding, which the config-3 chain
+// (running-sum positions, a window centre that jumps at half-integers) amplifies to 3.7e-5 of the output peak
+// (profiles/r02_p0_sensitivity.txt).  Only the band [NL, NU) and the two neighbours of its peak matter to the tracker:
+// <= a dozen bins x n_fft samples per frame, a windowed direct DFT in float64 -- ~0.03 GFLOP on config 3.
+// One 256-thread workgroup per frame.  The frame is the reference's: reflect-padded by n_fft/2, sample x window rounded to
+// float32 (segment_array, util/fourier.py:160-166), zero-extended to n_fft * zeropad, spectrum / sqrt(n_fft), + 1e-7.
+constexpr int kRefineMaxBins = 2048;
+__device__ __forceinline__ double refined_mag(const float* __restrict__ x, int64_t n, int64_t xs, const float* __restrict__ win,
+                                              int n_fft, int hop, int N, int64_t frame, int k, double* red) {
+  // all 256 threads: sum_n xw[n] exp(-2 pi i k n / N)
+  double re = 0.0, im = 0.0;
+  const int64_t base = frame * hop - n_fft / 2;
+  const int64_t m = 2 * (n - 1);
+  for (int q = threadIdx.x; q < n_fft; q += blockDim.x) {
+    int64_t j = base + q;
+    if (j < 0 || j >= n) {                                   // np.pad(..., mode='reflect')
+      j = ((j % m) + m) % m;
+      if (j >= n) j = m - j;
+    }
+    const float xw = x[j * xs] * win[q];                     // float32 product, like the reference's frame matrix
+    const long long r = ((long long)k * q) % N;
+    double sn, cs;
+    sincospi(2.0 * (double)r / (double)N, &sn, &cs);
+    re += (double)xw * cs;
+    im -= (double)xw * sn;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    re += __shfl_xor(re, o, kWave);
+    im += __shfl_xor(im, o, kWave);
+  }
+  __syncthreads();                                           // red[] free again
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    red[2 * (threadIdx.x / kWave)] = re;
+    red[2 * (threadIdx.x / kWave) + 1] = im;
+  }
+  __syncthreads();
+  re = im = 0.0;
+  for (int w = 0; w < (int)(blockDim.x / kWave); ++w) {
+    re += red[2 * w];
+    im += red[2 * w + 1];
+  }
+  return sqrt(re * re + im * im) / sqrt((double)n_fft) + 1e-7;
+}
+
+__global__ __launch_bounds__(256) void k_track_peak_refined(const float* __restrict__ x, int64_t n, int64_t xs,
+                                                            const float* __restrict__ win, int n_fft, int hop, int zeropad,
+                                                            int bins, int64_t frame_0, int64_t count, int mode, double centre,
+                                                            double* __restrict__ freqs, double sr, double tol,
+                                                            int* __restrict__ status) {
+  __shared__ double red[8];
+  extern __shared__ double bandmag[];                        // [NU - NL]
+  const int64_t i = blockIdx.x;
+  const int fft_size = n_fft * zeropad;
+  const Band b = mode == 0 ? band_limits(freqs[i], tol, fft_size, sr, bins)
+                           : band_limits(centre, i > 2 ? tol / 2 : tol, fft_size, sr, bins);
+  if (b.NL < 0 || b.NL >= b.NU) {
+    if (threadIdx.x == 0) atomicOr(status, 1);
+    return;
+  }
+  const int nb = b.NU - b.NL;
+  if (nb > kRefineMaxBins) {
+    if (threadIdx.x == 0) atomicOr(status, 8);
+    return;
+  }
+  const int64_t frame = frame_0 + i;
+  for (int k = 0; k < nb; ++k) {
+    const double v = refined_mag(x, n, xs, win, n_fft, hop, fft_size, frame, b.NL + k, red);
+    if (threadIdx.x == 0) bandmag[k] = v;
+  }
+  __syncthreads();
+  int arg = b.NL;
+  double best = bandmag[0];
+  for (int k = 1; k < nb; ++k) {                             // every thread the same walk: first occurrence of the maximum
+    if (bandmag[k] > best) {
+      best = bandmag[k];
+      arg = b.NL + k;
+    }
+  }
+  double xq = (double)arg;
+  if (b.past_end || arg == bins - 1) {                       // uniform across the block
+    if (threadIdx.x == 0) {
+      atomicOr(status, b.past_end ? 4 : 2);
+      freqs[i] = xq / (double)fft_size * sr;
+    }
+    return;
+  }
+  const int km = (arg - 1 + bins) % bins, kp = arg + 1;
+  const double fm = (km >= b.NL && km < b.NU) ? bandmag[km - b.NL] : refined_mag(x, n, xs, win, n_fft, hop, fft_size, frame, km, red);
+  const double fp = (kp >= b.NL && kp < b.NU) ? bandmag[kp - b.NL] : refined_mag(x, n, xs, win, n_fft, hop, fft_size, frame, kp, red);
+  if (fm < best && best > fp) xq = 0.5 * (fm - fp) / (fm - 2.0 * best + fp) + xq;     // parabolic()
+  if (threadIdx.x == 0) freqs[i] = xq / (double)fft_size * sr;
+}
+
 // CenterOfGravity: the band of frame i+1 depends on the result of frame i -> one wave walks the frames,
 // its 64 lanes share the bins of the current band.
 __global__ __launch_bounds__(64) void k_track_cog(const float* __restrict__ mag, int bins, int64_t frame_0, int64_t count,
@@ -486,6 +582,38 @@ int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins,
   }
   PAR_HIP_CHECK(hipGetLastError());
   return check_empty(status, s, "par_track_peak_f64");
+}
+
+// PeakTracker / PeakTrackTracker with the band magnitudes recomputed from the signal in float64 (see k_track_peak_refined).
+// x: the channel the spectrogram was made from (float32, element stride x_stride), window: the STFT window (float32[n_fft]).
+// Bands wider than 2048 bins: PAR_ERR_UNSUPPORTED (the caller falls back to the float32 spectrogram).
+int par_track_peak_refined_f64(int device, const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad,
+                               const float* window, int bins, int64_t n_frames, int64_t frame_0, int64_t count, double* freqs,
+                               double sr, double tolerance_oct, int mode, int32_t* status, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(x && window && freqs && status, PAR_ERR_ARG, "par_track_peak_refined_f64: null pointer");
+  PAR_REQUIRE(n >= 2 && x_stride >= 1 && n_fft >= 2 && hop >= 1 && zeropad >= 1 && bins == n_fft * zeropad / 2 + 1 && count >= 0 &&
+              frame_0 >= 0 && frame_0 + count <= n_frames && n_frames <= n / hop + 1, PAR_ERR_ARG,
+              "par_track_peak_refined_f64: bad args (n=%lld n_fft=%d hop=%d zeropad=%d bins=%d frame_0=%lld count=%lld n_frames=%lld)",
+              (long long)n, n_fft, hop, zeropad, bins, (long long)frame_0, (long long)count, (long long)n_frames);
+  PAR_REQUIRE(mode == 0 || mode == 1, PAR_ERR_ARG, "par_track_peak_refined_f64: mode must be 0 or 1");
+  if (count == 0) return PAR_OK;
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipStream_t s = as_stream(stream);
+  PAR_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), s));
+  double centre = 0.0;
+  if (mode == 1) {
+    PAR_HIP_CHECK(hipMemcpyAsync(&centre, freqs, sizeof(double), hipMemcpyDeviceToHost, s));
+    PAR_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  hipLaunchKernelGGL(k_track_peak_refined, dim3((unsigned)count), dim3(256), kRefineMaxBins * sizeof(double), s, x, n, x_stride,
+                     window, n_fft, hop, zeropad, bins, frame_0, count, mode, centre, freqs, sr, tolerance_oct, status);
+  PAR_HIP_CHECK(hipGetLastError());
+  int h = 0;
+  PAR_HIP_CHECK(hipMemcpyAsync(&h, status, sizeof(h), hipMemcpyDeviceToHost, s));
+  PAR_HIP_CHECK(hipStreamSynchronize(s));
+  PAR_REQUIRE(!(h & 8), PAR_ERR_UNSUPPORTED, "par_track_peak_refined_f64: a tracking band is wider than %d bins", kRefineMaxBins);
+  return check_empty(status, s, "par_track_peak_refined_f64");
 }
 
 int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,

@@ -13,6 +13,7 @@ import warnings
 import logging
 
 import numpy as np
+import scipy.signal
 import torch
 
 from . import _dev, filters, fourier, resampling, wow_detection
@@ -53,10 +54,13 @@ def respeed(signal, sr, trail, fft_size=1024, hop=256, zeropad=1, mode="Peak", t
     n = sig2d.shape[0]
     sig_t = _dev.to_dev(sig2d, torch.float32, dev)                       # (n, ch) resident in HBM
     ch = sig2d.shape[1]
-    spec = fourier.get_mag(sig_t.reshape(-1)[0::ch] if ch > 1 else sig_t.reshape(-1), fft_size, hop,
-                           "blackmanharris", zeropad)                      # device tensor (bins, frames)
+    chan0 = sig_t.reshape(-1)[0::ch] if ch > 1 else sig_t.reshape(-1)
+    spec = fourier.get_mag(chan0, fft_size, hop, "blackmanharris", zeropad)      # device tensor (bins, frames)
+    # Peak / Peak Track read their band from the signal in float64 (what the reference's numpy backend hands them)
+    refine = {"x": chan0, "n_fft": fft_size, "zeropad": zeropad,
+              "window": _dev.to_dev(scipy.signal.get_window("blackmanharris", fft_size).astype(np.float32), torch.float32, dev)}
     track = wow_detection.wow_detectors[mode](spec, sig2d, list(trail), fft_size * zeropad, hop, sr, tolerance_st,
-                                              "Linear")
+                                              "Linear", refine=refine)
     curve = master_speed_curve([(track.times, trace_to_speed(track.freqs))], n / sr, sr, hop, bands)
     st_t = _dev.to_dev(curve[:, 0] * sr, torch.float64, dev)
     sp_t = _dev.to_dev(np.ascontiguousarray(curve[:, 1]), torch.float64, dev)

@@ -123,7 +123,12 @@ class Track:
     tooltip = ""
 
     def __init__(self, spectrum, signal, trail, fft_size, hop, sr, tolerance_st=1, adaptation_mode="Linear",
-                 dB_cutoff=75):
+                 dB_cutoff=75, refine=None):
+        # refine (optional, beyond the reference's signature): {"x": 1-D float32 device tensor (the channel the spectrogram
+        # was made from, possibly a strided view), "n_fft", "zeropad", "window": float32 device tensor[n_fft]} -- Peak and
+        # Peak Track then re-evaluate their band magnitudes from the signal in float64 (par_track_peak_refined_f64), which
+        # is what the reference's numpy backend hands them; without it they read the float32 spectrogram
+        self.refine = refine
         self.spectrum, self.signal = spectrum, signal
         self.fft_size, self.hop, self.sr = fft_size, hop, sr
         self.num_bins, n_frames = spectrum.shape
@@ -156,6 +161,33 @@ class Track:
                           _dev.stream_ptr(dev)))
         self.freqs[:] = f_t.cpu().numpy()
 
+    def _trace_refined(self, mode, needs_first=False):
+        """Band magnitudes from the signal in float64 when the caller supplied `refine`; False -> use the spectrogram."""
+        rf = self.refine
+        if not rf:
+            return False
+        if len(self.freqs) == 0:
+            if needs_first:
+                raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+            return True
+        x_t, win_t = rf["x"], rf["window"]
+        dev = _dev.device_index(x_t.device)
+        n_fft, zp = int(rf["n_fft"]), int(rf.get("zeropad", 1))
+        if n_fft * zp != self.fft_size or x_t.ndim != 1:
+            return False
+        stride = x_t.stride(0)
+        f_t = _dev.to_dev(self.freqs, torch.float64, dev)
+        status = _dev.empty(1, torch.int32, dev)
+        try:
+            _lib.check(_lib.lib().par_track_peak_refined_f64(
+                dev, _dev.ptr(x_t), x_t.shape[0], stride, n_fft, self.hop, zp, _dev.ptr(win_t), self.num_bins,
+                self.spectrum.shape[1], self.frame_0, len(self.freqs), _dev.ptr(f_t), float(self.sr), float(self.tolerance),
+                mode, _dev.ptr(status), _dev.stream_ptr(dev)))
+        except _lib.ParUnsupported:
+            return False
+        self.freqs[:] = f_t.cpu().numpy()
+        return True
+
 
 class CenterOfGravity(Track):
     name = 'Center of Gravity'
@@ -168,16 +200,17 @@ class PeakTracker(Track):
     name = 'Peak'
     tooltip = "Tracks the mouse input to the loudest peak frequency"
 
-    def trace(self):          # util/wow_detection.py:294-304 -> k_track_peak
-        self._trace_on_device(_lib.lib().par_track_peak_f64, 0)
-
+    def trace(self):          # util/wow_detection.py:294-304 -> k_track_peak (or k_track_peak_refined)
+        if not self._trace_refined(0):
+            self._trace_on_device(_lib.lib().par_track_peak_f64, 0)
 
 class PeakTrackTracker(Track):
     name = 'Peak Track'
     tooltip = "Follows the first peak frequency established"
 
     def trace(self):          # util/wow_detection.py:307-327 -> k_track_peak_fixed
-        self._trace_on_device(_lib.lib().par_track_peak_f64, 1, needs_first=True)
+        if not self._trace_refined(1, needs_first=True):
+            self._trace_on_device(_lib.lib().par_track_peak_f64, 1, needs_first=True)
 
 
 def crossing_periods_to_freqs(crossings, sr, t_first, times):

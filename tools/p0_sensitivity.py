@@ -75,7 +75,7 @@ def table(c3=False, gpu=False, out=sys.stdout):
         from pyaudiorestoration_amd import pipeline
         r = pipeline.respeed(x, sr, trail, n_fft, hop, 1, "Peak", 0.5, (0, 20), 32)
         pos, y = r["positions"].cpu().numpy(), r["output"].cpu().numpy()[:, 0]
-        res["THIS BUILD: K_stft -> K_track -> plan -> K_sinc (float32 spectrogram)"] = (
+        res["THIS BUILD: K_stft -> K_track (band re-read from the signal, float64) -> K_sinc"] = (
             r["freqs"], r["speed_curve"], pos, np.concatenate([y[a:b] for a, b in windows_of(len(pos))]))
     ref = res[GOLDEN]
     print(f"{'config 3 (flutter_192.flac)' if c3 else 'pilot (tests/golden/pipeline.npz)'}: {len(x)} samples, sr {sr}", file=out)

@@ -15,6 +15,9 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 os.makedirs(prof, exist_ok=True)
 py = sys.executable
+sys.path.insert(0, root)
+from pyaudiorestoration_amd import build as _build
+digest = _build.source_digest()            # the box has no .git: the kernel sources themselves are the version
 stats = subprocess.check_output([py, os.path.join(root, "tools", "rocpd_stats.py"), os.path.join(src, "trace_results.db")], text=True)
 open(os.path.join(prof, f"{tag}_kernel_stats.txt"), "w").write(
     "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline (default 3600-s workload)\n" + stats)
@@ -52,7 +55,7 @@ if fetch and write:
          "samples_per_launch": n, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
          "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "hbm_bytes_per_sample": (2 * fetch + write) * 1024 / n,
          "correction": "FETCH_SIZE x2 (gfx950 coalesced-read under-count, MI355X_MICROARCH.md HBM section), KiB units",
-         "source": f"profiles/{tag}_pmc.txt"}
+         "source": f"profiles/{tag}_pmc.txt", "source_digest": digest}
     json.dump(t, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     print(t)
 valu = vals.get(("k_sinc", "SQ_INSTS_VALU"))
@@ -68,7 +71,7 @@ if valu:
     v = {"kernel": bench["roofline"].get("kernel", "k_sinc"), "samples_per_launch": n, "SQ_INSTS_VALU_per_launch": valu,
          "valu_lane_instr_per_output": valu * 64 / n, "fma_stream_Tlaneops": fma,
          "note": "SQ_INSTS_VALU counts wave64 instructions; x64 lanes / output samples of the launch",
-         "source": f"profiles/{tag}_pmc.txt"}
+         "source": f"profiles/{tag}_pmc.txt", "source_digest": digest}
     json.dump(v, open(os.path.join(prof, "pmc_valu.json"), "w"), indent=1)
     print(v)
 print(stats[:1500])
