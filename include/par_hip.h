@@ -91,6 +91,14 @@ int par_istft_f32(int device, const float* spec, int64_t n_frames, int n_fft, in
  * spec[i] *= 10^(gain_db[i]/20) for a frame-major complex64 spectrogram and a float32 mask of `count` bins. */
 int par_spec_apply_gain_db_c64(int device, float* spec, const float* gain_db, int64_t count, void* stream);
 
+/* Sparse dropout healing (r03; dropout_healer_gui.py:111-166 touches only the marked boxes, and STFT -> ISTFT is the
+ * identity elsewhere): copies `n_seg` sample ranges between two signals, dst[dst_start[k] + i] = src(src_start[k] + i)
+ * for i < len[k].  run_start[k] = sum of len[0..k) (exclusive prefix), total = sum of len.  padded != 0: the source is the
+ * reference's fix_length(signal, n_padded) (zeros from sample n_valid on, :120) under the STFT's np.pad(.., 'reflect')
+ * (util/fourier.py:78-82), so a range may start before sample 0 or end behind n_padded.  All index arrays on the device. */
+int par_copy_segments_f32(int device, const float* src, int64_t src_stride, int64_t n_valid, int64_t n_padded, int padded,
+                          const int64_t* src_start, const int64_t* dst_start, const int64_t* len, const int64_t* run_start,
+                          int64_t n_seg, int64_t total, float* dst, int64_t dst_stride, void* stream);
 /* Gain mask of the dropout healer for a BATCH of markers (dropout_healer_gui.py:135-159): for each marker
  * (frame_b, frame_a, fs, bin_l, bin_u -- int32[n_markers][5] in device memory, the integers the reference
  * derives at :136-142) the mean dB of the fs frames before/after the box per bin, the linear fill across the

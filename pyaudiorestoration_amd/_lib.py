@@ -35,6 +35,7 @@ SIGNATURES = {
     "par_istft_scratch_floats": (c_i64, [c_i64, c_int, c_int]),
     "par_istft_f32": (c_int, [c_int, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "par_spec_apply_gain_db_c64": (c_int, [c_int, c_vp, c_vp, c_i64, c_vp]),
+    "par_copy_segments_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "par_inpaint_gain_db_c64": (c_int, [c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "par_spec_apply_gain_boxes_c64": (c_int, [c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "par_flac_info": (c_int, [c_vp, c_sz, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),

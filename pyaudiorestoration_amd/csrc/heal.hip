@@ -92,6 +92,65 @@ __global__ void __launch_bounds__(256) k_band_mean_db(const float* __restrict__ 
 
 }  // namespace par
 
+// ---- sparse healing (r03): only the frames a marker can influence go through STFT -> inpaint -> ISTFT ------------------
+// Outside the boxes (plus their `surrounding` frames and one window of overlap on either side) STFT -> ISTFT is the
+// identity to 1.6e-8, so the healed signal equals the input there.  The host cuts the padded signal into the
+// sample ranges ("segments") whose frames matter, lines them up in ONE short pseudo-signal on the original frame grid,
+// runs the dense kernels on that, and copies the valid interior of every segment back over a copy of the input.
+// One kernel serves both directions: dst[dst_start[k] + i] = src(src_start[k] + i), i < len[k]; with `padded` the source
+// is the reference's fix_length(signal, n + n_fft/2) (zeros behind sample n_valid) under np.pad(.., n_fft/2, 'reflect').
+__device__ __forceinline__ long long heal_reflect(long long q, long long n) {
+  if (n == 1) return 0;
+  const long long P = 2 * (n - 1);
+  q %= P;
+  if (q < 0) q += P;
+  return q < n ? q : P - q;
+}
+__global__ void __launch_bounds__(256) k_copy_segments(const float* __restrict__ src, int64_t src_stride, int64_t n_valid,
+                                                       int64_t n_padded, int padded, const int64_t* __restrict__ src_start,
+                                                       const int64_t* __restrict__ dst_start, const int64_t* __restrict__ len,
+                                                       const int64_t* __restrict__ run_start, int64_t n_seg, int64_t total,
+                                                       float* __restrict__ dst, int64_t dst_stride) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // e-th copied sample over all segments
+  if (e >= total) return;
+  // the block's first sample finds its segment by bisection once (wave-uniform: scalar loads); a thread then walks on from
+  // there -- segments are thousands of samples long, so that is 0 or 1 step
+  const int64_t e0 = (int64_t)blockIdx.x * blockDim.x;
+  int64_t lo = 0, hi = n_seg - 1;                                           // last k with run_start[k] <= e0
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (run_start[mid] <= e0) lo = mid; else hi = mid - 1;
+  }
+  while (lo + 1 < n_seg && run_start[lo + 1] <= e) ++lo;
+  const int64_t i = e - run_start[lo];
+  if (i >= len[lo]) return;
+  long long q = src_start[lo] + i;
+  float v;
+  if (padded) {
+    if (q < 0 || q >= n_padded) q = heal_reflect(q, n_padded);          // only at the two ends of the file
+    v = q < n_valid ? src[q * src_stride] : 0.0f;
+  } else {
+    v = src[q * src_stride];
+  }
+  dst[(dst_start[lo] + i) * dst_stride] = v;
+}
+
+extern "C" int par_copy_segments_f32(int device, const float* src, int64_t src_stride, int64_t n_valid, int64_t n_padded,
+                                     int padded, const int64_t* src_start, const int64_t* dst_start, const int64_t* len,
+                                     const int64_t* run_start, int64_t n_seg, int64_t total, float* dst, int64_t dst_stride,
+                                     void* stream) {
+  using namespace par;
+  PAR_REQUIRE(src && dst && src_start && dst_start && len && run_start, PAR_ERR_ARG, "par_copy_segments_f32: null pointer");
+  PAR_REQUIRE(n_seg >= 0 && total >= 0 && src_stride >= 1 && dst_stride >= 1 && (!padded || (n_padded >= 1 && n_valid >= 0)),
+              PAR_ERR_ARG, "par_copy_segments_f32: bad sizes");
+  if (n_seg == 0 || total == 0) return PAR_OK;
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), src, src_stride, n_valid,
+                     n_padded, padded, src_start, dst_start, len, run_start, n_seg, total, dst, dst_stride);
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
 extern "C" int par_inpaint_gain_db_c64(int device, const float* spec, int64_t n_frames, int64_t bins,
                                        const int32_t* markers, int64_t n_markers, float* gain_db, void* stream) {
   using namespace par;

@@ -43,6 +43,23 @@ class timed_log:
         logging.info("%s %0.2fs", self.method_name, perf_counter() - self.t0)
 
 
+_window_cache = {}
+
+
+def window_dev(window_name, n_fft, dev):
+    """scipy.signal.get_window(name, n_fft) (periodic, like util/fourier.py:66) as a float32 device tensor, kept per
+    (name, size, device): a pageable upload per call is a stream synchronisation per call."""
+    key = (window_name if isinstance(window_name, (str, tuple)) else None, int(n_fft), dev)
+    if key[0] is None:
+        return _dev.to_dev(dsp.get_window(window_name, n_fft).astype(np.float32), torch.float32, dev)
+    w = _window_cache.get(key)
+    if w is None:
+        if len(_window_cache) > 64:
+            _window_cache.clear()
+        w = _window_cache[key] = _dev.to_dev(dsp.get_window(window_name, n_fft).astype(np.float32), torch.float32, dev)
+    return w
+
+
 def stft_dev(x_t, n_fft, step, window_t, zeropad=1, mode=0, x_stride=1, n=None, dev=None):
     """Device-resident STFT.  x_t: float32 tensor (element stride x_stride, logical length n).
     Returns a tensor with logical shape (bins, frames) that is a transposed view of the frame-major
@@ -84,7 +101,7 @@ def stft(x, n_fft=1024, step=512, window_name='blackmanharris', zeropad=1, _mode
         if x.ndim != 1:
             raise ValueError('x must be 1D')
         dev = _dev.device_index(x.device)
-        window = _dev.to_dev(dsp.get_window(window_name, n_fft).astype(np.float32), torch.float32, dev)
+        window = window_dev(window_name, n_fft, dev)
         xs = x if x.dtype == torch.float32 else x.to(torch.float32)
         stride = xs.stride(0) if xs.numel() > 1 else 1
         return stft_dev(xs, n_fft, step, window, zeropad, _mode, x_stride=max(stride, 1), n=xs.shape[0], dev=dev)
@@ -136,10 +153,10 @@ def istft(stft_matrix, hop_length=None, win_length=None, window_name='blackmanha
         raise NotImplementedError("HIP istft supports center=True and win_length == n_fft (the shipped call sites)")
     if hop_length is None:
         hop_length = int(win_length // 4)
-    window = dsp.get_window(window_name, win_length, fftbins=True).astype(np.float32)
     if isinstance(stft_matrix, torch.Tensor):
         dev = _dev.device_index(stft_matrix.device)
-        return istft_dev(stft_matrix, hop_length, _dev.to_dev(window, torch.float32, dev), length, dev)
+        return istft_dev(stft_matrix, hop_length, window_dev(window_name, win_length, dev), length, dev)
+    window = dsp.get_window(window_name, win_length, fftbins=True).astype(np.float32)
     dev = _dev.device_index(None)
     S = np.asarray(stft_matrix)
     spec_t = _dev.to_dev(S.T, torch.complex64, dev).T

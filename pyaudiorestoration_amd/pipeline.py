@@ -112,31 +112,18 @@ def marker_geometry(marker, sr, hop, fft_size):
 
 
 def _check_geometry(geo, frames):
-    for (fb, fa, fs, bl, bu) in geo:
-        # the reference would slice with a negative start / past the end and average an empty slice (NaN
-        # gain -> NaN audio), or hand RegularGridInterpolator an empty axis; refuse both
-        if fb - fs < 0 or fa + fs > frames or fa - fb < 1:
-            raise ValueError(f"dropout marker frames [{fb}-{fs}, {fa}+{fs}) leave the {frames}-frame spectrogram or are empty")
-        if bu - bl < 1:
-            raise ValueError("dropout marker spans no frequency bin")
-
-
-def inpaint_gain_dev(spec_fm, geometry, dev=None, gain=None):
-    """Gain mask (dB, float32 [frames][bins]) for a batch of marker geometries on a frame-major complex64
-    device spectrogram: ONE launch of K_heal for all markers (dropout_healer_gui.py:135-159).
-    `gain`: an all-zero mask to reuse (heal_spectrum_dev leaves it all-zero again)."""
-    from . import _lib
-    dev = _dev.device_index(dev)
-    frames, bins = spec_fm.shape
-    geo = np.asarray(geometry, dtype=np.int64).reshape(-1, 5)
-    _check_geometry(geo, frames)
-    if gain is None:
-        gain = torch.zeros((frames, bins), dtype=torch.float32, device=spec_fm.device)
-    if len(geo):
-        geo_t = _dev.to_dev(np.ascontiguousarray(geo, dtype=np.int32), torch.int32, dev)
-        _lib.check(_lib.lib().par_inpaint_gain_db_c64(dev, _dev.ptr(spec_fm), frames, bins, _dev.ptr(geo_t), len(geo),
-                                                      _dev.ptr(gain), _dev.stream_ptr(dev)))
-    return gain
+    geo = np.asarray(geo, dtype=np.int64).reshape(-1, 5)
+    if len(geo) == 0:
+        return
+    fb, fa, fs, bl, bu = (geo[:, k] for k in range(5))
+    # the reference would slice with a negative start / past the end and average an empty slice (NaN
+    # gain -> NaN audio), or hand RegularGridInterpolator an empty axis; refuse both
+    bad = (fb - fs < 0) | (fa + fs > frames) | (fa - fb < 1)
+    if np.any(bad):
+        k = int(np.flatnonzero(bad)[0])
+        raise ValueError(f"dropout marker frames [{fb[k]}-{fs[k]}, {fa[k]}+{fs[k]}) leave the {frames}-frame spectrogram or are empty")
+    if np.any(bu - bl < 1):
+        raise ValueError("dropout marker spans no frequency bin")
 
 
 def heal_spectrum_dev(spec_fm, geometry, dev=None, gain=None):
@@ -145,43 +132,166 @@ def heal_spectrum_dev(spec_fm, geometry, dev=None, gain=None):
     from . import _lib
     dev = _dev.device_index(dev)
     frames, bins = spec_fm.shape
-    geo = np.asarray(geometry, dtype=np.int64).reshape(-1, 5)
-    _check_geometry(geo, frames)
+    if torch.is_tensor(geometry):                        # already checked and on the device: int32 [n][5]
+        geo, geo_t = geometry, geometry
+    else:
+        geo = np.asarray(geometry, dtype=np.int64).reshape(-1, 5)
+        _check_geometry(geo, frames)
+        geo_t = None
     if gain is None:
         gain = torch.zeros((frames, bins), dtype=torch.float32, device=spec_fm.device)
     if len(geo):
         L = _lib.lib()
-        geo_t = _dev.to_dev(np.ascontiguousarray(geo, dtype=np.int32), torch.int32, dev)
+        if geo_t is None:
+            geo_t = _dev.to_dev(np.ascontiguousarray(geo, dtype=np.int32), torch.int32, dev)
         args = (dev, _dev.ptr(spec_fm), frames, bins, _dev.ptr(geo_t), len(geo), _dev.ptr(gain), _dev.stream_ptr(dev))
         _lib.check(L.par_inpaint_gain_db_c64(*args))
         _lib.check(L.par_spec_apply_gain_boxes_c64(*args))
     return gain
 
 
-def heal_dropouts(signal, sr, markers, fft_size=512, hop=32, channels=None, device=None):
+def heal_segments(geometry, frames_total, n_pad, n, fft_size, hop):
+    """Sparse plan of the healer: which frames can a marker influence, and how do they line up in one short pseudo-signal?
+    A box modifies frames [fb, fa) and reads fs frames on either side; a modified frame reaches samples half a window away,
+    and rebuilding those samples needs every frame that overlaps them: frames [min(fb - fs, fb - R + 1), max(fa + fs,
+    fa + R - 1)) with R = fft_size / hop.  Overlapping ranges merge into segments [g0, g1); segment k becomes the samples
+    [g0 hop - fft/2, (g1 - 1) hop + fft/2) of the padded signal, placed at a multiple of hop in the pseudo-signal so that
+    its frames sit on the pseudo-signal's own frame grid.  A segment within R frames of either end of the file is extended
+    to that end and keeps it as the pseudo-signal's end (the transform's reflect padding is then the original's).
+    -> None when the dense path should be taken, else dict(src, dst, len: sample ranges to gather; frame_shift per box;
+    v_src, v_dst, v_len: valid ranges to copy back; total)."""
+    geo = np.asarray(geometry, dtype=np.int64).reshape(-1, 5)
+    R = fft_size // hop
+    if len(geo) == 0 or fft_size % (2 * hop) or R < 2:
+        return None
+    fb, fa, fs = geo[:, 0], geo[:, 1], geo[:, 2]
+    lo = np.minimum(fb - fs, fb - R + 1)
+    hi = np.maximum(fa + fs, fa + R - 1)
+    order = np.argsort(lo, kind="stable")
+    lo_s, hi_s = lo[order], hi[order]
+    reach = np.maximum.accumulate(hi_s)                   # furthest frame any earlier box needs
+    first = np.ones(len(geo), dtype=bool)
+    first[1:] = lo_s[1:] > reach[:-1]                     # a box that starts behind everything before it opens a segment
+    seg_id = np.cumsum(first) - 1
+    seg_of = np.empty(len(geo), dtype=np.int64)
+    seg_of[order] = seg_id
+    g0 = lo_s[first]
+    g1 = np.maximum.reduceat(hi_s, np.flatnonzero(first))
+    n_seg = len(g0)
+    half = fft_size // 2
+    at_start, at_end = g0 < R, g1 > frames_total - R
+    if np.any(at_start & at_end) or np.any(at_start[1:]) or np.any(at_end[:-1]):
+        return None                                       # one segment spans the file (the others cannot happen when sorted)
+    s0 = np.where(at_start, 0, g0 * hop - half)
+    s1 = np.where(at_end, n_pad, (g1 - 1) * hop + half)
+    v0 = np.where(at_start, 0, (g0 - 1) * hop + half)
+    v1 = np.where(at_end, n, np.minimum(n, g1 * hop - half))
+    ln = s1 - s0
+    dst = np.concatenate(([0], np.cumsum(ln)[:-1]))
+    at = int(np.sum(ln))
+    shift = (dst - s0) // hop                             # pseudo-signal frame = original frame + shift
+    keep = v1 > v0
+    src, v_src, v_dst, v_len = s0, (dst + v0 - s0)[keep], v0[keep], (v1 - v0)[keep]
+    segs = range(n_seg)
+    if at > 0.6 * n_pad:
+        return None
+    return {"src": np.asarray(src, np.int64), "dst": np.asarray(dst, np.int64), "len": np.asarray(ln, np.int64),
+            "frame_shift": np.asarray(shift, np.int64)[seg_of], "v_src": np.asarray(v_src, np.int64),
+            "v_dst": np.asarray(v_dst, np.int64), "v_len": np.asarray(v_len, np.int64), "total": int(at), "segments": len(segs)}
+
+
+def _copy_segments(src_t, src_stride, n_valid, n_padded, padded, src_start, dst_start, lens, dst_t, dst_stride, dev, cache=None,
+                   key=None):
+    """cache / key: a dict that keeps the device copy of the index arrays (a plan serves every channel of a file)."""
+    from . import _lib
+    if len(lens) == 0:
+        return
+    idx = cache.get((key, dev)) if cache is not None else None
+    if idx is None:
+        run = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64)
+        idx = _dev.to_dev(np.stack((src_start, dst_start, lens, run)), torch.int64, dev)
+        if cache is not None:
+            cache[(key, dev)] = idx
+    _lib.check(_lib.lib().par_copy_segments_f32(dev, _dev.ptr(src_t), src_stride, n_valid, n_padded, int(padded), _dev.ptr(idx[0]),
+                                                _dev.ptr(idx[1]), _dev.ptr(idx[2]), _dev.ptr(idx[3]), len(lens), int(np.sum(lens)),
+                                                _dev.ptr(dst_t), dst_stride, _dev.stream_ptr(dev)))
+
+
+def heal_dropouts_dev(sig_t, n, ch, c, geometry, fft_size, hop, out_t, dev, sparse=None, gain=None, plan=None):
+    """One channel of the healer, device to device: sig_t (n, ch) float32 interleaved -> out_t (n, ch), channel c.
+    sparse None: decide from the markers (heal_segments); True / False force a path (True still falls back to the dense
+    path when the markers cover most of the file); plan: a heal_segments result for these markers (it depends on the
+    markers only: one plan serves every channel of a file).  Returns (gain mask for reuse, plan or None)."""
+    n_pad = n + fft_size // 2
+    frames_total = n_pad // hop + 1
+    if plan is None and sparse is not False:
+        plan = heal_segments(geometry, frames_total, n_pad, n, fft_size, hop)
+    flat_in, flat_out = sig_t.reshape(-1), out_t.reshape(-1)
+    if plan is None:
+        # the reference's own dataflow (dropout_healer_gui.py:120-164): pad, transform everything, heal, invert everything
+        pad_t = _dev.empty(n_pad, torch.float32, dev)
+        pad_t[:n] = flat_in[c::ch]
+        pad_t[n:] = 0.0
+        S = fourier.stft(pad_t, n_fft=fft_size, step=hop)                  # (bins, frames) device
+        healed = S.T.contiguous()                                          # frame-major [frames][bins]
+        gain = heal_spectrum_dev(healed, geometry, dev, gain)              # mask is zero again: reused by the next channel
+        flat_out[c::ch] = fourier.istft(healed.T, length=n, hop_length=hop)
+        return gain, None
+    geo = np.array(geometry, dtype=np.int64).reshape(-1, 5)
+    T = plan["total"]
+    xs = _dev.empty(T, torch.float32, dev)
+    cache = plan.setdefault("_device", {})
+    _copy_segments(flat_in[c:], ch, n, n_pad, True, plan["src"], plan["dst"], plan["len"], xs, 1, dev, cache, "gather")
+    S = fourier.stft(xs, n_fft=fft_size, step=hop)
+    healed = S.T.contiguous()
+    geo_t = cache.get(("geo", dev))
+    if geo_t is None:
+        geo[:, 0] += plan["frame_shift"]
+        geo[:, 1] += plan["frame_shift"]
+        _check_geometry(geo, healed.shape[0])
+        geo_t = cache[("geo", dev)] = _dev.to_dev(np.ascontiguousarray(geo, dtype=np.int32), torch.int32, dev)
+    if gain is not None and gain.shape != healed.shape:
+        gain = None
+    gain = heal_spectrum_dev(healed, geo_t, dev, gain)
+    ys = fourier.istft(healed.T, length=T, hop_length=hop)
+    if ch == 1 and flat_out.data_ptr() != flat_in.data_ptr():
+        flat_out.copy_(flat_in)
+    elif flat_out.data_ptr() != flat_in.data_ptr():
+        flat_out[c::ch] = flat_in[c::ch]
+    _copy_segments(ys, 1, T, T, False, plan["v_src"], plan["v_dst"], plan["v_len"], flat_out[c:], ch, dev, cache, "scatter")
+    return gain, plan
+
+
+def heal_dropouts(signal, sr, markers, fft_size=512, hop=32, channels=None, device=None, sparse=None):
     """Spectral inpainting of marked dropouts -- headless restatement of
     dropout_healer_gui.Canvas.resample_files (dropout_healer_gui.py:111-166).
 
     signal: float32 (n, ch).  markers: iterable of (a0, a1, b0, b1, surrounding) = the reference's
     DropoutSample.to_cfg() (util/markers.py:368-388, 424-426): corner (t, f) pairs and the
     surrounding factor.  STFT, the per-marker targets and gain mask (all markers in one launch), gain
-    application and ISTFT run on the device; only the healed channel returns to the host."""
+    application and ISTFT run on the device; only the healed channel returns to the host.
+
+    sparse (r03): the reference transforms the whole file, multiplies by a gain mask that is 1 outside the boxes and
+    inverts the whole file; outside the reach of the boxes that round trip is the identity to 1.6e-8.  By default only
+    the frames a box can influence are transformed (heal_segments) and the rest of the signal is copied; sparse=False
+    takes the reference-shaped dense path."""
     dev = _dev.device_index(device)
     sig2d = signal[:, None] if signal.ndim == 1 else signal
     n, ch = sig2d.shape
     if channels is None:
         channels = range(ch)
-    out = np.empty(sig2d.shape, dtype=sig2d.dtype)
-    y_pad = fourier.fix_length(sig2d, n + fft_size // 2, axis=0)
-    pad_t = _dev.to_dev(y_pad, torch.float32, dev)                      # (n + fft/2, ch) in HBM
+    sig_t = _dev.to_dev(np.ascontiguousarray(sig2d), torch.float32, dev)    # (n, ch) in HBM
+    out_t = _dev.empty((n, ch), torch.float32, dev)
     geometry = [marker_geometry(m, sr, hop, fft_size) for m in markers]
-    gain = None
+    _check_geometry(np.asarray(geometry, dtype=np.int64).reshape(-1, 5), (n + fft_size // 2) // hop + 1)
+    gain, plan = None, None
+    geometry = np.asarray(geometry, dtype=np.int64).reshape(-1, 5)
     for c in channels:
-        S = fourier.stft(pad_t.reshape(-1)[c::ch] if ch > 1 else pad_t.reshape(-1), n_fft=fft_size, step=hop)  # (bins, frames) device
-        healed = S.T.contiguous()                                          # frame-major [frames][bins]
-        gain = heal_spectrum_dev(healed, geometry, dev, gain)              # mask is zero again: reused by the next channel
-        y = fourier.istft(healed.T, length=n, hop_length=hop)
-        out[:, c] = y.cpu().numpy()
+        gain, plan = heal_dropouts_dev(sig_t, n, ch, c, geometry, fft_size, hop, out_t, dev, sparse, gain, plan)
+    out = np.empty(sig2d.shape, dtype=sig2d.dtype)                          # channels not selected stay uninitialised, like the reference's np.empty
+    got = out_t.cpu().numpy()
+    for c in channels:
+        out[:, c] = got[:, c]
     return out
 
 

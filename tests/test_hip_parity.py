@@ -1466,6 +1466,52 @@ def test_config4_x256_tiles_one_launch(par):
         d = np.max(np.abs(got[k * n1 + edge:(k + 1) * n1 - edge] - want[edge:n1 - edge])) / scale
         worst = max(worst, d)
     assert worst < TOL, worst
+    # r03: that call took the SPARSE path (only the frames a box can reach are transformed); the reference-shaped dense
+    # path (transform and invert the whole 82.6 M-sample signal) gives the same signal
+    plan = par.pipeline.heal_segments([par.pipeline.marker_geometry(mk, sr, hop, n_fft) for mk in all_marks],
+                                      (n1 * tiles + n_fft // 2) // hop + 1, n1 * tiles + n_fft // 2, n1 * tiles, n_fft, hop)
+    assert plan is not None and plan["total"] < 0.45 * n1 * tiles, plan and plan["total"]
+    dense = par.pipeline.heal_dropouts(np.tile(x1, tiles), sr, all_marks, n_fft, hop, sparse=False)[:, 0]
+    assert np.max(np.abs(dense - got)) / scale < 2e-6
+
+
+def test_sparse_heal_equals_dense_and_oracle(par):
+    """Sparse healing (r03) against the dense path and the oracle: boxes at the very start and end of the file (segments
+    that keep the file's own reflect edge), overlapping and nested boxes (merged segments), far-apart boxes, stereo with a
+    channel selection; and a marker set that covers most of the file, which must fall back to the dense path."""
+    from oracle import oracle_np as O
+    sr, n_fft, hop = 44100, 512, 32
+    rng = np.random.default_rng(21)
+    n = 400_000
+    x = (0.4 * rng.standard_normal(n)).astype(np.float32)
+    x[50_000:50_400] *= 0.05                                            # a few real dips
+    x[200_000:200_900] *= 0.1
+    dur = n / sr
+    marks = [(0.012, 400.0, 0.030, 9000.0, 0.5),                       # surrounding frames reach frame 0..: file start
+             (1.130, 500.0, 1.142, 8000.0, 0.5), (1.136, 300.0, 1.150, 6000.0, 1.0),        # overlapping
+             (4.530, 800.0, 4.551, 12000.0, 0.5), (4.535, 2000.0, 4.540, 4000.0, 0.5),      # nested
+             (7.000, 100.0, 7.004, 20000.0, 2.0),
+             (dur - 0.040, 400.0, dur - 0.022, 9000.0, 0.5)]           # close to the end of the file
+    plan = par.pipeline.heal_segments([par.pipeline.marker_geometry(m, sr, hop, n_fft) for m in marks],
+                                      (n + n_fft // 2) // hop + 1, n + n_fft // 2, n, n_fft, hop)
+    assert plan is not None and plan["segments"] == 5 and plan["total"] < 0.1 * n
+    want = O.heal_dropouts(x, sr, marks, n_fft, hop)[:, 0]
+    sparse = par.pipeline.heal_dropouts(x, sr, marks, n_fft, hop, sparse=True)[:, 0]
+    dense = par.pipeline.heal_dropouts(x, sr, marks, n_fft, hop, sparse=False)[:, 0]
+    scale = np.max(np.abs(want))
+    assert np.max(np.abs(dense - want)) / scale < TOL and np.max(np.abs(sparse - want)) / scale < TOL
+    assert np.max(np.abs(sparse - dense)) / scale < 2e-6
+    assert np.max(np.abs(sparse - x)) / scale > 1e-2                    # the boxes did change something
+    st = np.stack((x, x[::-1]), axis=1)
+    got2 = par.pipeline.heal_dropouts(st, sr, marks, n_fft, hop, channels=(1,), sparse=True)
+    want2 = O.heal_dropouts(np.ascontiguousarray(x[::-1]), sr, marks, n_fft, hop)[:, 0]
+    assert np.max(np.abs(got2[:, 1] - want2)) / np.max(np.abs(want2)) < TOL
+    # markers all over the file: the plan declines and the dense path runs
+    many = [(t, 500.0, t + 0.01, 9000.0, 0.5) for t in np.arange(0.05, dur - 0.1, 0.03)]
+    assert par.pipeline.heal_segments([par.pipeline.marker_geometry(m, sr, hop, n_fft) for m in many],
+                                      (n + n_fft // 2) // hop + 1, n + n_fft // 2, n, n_fft, hop) is None
+    got3 = par.pipeline.heal_dropouts(x, sr, many, n_fft, hop)[:, 0]
+    assert np.max(np.abs(got3 - O.heal_dropouts(x, sr, many, n_fft, hop)[:, 0])) / scale < TOL
 
 
 @pytest.mark.parametrize("n_fft,hop,zp", [(16384, 4096, 1), (65536, 16384, 1), (4096, 1024, 4), (32768, 5000, 2), (1048576, 262144, 1),
