@@ -86,6 +86,57 @@ def f32(x):
     return "%sf" % repr(v) if ("e" in repr(v) or "." in repr(v)) else "%s.0f" % repr(v)
 
 
+# ---- Farrow bank of the fc = 1 path on the matrix cores (r03) -------------------------------------------------------
+# The taps n >= 5 of the unity path are polynomials in q = shift^2 with FIXED coefficients: six fixed FIR filters on the
+# input grid (e0 e1 e2: symmetric, coefficient c_k[|n|]; d0 d1 d2: antisymmetric, sign(n) |n| c_k[|n|]).  K_sinc evaluates
+# them with v_mfma_f32_16x16x32_f16: D[(filter, position i)][block b] += A[(f, i)][k] B[k][b], B[k][b] = x16[8 b + k].
+# This emits the constant A fragments: M tile rows m = (filter m >> 3, position i = m & 7); lane: row m = lane & 15,
+# g = lane >> 4; element j of slice ks: tap n = 32 ks + 8 g + j - 31 - i.  float16 has 11 bits, so the dominant pair is
+# split hi + lo * 2^-12; everything is scaled by 32 (keeps the smallest coefficients normal).
+# Fragments 0-2 (e0 d0)h slices 0-2; 3-4 (e1 d1)h slices 0-1; 5-7 (e0 d0)lo slices 0-2; 8-9 (e2 d2)h slices 0-1.
+FARROW_SCALE = 32.0
+FARROW_LO = 4096.0
+FARROW_FRAGS = ((0, 3, 0, 0), (0, 3, 1, 0), (0, 3, 2, 0), (1, 4, 0, 0), (1, 4, 1, 0),
+                (0, 3, 0, 1), (0, 3, 1, 1), (0, 3, 2, 1), (2, 5, 0, 0), (2, 5, 1, 0))
+
+
+def farrow_fragments(NT):
+    """uint16 [10][64][8]: the float16 bit patterns of the constant A fragments (NT = 32 only: 63 taps + 8 positions fit
+    three 32-tap slices)."""
+    assert NT == 32
+    _, _, rows = tables(NT)
+
+    def coef(f, n):
+        a = abs(n)
+        if a < 5 or a >= NT:
+            return 0.0
+        mode, A, B, C = rows[a]
+        A, B, C = float(np.float32(A)), float(np.float32(B)), float(np.float32(C))
+        sg = -1.0 if n < 0 else 1.0
+        fa = float(np.float32(np.float32(a) * np.float32(A)))
+        fb = float(np.float32(np.float32(a) * np.float32(B)))
+        fc = float(np.float32(np.float32(a) * np.float32(C)))
+        v = (A, B if mode <= 2 else 0.0, C if mode == 1 else 0.0, sg * fa, sg * fb if mode <= 2 else 0.0,
+             sg * fc if mode == 1 else 0.0)[f]
+        return FARROW_SCALE * v
+    for f in (1, 2, 4, 5):                                 # (e1 d1) and (e2 d2) skip slice 2: no tap of theirs may sit there
+        for i in range(8):
+            for k in range(64, 96):
+                assert coef(f, k - 31 - i) == 0.0
+    for f in (0, 3):
+        for i in range(8):
+            assert coef(f, 96 - 31 - i) == 0.0 and coef(f, -32 - i) == 0.0   # everything of the window inside K = 96
+    out = np.zeros((len(FARROW_FRAGS), 64, 8), dtype=np.float16)
+    for fr, (fe, fd, ks, lo) in enumerate(FARROW_FRAGS):
+        for lane in range(64):
+            m, g = lane & 15, lane >> 4
+            for j in range(8):
+                cf = coef(fd if (m >> 3) else fe, 32 * ks + 8 * g + j - 31 - (m & 7))
+                hi = np.float16(cf)
+                out[fr, lane, j] = np.float16((cf - float(hi)) * FARROW_LO) if lo else hi
+    return out.view(np.uint16)
+
+
 def render():
     out = ["// GENERATED by tools/gen_sinc_taps.py -- do not edit.  Compile-time tap tables of the NT-specialised K_sinc loops.",
            "#pragma once", "", "namespace par {", "",
@@ -99,6 +150,19 @@ def render():
             out.append("  static constexpr float %s[%d] = {%s};" % (name, NT + 1, ", ".join(f32(r[idx]) for r in rows)))
         out.append("};")
         out.append("")
+    fr = farrow_fragments(32).reshape(-1, 2)
+    words = (fr[:, 0].astype(np.uint32) | (fr[:, 1].astype(np.uint32) << 16))
+    out.append("// Constant A fragments of the unity path's Farrow bank on the matrix cores (tools/gen_sinc_taps.py, farrow_fragments):")
+    out.append("// [10 fragments][64 lanes][8 halves] as 32-bit words, 10 KB; scale %g, lo parts x %g." % (FARROW_SCALE, FARROW_LO))
+    out.append("constexpr int kFarrowFrags = %d;" % len(FARROW_FRAGS))
+    out.append("constexpr float kFarrowScaleInv = %sf, kFarrowLoInv = %sf;" % (repr(1.0 / FARROW_SCALE), repr(1.0 / FARROW_LO)))
+    out.append("#ifdef __HIPCC__")
+    out.append("__device__ const unsigned int kFarrowFrags32[%d] = {" % len(words))
+    for i in range(0, len(words), 12):
+        out.append("  " + ", ".join("0x%08xu" % w for w in words[i:i + 12]) + ",")
+    out.append("};")
+    out.append("#endif")
+    out.append("")
     out += ["}  // namespace par", ""]
     return "\n".join(out)
 

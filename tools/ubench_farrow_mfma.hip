@@ -174,7 +174,9 @@ __global__ __launch_bounds__(256, MODE ? 5 : 6) void k_far(const float* __restri
   const int l = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   unsigned char* wbase = lds_raw + (MODE ? kFrags * 1024 : 0) + wv * kWaveBytes;
   if (MODE == 1) {                                   // the constant A fragments: [fragment][lane] 16 bytes
-    for (int i = threadIdx.x; i < kFrags * 64; i += blockDim.x) reinterpret_cast<half8*>(lds_raw)[i] = btab[i];
+    // the product's own table (csrc/sinc_taps_gen.h, tools/gen_sinc_taps.py); UB_HOST_TABLE=1 passes the host-built copy instead
+    const half8* tab = btab ? btab : reinterpret_cast<const half8*>(par::kFarrowFrags32);
+    for (int i = threadIdx.x; i < kFrags * 64; i += blockDim.x) reinterpret_cast<half8*>(lds_raw)[i] = tab[i];
     __syncthreads();
   }
   float* tile = reinterpret_cast<float*>(wbase);
@@ -343,6 +345,10 @@ int main(int argc, char** argv) {
   float *d_sig, *d_out;
   CHECK(hipMalloc(&d_btab, btab.size() * 2));
   CHECK(hipMemcpy(d_btab, btab.data(), btab.size() * 2, hipMemcpyHostToDevice));
+  if (!getenv("UB_HOST_TABLE")) {                      // default: the generated table compiled into the product
+    CHECK(hipFree(d_btab));
+    d_btab = nullptr;
+  }
   CHECK(hipMalloc(&d_sig, len_in * 4));
   CHECK(hipMalloc(&d_out, n_out * 4));
   std::vector<float> sig(len_in), outv(n_out);
