@@ -898,6 +898,58 @@ def test_block_records_cover_benchmark_and_flutter_curves(par):
         assert same_resample(fused, via_pos), (name, float((fused - via_pos).abs().max() / via_pos.abs().max()))
 
 
+def test_unity_path_matrix_core_bank(par):
+    """r03: on the fc = 1 path of the mono NT = 32 kernel the taps n >= 5 are a Farrow bank on the matrix cores (float16 hi/lo
+    split, csrc/sinc.hip unity_far_mfma).  A tape that only runs FAST (speed 1.000 .. 1.010: every wave is on that path)
+    against the C oracle, for signals that suit float16 and for ones that do not and must take the literal-FMA loops:
+    full-scale noise, a Nyquist tone, a 90 dB quieter passage next to a loud one, samples of 1e5 (float16 overflow), 1e-6
+    (its lo part would go subnormal), and NaN / Inf samples, whose footprint in the output must be the reference's window
+    (offsets -NT .. NT-1) exactly."""
+    from oracle import oracle_c as C
+    t = par.torch
+    sr, dur, NT = 192000, 3.0, 32
+    n = int(sr * dur)
+    m = n // 256
+    st = np.linspace(0, n, m)
+    sp = 1.005 + 0.005 * np.sin(2 * np.pi * 0.55 * st / sr + 0.7)
+    st_t, sp_t = t.from_numpy(st).cuda(), t.from_numpy(sp).cuda()
+    plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
+    assert plan.fused_ok
+    pos, _ = C.speed_to_pos(st, sp, n)
+    rng = np.random.default_rng(12)
+    base = rng.uniform(-1, 1, n).astype(np.float32)
+    cases = {"noise": base, "nyquist": np.cos(np.pi * np.arange(n)).astype(np.float32)}
+    quiet = base.copy()
+    quiet[n // 3:2 * n // 3] *= np.float32(3e-5)
+    cases["loud next to quiet"] = quiet
+    cases["1e5"] = base * np.float32(1e5)
+    cases["1e-6"] = base * np.float32(1e-6)
+    for name, sig in cases.items():
+        want = C.sinc(pos, sig, NT, threads=8)
+        got = par.resampling.varispeed_fused_dev(plan, t.from_numpy(sig).cuda(), NT).cpu().numpy()
+        assert relerr(got, want) < TOL, (name, relerr(got, want))
+        if name == "loud next to quiet":                                  # the quiet third on its own scale: float16's 11 bits
+            a, b = n // 3 + 4000, 2 * n // 3 - 4000                      # would not do, hi + lo does
+            ia, ib = np.searchsorted(pos, [a, b])
+            assert relerr(got[ia:ib], want[ia:ib]) < TOL
+    bad = base.copy()
+    bad[100_000] = np.nan
+    bad[300_001] = np.inf
+    bad[400_000:400_003] = -np.inf
+    want = C.sinc(pos, bad, NT, threads=8)
+    got = par.resampling.varispeed_fused_dev(plan, t.from_numpy(bad).cuda(), NT).cpu().numpy()
+    # an infinite sample gives +-Inf or (Inf - Inf, 0 x Inf) NaN depending on the order of the sum: the FOOTPRINT of the
+    # non-finite outputs is what must agree; a NaN sample alone must give exactly the reference's NaN set
+    assert np.array_equal(np.isfinite(got), np.isfinite(want)) and (~np.isfinite(want)).sum() > 150
+    ok = np.isfinite(want)
+    assert relerr(got[ok], want[ok]) < TOL
+    only_nan = base.copy()
+    only_nan[123_456] = np.nan
+    want = C.sinc(pos, only_nan, NT, threads=8)
+    got = par.resampling.varispeed_fused_dev(plan, t.from_numpy(only_nan).cuda(), NT).cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and 60 <= np.isnan(want).sum() <= 66
+
+
 def test_fused_extreme_curves_and_channels(par):
     """Fused path under stress: fast curves whose tiles overflow the LDS stage (float64 slow path),
     slow curves (many outputs per input), stereo strided views, tiny NT and NT = 100."""
