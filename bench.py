@@ -146,7 +146,7 @@ def heal_secondary(dev, tiles=256):
     y = torch.empty(n, dtype=torch.float32, device=x.device)
 
     def step():
-        _lib.check(L.par_stft_f32(dev, _dev.ptr(x), n + n_fft // 2, 1, n_fft, hop, 1, _dev.ptr(win), _dev.ptr(spec), 0, s))
+        _lib.check(L.par_stft_f32(dev, _dev.ptr(x), n + n_fft // 2, 1, n_fft, hop, 1, _dev.ptr(win), _dev.ptr(spec), 0, 0, s))
         _lib.check(L.par_inpaint_gain_db_c64(dev, _dev.ptr(spec), frames, bins, _dev.ptr(geo), len(marks), _dev.ptr(gain), s))
         _lib.check(L.par_spec_apply_gain_boxes_c64(dev, _dev.ptr(spec), frames, bins, _dev.ptr(geo), len(marks), _dev.ptr(gain), s))
         _lib.check(L.par_istft_f32(dev, _dev.ptr(spec), frames, n_fft, hop, _dev.ptr(win), None, _dev.ptr(y), n, n_fft // 2, s))

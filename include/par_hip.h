@@ -60,8 +60,11 @@ int par_stream_sync(int device, void* stream);
  * n_fft*zeropad must be a power of two in [16, 16384] (larger: par_stft_big_f32); otherwise PAR_ERR_UNSUPPORTED.
  */
 int64_t par_stft_frames(int64_t n, int n_fft, int hop);
+/* out_pitch (r03): elements (float, or float2 for mode 0) from one frame's row to the next; 0 = bins (packed rows).  A pitch
+ * that is a multiple of 32 floats starts every magnitude row on a 128-byte line: a 513-bin row is 2052 bytes, packed rows
+ * straddle lines at both ends and the streaming stores of neighbouring frames wrote 1.21x the bytes (WRITE_SIZE, r02). */
 int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad,
-                 const float* window, float* out, int mode, void* stream);
+                 const float* window, float* out, int mode, int64_t out_pitch, void* stream);
 
 /* The same transform for frames of more than 8192 points (n_fft*zeropad a power of two in (8192, 2^21]; the GUI offers
  * FFT sizes up to 2^20, util/widgets.py:333-349): a four-step FFT in two passes over HBM (columns, then rows fused with
@@ -120,7 +123,7 @@ int par_spec_apply_gain_boxes_c64(int device, float* spec, int64_t n_frames, int
 /* Band volume curve of the dropout detector (dropout_healer_gui.py:195-203):
  * out[i] = mean_b 20*log10(mag[frame_b+i][b]), b in [bin_l, bin_u), i in [0, frame_a-frame_b); f64 out.
  *   mag  device f32 [n_frames][bins] frame-major magnitude (get_mag output, already + 1e-7). */
-int par_band_mean_db_f32(int device, const float* mag, int64_t n_frames, int64_t bins, int bin_l, int bin_u,
+int par_band_mean_db_f32(int device, const float* mag, int64_t n_frames, int64_t bins, int64_t mag_pitch, int bin_l, int bin_u,
                          int64_t frame_b, int64_t frame_a, double* out, void* stream);
 
 /* ---- R1: speed curve -> fractional read positions ----------------------------------
@@ -252,7 +255,9 @@ int par_synth_speed_curve_f64(int device, double* sampletimes, double* speeds, i
  * Replaces the trace() loops of PeakTracker / PeakTrackTracker (util/wow_detection.py:294-327)
  * with Track.set_bin_limits (:97-107), get_peak (:119-134), is_peak (:136-139) and
  * correlation.parabolic (util/correlation.py:42-46).
- *   mag      device f32 frame-major [n_frames][bins]
+ *   mag      device f32 frame-major [n_frames][bins], rows mag_pitch floats apart (0 = bins: packed; par_stft_f32's
+ *            out_pitch).  The same parameter on par_track_cog_f64 / par_track_corr_f64 / par_piptrack_f32 /
+ *            par_band_mean_db_f32.
  *   freqs    device f64[count]: in = sampled trail (sample_trail :66-76), out = traced frequencies
  *   mode 0   PeakTracker: band re-centred on freqs[i] every frame
  *   mode 1   PeakTrackTracker: band fixed on freqs[0]; tolerance halves for i > 2
@@ -261,8 +266,8 @@ int par_synth_speed_curve_f64(int device, double* sampletimes, double* speeds, i
  *            bin is its IndexError (is_peak reads the bin above): PAR_ERR_INDEX; a Center-of-Gravity band past the last
  *            bin is its broadcast ValueError: PAR_ERR_SHAPE.  Synchronises.
  */
-int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
-                       double* freqs, int fft_size, double sr, double tolerance_oct, int mode, int32_t* status,
+int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t mag_pitch, int64_t frame_0,
+                       int64_t count, double* freqs, int fft_size, double sr, double tolerance_oct, int mode, int32_t* status,
                        void* stream);
 /* The same two trackers with the band magnitudes RE-EVALUATED FROM THE SIGNAL in float64 (r03): the reference's numpy
  * backend (util/fourier.py:136-157) hands Track.get_peak (util/wow_detection.py:119-134) float64 containers, and the
@@ -277,7 +282,7 @@ int par_track_peak_refined_f64(int device, const float* x, int64_t n, int64_t x_
                                const float* window, int bins, int64_t n_frames, int64_t frame_0, int64_t count, double* freqs,
                                double sr, double tolerance_oct, int mode, int32_t* status, void* stream);
 /* CenterOfGravity.trace (util/wow_detection.py:256-291): sequential band adaptation. */
-int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
+int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t mag_pitch, int64_t frame_0, int64_t count,
                       double* freqs, int fft_size, double sr, double tolerance_oct, int32_t* status, void* stream);
 
 /* W4: CorrelationTracker.trace (util/wow_detection.py:396-436) for all frames in one call: the band [NL, NU) of frames
@@ -295,10 +300,10 @@ int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, 
  * published source, parity unpinned): thresholded local maxima of every magnitude column inside [fmin, fmax), refined by
  * a parabola.  mag: device f32 [n_frames][bins] as par_stft_f32 mode 1 writes it; S = (mag - offset) * scale gives the
  * |stft| librosa works on (offset 1e-7, scale sqrt(n_fft)).  pitches / mags: device f32 [n_frames][bins] out. */
-int par_piptrack_f32(int device, const float* mag, int64_t n_frames, int bins, float scale, float offset, int fft_size,
+int par_piptrack_f32(int device, const float* mag, int64_t n_frames, int bins, int64_t mag_pitch, float scale, float offset, int fft_size,
                      double sr, double fmin, double fmax, float threshold, float* pitches, float* mags, void* stream);
 int64_t par_track_corr_work_len(int64_t count, int n);
-int par_track_corr_f64(int device, const float* mag, int64_t n_frames, int bins, int NL, int NU, int64_t count,
+int par_track_corr_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t mag_pitch, int NL, int NU, int64_t count,
                        const double* M, const double* wind, int n, double log_span, double log_mean, double* work,
                        double* freqs, int32_t* status, void* stream);
 

@@ -31,7 +31,7 @@ SIGNATURES = {
     "par_event_elapsed_ms": (c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_float)]),
     "par_stream_sync": (c_int, [c_int, c_vp]),
     "par_stft_frames": (c_i64, [c_i64, c_int, c_int]),
-    "par_stft_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
+    "par_stft_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp]),
     "par_istft_scratch_floats": (c_i64, [c_i64, c_int, c_int]),
     "par_istft_f32": (c_int, [c_int, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "par_spec_apply_gain_db_c64": (c_int, [c_int, c_vp, c_vp, c_i64, c_vp]),
@@ -43,7 +43,7 @@ SIGNATURES = {
     "par_flac_decode_f32": (c_int, [c_vp, c_sz, c_vp, c_i64, c_int, c_int, ctypes.POINTER(c_i64)]),
     "par_zero_crossings_work_len": (c_i64, [c_i64]),
     "par_zero_crossings_f64": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64), c_vp]),
-    "par_band_mean_db_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_int, c_int, c_i64, c_i64, c_vp, c_vp]),
+    "par_band_mean_db_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_i64, c_vp, c_vp]),
     "par_lag_to_pos_f64": (c_int, [c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, ctypes.POINTER(c_i64),
                                    ctypes.POINTER(c_int), c_vp]),
     "par_speed_plan_bytes": (c_sz, [c_i64]),
@@ -69,20 +69,20 @@ SIGNATURES = {
     "par_linear_resample_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "par_synth_signal_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_dbl, c_u64, c_vp]),
     "par_synth_speed_curve_f64": (c_int, [c_int, c_vp, c_vp, c_i64, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_vp]),
-    "par_track_peak_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_int, c_vp, c_vp]),
+    "par_track_peak_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_int, c_vp, c_vp]),
     "par_track_peak_refined_f64": (c_int, [c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_int, c_i64, c_i64, c_i64, c_vp,
                                            c_dbl, c_dbl, c_int, c_vp, c_vp]),
     "par_sosfiltfilt_work_len": (c_i64, [c_i64, c_i64]),
     "par_sosfiltfilt_f64": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
-    "par_track_cog_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]),
+    "par_track_cog_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]),
     "par_stft_big_scratch_bytes": (ctypes.c_size_t, [c_i64, c_int, c_int, c_int]),
     "par_stft_big_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, ctypes.c_size_t, c_vp]),
     "par_xcorr_scratch_bytes": (ctypes.c_size_t, [c_i64, c_i64]),
     "par_xcorr_f64": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "par_find_delay_f64": (c_int, [c_int, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp, c_vp]),
-    "par_piptrack_f32": (c_int, [c_int, c_vp, c_i64, c_int, c_float, c_float, c_int, c_dbl, c_dbl, c_dbl, c_float, c_vp, c_vp, c_vp]),
+    "par_piptrack_f32": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_float, c_float, c_int, c_dbl, c_dbl, c_dbl, c_float, c_vp, c_vp, c_vp]),
     "par_track_corr_work_len": (c_i64, [c_i64, c_int]),
-    "par_track_corr_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_int, c_int, c_i64, c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp,
+    "par_track_corr_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_int, c_int, c_i64, c_vp, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp,
                                    c_vp, c_vp]),
 }
 

@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int par_version(void) { return 100; }
+int par_version(void) { return 101; }
 
 int par_device_count(void) {
   int n = 0;

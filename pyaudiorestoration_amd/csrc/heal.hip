@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) k_apply_gain_boxes(float2* __restrict__ s
 }
 
 // one wave per frame, lanes stride over the band; mag is the float32 magnitude (already + 1e-7)
-__global__ void __launch_bounds__(256) k_band_mean_db(const float* __restrict__ mag, int64_t bins, int bin_l, int bin_u,
+__global__ void __launch_bounds__(256) k_band_mean_db(const float* __restrict__ mag, int64_t bins /* row pitch */, int bin_l, int bin_u,
                                                       int64_t frame_b, int64_t count, double* __restrict__ out) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
@@ -179,10 +179,11 @@ extern "C" int par_spec_apply_gain_boxes_c64(int device, float* spec, int64_t n_
   return PAR_OK;
 }
 
-extern "C" int par_band_mean_db_f32(int device, const float* mag, int64_t n_frames, int64_t bins, int bin_l, int bin_u,
-                                    int64_t frame_b, int64_t frame_a, double* out, void* stream) {
+extern "C" int par_band_mean_db_f32(int device, const float* mag, int64_t n_frames, int64_t bins, int64_t mag_pitch, int bin_l,
+                                    int bin_u, int64_t frame_b, int64_t frame_a, double* out, void* stream) {
   using namespace par;
   PAR_REQUIRE(mag && out, PAR_ERR_ARG, "par_band_mean_db_f32: null pointer");
+  PAR_REQUIRE(mag_pitch == 0 || mag_pitch >= bins, PAR_ERR_ARG, "par_band_mean_db_f32: mag_pitch < bins");
   PAR_REQUIRE(0 <= bin_l && bin_l < bin_u && bin_u <= bins, PAR_ERR_ARG, "par_band_mean_db_f32: empty or out-of-range band [%d, %d) of %lld bins",
               bin_l, bin_u, (long long)bins);
   PAR_REQUIRE(0 <= frame_b && frame_b <= frame_a && frame_a <= n_frames, PAR_ERR_ARG,
@@ -191,8 +192,8 @@ extern "C" int par_band_mean_db_f32(int device, const float* mag, int64_t n_fram
   const int64_t count = frame_a - frame_b;
   if (count == 0) return PAR_OK;
   PAR_HIP_CHECK(hipSetDevice(device));
-  hipLaunchKernelGGL(k_band_mean_db, dim3((unsigned)ceil_div(count, 4)), dim3(256), 0, as_stream(stream), mag, bins, bin_l,
-                     bin_u, frame_b, count, out);
+  hipLaunchKernelGGL(k_band_mean_db, dim3((unsigned)ceil_div(count, 4)), dim3(256), 0, as_stream(stream), mag,
+                     mag_pitch ? mag_pitch : bins, bin_l, bin_u, frame_b, count, out);
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
                                                                   int n_fft, int hop, const float* __restrict__ window,
                                                                   const float2* __restrict__ tw,
                                                                   const float2* __restrict__ post, float* __restrict__ out,
-                                                                  int64_t n_frames, float scale) {
+                                                                  int64_t n_frames, float scale, int64_t pitch) {
   const int64_t x_stride = UNIT ? 1 : x_stride_arg;
   constexpr int mode = MODE;
   using G = FftGeom<LOGH>;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
     // The complex one is re-read right away by the inpaint / ISTFT kernels: regular stores (streaming ones cost
     // 2 % on the config-4 chain).
     if constexpr (mode == 0) {
-      reinterpret_cast<float2*>(out)[fr * bins + k] = make_float2(re * hs, im * hs);
+      reinterpret_cast<float2*>(out)[fr * pitch + k] = make_float2(re * hs, im * hs);
     } else {
       // v_sqrt_f32 itself (1 ulp): the correctly rounded sqrtf costs 16 instructions per bin, mostly compares and selects
       const float mag = fmaf(__builtin_amdgcn_sqrtf(fmaf(re, re, im * im)), hs, 1e-7f);
@@ -336,8 +336,8 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
       // complete their lines together with the neighbouring frames', in L2, and went to HBM piecemeal as streaming stores
       // (n_fft = 64, hop 16 on 57.6 M samples: 0.81 ms streaming, 0.39 ms plain; n_fft = 256: 0.26 against 0.31)
       if (kRowStage) Mg[k] = mag;
-      else if (PAR_STFT_STORE == 1 || T < 16) out[fr * bins + k] = mag;
-      else __builtin_nontemporal_store(mag, out + fr * bins + k);
+      else if (PAR_STFT_STORE == 1 || T < 16) out[fr * pitch + k] = mag;
+      else __builtin_nontemporal_store(mag, out + fr * pitch + k);
     }
   };
   // LDS slots of the pair (k, H - k), k = j + i T: with T a multiple of 8 the padding is linear in i, so both are one
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_stft(const float* __
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     typedef float vf4 __attribute__((ext_vector_type(4)));
-    const int64_t e0 = fr * bins, e1 = e0 + bins;
+    const int64_t e0 = fr * pitch, e1 = e0 + bins;
     const int64_t a0 = (e0 + 3) & ~3ll, a1 = e1 & ~3ll;
     for (int64_t e = a0 + 4 * j; e < a1; e += 4 * T) {
       const float* m = Mg + (e - e0);
@@ -1065,9 +1065,11 @@ static int ilog2(int v) {
 }
 
 int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad,
-                 const float* window, float* out, int mode, void* stream) {
+                 const float* window, float* out, int mode, int64_t out_pitch, void* stream) {
   using namespace par;
   PAR_REQUIRE(x && window && out, PAR_ERR_ARG, "par_stft_f32: null pointer");
+  const int64_t pitch = out_pitch ? out_pitch : (int64_t)n_fft * zeropad / 2 + 1;     // elements (float or float2) between rows
+  PAR_REQUIRE(pitch >= (int64_t)n_fft * zeropad / 2 + 1, PAR_ERR_ARG, "par_stft_f32: out_pitch %lld < bins", (long long)out_pitch);
   PAR_REQUIRE(n >= 1 && x_stride >= 1 && hop >= 1 && zeropad >= 1 && n_fft >= 2, PAR_ERR_ARG, "par_stft_f32: bad sizes");
   PAR_REQUIRE(mode == 0 || mode == 1, PAR_ERR_ARG, "par_stft_f32: mode must be 0 (complex) or 1 (magnitude)");
   const int64_t M64 = (int64_t)n_fft * zeropad;
@@ -1084,7 +1086,7 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
   hipLaunchKernelGGL((k_stft<LH, MD, UN>), dim3((unsigned)(ceil_div(ceil_div(n_frames, FftGeom<LH>::Frames), 8) * 8)), dim3(FftGeom<LH>::Threads),  \
                      (size_t)FftGeom<LH>::Frames * FftGeom<LH>::FrameLds * sizeof(float2) +                              \
                          (PAR_STFT_STORE == 3 ? (size_t)FftGeom<LH>::Frames * ((1 << LH) + 4) * sizeof(float) : 0),      \
-                     as_stream(stream), x, n, x_stride, n_fft, hop, window, tw.w, tw.post, out, n_frames, scale)
+                     as_stream(stream), x, n, x_stride, n_fft, hop, window, tw.w, tw.post, out, n_frames, scale, pitch)
 #define PAR_STFT_LAUNCH(LH)                                                                                          \
   do {                                                                                                               \
     if (mode == 1 && x_stride == 1) PAR_STFT_LAUNCH_MU(LH, 1, true);                                                 \

@@ -81,24 +81,24 @@ __device__ __forceinline__ bool empty_band(const Band& b, int* __restrict__ empt
   return true;
 }
 
-__global__ void k_track_peak(const float* __restrict__ mag, int bins, int64_t frame_0, int64_t count,
+__global__ void k_track_peak(const float* __restrict__ mag, int bins, int64_t pitch, int64_t frame_0, int64_t count,
                              double* __restrict__ freqs, int fft_size, double sr, double tol, int* __restrict__ empty) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const Band b = band_limits(freqs[i], tol, fft_size, sr, bins);     // PeakTracker: band follows the drawn trail
   if (empty_band(b, empty)) return;
-  freqs[i] = peak_freq(mag + (frame_0 + i) * bins, b, bins, fft_size, sr, empty);
+  freqs[i] = peak_freq(mag + (frame_0 + i) * pitch, b, bins, fft_size, sr, empty);
 }
 
 // PeakTrackTracker: band fixed on the first trail frequency (read back by the host entry point).
-__global__ void k_track_peak_fixed(const float* __restrict__ mag, int bins, int64_t frame_0, int64_t count,
+__global__ void k_track_peak_fixed(const float* __restrict__ mag, int bins, int64_t pitch, int64_t frame_0, int64_t count,
                                    double centre, double* __restrict__ freqs, int fft_size, double sr, double tol,
                                    int* __restrict__ empty) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const Band b = band_limits(centre, i > 2 ? tol / 2 : tol, fft_size, sr, bins);
   if (empty_band(b, empty)) return;
-  freqs[i] = peak_freq(mag + (frame_0 + i) * bins, b, bins, fft_size, sr, empty);
+  freqs[i] = peak_freq(mag + (frame_0 + i) * pitch, b, bins, fft_size, sr, empty);
 }
 
 // Peak / Peak Track on band magnitudes re-evaluated from the SIGNAL in float64 (r03).  The reference's numpy backend hands
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void k_track_peak_refined(const float* __restr
 
 // CenterOfGravity: the band of frame i+1 depends on the result of frame i -> one wave walks the frames,
 // its 64 lanes share the bins of the current band.
-__global__ __launch_bounds__(64) void k_track_cog(const float* __restrict__ mag, int bins, int64_t frame_0, int64_t count,
+__global__ __launch_bounds__(64) void k_track_cog(const float* __restrict__ mag, int bins, int64_t pitch, int64_t frame_0, int64_t count,
                                                    double* __restrict__ freqs, int fft_size, double sr, double tol,
                                                    int* __restrict__ empty) {
   // Frame i + 1's band follows from frame i's result: the frames are walked by one wave.  What the walk can hide it
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64) void k_track_cog(const float* __restrict__ mag,
       if (lane == 0) atomicOr(empty, 4);
       return;
     }
-    const float* col = mag + (frame_0 + i) * bins;
+    const float* col = mag + (frame_0 + i) * pitch;
     const int L = b.NU - b.NL;
     double num = 0.0, den = 0.0;
     if (L <= kWave) {
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) void k_track_cog(const float* __restrict__ mag,
       }
       float m = (pNL == b.NL && pNU == b.NU) ? pre : (lane < L ? col[b.NL + lane] : 0.0f);
       if (i + 1 < count) {                                 // next frame, this band: in flight under the reduction below
-        pre = lane < L ? col[bins + b.NL + lane] : 0.0f;
+        pre = lane < L ? col[pitch + b.NL + lane] : 0.0f;
         pNL = b.NL;
         pNU = b.NU;
       }
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64) void k_track_cog(const float* __restrict__ mag,
 //   k_corr_peak:     same[j] = sum_m a[m + j - n/2] b[m] / (|a| |b|)  ('same' part of scipy.signal.correlate), first
 //                    argmax, parabolic() with the reference's f[-1] wrap at peak 0; peak n-1 is its IndexError
 //   k_corr_finish:   np.cumsum in order, scaled to octaves, freqs = 2^(log2 mean + drift)
-__global__ __launch_bounds__(256) void k_corr_resample(const float* __restrict__ mag, int bins, int NL, int nb, int64_t count,
+__global__ __launch_bounds__(256) void k_corr_resample(const float* __restrict__ mag, int64_t bins, int NL, int nb, int64_t count,
                                                        const double* __restrict__ M, const double* __restrict__ wind, int n,
                                                        double* __restrict__ R) {
   extern __shared__ double yb[];                           // the frame's band
@@ -471,13 +471,13 @@ __global__ __launch_bounds__(256) void k_zc_write(const double* __restrict__ x, 
 // with magnitude S[k] + b shift / 2; everything else is 0.  Threshold = `threshold` x the column maximum; local maximum:
 // x[k] > x[k-1] and x[k] >= x[k+1] on the edge-padded, thresholded column.  One wave per frame; S = (mag - offset) * scale
 // undoes get_mag's + 1e-7 and 1/sqrt(n_fft) so the magnitudes are librosa's |stft|.
-__global__ __launch_bounds__(256) void k_piptrack(const float* __restrict__ mag, int bins, int64_t n_frames, float scale,
+__global__ __launch_bounds__(256) void k_piptrack(const float* __restrict__ mag, int bins, int64_t pitch, int64_t n_frames, float scale,
                                                   float offset, int fft_size, double sr, double fmin, double fmax,
                                                   float threshold, float* __restrict__ pitches, float* __restrict__ mags) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t fr = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
   if (fr >= n_frames) return;
-  const float* row = mag + fr * bins;
+  const float* row = mag + fr * pitch;
   float m = -INFINITY;
   for (int k = lane; k < bins; k += kWave) {
     const float x = (row[k] - offset) * scale;
@@ -557,10 +557,12 @@ static int check_empty(int* d_flag, hipStream_t s, const char* who) {
   return PAR_OK;
 }
 
-int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
+int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t mag_pitch, int64_t frame_0, int64_t count,
                        double* freqs, int fft_size, double sr, double tolerance_oct, int mode, int32_t* status,
                        void* stream) {
   using namespace par;
+  const int64_t pitch = mag_pitch ? mag_pitch : bins;
+  PAR_REQUIRE(pitch >= bins, PAR_ERR_ARG, "par_track_peak_f64: mag_pitch < bins");
   PAR_REQUIRE(status, PAR_ERR_ARG, "par_track_peak_f64: status word missing");
   PAR_REQUIRE(mag && freqs && bins >= 3 && count >= 0 && frame_0 >= 0 && frame_0 + count <= n_frames, PAR_ERR_ARG,
               "par_track_peak_f64: bad args (frame_0=%lld count=%lld n_frames=%lld)", (long long)frame_0,
@@ -571,13 +573,13 @@ int par_track_peak_f64(int device, const float* mag, int64_t n_frames, int bins,
   hipStream_t s = as_stream(stream);
   PAR_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), s));
   if (mode == 0) {
-    hipLaunchKernelGGL(k_track_peak, dim3((unsigned)ceil_div(count, 64)), dim3(64), 0, s, mag, bins, frame_0, count,
+    hipLaunchKernelGGL(k_track_peak, dim3((unsigned)ceil_div(count, 64)), dim3(64), 0, s, mag, bins, pitch, frame_0, count,
                        freqs, fft_size, sr, tolerance_oct, status);
   } else {
     double centre = 0.0;
     PAR_HIP_CHECK(hipMemcpyAsync(&centre, freqs, sizeof(double), hipMemcpyDeviceToHost, s));
     PAR_HIP_CHECK(hipStreamSynchronize(s));
-    hipLaunchKernelGGL(k_track_peak_fixed, dim3((unsigned)ceil_div(count, 64)), dim3(64), 0, s, mag, bins, frame_0, count,
+    hipLaunchKernelGGL(k_track_peak_fixed, dim3((unsigned)ceil_div(count, 64)), dim3(64), 0, s, mag, bins, pitch, frame_0, count,
                        centre, freqs, fft_size, sr, tolerance_oct, status);
   }
   PAR_HIP_CHECK(hipGetLastError());
@@ -616,16 +618,18 @@ int par_track_peak_refined_f64(int device, const float* x, int64_t n, int64_t x_
   return check_empty(status, s, "par_track_peak_refined_f64");
 }
 
-int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t frame_0, int64_t count,
+int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t mag_pitch, int64_t frame_0, int64_t count,
                       double* freqs, int fft_size, double sr, double tolerance_oct, int32_t* status, void* stream) {
   using namespace par;
+  const int64_t pitch = mag_pitch ? mag_pitch : bins;
+  PAR_REQUIRE(pitch >= bins, PAR_ERR_ARG, "par_track_cog_f64: mag_pitch < bins");
   PAR_REQUIRE(status, PAR_ERR_ARG, "par_track_cog_f64: status word missing");
   PAR_REQUIRE(mag && freqs && bins >= 3 && count >= 0 && frame_0 >= 0 && frame_0 + count <= n_frames, PAR_ERR_ARG,
               "par_track_cog_f64: bad args");
   if (count == 0) return PAR_OK;
   PAR_HIP_CHECK(hipSetDevice(device));
   PAR_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int32_t), as_stream(stream)));
-  hipLaunchKernelGGL(k_track_cog, dim3(1), dim3(64), 0, as_stream(stream), mag, bins, frame_0, count, freqs, fft_size, sr,
+  hipLaunchKernelGGL(k_track_cog, dim3(1), dim3(64), 0, as_stream(stream), mag, bins, pitch, frame_0, count, freqs, fft_size, sr,
                      tolerance_oct, status);
   PAR_HIP_CHECK(hipGetLastError());
   return check_empty(status, as_stream(stream), "par_track_cog_f64");
@@ -637,7 +641,7 @@ int par_track_cog_f64(int device, const float* mag, int64_t n_frames, int bins, 
 // (the reference's parabolic() raises IndexError there).
 int64_t par_track_corr_work_len(int64_t count, int n) { return (count + 1) * (int64_t)n + count; }
 
-int par_track_corr_f64(int device, const float* mag, int64_t n_frames, int bins, int NL, int NU, int64_t count,
+int par_track_corr_f64(int device, const float* mag, int64_t n_frames, int bins, int64_t mag_pitch, int NL, int NU, int64_t count,
                        const double* M, const double* wind, int n, double log_span, double log_mean, double* work,
                        double* freqs, int32_t* status, void* stream) {
   using namespace par;
@@ -664,7 +668,8 @@ int par_track_corr_f64(int device, const float* mag, int64_t n_frames, int bins,
       done.insert(device);
     }
   }
-  hipLaunchKernelGGL(k_corr_resample, dim3((unsigned)(count + 1)), dim3(256), band_lds, s, mag, bins, NL, nb, count, M, wind, n, R);
+  hipLaunchKernelGGL(k_corr_resample, dim3((unsigned)(count + 1)), dim3(256), band_lds, s, mag, mag_pitch ? mag_pitch : (int64_t)bins, NL, nb,
+                     count, M, wind, n, R);
   const size_t ab_lds = 2 * (size_t)n * sizeof(double);
   if (ab_lds <= 131072) {                                  // n <= 8192: both frames in LDS (up to 128 of the CU's 160 KB)
     if (ab_lds > 65536) {
@@ -691,7 +696,7 @@ int par_track_corr_f64(int device, const float* mag, int64_t n_frames, int bins,
 }
 
 // librosa.piptrack on a frame-major magnitude spectrogram (see k_piptrack); pitches / mags: [n_frames][bins] float32.
-int par_piptrack_f32(int device, const float* mag, int64_t n_frames, int bins, float scale, float offset, int fft_size,
+int par_piptrack_f32(int device, const float* mag, int64_t n_frames, int bins, int64_t mag_pitch, float scale, float offset, int fft_size,
                      double sr, double fmin, double fmax, float threshold, float* pitches, float* mags, void* stream) {
   using namespace par;
   PAR_REQUIRE(mag && pitches && mags, PAR_ERR_ARG, "par_piptrack_f32: null pointer");
@@ -700,7 +705,8 @@ int par_piptrack_f32(int device, const float* mag, int64_t n_frames, int bins, f
   PAR_HIP_CHECK(hipSetDevice(device));
   fmin = fmin > 0.0 ? fmin : 0.0;
   fmax = fmax < sr / 2 ? fmax : sr / 2;
-  hipLaunchKernelGGL(k_piptrack, dim3((unsigned)ceil_div(n_frames, 4)), dim3(256), 0, as_stream(stream), mag, bins, n_frames, scale,
+  hipLaunchKernelGGL(k_piptrack, dim3((unsigned)ceil_div(n_frames, 4)), dim3(256), 0, as_stream(stream), mag, bins,
+                     mag_pitch ? mag_pitch : (int64_t)bins, n_frames, scale,
                      offset, fft_size, sr, fmin, fmax, threshold, pitches, mags);
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;

@@ -70,6 +70,14 @@ def stft_dev(x_t, n_fft, step, window_t, zeropad=1, mode=0, x_stride=1, n=None, 
         n = x_t.numel() // x_stride
     bins = (n_fft * zeropad) // 2 + 1
     frames = int(L.par_stft_frames(n, n_fft, step))
+    if mode == 1 and n_fft * zeropad <= 16384 and bins >= 32:
+        # magnitude rows start on 128-byte lines (packed 2052-byte rows of the usual 1024-point transform straddle lines at
+        # both ends: 1.21x the bytes written); the caller gets the (bins, frames) view of the pitched buffer
+        pitch = (bins + 31) // 32 * 32
+        buf = _dev.empty((frames, pitch), torch.float32, dev)
+        _lib.check(L.par_stft_f32(dev, _dev.ptr(x_t), n, x_stride, n_fft, step, zeropad, _dev.ptr(window_t), _dev.ptr(buf), mode,
+                                  pitch, _dev.stream_ptr(dev)))
+        return buf[:, :bins].T
     out = _dev.empty((frames, bins), torch.complex64 if mode == 0 else torch.float32, dev)
     if n_fft * zeropad > 16384:           # four-step transform through a scratch of one complex H-point array per frame of a batch
         nbytes = int(L.par_stft_big_scratch_bytes(n, n_fft, step, zeropad))
@@ -78,7 +86,7 @@ def stft_dev(x_t, n_fft, step, window_t, zeropad=1, mode=0, x_stride=1, n=None, 
                                       mode, _dev.ptr(scratch), nbytes, _dev.stream_ptr(dev)))
         return out.T
     _lib.check(L.par_stft_f32(dev, _dev.ptr(x_t), n, x_stride, n_fft, step, zeropad, _dev.ptr(window_t), _dev.ptr(out),
-                              mode, _dev.stream_ptr(dev)))
+                              mode, 0, _dev.stream_ptr(dev)))
     return out.T
 
 

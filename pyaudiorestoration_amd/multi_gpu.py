@@ -41,7 +41,19 @@ class RankContext:
             os.environ.setdefault("MASTER_PORT", "29533")
             if backend is None:
                 backend = os.environ.get("PAR_DIST_BACKEND") or "gloo"      # host-side coordination only
-            dist.init_process_group(backend)
+            # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."): the benchmark's stdout is ONE
+            # JSON line, so file descriptor 1 points at stderr while the group forms (and for the first collective)
+            import sys
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
             self.distinct_devices = 0
             if torch.cuda.is_available():
                 n_dev = torch.cuda.device_count()

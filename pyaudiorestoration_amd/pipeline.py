@@ -303,14 +303,16 @@ def band_volume_db(mag, sr, fft_size, hop, t_0, t_1, f_lower, f_upper, device=No
     dev = _dev.device_index(device)
     if not torch.is_tensor(mag):
         mag = _dev.to_dev(np.ascontiguousarray(np.asarray(mag, dtype=np.float32).T), torch.float32, dev).T
-    fm = mag.T if mag.T.is_contiguous() else mag.T.contiguous()
+    fm = mag.T
+    if not (fm.stride(1) == 1 and fm.stride(0) >= fm.shape[1]):
+        fm = fm.contiguous()
     frames, bins = fm.shape
     frame_b, frame_a = int(t_0 * sr / hop), int(t_1 * sr / hop)
     f2b = lambda f: max(1, min(fft_size // 2, int(round(f * fft_size / sr))))
     bin_l, bin_u = f2b(f_lower), f2b(f_upper)
     frame_a = min(frame_a, frames)                                        # numpy slicing clamps the end
     vol = _dev.empty(max(0, frame_a - frame_b), torch.float64, dev)
-    _lib.check(_lib.lib().par_band_mean_db_f32(dev, _dev.ptr(fm), frames, bins, bin_l, bin_u, frame_b, frame_a,
+    _lib.check(_lib.lib().par_band_mean_db_f32(dev, _dev.ptr(fm), frames, bins, fm.stride(0), bin_l, bin_u, frame_b, frame_a,
                                                _dev.ptr(vol), _dev.stream_ptr(dev)))
     return vol.cpu().numpy(), frame_b
 

@@ -83,11 +83,15 @@ def band_to_bins(f_lo, f_hi, fft_size, sr, n_bins, min_bins=MIN_BAND_BINS):
 
 
 def spectrum_to_device(spectrum, dev=None):
-    """(bins, frames) numpy/torch spectrogram -> frame-major float32 device tensor [frames][bins].
-    Zero-copy when it already is the transposed view K_stft returned."""
+    """(bins, frames) numpy/torch spectrogram -> frame-major float32 device tensor [frames][bins] whose rows may be more than
+    `bins` floats apart (stride(0) = the pitch K_stft wrote with, stride(1) = 1).  Zero-copy when it already is the
+    transposed view K_stft returned."""
     dev = _dev.device_index(dev)
     if isinstance(spectrum, torch.Tensor):
-        return spectrum.T.to(device=f"cuda:{dev}", dtype=torch.float32).contiguous()
+        fm = spectrum.T
+        if fm.device.type == "cuda" and fm.dtype == torch.float32 and fm.ndim == 2 and fm.stride(1) == 1 and fm.stride(0) >= fm.shape[1]:
+            return fm
+        return fm.to(device=f"cuda:{dev}", dtype=torch.float32).contiguous()
     return _dev.to_dev(np.asarray(spectrum).T, torch.float32, dev)
 
 
@@ -156,7 +160,7 @@ class Track:
         dev, mag = self._device_spectrum()
         f_t = _dev.to_dev(self.freqs, torch.float64, dev)
         status = _dev.empty(1, torch.int32, dev)              # "empty band" word: ParEmptyBand (a ValueError) if set
-        _lib.check(kernel(dev, _dev.ptr(mag), mag.shape[0], mag.shape[1], self.frame_0, len(self.freqs), _dev.ptr(f_t),
+        _lib.check(kernel(dev, _dev.ptr(mag), mag.shape[0], mag.shape[1], mag.stride(0), self.frame_0, len(self.freqs), _dev.ptr(f_t),
                           self.fft_size, float(self.sr), float(self.tolerance), *extra, _dev.ptr(status),
                           _dev.stream_ptr(dev)))
         self.freqs[:] = f_t.cpu().numpy()
@@ -242,13 +246,13 @@ def piptrack_dev(mag_t, fft_size, sr, fmin, fmax, threshold=0.1, scale=None, off
     frame-major buffer): (pitches, magnitudes), both (bins, frames) float32 device tensors.  `scale` / `offset` undo
     get_mag's 1/sqrt(n_fft) and + 1e-7 (defaults), so the magnitudes are those of librosa's own |stft|."""
     dev = _dev.device_index(dev if dev is not None else mag_t.device)
-    fm = mag_t.T                                            # frame-major [frames][bins]
-    if not fm.is_contiguous():
+    fm = mag_t.T                                            # frame-major [frames][bins], rows stride(0) floats apart
+    if not (fm.stride(1) == 1 and fm.stride(0) >= fm.shape[1]):
         fm = fm.contiguous()
     frames, bins = fm.shape
     pitches = _dev.empty((frames, bins), torch.float32, dev)
     mags = _dev.empty((frames, bins), torch.float32, dev)
-    _lib.check(_lib.lib().par_piptrack_f32(dev, _dev.ptr(fm), frames, bins, float(np.sqrt(fft_size) if scale is None else scale),
+    _lib.check(_lib.lib().par_piptrack_f32(dev, _dev.ptr(fm), frames, bins, fm.stride(0), float(np.sqrt(fft_size) if scale is None else scale),
                                            float(offset), int(fft_size), float(sr), float(fmin), float(fmax), float(threshold),
                                            _dev.ptr(pitches), _dev.ptr(mags), _dev.stream_ptr(dev)))
     return pitches.T, mags.T
@@ -310,7 +314,7 @@ class CorrelationTracker(Track):
         work = _dev.empty(int(L.par_track_corr_work_len(count, n)), torch.float64, dev)
         f_t = _dev.empty(count, torch.float64, dev)
         status = _dev.empty(1, torch.int32, dev)
-        _lib.check(L.par_track_corr_f64(dev, _dev.ptr(mag), mag.shape[0], mag.shape[1], self.NL, self.NU, count, _dev.ptr(M_t),
+        _lib.check(L.par_track_corr_f64(dev, _dev.ptr(mag), mag.shape[0], mag.shape[1], mag.stride(0), self.NL, self.NU, count, _dev.ptr(M_t),
                                         _dev.ptr(w_t), n, float(log_f[-1] - log_f[0]), float(np.log2((f_lo + f_hi) / 2)),
                                         _dev.ptr(work), _dev.ptr(f_t), _dev.ptr(status), _dev.stream_ptr(dev)))
         self.freqs[:] = f_t.cpu().numpy()

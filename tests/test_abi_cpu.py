@@ -39,7 +39,7 @@ def test_pure_host_entry_points_and_argument_errors():
     # null pointers are rejected before any HIP call
     rc = L.par_sinc_resample_f32(0, None, 10, None, 1, 10, 32, None, 1, None)
     assert rc == 1 and "null" in _lib.last_error()
-    rc = L.par_stft_f32(0, ctypes.c_void_p(8), 100, 1, 1000, 10, 1, ctypes.c_void_p(8), ctypes.c_void_p(8), 0, None)
+    rc = L.par_stft_f32(0, ctypes.c_void_p(8), 100, 1, 1000, 10, 1, ctypes.c_void_p(8), ctypes.c_void_p(8), 0, 0, None)
     assert rc == 3 and "power of two" in _lib.last_error()      # PAR_ERR_UNSUPPORTED -> caller falls through
     with pytest.raises(_lib.ParUnsupported):
         _lib.check(rc)

@@ -43,7 +43,7 @@ ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
 
 def step(rec=False):
     if rec: ev[0].record()
-    _lib.check(L.par_stft_f32(dev, _dev.ptr(x), n + n_fft // 2, 1, n_fft, hop, 1, _dev.ptr(win), _dev.ptr(spec), 0, s))
+    _lib.check(L.par_stft_f32(dev, _dev.ptr(x), n + n_fft // 2, 1, n_fft, hop, 1, _dev.ptr(win), _dev.ptr(spec), 0, 0, s))
     if rec: ev[1].record()
     _lib.check(L.par_inpaint_gain_db_c64(dev, _dev.ptr(spec), frames, bins, _dev.ptr(geo_t), len(geo), _dev.ptr(gain), s))
     if rec: ev[2].record()
