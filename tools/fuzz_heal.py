@@ -17,14 +17,14 @@ from pyaudiorestoration_amd import pipeline as P
 warnings.simplefilter("ignore")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 t_end = time.time() + budget
-case = refused = 0
-worst = 0.0
+case = refused = sparse_cases = 0
+worst = worst_sd = 0.0
 while time.time() < t_end:
     rng = np.random.default_rng(case)
     sr = int(rng.choice([22050, 44100, 96000]))
     n_fft = int(rng.choice([256, 512, 1024]))
     hop = int(rng.choice([n_fft // 16, n_fft // 8, n_fft // 4]))
-    n = int(rng.integers(12000, 50000))
+    n = int(rng.integers(12000, 50000)) if rng.random() < 0.5 else int(rng.integers(150000, 400000))   # long ones: the sparse path
     x = (0.3 * np.sin(2 * np.pi * rng.uniform(300, 5000) * np.arange(n) / sr) + 0.05 * rng.standard_normal(n)).astype(np.float32)
     dur = n / sr
     marks = []
@@ -48,10 +48,16 @@ while time.time() < t_end:
             continue
         raise SystemExit(f"case {case}: a box outside the spectrogram was accepted")
     want = O.heal_dropouts(x, sr, marks, n_fft, hop)
-    got = P.heal_dropouts(x, sr, marks, n_fft, hop)
-    err = float(np.max(np.abs(got - want)) / max(float(np.max(np.abs(want))), 1e-30))
+    got = P.heal_dropouts(x, sr, marks, n_fft, hop)                      # sparse where the boxes leave most of the file alone (r03)
+    dense = P.heal_dropouts(x, sr, marks, n_fft, hop, sparse=False)      # the reference-shaped dataflow
+    scale = max(float(np.max(np.abs(want))), 1e-30)
+    if P.heal_segments(geo, frames, n + n_fft // 2, n, n_fft, hop) is not None:
+        sparse_cases += 1
+        worst_sd = max(worst_sd, float(np.max(np.abs(got - dense)) / scale))
+    err = max(float(np.max(np.abs(got - want)) / scale), float(np.max(np.abs(dense - want)) / scale))
     # the boost (up to tens of dB) multiplies the ~1e-7 float32 rounding noise of either STFT: 1e-5 is reached at ~40 dB
     assert np.all(np.isfinite(got)) and err < 5e-5, (case, err, sr, n_fft, hop, n, marks)
     worst = max(worst, err)
     case += 1
-print(f"heal fuzz ok: {case} cases ({refused} with out-of-range boxes refused), worst relative error {worst:.2e}")
+print(f"heal fuzz ok: {case} cases ({refused} with out-of-range boxes refused, {sparse_cases} through the sparse path), worst relative "
+      f"error {worst:.2e}, worst sparse - dense difference {worst_sd:.2e}")
