@@ -66,9 +66,11 @@ int64_t par_stft_frames(int64_t n, int n_fft, int hop);
 int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad,
                  const float* window, float* out, int mode, int64_t out_pitch, void* stream);
 
-/* The same transform for frames of more than 8192 points (n_fft*zeropad a power of two in (8192, 2^21]; the GUI offers
- * FFT sizes up to 2^20, util/widgets.py:333-349): a four-step FFT in two passes over HBM (columns, then rows fused with
- * the real-transform untangle: only one H-point array per frame is ever stored).
+/* The same transform for frames of more than 8192 points (n_fft*zeropad a power of two in (8192, 2^24]; the GUI offers
+ * FFT sizes up to 2^20 with zero-padding up to 16, util/widgets.py:333-351): up to 2^21 points a four-step FFT in two
+ * passes over HBM (columns, then rows fused with the real-transform untangle: only one H-point array per frame is ever
+ * stored); 2^22 .. 2^24 points (r03) as 2, 4 or 8 decimated 2^20-point sequences through that transform, recombined and
+ * untangled bin by bin, a frame at a time (scratch: two H-point arrays).
  *   scratch  device memory of par_stft_big_scratch_bytes(n, n_fft, hop, zeropad) bytes (caller-owned) */
 size_t par_stft_big_scratch_bytes(int64_t n, int n_fft, int hop, int zeropad);
 int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_fft, int hop, int zeropad,

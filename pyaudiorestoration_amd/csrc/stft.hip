@@ -669,6 +669,87 @@ static int big_fft_c2c(int device, float2* A, float2* Z, int64_t H, int64_t batc
   return PAR_OK;
 }
 
+// ---- transforms of 2^22 .. 2^24 points (r03): one more radix step around the four-step transform ------------------------
+// The GUI offers FFT sizes to 2^20 with zero-padding to 16 (util/widgets.py:334-351): frames of up to 2^24 real points, an
+// H = 2^23-point complex sequence z.  The four-step core holds rows / columns of <= 1024 points (H <= 2^20), so the
+// sequence is decimated in time by R = H / 2^20 (2, 4 or 8): z_r[m] = z[R m + r] are R sequences of 2^20 points,
+// transformed as a batch by big_fft_c2c, and
+//     Z[k' + H' q] = sum_r W_R^(r q) (W_H^(r k') Z_r[k'])          k' < H' = 2^20, q < R
+// is formed bin by bin in the kernel that also untangles the real transform and writes |X| or X.  Five passes over an
+// H-point array per frame instead of the four-step's three, for sizes the reference's CPU chain needs seconds per frame for.
+//   k_huge_gather   z_r[m] = (xw[2 (R m + r)], xw[2 (R m + r) + 1]): window, reflect boundary, zero padding
+//   k_huge_out      R-point recombination with float64 twiddles, untangle, magnitude
+__global__ __launch_bounds__(256) void k_huge_gather(const float* __restrict__ x, int64_t n, int64_t x_stride, int n_fft, int hop,
+                                                     const float* __restrict__ window, int64_t frame, int logR, int64_t Hp,
+                                                     float2* __restrict__ z) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // t = r Hp + m
+  if (t >= (Hp << logR)) return;
+  const int64_t r = t / Hp, m = t - r * Hp;
+  const int64_t i = (m << logR) + r;                                        // packed point of the frame
+  const long long base = (long long)frame * hop - (n_fft >> 1);
+  float2 v = make_float2(0.0f, 0.0f);
+  const int64_t t0 = 2 * i;
+  if (t0 < n_fft) v.x = window[t0] * x[reflect_index(base + t0, n) * x_stride];
+  if (t0 + 1 < n_fft) v.y = window[t0 + 1] * x[reflect_index(base + t0 + 1, n) * x_stride];
+  z[t] = v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_huge_out(const float2* __restrict__ Zr, int logR, int64_t Hp, float* __restrict__ out,
+                                                  int64_t row, float scale) {
+  const int64_t kp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // k' < H'
+  if (kp >= Hp) return;
+  const int R = 1 << logR;
+  const int64_t H = Hp << logR;
+  // the R bins k' + H' q of this thread and their partners H - k = (H' - k') + H' (R - 1 - q)  (k' = 0: H' ((R - q) mod R))
+  const int64_t kc = kp == 0 ? 0 : Hp - kp;
+  double ar[8], ai[8], br[8], bi[8];                                        // W_H^(r k') Z_r[k'] and the same at k'' = kc
+  double s1, c1, s2, c2;
+  sincospi(-2.0 * (double)kp / (double)H, &s1, &c1);
+  sincospi(-2.0 * (double)kc / (double)H, &s2, &c2);
+  double w1r = 1.0, w1i = 0.0, w2r = 1.0, w2i = 0.0;
+  for (int r = 0; r < R; ++r) {
+    const float2 a = Zr[(int64_t)r * Hp + kp], b = Zr[(int64_t)r * Hp + kc];
+    ar[r] = (double)a.x * w1r - (double)a.y * w1i;
+    ai[r] = (double)a.x * w1i + (double)a.y * w1r;
+    br[r] = (double)b.x * w2r - (double)b.y * w2i;
+    bi[r] = (double)b.x * w2i + (double)b.y * w2r;
+    const double t1 = w1r * c1 - w1i * s1, t2 = w2r * c2 - w2i * s2;
+    w1i = w1r * s1 + w1i * c1;
+    w1r = t1;
+    w2i = w2r * s2 + w2i * c2;
+    w2r = t2;
+  }
+  const double hs = 0.5 * (double)scale;
+  for (int q = 0; q < R; ++q) {
+    const int qp = kp == 0 ? (R - q) & (R - 1) : R - 1 - q;                // the partner's q
+    double zr = 0.0, zi = 0.0, pr = 0.0, pi_ = 0.0;
+    for (int r = 0; r < R; ++r) {                                           // W_R^(r q): exact multiples of 1/R turns
+      double sq, cq, sp, cp;
+      sincospi(-2.0 * (double)((r * q) & (R - 1)) / (double)R, &sq, &cq);
+      sincospi(-2.0 * (double)((r * qp) & (R - 1)) / (double)R, &sp, &cp);
+      zr += ar[r] * cq - ai[r] * sq;
+      zi += ar[r] * sq + ai[r] * cq;
+      pr += br[r] * cp - bi[r] * sp;
+      pi_ += br[r] * sp + bi[r] * cp;
+    }
+    // X[k] = (Z[k] + conj Z[H-k])/2 - i W_2H^k (Z[k] - conj Z[H-k])/2
+    const int64_t k = kp + Hp * q;
+    double sk, ck;
+    sincospi(-(double)k / (double)H, &sk, &ck);
+    const double evr = zr + pr, evi = zi - pi_, dr = zr - pr, di = zi + pi_;
+    const double tr = ck * dr - sk * di, ti = ck * di + sk * dr;            // W^k (Z[k] - conj Z[H-k])
+    const double xr = (evr + ti) * hs, xi = (evi - tr) * hs;
+    if (MODE == 0) reinterpret_cast<float2*>(out)[row + k] = make_float2((float)xr, (float)xi);
+    else out[row + k] = (float)(sqrt(xr * xr + xi * xi) + 1e-7);
+    if (k == 0) {                                                           // bin H: X[H] = Re Z[0] - Im Z[0]
+      const double xh = (zr - zi) * 2.0 * hs;
+      if (MODE == 0) reinterpret_cast<float2*>(out)[row + H] = make_float2((float)xh, 0.0f);
+      else out[row + H] = (float)(fabs(xh) + 1e-7);
+    }
+  }
+}
+
 // ---- X2: normalised cross-correlation and delay search (util/correlation.py:6-39) ---------------------------
 // scipy.signal.correlate(a/|a|, b/|b|, 'full') through ONE complex transform of z = a + i b (both zero-padded to
 // N >= len a + len b - 1): A_k = (Z_k + conj Z_{N-k})/2, B_k = (Z_k - conj Z_{N-k})/(2i), cross spectrum A conj(B),
@@ -1129,6 +1210,7 @@ int par_stft_f32(int device, const float* x, int64_t n, int64_t x_stride, int n_
 // par_stft_big_scratch_bytes() (one H-point complex array per frame of a batch; a batch fills up to 1 GiB).
 size_t par_stft_big_scratch_bytes(int64_t n, int n_fft, int hop, int zeropad) {
   const int64_t M = (int64_t)n_fft * zeropad;
+  if (M > (1ll << 21) && M <= (1ll << 24)) return (size_t)(2 * (M / 2) * (int64_t)sizeof(float2));   // z_r and Z_r of ONE frame
   if (M <= 8192 || M > (1ll << 21)) return 0;
   // frames per batch: as many as fit 1 GiB of scratch (at least 16, at most what one grid dimension takes): 16-frame
   // batches made the 16384-point transform launch-bound (880 batches of three small launches: 16 ms for a 10-minute file)
@@ -1147,13 +1229,38 @@ int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, in
   PAR_REQUIRE(n >= 1 && x_stride >= 1 && hop >= 1 && zeropad >= 1 && n_fft >= 2, PAR_ERR_ARG, "par_stft_big_f32: bad sizes");
   PAR_REQUIRE(mode == 0 || mode == 1, PAR_ERR_ARG, "par_stft_big_f32: mode must be 0 (complex) or 1 (magnitude)");
   const int64_t M64 = (int64_t)n_fft * zeropad;
-  PAR_REQUIRE(M64 > 8192 && M64 <= (1ll << 21) && (M64 & (M64 - 1)) == 0 && (n_fft % 2) == 0, PAR_ERR_UNSUPPORTED,
-              "par_stft_big_f32: n_fft*zeropad=%lld is not a power of two in (8192, 2^21]", (long long)M64);
+  PAR_REQUIRE(M64 > 8192 && M64 <= (1ll << 24) && (M64 & (M64 - 1)) == 0 && (n_fft % 2) == 0, PAR_ERR_UNSUPPORTED,
+              "par_stft_big_f32: n_fft*zeropad=%lld is not a power of two in (8192, 2^24]", (long long)M64);
   PAR_REQUIRE(scratch_bytes >= par_stft_big_scratch_bytes(n, n_fft, hop, zeropad), PAR_ERR_WORKSPACE,
               "par_stft_big_f32: scratch %zu < %zu", scratch_bytes, par_stft_big_scratch_bytes(n, n_fft, hop, zeropad));
   PAR_HIP_CHECK(hipSetDevice(device));
   hipStream_t s = as_stream(stream);
   const int64_t H = M64 / 2;
+  if (M64 > (1ll << 21)) {
+    // 2^22 .. 2^24 points: R = H / 2^20 decimated sequences of 2^20 points through the four-step transform, recombined and
+    // untangled bin by bin (k_huge_gather / k_huge_out), a frame at a time
+    const int64_t Hp = 1ll << 20;
+    int logR = 0;
+    while ((Hp << logR) < H) ++logR;
+    float2* z = static_cast<float2*>(scratch);
+    float2* Z = z + H;
+    const int64_t frames = par_stft_frames(n, n_fft, hop);
+    const float scale_h = (float)(1.0 / sqrt((double)n_fft));
+    for (int64_t f = 0; f < frames; ++f) {
+      hipLaunchKernelGGL(k_huge_gather, dim3((unsigned)ceil_div(H, 256)), dim3(256), 0, s, x, n, x_stride, n_fft, hop, window, f, logR,
+                         Hp, z);
+      const int rc = big_fft_c2c(device, z, Z, Hp, (int64_t)1 << logR, s);
+      if (rc != PAR_OK) return rc;
+      if (mode == 0)
+        hipLaunchKernelGGL(k_huge_out<0>, dim3((unsigned)ceil_div(Hp, 256)), dim3(256), 0, s, (const float2*)Z, logR, Hp, out,
+                           f * (H + 1), scale_h);
+      else
+        hipLaunchKernelGGL(k_huge_out<1>, dim3((unsigned)ceil_div(Hp, 256)), dim3(256), 0, s, (const float2*)Z, logR, Hp, out,
+                           f * (H + 1), scale_h);
+    }
+    PAR_HIP_CHECK(hipGetLastError());
+    return PAR_OK;
+  }
   // N1 >= N2, both in [64, 1024]: the balanced split, except 2^15 = 512 x 64 -- both pure radix-8 sizes (five radix-8 stages
   // instead of 256 x 128's four plus a radix-4 and a radix-2 stage) -- and 2^14 = 256 x 64 (one remainder stage instead of two)
   const int L = ilog2((int)H), l1 = L == 15 ? 9 : (L == 14 ? 8 : (L + 1) / 2), l2 = L - l1;

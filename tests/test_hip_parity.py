@@ -1593,6 +1593,25 @@ def test_stft_above_8192_four_step(par, n_fft, hop, zp):
         assert relerr(got2, np.abs(C.stft(np.ascontiguousarray(x[1:]), n_fft, hop, win, zp, mode=0, threads=8)) + 1e-7) < TOL
 
 
+@pytest.mark.parametrize("n_fft,hop,zp", [(262144, 100000, 16), (1048576, 524288, 8), (1048576, 700001, 16)])
+def test_stft_frames_of_2_22_to_2_24_points(par, n_fft, hop, zp):
+    """The GUI's largest combinations (FFT size up to 2^20 x zero-padding up to 16, util/widgets.py:334-351): frames of
+    2^22, 2^23 and 2^24 points go through one more radix step around the four-step transform (k_huge_gather / k_huge_out)
+    instead of falling through to the reference's CPU chain (r02).  Complex and magnitude against the C oracle's float64
+    FFT of the same float32 frames; the first and last frames hang over the ends of the signal (reflect boundary)."""
+    from oracle import oracle_c as C
+    import scipy.signal
+    n = 2 * n_fft + 54321
+    x = inputs.noise(n, 23) + inputs.sine(n, 4321.5, 192000, 0.5)
+    win = scipy.signal.get_window("blackmanharris", n_fft).astype(np.float32)
+    want = C.stft(x, n_fft, hop, win, zp, mode=0, threads=8)
+    got = par.fourier.stft(x, n_fft, hop, "blackmanharris", zp)
+    assert got.shape == want.shape == (n_fft * zp // 2 + 1, n // hop + 1)
+    assert relerr(got, want) < TOL
+    mag = par.fourier.get_mag(par.torch.from_numpy(x).cuda(), n_fft, hop, "blackmanharris", zp).cpu().numpy()
+    assert relerr(mag, np.abs(want) + 1e-7) < TOL
+
+
 @pytest.mark.parametrize("n_fft,hop,zp", [(16384, 4096, 1), (4096, 1000, 4), (16384, 16391, 1)])
 def test_four_step_entry_point_at_its_smallest_size(par, n_fft, hop, zp):
     """par_stft_big_f32 accepts n_fft*zeropad = 16384 (fourier.stft sends that size to the single-workgroup kernel, so only a
