@@ -834,6 +834,48 @@ __global__ __launch_bounds__(1024) void k_xc_argmax(const double* __restrict__ v
   }
   if (threadIdx.x == 0) *arg = bi[0];
 }
+constexpr int kXcCand = 64;                        // rival peaks find_delay re-evaluates exactly
+// Rival peaks: the float32 transform finds the peak to ~1e-6 of its height; a periodic tone, or the +/- lobes
+// under ignore_phase, can put another local maximum within that distance of the top more than two lags away, and the
+// reference's float64 argmax may pick that one.  Every local maximum (of |v| under use_abs) within `tol` of the
+// transform's top, more than two lags from it, is listed (up to kXcCand of them) for exact re-evaluation.
+__global__ __launch_bounds__(1024) void k_xc_candidates(const double* __restrict__ v, int64_t n, int use_abs,
+                                                        const long long* __restrict__ arg, double tol,
+                                                        long long* __restrict__ cand, int* __restrict__ n_cand) {
+  const long long top = *arg;
+  const double m = use_abs ? fabs(v[top]) : v[top];
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    if (i >= top - 2 && i <= top + 2) continue;
+    const double x = use_abs ? fabs(v[i]) : v[i];
+    if (!(x >= m - tol)) continue;
+    const double xl = i > 0 ? (use_abs ? fabs(v[i - 1]) : v[i - 1]) : -INFINITY;
+    const double xr = i + 1 < n ? (use_abs ? fabs(v[i + 1]) : v[i + 1]) : -INFINITY;
+    if (x >= xl && x >= xr) {
+      const int slot = atomicAdd(n_cand, 1);
+      if (slot < kXcCand) cand[slot] = i;
+    }
+  }
+}
+// exact 'same' correlation value at every listed lag (one workgroup per entry, float64)
+__global__ __launch_bounds__(256) void k_xc_exact_list(const double* __restrict__ a, int64_t na, const double* __restrict__ b,
+                                                       int64_t nb, const double* __restrict__ norms,
+                                                       const long long* __restrict__ list, double* __restrict__ vals) {
+  __shared__ double part[4];
+  const int64_t j = list[blockIdx.x];
+  double acc = 0.0;
+  if (j >= 0 && j < na) {
+    const int64_t sh = j + (nb - 1) / 2 - (nb - 1);
+    for (int64_t t = threadIdx.x; t < nb; t += 256) {
+      const int64_t ia = t + sh;
+      if (ia >= 0 && ia < na) acc += a[ia] * b[t];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) vals[blockIdx.x] = (part[0] + part[1] + part[2] + part[3]) / (norms[0] * norms[1]);
+}
 // exact 'same' correlation values at lags c0 .. c0+count-1 (one workgroup per lag, float64):
 // same[j] = sum_t a[t + j + (nb-1)//2 - (nb-1)] b[t] / (|a| |b|)
 __global__ __launch_bounds__(256) void k_xc_exact(const double* __restrict__ a, int64_t na, const double* __restrict__ b,
@@ -1337,7 +1379,7 @@ static int64_t xc_fft_len(int64_t na, int64_t nb) {
 }
 size_t par_xcorr_scratch_bytes(int64_t na, int64_t nb) {
   if (na < 1 || nb < 1) return 0;
-  return (size_t)(2 * xc_fft_len(na, nb) * sizeof(float2) + 64 + (size_t)(na + nb + 16) * sizeof(double));
+  return (size_t)(2 * xc_fft_len(na, nb) * sizeof(float2) + 64 + (size_t)(na + nb + 16 + 2 * par::kXcCand + 8) * sizeof(double));
 }
 
 static int xcorr_full(int device, const double* a, int64_t na, const double* b, int64_t nb, void* scratch, double* full,
@@ -1418,6 +1460,38 @@ int par_find_delay_f64(int device, const double* a, int64_t na, const double* b,
   double* vals = full + (na + nb - 1);                                 // 7 values behind the correlation (scratch holds 16 spare)
   const double* same = full + (nb - 1) / 2;                            // 'same': na values centred on the full output
   hipLaunchKernelGGL(k_xc_argmax, dim3(1), dim3(1024), 0, s, same, na, ignore_phase, arg);
+  {
+    // rival peaks within the float32 transform's error of the top: exact values decide, the lowest lag wins a tie
+    // (np.argmax returns the first maximum)
+    long long* cand = reinterpret_cast<long long*>(vals + 8);
+    double* cvals = vals + 8 + kXcCand;
+    int* n_cand = reinterpret_cast<int*>(cvals + kXcCand);
+    PAR_HIP_CHECK(hipMemsetAsync(n_cand, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_xc_candidates, dim3(1), dim3(1024), 0, s, same, na, ignore_phase, (const long long*)arg, 4.0e-6, cand, n_cand);
+    int nc = 0;
+    long long top = 0;
+    PAR_HIP_CHECK(hipMemcpyAsync(&nc, n_cand, sizeof(int), hipMemcpyDeviceToHost, s));
+    PAR_HIP_CHECK(hipMemcpyAsync(&top, arg, sizeof(top), hipMemcpyDeviceToHost, s));
+    PAR_HIP_CHECK(hipStreamSynchronize(s));
+    if (nc > 0 && nc <= kXcCand) {                       // more rivals than slots: a plateau, the transform's top stands
+      long long lags[kXcCand + 1];
+      double ex[kXcCand + 1];
+      PAR_HIP_CHECK(hipMemcpyAsync(lags, cand, nc * sizeof(long long), hipMemcpyDeviceToHost, s));
+      PAR_HIP_CHECK(hipStreamSynchronize(s));
+      lags[nc] = top;
+      PAR_HIP_CHECK(hipMemcpyAsync(cand, lags, (nc + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(k_xc_exact_list, dim3((unsigned)(nc + 1)), dim3(256), 0, s, a, na, b, nb, (const double*)norms,
+                         (const long long*)cand, cvals);
+      PAR_HIP_CHECK(hipMemcpyAsync(ex, cvals, (nc + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+      PAR_HIP_CHECK(hipStreamSynchronize(s));
+      int best = nc;
+      for (int c = 0; c < nc; ++c) {
+        const double x = ignore_phase ? fabs(ex[c]) : ex[c], y = ignore_phase ? fabs(ex[best]) : ex[best];
+        if (x > y || (x == y && lags[c] < lags[best])) best = c;
+      }
+      if (lags[best] != top) PAR_HIP_CHECK(hipMemcpyAsync(arg, &lags[best], sizeof(long long), hipMemcpyHostToDevice, s));
+    }
+  }
   // exact values at arg-3 .. arg+3; the final peak is the best of arg-2 .. arg+2
   hipLaunchKernelGGL(k_xc_exact, dim3(7), dim3(256), 0, s, a, na, b, nb, (const double*)norms, (const long long*)arg, (int64_t)-3,
                      vals);

@@ -262,8 +262,8 @@ class PartialsTracker(Track):
     """util/wow_detection.py:361-387: the reference computes librosa.piptrack(y=signal[:, 0], fmin=min(trail),
     fmax=max(trail), threshold=0.15) and SHOWS the pitch map in a matplotlib window -- it never writes self.freqs, so the
     traced line is the drawn trail.  Here the map is computed on the device (K_stft with librosa's Hann window, then
-    par_piptrack_f32) and kept as .pitches / .magnitudes ((bins, frames) device tensors); no window is opened.  The frames
-    at the two ends differ from librosa >= 0.10's: its STFT pads with zeros, K_stft reflects like the reference's own."""
+    par_piptrack_f32) and kept as .pitches / .magnitudes ((bins, frames) device tensors); no window is opened.  The
+    signal is zero-padded like librosa >= 0.10's centred STFT (where hop divides fft_size / 2)."""
     name = 'Partials'
 
     def trace(self):
@@ -272,7 +272,19 @@ class PartialsTracker(Track):
         fl, fu = float(np.min(self.freqs)), float(np.max(self.freqs))
         dev = _dev.device_index(self.spectrum.device if isinstance(self.spectrum, torch.Tensor) else None)
         sig = np.ascontiguousarray(np.asarray(self.signal)[:, 0], dtype=np.float32)
-        mag = fourier.get_mag(_dev.to_dev(sig, torch.float32, dev), self.fft_size, self.hop, "hann", 1)
+        half = self.fft_size // 2
+        if half % self.hop == 0:
+            # librosa >= 0.10 centres its frames on a ZERO-padded signal (pad_mode="constant"); K_stft reflects.  With the
+            # zeros put there explicitly, frame f of the signal is frame f + half/hop of the padded one, whose window never
+            # reaches the padded signal's own (reflected) ends
+            padded = _dev.empty(len(sig) + 2 * half, torch.float32, dev)
+            padded.zero_()
+            padded[half:half + len(sig)] = _dev.to_dev(sig, torch.float32, dev)
+            full = fourier.get_mag(padded, self.fft_size, self.hop, "hann", 1)
+            skip = half // self.hop
+            mag = full[:, skip:skip + len(sig) // self.hop + 1]
+        else:                                           # frames of the padded signal do not line up: reflected edges (two frames differ)
+            mag = fourier.get_mag(_dev.to_dev(sig, torch.float32, dev), self.fft_size, self.hop, "hann", 1)
         self.pitches, self.magnitudes = piptrack_dev(mag, self.fft_size, self.sr, fl, fu, threshold=0.15, dev=dev)
         logging.info("Partials: pitch / magnitude maps are in .pitches / .magnitudes; the interactive plot is not shown")
 

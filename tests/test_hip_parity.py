@@ -1727,6 +1727,33 @@ def test_partials_tracker_piptrack(par):
     pk = tr.pitches.cpu().numpy()
     hits = pk[:, 40:-40]                                      # the pilot's 4 kHz line, flutter included
     assert ((hits > 3900) & (hits < 4100)).sum(axis=0).min() == 1
+    # the edge frames are those of librosa >= 0.10's zero-padded centred STFT, not K_stft's reflected ones
+    xz = np.concatenate((np.zeros(n_fft // 2, np.float32), x, np.zeros(n_fft // 2, np.float32)))
+    Sz = (O.get_mag(xz, n_fft, hop, "hann")[:, (n_fft // 2) // hop:][:, :mag.shape[1]] - 1e-7) * np.sqrt(n_fft)
+    wp, _ = O.piptrack(Sz.astype(np.float32), sr, n_fft, 3950.0, 4080.0, 0.15)
+    for fr in (0, 1, mag.shape[1] - 1):
+        assert np.array_equal(pk[:, fr] != 0, wp[:, fr] != 0) and np.max(np.abs(pk[:, fr] - wp[:, fr])) < 0.05, fr
+
+
+def test_find_delay_rival_peaks(par):
+    """the float32 transform locates the correlation peak to ~1e-6 of its height; when another peak sits within
+    that distance of the top more than two lags away (a repeated passage; the +/- lobes under ignore_phase) the reference's
+    float64 argmax may pick the other one, a whole passage away.  The rivals are re-evaluated exactly: a second copy of the
+    template that is 3e-7 LOUDER than the first must win, an equal one must lose to the lower lag, and under ignore_phase
+    an inverted, 3e-7 louder copy must win."""
+    from oracle import oracle_np as O
+    rng = np.random.default_rng(33)
+    T = rng.standard_normal(4000)
+    for scale2, ign in ((1.0 + 3e-7, False), (1.0 - 3e-7, False), (-(1.0 + 3e-7), True)):
+        a = 1e-9 * rng.standard_normal(60000)                  # (a louder floor would decide between the peaks itself)
+        a[10000:14000] += T
+        a[30517:34517] += scale2 * T
+        b = np.zeros(60000)
+        b[28000:32000] = T
+        want_d, want_c = O.find_delay(a.copy(), b.copy(), ignore_phase=ign)
+        got_d, got_c = par.correlation.find_delay(a.copy(), b.copy(), ignore_phase=ign)
+        assert abs(got_d - want_d) < 1e-6 and abs(got_c - want_c) < 1e-9, (scale2, ign, got_d, want_d)
+        assert abs(want_d - (-18000 if abs(scale2) < 1 else 2517)) < 1.0             # the test does distinguish the two passages
 
 
 def test_correlation_of_long_windows(par):
