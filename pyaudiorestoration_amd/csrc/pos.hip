@@ -1004,7 +1004,13 @@ __global__ void k_tile_seg(const double* __restrict__ sp, const int64_t* __restr
       hd.c_last = 0;
       hd.iT = lo;
       hd.mn_rel = 0;
-      hd.flags = ok ? 0 : 1;
+      // bit 1: some segment under the tile (or the one behind it: the last output's period reaches there) touches
+      // speed >= 1, i.e. the tile may hold fc = 1 outputs.  A hint only: K_sinc's matrix-core path is taken by workgroups
+      // whose tile carries it, everything else computes the same numbers on the vector path.
+      bool may_unity = false;
+      for (long long q = lo; q < nseg && seg_start[q] <= sample + kSincTileOutputs; ++q)
+        may_unity = may_unity || !(sp[q] < kUnityHintBelow) || !(sp[q + 1] < kUnityHintBelow);
+      hd.flags = (ok ? 0 : 1) | (may_unity ? kTileMayUnity : 0);
       hdr[x] = hd;
     }
   }

@@ -193,8 +193,10 @@ struct TileHdr {
   long long c_last;         // (unused)
   long long iT;             // segment of the tile's first output
   int mn_rel;               // (unused)
-  int flags;                // 1: positions out of range (tile takes the float64 path)
+  int flags;                // 1: positions out of range (tile takes the float64 path); kTileMayUnity: see k_tile_seg
 };
+constexpr int kTileMayUnity = 2;
+constexpr double kUnityHintBelow = 0.9999998;    // float32 period - 1 rounds to 0 well above this speed
 static_assert(sizeof(TileHdr) == 32, "TileHdr is one s_load_dwordx8");
 constexpr int kBlocksPerTile = (int)(kSincTileOutputs / kRec);
 constexpr int kTileStarts = 6;     // seg_start of the tile's first segment and the five behind it (k_block_rec's lookup)
