@@ -1566,6 +1566,30 @@ def test_sparse_heal_equals_dense_and_oracle(par):
     assert np.max(np.abs(got3 - O.heal_dropouts(x, sr, many, n_fft, hop)[:, 0])) / scale < TOL
 
 
+def test_heal_gain_kernel_band_shapes(par):
+    """The gain kernels split a box into (bin, frame lane) threads: bands wider than one 256-bin chunk (2048-point frames,
+    100 Hz .. 20 kHz = 925 bins: four chunks, the last one partial), a 3-bin band (85 frame lanes, most of them without a
+    surrounding frame to sum), a one-frame box and overlapping boxes of different widths, dense and sparse, against the
+    oracle's serial marker loop."""
+    from oracle import oracle_np as O
+    sr = 44100
+    rng = np.random.default_rng(33)
+    n = 260_000
+    x = (0.3 * rng.standard_normal(n)).astype(np.float32)
+    for a, b in ((40_000, 40_700), (120_000, 120_090), (200_000, 201_500)):
+        x[a:b] *= 0.03
+    for n_fft, hop in ((2048, 128), (512, 32)):
+        marks = [(40_000 / sr, 100.0, 40_700 / sr, 20000.0, 0.5),           # wide band
+                 (120_000 / sr, 1000.0, 120_090 / sr, 1000.0 + 2.6 * sr / n_fft, 1.0),      # ~3 bins, a frame or two wide
+                 (200_000 / sr, 300.0, 201_500 / sr, 12000.0, 0.5), (200_400 / sr, 2000.0, 200_900 / sr, 2300.0, 2.0)]
+        want = O.heal_dropouts(x, sr, marks, n_fft, hop)[:, 0]
+        scale = np.max(np.abs(want))
+        for sparse in (False, True):
+            got = par.pipeline.heal_dropouts(x, sr, marks, n_fft, hop, sparse=sparse)[:, 0]
+            assert np.max(np.abs(got - want)) / scale < TOL, (n_fft, sparse)
+        assert np.max(np.abs(want - x)) / scale > 1e-2
+
+
 @pytest.mark.parametrize("n_fft,hop,zp", [(16384, 4096, 1), (65536, 16384, 1), (4096, 1024, 4), (32768, 5000, 2), (1048576, 262144, 1),
                                            (32768, 8192, 1), (8192, 3000, 4), (1048576, 524288, 2), (131072, 40000, 4)])
 def test_stft_above_8192_four_step(par, n_fft, hop, zp):
