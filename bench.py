@@ -449,7 +449,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None,
-                    help="timed steps (default: 150 mono files ~ 1 s of timed region at N = 1; 2 archive passes in the config-5 mode)")
+                    help="timed steps (default: 200 mono files = 1.2 s of timed region at N = 1; 2 archive passes in the config-5 mode)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--seconds", type=float, default=3600.0, help="file duration (default: the 60-min config)")
     ap.add_argument("--sr", type=int, default=192000)
@@ -474,7 +474,7 @@ def main():
         sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={env_world} ranks")
     batch_mode = a.gpus > 1 or a.config5 or a.dry_run
     if a.steps is None:
-        a.steps = 2 if batch_mode else 150
+        a.steps = 2 if batch_mode else 200
     if a.warmup is None:
         a.warmup = 1 if batch_mode else 3
     if a.dry_run:
