@@ -535,20 +535,24 @@ def main():
         slot_free = [None, None]                        # main-stream event: K_sinc that read this slot is done
         state = {"k": 0, "len": plan_fused(0, sp_)}    # pipeline prologue: plan of the first file
         ev_pairs = []
-        # reference point outside the timed region: K_sinc with the GPU to itself (no plan underneath)
+        # reference point outside the timed region: K_sinc with the GPU to itself (no plan underneath), launched back to
+        # back like the timed steps -- 30 launches, the last 20 timed.  (A single launch on an idle GPU, which is what this
+        # measured until r03, runs 8-10 % slower: the clocks have to come up first.  Sustained, the kernel sits at the
+        # board's power limit, ~1.37 kW at 2.0-2.2 GHz: tools/exp/sustained_clock.py.)
         alone = []
-        for _ in range(3):
-            e0, e1, ms = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_float(0)
-            _lib.check(L.par_event_create(ctypes.byref(e0)))
-            _lib.check(L.par_event_create(ctypes.byref(e1)))
-            _lib.check(L.par_event_record(e0, sp_))
+        e0, e1, ms = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_float(0)
+        _lib.check(L.par_event_create(ctypes.byref(e0)))
+        _lib.check(L.par_event_create(ctypes.byref(e1)))
+        for i in range(30):
+            if i == 10:
+                _lib.check(L.par_event_record(e0, sp_))
             _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(spd), m, _dev.ptr(work[0]), _dev.ptr(aux[0]), cap,
                                                  state["len"], _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, sp_))
-            _lib.check(L.par_event_record(e1, sp_))
-            _lib.check(L.par_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
-            alone.append(ms.value)
-            L.par_event_destroy(e0)
-            L.par_event_destroy(e1)
+        _lib.check(L.par_event_record(e1, sp_))
+        _lib.check(L.par_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+        alone.append(ms.value / 20)
+        L.par_event_destroy(e0)
+        L.par_event_destroy(e1)
 
         def step(timed):
             k = state["k"]
@@ -649,7 +653,7 @@ def main():
             res["roofline"]["frac_alone"] = round(ALGO_BYTES_PER_SAMPLE * samples_per_launch / (k_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             res["roofline"]["note"] += ("; kernel_ms is measured in the timed region, where the next file's plan kernels "
                                         "share the GPU with K_sinc; kernel_ms_alone / frac_alone = the same launch with the "
-                                        "GPU to itself, measured before the timed region")
+                                        "GPU to itself, 20 launches back to back before the timed region")
         # What actually limits the kernel: VALU issue.  Instruction count per output from the committed PMC pass
         # (SQ_INSTS_VALU, profiles/), rate from this run's HIP-event time; ceilings: 2 cycles per wave64 instruction
         # per SIMD at the 2.4 GHz peak clock (MI355X_MICROARCH.md) and the rate a pure v_fma_f32 stream measured
