@@ -304,6 +304,9 @@ __global__ void __launch_bounds__(256) k_speed_sum(const double* __restrict__ sp
 // Checkpoint stores go through a 64 x 16 LDS transpose: written lane-by-lane they would be 64 scattered 8-byte
 // stores per instruction (one segment ~ 33 slots apart per lane: a 64-byte DRAM sector per 8 useful bytes);
 // transposed, a quarter wave writes 16 consecutive slots of ONE segment (128-byte runs).
+#ifndef PAR_SEG_SUM_PREDICT
+#define PAR_SEG_SUM_PREDICT 1     // k_seg_sum: divisions of gentle ramps start from the previous block's reciprocals (A/B knob)
+#endif
 constexpr int kCkRound = 16;       // checkpoints per lane per transpose round (= 128 cumsum steps; 8.7 KB LDS per wave)
 __device__ __forceinline__ int f64_exponent(double x) { return (int)((__double_as_longlong(x) >> 52) & 0x7ff); }
 
@@ -361,6 +364,16 @@ __global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, c
   const long long n_blocks = n / kCk;                       // full kCk-step blocks
   const long long max_blocks = wave_max_ll(n_blocks);
   double c = 0.0;
+  // Gentle ramps (every lane of the wave: the speed changes by <= 1e-5 of itself over kCk steps) start each division from
+  // the reciprocal kCk steps back, 1/(b + d) = x - x^2 d + O(x^3 d^2) <= 1e-10 off, instead of from v_rcp_f64's 2^-27 or so:
+  // ONE Newton step then lands within half an ulp and the residual correction of recip_unscaled rounds it correctly
+  // (Markstein: any start within one ulp does) -- the same bits for a quarter-rate v_rcp_f64 and two fmas less per step.
+  const double smin_ = fabs(r.s0) < fabs(r.s0 + r.ds) ? fabs(r.s0) : fabs(r.s0 + r.ds);
+  const double d8 = r.ds * r.y * (double)kCk;                 // b_{k + kCk} - b_k (to a rounding)
+  const bool pred = PAR_SEG_SUM_PREDICT && __all(r.fast && fabs(d8) <= 1.0e-5 * smin_);
+  double xp[kCk];                                             // the reciprocals of the previous block
+#pragma unroll
+  for (int u = 0; u < kCk; ++u) xp[u] = 0.0;
   for (long long b0 = 0; b0 < max_blocks; b0 += kCkRound) {
     int filled = 0;
     for (int w = 0; w < kCkRound; ++w) {
@@ -368,8 +381,20 @@ __global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, c
       if (b >= n_blocks) break;
       const double a0 = (double)(b * kCk);
       double rr[kCk];                                         // kCk independent divisions in flight per block
+      if (pred && b > 0) {
 #pragma unroll
-      for (int u = 0; u < kCk; ++u) rr[u] = ramp_recip(a0 + (double)u, r);
+        for (int u = 0; u < kCk; ++u) {
+          const double bs = ramp_value(a0 + (double)u, r);
+          const double x0 = __builtin_fma(-xp[u], xp[u] * d8, xp[u]);
+          const double x1 = __builtin_fma(x0, __builtin_fma(-bs, x0, 1.0), x0);
+          rr[u] = __builtin_fma(__builtin_fma(-bs, x1, 1.0), x1, x1);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < kCk; ++u) rr[u] = ramp_recip(a0 + (double)u, r);
+      }
+#pragma unroll
+      for (int u = 0; u < kCk; ++u) xp[u] = rr[u];
 #pragma unroll
       for (int u = 0; u < kCk; ++u) c = c + rr[u];
       T[lane][w] = c;                                         // checkpoint b + 1

@@ -126,12 +126,15 @@ __device__ __forceinline__ Ramp make_ramp(double s0, double s1, long long n) {
 // q = RN(q0 + r*y) is the correctly rounded a/b  (checked exhaustively for n <= 6000 on the host).
 // `a` is the step index k as a double (exact below 2^53); callers that walk consecutive k pass a0 + u with a0
 // converted once, which replaces a 64-bit integer conversion per step by one exact float64 add.
-__device__ __forceinline__ double ramp_recip(double a, const Ramp& r) {
+__device__ __forceinline__ double ramp_value(double a, const Ramp& r) {
 #pragma clang fp contract(off)   // block scope: also holds when included from files built with contraction on
   const double q0 = a * r.y;
   const double rem = __builtin_fma(-q0, r.nm1, a);
   const double q = __builtin_fma(rem, r.y, q0);
-  const double bs = q * r.ds + r.s0;          // not fused (-ffp-contract=off)
+  return q * r.ds + r.s0;                     // not fused (-ffp-contract=off)
+}
+__device__ __forceinline__ double ramp_recip(double a, const Ramp& r) {
+  const double bs = ramp_value(a, r);
   return r.fast ? recip_unscaled(bs) : 1.0 / bs;
 }
 

@@ -189,6 +189,36 @@ def test_speed_to_pos_golden_bit_exact(par, golden):
     assert np.array_equal(par.resampling.speed_to_pos(g["untrimmed_st"], g["untrimmed_sp"], 10000), g["untrimmed_pos"])
 
 
+def test_gentle_ramps_reciprocals_from_the_previous_block(par):
+    """k_seg_sum starts the divisions of a gentle ramp from the reciprocals eight steps back (one Newton step + the residual
+    correction instead of v_rcp_f64 + two): the positions must stay bit-identical to numpy's divisions -- speeds from 0.07 to
+    50 (segments of 18 .. 12 800 steps), ramps right at the 1e-5 gate, constant segments, and a wave that mixes gentle and
+    steep segments (which must take the ordinary path), through the position array and through the fused checkpoints."""
+    from oracle import oracle_c as C
+    import torch
+    rng = np.random.default_rng(61)
+    for scale, m, hop in ((1.0, 6000, 256), (0.07, 3000, 256), (50.0, 800, 256), (0.9, 5000, 64), (3.3, 2000, 1024)):
+        st = np.arange(m) * float(hop)
+        gentle = scale * (1.0 + 0.01 * np.sin(np.arange(m) * 0.013 + 0.4) + 1e-7 * rng.standard_normal(m))
+        at_gate = scale * (1.0 + np.cumsum(rng.choice([-1.0, 0.0, 1.0], m)) * 1.2e-6 * hop / 8)       # |d8| ~ 1.2e-5 speed: both sides
+        mixed = gentle.copy()
+        mixed[::97] *= 1.03                                                   # one steep segment in most waves
+        for sp in (gentle, at_gate, mixed):
+            sp = np.maximum(sp, 0.065 * max(scale, 1.0) if scale >= 1 else 0.065)
+            n_in = int(st[-1] * float(np.mean(sp)) * 0.97)
+            ref, _ = C.speed_to_pos(st, sp, n_in)
+            pos = par.resampling.speed_to_pos(st, sp, n_in)
+            assert len(pos) == len(ref) and np.array_equal(pos, ref), (scale, hop)
+            plan = par.resampling.speed_plan_dev(torch.from_numpy(st).cuda(), torch.from_numpy(sp).cuda(), n_in, fused=True)
+            if plan.fused_ok:
+                buf = torch.empty(plan.len_out, dtype=torch.float64, device="cuda")
+                from pyaudiorestoration_amd import _dev, _lib
+                _lib.check(_lib.lib().par_speed_to_pos_fill_fused(0, _dev.ptr(plan.speeds_t), plan.m, _dev.ptr(plan.work),
+                                                                  _dev.ptr(plan.aux), plan.max_out, _dev.ptr(buf), plan.len_out,
+                                                                  _dev.stream_ptr(0)))
+                assert np.array_equal(buf.cpu().numpy(), ref), (scale, hop, "checkpoints")
+
+
 def test_speed_to_pos_vs_c_oracle_long(par):
     from oracle import oracle_c as C
     sr, dur = 192000, 20.0
