@@ -210,6 +210,11 @@ int par_varispeed_fused_f32(int device, const double* speeds, int64_t m, const v
                             int64_t max_out, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in,
                             int NT, float* out, int64_t out_stride, void* stream);
 
+/* Diagnostic: how many 1024-output tiles of the LAST par_varispeed_fused_f32 launch on this aux buffer the streaming kernel
+ * (mono, NT = 32, unit strides) handed to the block kernel (blocks outside the record model, window-centre ties, input that
+ * float16 does not suit, the file's ends).  Synchronises the stream.  0 when the streaming kernel did not run. */
+int par_fused_redo_tiles(int device, const void* aux, int64_t max_out, int64_t m, int* tiles, void* stream);
+
 /* Stereo form: two channels of ONE file (same positions; sig0/sig1 and out0/out1 share the strides -- e.g. the two
  * columns of an interleaved (n, 2) array: sig1 = sig0 + 1, stride 2) in one launch.  Outputs equal two
  * par_varispeed_fused_f32 calls to float32 rounding (the lane/output map differs); position regeneration, prologue and tap weights are evaluated once for both. */

@@ -17,6 +17,7 @@ PER_FILE = {"pos.hip": ["-ffp-contract=off"],
             "lag.hip": ["-ffp-contract=off"],
             # SLP packing into v_pk_*_f32 buys no throughput on gfx950 and costs v_mov shuffles
             "sinc.hip": ["-fno-slp-vectorize"],
+            "sinc2.hip": ["-fno-slp-vectorize"],
             "stft.hip": ["-fno-slp-vectorize"]}
 
 

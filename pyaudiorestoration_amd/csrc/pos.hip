@@ -1206,8 +1206,12 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
     cubic |= s1.fast == 2;
   }
   BlockRec o;
-  o.w0 = ((unsigned)((int)rel0 << 16)) | (ustar - 1u) | (((ustar < (unsigned)kRec) || rem == kRec) ? kRecE0 : 0u) |
-         (end1 ? kRecE1 : 0u) | (slow0 ? kRecSlow0 : 0u) | (slow1 ? kRecSlow1 : 0u) | (cubic ? kRecCubic : 0u);
+  const bool e0 = (ustar < (unsigned)kRec) || rem == kRec;
+  // bits 10-15 (streaming kernel, sinc2.hip): u of the block's output that is the last one of its segment (63: none).  A
+  // block with two of them (a segment of < 32 outputs that ends with the block) is left to the block kernel.
+  if (end1) slow1 = 1u;
+  o.w0 = ((unsigned)((int)rel0 << 16)) | (ustar - 1u) | (e0 ? kRecE0 : 0u) | (end1 ? kRecE1 : 0u) | (slow0 ? kRecSlow0 : 0u) |
+         (slow1 ? kRecSlow1 : 0u) | (cubic ? kRecCubic : 0u) | ((e0 ? ustar - 1u : 63u) << kRecLastShift);
   o.F = (float)(q0.a0 - r0);
   o.e1 = (float)q0.a1m1;
   o.e2 = (float)q0.a2;

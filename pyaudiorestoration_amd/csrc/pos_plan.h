@@ -177,6 +177,8 @@ static_assert(sizeof(SegFast) == 32, "SegFast is loaded as two 16-byte words");
 //   bit  7/8  slow0 / slow1: that piece is not covered by the model (steep ramp, speed far from 1, very short segments,
 //             |p| out of range, the file's last output): its outputs are placed by place_fast / place_exact instead
 //   bit  9    cubic: evaluate the e3 term (either piece)
+//   bits 10-15 lastu: the u of the E0 output, 63 if none (what the streaming kernel reads instead of E0 / E1; a block with
+//             an E1 output as well is flagged slow1)
 // The last output of a segment matters because its period to the next position is the PREVIOUS increment (the next
 // segment starts at this ramp's end speed).
 // The second piece (same layout, its own polynomial in the same u') lives in a parallel array that only boundary
@@ -188,6 +190,7 @@ struct BlockRec {
   float F, e1, e2;
 };
 static_assert(sizeof(BlockRec) == 16, "BlockRec is one 16-byte word");
+constexpr int kRecLastShift = 10;     // bits 10-15: u of the output that ends a segment inside the block (63: none)
 constexpr unsigned kRecE0 = 1u << 5, kRecE1 = 1u << 6, kRecSlow0 = 1u << 7, kRecSlow1 = 1u << 8, kRecCubic = 1u << 9;
 typedef BlockRec BlockRec2;
 // Tile header: everything K_sinc needs before it can stage a tile's input span, in ONE scalar load.
@@ -204,14 +207,16 @@ static_assert(sizeof(TileHdr) == 32, "TileHdr is one s_load_dwordx8");
 constexpr int kBlocksPerTile = (int)(kSincTileOutputs / kRec);
 constexpr int kTileStarts = 6;     // seg_start of the tile's first segment and the five behind it (k_block_rec's lookup)
 // aux buffer of a fused plan: [ck_len checkpoints (f64)] [tile map (int64)] [m SegFast] [tiles TileHdr] [blocks BlockRec]
-// [blocks BlockRec2 (sparse)] [tiles x kTileStarts int64]
+// [blocks BlockRec2 (sparse)] [tiles x kTileStarts int64] [16 x int32: redo count ...] [tiles x int32: redo list]
+// The redo list is K_sinc's own scratch: tiles the streaming kernel (sinc2.hip) hands to the block kernel, rebuilt by every
+// launch -- one K_sinc launch per plan at a time.
 inline size_t fused_ck_len(int64_t max_out, int64_t m) { return (size_t)(max_out / kCk + m + 16); }
 inline size_t fused_tiles(int64_t max_out) { return (size_t)(max_out / kSincTileOutputs + 4); }
 inline size_t fused_blocks(int64_t max_out) { return fused_tiles(max_out) * kBlocksPerTile; }
 inline size_t fused_aux_bytes(int64_t max_out, int64_t m) {
   return (fused_ck_len(max_out, m) + fused_tiles(max_out)) * 8 + (size_t)m * sizeof(SegFast) +
          fused_tiles(max_out) * (sizeof(TileHdr) + kTileStarts * 8) +
-         fused_blocks(max_out) * (sizeof(BlockRec) + sizeof(BlockRec2));
+         fused_blocks(max_out) * (sizeof(BlockRec) + sizeof(BlockRec2)) + 64 + fused_tiles(max_out) * 4;
 }
 struct FusedAux {            // views into the aux buffer
   double* ck;
@@ -221,6 +226,8 @@ struct FusedAux {            // views into the aux buffer
   BlockRec* rec;
   BlockRec2* rec2;
   long long* tile_st;
+  int* redo_count;           // [16]: [0] tiles in the list
+  int* redo_list;
 };
 inline FusedAux fused_aux_view(void* aux, int64_t max_out, int64_t m) {
   FusedAux v;
@@ -231,6 +238,8 @@ inline FusedAux fused_aux_view(void* aux, int64_t max_out, int64_t m) {
   v.rec = reinterpret_cast<BlockRec*>(v.hdr + fused_tiles(max_out));
   v.rec2 = reinterpret_cast<BlockRec2*>(v.rec + fused_blocks(max_out));
   v.tile_st = reinterpret_cast<long long*>(v.rec2 + fused_blocks(max_out));
+  v.redo_count = reinterpret_cast<int*>(v.tile_st + fused_tiles(max_out) * kTileStarts);
+  v.redo_list = v.redo_count + 16;
   return v;
 }
 

@@ -1,0 +1,622 @@
+// K_sinc, streaming form (r04) -- the north-star kernel for mono NT = 32 files on unit strides.
+//
+// Semantics: resampling.sinc_core (reference util/resampling.py:51-90), fused with the speed curve like k_sinc_fused (sinc.hip).
+//
+// Shape.  ONE WAVE = one worker that streams over kTilesPerWave consecutive 1024-output tiles of the file; waves never meet
+// (no workgroup, no barrier).  A pass takes the next 128 outputs (two per lane), places them from the plan's block records,
+// and evaluates their windows against ONE 128-centre stretch of the input grid [ws, ws + 128), ws = the first centre rounded
+// down to 8; outputs whose centre lies beyond it (a handful: periods differ from 1 by <= 3 %) simply open the next pass.
+//   * taps 3 <= |n| <= 31: a Farrow bank in q = shift^2 (minimax polynomials of (win_n/pi)/(n^2 - q), tools/sinc2_model.py) --
+//     six fixed FIR filters on the input grid, evaluated for the pass's 128 centres on the matrix cores
+//     (v_mfma_f32_16x16x32_f16, signal and dominant filter pair split float16 hi + lo 2^-12: 15 MFMAs), the 13 constant
+//     fragments RESIDENT IN REGISTERS for the life of the wave; the bank goes through the wave's own 6.5 KB of LDS and every
+//     output gathers its centre's row (one 16-byte + one 4-byte read);
+//   * fc < 1 (read head slower than the output clock): the cut-off sits in the numerators sin(pi fc (n - s)); with a
+//     pass-uniform g0 = 1 - fc0 it moves onto the SIGNAL -- two modulated images A_k = x_k sin(pi g0 k), B_k = x_k cos(pi g0 k)
+//     through the same bank, far = -cos(psi) U(A) - sin(psi) U(B) -- and a lane's own deviation eps = fc - fc0 enters through
+//     one more fixed filter pair (H, H1) to second order (derivation and error budget: tools/sinc2_model.py);
+//   * taps |n| <= 2 on the vector units with the lane's exact shift and fc (two reciprocals per output);
+//   * the input streams through a 512-sample ring per wave: 128-sample chunks are fetched two passes ahead into registers,
+//     converted ONCE (float32 ring for the near taps, float16 hi / lo images for the bank) -- no halo is ever re-read or
+//     re-converted; block records of the next pass are fetched while the current one computes.
+// What the record model or float16 do not cover goes to the block kernel through a tile list (k_sinc_fused_list, sinc.hip):
+// blocks flagged slow, outputs within the reference's own rounding of a half-integer position (window-centre ties), input
+// that is non-finite / >= 32768 / all but silent, chunks that reach over the file's ends.  Every window centre is the
+// reference's rint(p) either way.
+#define PAR_WANT_BANK2 1
+#include "par_common.h"
+#include "pos_plan.h"
+#include "sinc_taps_gen.h"
+#include "sinc_common.h"
+#include <limits.h>
+
+#ifndef PAR_S2_TILES
+#define PAR_S2_TILES 8          // tiles per wave
+#endif
+#ifndef PAR_S2_WAVES
+#define PAR_S2_WAVES 3          // waves per SIMD the kernel is built for (registers <= 512 / this)
+#endif
+#ifndef PAR_S2_EXP
+#define PAR_S2_EXP 0            // timing builds, never shipped: 1 no MFMAs, 2 no near taps, 4 no stores, 8 no conversion, 16 unity maths on every pass
+#endif
+
+namespace par {
+
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+constexpr int kRing = 512;                       // samples per ring (float32 and float16 images alike)
+constexpr int kPass = 128;                       // centres per pass = outputs tried per pass
+constexpr float kEpsTol = 1.5e-4f;               // |fc - fc0| a pass admits (second-order treatment: tools/sinc2_model.py)
+constexpr float kQuiet = 0.0001220703125f;       // 2^-13: a chunk whose loudest sample is below this (and not 0) leaves float16's range
+
+struct S2Lds {
+  float ring_head[4];                            // [2], [3] mirror ring[510], ring[511]
+  float ring[kRing];
+  float ring_tail[8];                            // mirrors ring[0 .. 7]
+  _Float16 img[4][kRing];                        // x (or A) hi, lo x 4096; B hi, lo x 4096
+  float4v qa[kPass];                             // bank rows {e0, d0, e1, d1} of x / A, slot = ci ^ ((ci >> 3) & 7)
+  float4v qb[kPass];                             // of B
+  float4v qx[kPass];                             // .x = e2|d2 of x / A (halves), .y = e2|d2 of B, .z = H(A), .w = H(B) (float32 bits)
+  uint4 recs[16];                                // block records of the pass: [0..7] first pieces, [8..15] second pieces
+  float qy[kPass];                             // H1'(A) | H1'(B) (halves)
+};
+static_assert(offsetof(S2Lds, img) % 16 == 0 && offsetof(S2Lds, qa) % 16 == 0, "16-byte aligned fragments");
+
+#if PAR_S2_EXP & 64
+__device__ unsigned long long* g_s2_phase;       // [waves][8] cycle sums per phase (timing builds only)
+#define S2_MARK(k)                                              \
+  do {                                                          \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    ph_[k] += now_ - pt_;                                       \
+    pt_ = now_;                                                 \
+  } while (0)
+#else
+#define S2_MARK(k) do { } while (0)
+#endif
+
+struct S2Args {
+  int64_t len_out;
+  const float* sig;
+  int64_t len_in;
+  float* out;
+  const TileHdr* hdr;
+  const BlockRec* rec;
+  const BlockRec2* rec2;
+  int* redo_count;
+  int* redo_list;
+  int64_t n_full;                                // full tiles of the file
+  int64_t n_tiles;                               // tiles with a header
+};
+
+__device__ __forceinline__ float sinpi_poly(float z) {       // sin(pi x) / x as a polynomial in z = x^2, |x| <= 0.52
+  float p = -0.00737043094f;
+  p = fmaf(p, z, 0.0821458866f);
+  p = fmaf(p, z, -0.599264529f);
+  p = fmaf(p, z, 2.55016404f);
+  p = fmaf(p, z, -5.16771278f);
+  return fmaf(p, z, 3.14159265f);
+}
+
+// hi part of the float16 split.  The matrix cores flush subnormal float16 operands to zero (measured: a modulated image lost
+// its samples below 6.1e-5 near the modulator's zero crossings, 2e-5 of the peak): below float16's normal range the hi part is
+// zero and the lo part (x 4096) carries the value.
+__device__ __forceinline__ _Float16 hi16(float x) { return (_Float16)(fabsf(x) < 6.103515625e-05f ? 0.0f : x); }
+
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {
+  const half2v h = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float h_lo(unsigned w) { return (float)__builtin_bit_cast(half2v, w)[0]; }
+__device__ __forceinline__ float h_hi(unsigned w) { return (float)__builtin_bit_cast(half2v, w)[1]; }
+
+// the bank of one image over the pass's 128 centres: element k = 32 ks + 8 g + j of block bb is image sample offs + 8 bb + k
+template <bool GEN>
+__device__ __forceinline__ void bank_image(S2Lds& L, const half8v (&fr)[kBank2Frags], const int offs, const int l, const int sel) {
+  const int bb = l & 15, g = l >> 4;
+  const int i0 = offs + 8 * bb + 8 * g;
+  half8v xh[3], xl[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    const int ix = (i0 + 32 * ks) & (kRing - 1);
+    xh[ks] = *reinterpret_cast<const half8v*>(&L.img[2 * sel][ix]);
+    xl[ks] = *reinterpret_cast<const half8v*>(&L.img[2 * sel + 1][ix]);
+  }
+  float4v e0 = {0.0f, 0.0f, 0.0f, 0.0f}, lo = e0, e1 = e0, x1 = e0, e2 = e0, hh = e0;
+  if (!(PAR_S2_EXP & 1)) {
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[ks], xh[ks], e0, 0, 0, 0);
+      lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[5 + ks], xh[ks], lo, 0, 0, 0);
+      if (ks < 2) e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[3 + ks], xh[ks], e1, 0, 0, 0);
+      if (GEN) hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[10 + ks], xh[ks], hh, 0, 0, 0);
+      lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[ks], xl[ks], lo, 0, 0, 0);
+      if (ks < 2) {
+        x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[3 + ks], xl[ks], x1, 0, 0, 0);
+        e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[8 + ks], xh[ks], e2, 0, 0, 0);
+      }
+    }
+  } else {
+    e0[0] = (float)xh[0][0] + (float)xl[1][1] + (float)xh[2][2];
+  }
+  const float4v v0 = e0 + lo * kBank2LoInv, v1 = e1 + x1 * kBank2LoInv;
+  // rows 4 g .. 4 g + 3 of column bb: (e, d) of the block's positions 2 g and 2 g + 1
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int sl = (8 * bb + 2 * g + p) ^ (bb & 7);
+    const float4v row = {v0[2 * p], v0[2 * p + 1], v1[2 * p], v1[2 * p + 1]};
+    (sel ? L.qb : L.qa)[sl] = row;
+    const unsigned e2d2 = pack_h2(e2[2 * p] * 0.015625f, e2[2 * p + 1] * 0.015625f);     // / 64: float16 range for input up to 32768
+    float* qx = reinterpret_cast<float*>(&L.qx[sl]);
+    qx[sel] = __uint_as_float(e2d2);
+    if (GEN) {
+      qx[2 + sel] = hh[2 * p];
+      reinterpret_cast<_Float16*>(&L.qy[sl])[sel] = (_Float16)(hh[2 * p + 1] * 0.0009765625f);    // / 1024
+    }
+  }
+}
+
+// Direct-to-LDS loads as inline assembly: LDS address = M0 + 4 (or 16) x lane.  Through the compiler's builtin every later LDS
+// read that might alias the destination gets an s_waitcnt vmcnt(0) in front of it -- the very latency the stream is built to
+// hide.  Issued this way the compiler does not count them; the kernel waits for them itself (one vmcnt(0) at the head of a
+// pass, when they are a whole pass old).
+__device__ __forceinline__ void dma_dword(const float* gptr, const void* lds) {
+  const unsigned la = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds;
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(__builtin_amdgcn_readfirstlane(la)) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_dwordx4(const void* gptr, const void* lds) {
+  const unsigned la = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds;
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(__builtin_amdgcn_readfirstlane(la)) : "memory", "m0");
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Lane sets of a pass are PREFIXES of its 128 outputs (indices and window centres increase with the lane): they live as
+// counts in scalar registers, a lane tests one with a single compare, and the set algebra is SALU work.
+__device__ __forceinline__ int clamp64(int n) { return n < 0 ? 0 : (n > 64 ? 64 : n); }
+__device__ __forceinline__ unsigned long long prefix(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }   // 0 <= n <= 64
+
+struct S2Place {                                 // what placement hands to the rest of the pass
+  int c[2];                                      // window centres, relative to A0
+  float s[2], ep[2];                             // sub-sample shift; max(period - 1, 0)
+  unsigned long long bad_here, bad_next, gen;    // lanes outside the record model / tie margin (this tile, next tile); lanes with fc < 1
+};
+
+// Placement of the pass's outputs j0 + 64 r + l from their block records (pos_plan.h BlockRec).  EDGE = false: the whole pass
+// lies inside one tile and inside the wave's range (7 passes of 8) -- no lane sets, one anchor.
+template <bool EDGE>
+__device__ __forceinline__ void s2_place(const uint4 (&ra)[2], const uint4 (&rb)[2], const int u, const int l, const float tolf,
+                                         const int dA0, const int dA1, const int (&nv)[2], const int (&nt)[2], S2Place& P) {
+  const int uc = u - kRec / 2;
+  const float uf = (float)uc, u2f = uf * uf, tw1 = fmaf(2.0f, uf, 1.0f);
+  const bool any_cubic = __ballot(((ra[0].x | ra[1].x) & kRecCubic) != 0u) != 0ull;
+  P.bad_here = P.bad_next = P.gen = 0ull;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const unsigned m = ra[r].x;
+    const bool second = (unsigned)u > (m & 31u);
+    const uint4 q = second ? rb[r] : ra[r];
+    const float F = __uint_as_float(q.y), e1 = __uint_as_float(q.z), e2 = __uint_as_float(q.w);
+    const bool last = (unsigned)u == ((m >> kRecLastShift) & 63u);
+    float frac = fmaf(u2f, e2, fmaf(uf, e1, F));
+    float e = fmaf(e2, last ? tw1 - 2.0f : tw1, e1);             // period to the next position, minus 1
+    if (any_cubic && (m & kRecCubic)) {          // steeper ramps: e3 = (4/3) e2^2 / (1 + e1)
+      const float e3 = 1.33333333f * e2 * e2 * (1.0f - e1);
+      frac = fmaf(u2f * uf, e3, frac);
+      e = fmaf(e3, fmaf(3.0f, u2f, fmaf(last ? -3.0f : 3.0f, uf, 1.0f)), e);
+    }
+    const float ri = rintf(frac);
+    const float sh = frac - ri;
+    const int dA = EDGE ? (l < nt[r] ? dA0 : dA1) : dA0;
+    P.c[r] = dA + ((int)q.x >> 16) + uc + (int)ri;
+    P.s[r] = sh;
+    P.ep[r] = fmaxf(e, 0.0f);
+    // a block outside the record model (either piece), or a centre within the reference's own rounding of a tie
+    const unsigned long long bad = __ballot((m & (kRecSlow0 | kRecSlow1)) != 0u || !(fabsf(fabsf(sh) - 0.5f) > tolf));
+    const unsigned long long gen = __ballot(1.0f + P.ep[r] != 1.0f);
+    if (EDGE) {
+      P.bad_here |= bad & prefix(nv[r] < nt[r] ? nv[r] : nt[r]);
+      P.bad_next |= bad & prefix(nv[r]) & ~prefix(nt[r]);
+      P.gen |= gen & prefix(nv[r]);
+    } else {
+      P.bad_here |= bad;
+      P.gen |= gen;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Args a) {
+  using T32 = TapTab<32>;
+  __shared__ S2Lds L;
+  const int l = threadIdx.x;
+  const int64_t Ta = (int64_t)blockIdx.x * PAR_S2_TILES;
+  if (Ta >= a.n_full) return;
+  const int64_t Tb = Ta + PAR_S2_TILES < a.n_full ? Ta + PAR_S2_TILES : a.n_full;
+  const int64_t Ja = Ta * kSincTileOutputs, Jb = Tb * kSincTileOutputs;
+  // constant fragments: resident for the life of the wave
+  half8v fr[kBank2Frags];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(kBank2Frags32) + l;
+#pragma unroll
+    for (int f = 0; f < kBank2Frags; ++f) fr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
+  }
+  // tile headers of the range (+ the one behind it): lane i keeps tile Ta + i
+  long long A0;
+  int hd_dA, hd_fl;
+  {
+    const int64_t Ti = Ta + l < a.n_tiles ? Ta + l : a.n_tiles - 1;
+    const TileHdr h = a.hdr[l <= PAR_S2_TILES ? Ti : Ta];
+    A0 = __shfl(h.anchor, 0, kWave);
+    const long long d = h.anchor - A0;
+    hd_fl = h.flags | ((d > -0x40000000ll && d < 0x40000000ll) ? 0 : 1);
+    hd_dA = (int)d;
+  }
+  // images start zeroed: the bank reads up to 88 samples beyond what a pass has converted (against zero coefficients)
+  {
+    uint4* z = reinterpret_cast<uint4*>(&L.img[0][0]);
+    const uint4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(L.img) / 16 / kWave); ++i) z[i * kWave + l] = zero;
+  }
+  const float tolf = (float)((fabs((double)A0) + 2.0e7) * 1.2e-16 + 2.0e-10) + 2.0e-7f;
+  // ---- stream state (wave-uniform; indices of outputs are RELATIVE to Ja: 32-bit arithmetic throughout) ----
+  const int nJ = (int)(Jb - Ja);                 // outputs of the range
+  int j0 = 0;                                    // next output
+  int wbase = 0, conv_next = 0, dma_next = 0, dma_bad = INT_MAX, mode = 0;   // mode: 0 none, 1 plain image (fc = 1), 2 modulated images
+  float g0 = 0.0f;
+  // tile state: refreshed when j0 crosses a tile border
+  int tend = 0, dA0 = 0, dA1 = 0, fl0 = 0, fl1 = 0;
+  // results of the previous pass: stored one pass late, behind the wait for this pass's records -- gfx950 counts loads and
+  // stores in ONE counter, and a wave that waits for a load it issued behind a store waits for the store as well
+  float res_p[2] = {0.0f, 0.0f};
+  int nok_p[2] = {0, 0};
+  unsigned j_p = 0u;
+  float* const outW = a.out + Ja;
+  const uint4* const recW = reinterpret_cast<const uint4*>(a.rec) + (Ja >> kRecShift);
+  const uint4* const rec2W = reinterpret_cast<const uint4*>(a.rec2) + (Ja >> kRecShift);
+  // The block records of a pass (<= 5 blocks, first and second pieces) come into LDS by one 16-byte direct load per lane of
+  // lanes 0-15, issued as soon as the pass before knows where it ends -- no registers held across the pass.
+  auto load_records = [&](int jn) {
+    if (l < 16) dma_dwordx4((l < 8 ? recW : rec2W - 8) + (((unsigned)jn >> kRecShift) + (unsigned)l), &L.recs[0]);
+  };
+  load_records(0);
+  // chunk k = input samples [wbase + 128 k, + 128) (relative to A0) -> ring slot k & 3, straight from HBM/L2 into LDS; a
+  // chunk that reaches over the file's ends is not fetched
+  auto chunk_dma = [&](int k) {
+    const long long lo = A0 + wbase + (long long)kPass * k;
+    if (lo >= 0 && lo + kPass <= (long long)a.len_in) {
+      const float* gp = a.sig + lo + l;
+      float* dst = &L.ring[(k & 3) * kPass];
+      dma_dword(gp, dst);
+      dma_dword(gp + kWave, dst + kWave);
+    } else if (k < dma_bad) {
+      dma_bad = k;
+    }
+  };
+  auto push_tile = [&](int64_t T) {
+    if (l == 0) {
+      const int slot = atomicAdd(a.redo_count, 1);
+      a.redo_list[slot] = (int)T;
+    }
+  };
+  // the file's last, partial tile belongs to the block kernel
+  if (blockIdx.x == 0 && a.n_full < a.n_tiles) push_tile(a.n_full);
+
+#if PAR_S2_EXP & 64
+  unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_ = __builtin_readcyclecounter();
+#endif
+  while (j0 < nJ) {
+    S2_MARK(7);
+    j0 = __builtin_amdgcn_readfirstlane(j0);     // (the compiler does not see that the loop's state is wave-uniform)
+    wbase = __builtin_amdgcn_readfirstlane(wbase);
+    conv_next = __builtin_amdgcn_readfirstlane(conv_next);
+    dma_next = __builtin_amdgcn_readfirstlane(dma_next);
+    dma_bad = __builtin_amdgcn_readfirstlane(dma_bad);
+    mode = __builtin_amdgcn_readfirstlane(mode);
+    tend = __builtin_amdgcn_readfirstlane(tend);
+    if (j0 >= tend) {                            // a new tile: its anchor and flags, and those of the tile behind it
+      const int Tt = j0 >> 10;
+      tend = (Tt + 1) << 10;
+      dA0 = __builtin_amdgcn_readlane(hd_dA, Tt);
+      dA1 = __builtin_amdgcn_readlane(hd_dA, Tt + 1);
+      fl0 = __builtin_amdgcn_readlane(hd_fl, Tt);
+      fl1 = __builtin_amdgcn_readlane(hd_fl, Tt + 1);
+    }
+    // ---- 1. placement ----
+    // everything this pass reads from LDS that came by direct load (its records, its newest chunk) set out a pass ago;
+    // nothing younger is in flight (the stores of the pass before leave BEHIND this wait)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    wave_lds_fence();
+    const int u = (j0 + l) & (kRec - 1);         // the same for both rows
+    uint4 ra[2], rb[2];
+    {
+      const int b = (int)(((unsigned)(j0 + l) >> kRecShift) - ((unsigned)j0 >> kRecShift));      // 0 .. 2 (row 1: + 2)
+      ra[0] = L.recs[b];
+      rb[0] = L.recs[8 + b];
+      ra[1] = L.recs[b + 2];
+      rb[1] = L.recs[10 + b];
+    }
+    S2Place P;
+    int nv[2] = {64, 64};                        // valid lanes of row r: l < nv[r]
+    const bool interior = j0 + kPass <= tend && j0 + kPass <= nJ;
+    if (interior) {
+      const int nt[2] = {64, 64};
+      s2_place<false>(ra, rb, u, l, tolf, dA0, dA1, nv, nt, P);
+    } else {
+      const int jlim = ((fl1 & 1) && tend < nJ) ? tend : nJ;     // a tile out of range ends the pass at its border
+      int nt[2];                                 // lanes of this tile: l < nt[r]
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        nv[r] = clamp64(jlim - j0 - 64 * r);
+        nt[r] = clamp64(tend - j0 - 64 * r);
+      }
+      s2_place<true>(ra, rb, u, l, tolf, dA0, dA1, nv, nt, P);
+      if (P.bad_next != 0ull) {                  // bad lanes of the next tile end the pass at the border
+        nv[0] = nv[0] < nt[0] ? nv[0] : nt[0];
+        nv[1] = nv[1] < nt[1] ? nv[1] : nt[1];
+      }
+    }
+    int (&c)[2] = P.c;
+    float (&s)[2] = P.s;
+    float (&ep)[2] = P.ep;
+    // bad lanes of THIS tile send it to the block kernel
+    bool skip = (fl0 & 1) || P.bad_here != 0ull;
+    S2_MARK(0);
+    // the previous pass's outputs leave now: the records this pass waited for were issued before them
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (l < nok_p[r] && !(PAR_S2_EXP & 4)) outW[j_p + 64u * r + (unsigned)l] = res_p[r];
+    nok_p[0] = nok_p[1] = 0;
+    asm volatile("" ::: "memory");
+    const int c0 = __builtin_amdgcn_readfirstlane(c[0]);
+    const int ws = c0 & ~7;
+    // which outputs this pass finishes (centres inside [ws, ws + 128): a prefix of the valid lanes) -- and with that where the
+    // next pass starts: its records set out NOW, a whole pass ahead of their use
+    int ci[2], nok[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      ci[r] = c[r] - ws;
+      const unsigned long long in = __ballot(ci[r] < kPass);
+      nok[r] = interior ? __popcll(in) : __popcll(in & prefix(nv[r]));
+      ci[r] = l < nok[r] ? ci[r] : 0;
+    }
+    const int jn = j0 + nok[0] + nok[1];
+    wave_lds_fence();                            // every lane has read this pass's records
+    if (!skip) load_records(jn);
+    // ---- 2. the stream: mode, window, conversion ----
+    unsigned long long gen = P.gen;
+    if (!interior) gen = (__ballot(1.0f + ep[0] != 1.0f) & prefix(nv[0])) | (__ballot(1.0f + ep[1] != 1.0f) & prefix(nv[1]));
+    const bool all_unity = (gen == 0ull) | ((PAR_S2_EXP & 16) != 0);
+    const int want = all_unity ? 1 : 2;
+    float fc[2] = {1.0f, 1.0f}, gg[2] = {0.0f, 0.0f};
+    bool restart = mode != want || ws - wbase > (1 << 20);
+    if (want == 2) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        fc[r] = fast_rcp(1.0f + ep[r]);
+        gg[r] = ep[r] * fc[r];                   // 1 - fc
+      }
+      const unsigned long long far_off = (__ballot(!(fabsf(g0 - gg[0]) <= kEpsTol)) & prefix(nv[0])) | (__ballot(!(fabsf(g0 - gg[1]) <= kEpsTol)) & prefix(nv[1]));
+      restart = restart || far_off != 0ull;
+    }
+    if (!skip && restart) {
+      mode = want;
+      wbase = ws - 39;
+      conv_next = 0;
+      if (want == 2) {
+        g0 = __shfl(gg[0], nJ - j0 > 32 ? 32 : 0, kWave);
+        const unsigned long long far_off = (__ballot(!(fabsf(g0 - gg[0]) <= kEpsTol)) & prefix(nv[0])) | (__ballot(!(fabsf(g0 - gg[1]) <= kEpsTol)) & prefix(nv[1]));
+        if (far_off != 0ull) skip = true;        // a ramp too steep for one g0
+      }
+      dma_bad = INT_MAX;
+      dma_next = 0;                              // (the fetch below is the only exposed one of the stream: rare)
+    }
+    S2_MARK(1);
+    const int need_hi = ws + 160 - wbase;        // last window index the bank's non-zero coefficients meet
+    // chunks up to need_hi / 128 are converted below; the one behind them sets out now, a pass ahead.  (Its ring slot held the
+    // chunk four back, which ends before ws - 2: no near tap of this or a later pass reads it.)
+    if (!skip && dma_next <= need_hi / kPass + 1) {
+      const bool late = dma_next <= need_hi / kPass;             // only right behind a restart / a jump
+      while (dma_next <= need_hi / kPass + 1) chunk_dma(dma_next++);
+      if (late) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        wave_lds_fence();
+      }
+    }
+    if (!skip) {
+#pragma unroll 1
+      while (conv_next * kPass <= need_hi) {
+        if (conv_next >= dma_bad) {
+          skip = true;
+          break;
+        }
+        const int wi = conv_next * kPass + 2 * l;                    // window index of x0
+        const int ix = wi & (kRing - 1);
+        const float2 xx = *reinterpret_cast<const float2*>(&L.ring[ix]);
+        const float x0 = xx.x, x1 = xx.y;
+        const float am = fmaxf(fabsf(x0), fabsf(x1));                  // (maxnum: a NaN operand is dropped -- test both samples)
+        // float16 does not suit: non-finite or >= 32768 (NaN compares false), or all but silent
+        if (__ballot(!(fabsf(x0) < 32768.0f) || !(fabsf(x1) < 32768.0f)) != 0ull ||
+            (__ballot(am >= kQuiet) == 0ull && __ballot(am > 0.0f) != 0ull)) {
+          skip = true;
+          break;
+        }
+        if (ix < 8) *reinterpret_cast<float2*>(&L.ring_tail[ix]) = xx;
+        if (ix == kRing - 2) *reinterpret_cast<float2*>(&L.ring_head[2]) = xx;
+        if (!(PAR_S2_EXP & 8)) {
+          if (mode == 1) {
+            const half2v h = {hi16(x0), hi16(x1)};
+            const half2v lo = {(_Float16)((x0 - (float)h[0]) * 4096.0f), (_Float16)((x1 - (float)h[1]) * 4096.0f)};
+            *reinterpret_cast<half2v*>(&L.img[0][ix]) = h;
+            *reinterpret_cast<half2v*>(&L.img[1][ix]) = lo;
+          } else {
+            float ya[2], yb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const float x = t ? x1 : x0;
+              const float kf = (float)(wi + t);
+              const float ph = g0 * kf, pl = fmaf(g0, kf, -ph);       // g0 k as hi + lo: the phase is good to ~1e-8 turns
+              const float rn = rintf(ph);
+              const float rr = (ph - rn) + pl;
+              const float sg = ((int)rn & 1) ? -x : x;
+              ya[t] = sg * sinpi_half(rr);
+              yb[t] = sg * cospi_half(rr);
+            }
+            const half2v ha = {hi16(ya[0]), hi16(ya[1])}, hb = {hi16(yb[0]), hi16(yb[1])};
+            const half2v la = {(_Float16)((ya[0] - (float)ha[0]) * 4096.0f), (_Float16)((ya[1] - (float)ha[1]) * 4096.0f)};
+            const half2v lb = {(_Float16)((yb[0] - (float)hb[0]) * 4096.0f), (_Float16)((yb[1] - (float)hb[1]) * 4096.0f)};
+            *reinterpret_cast<half2v*>(&L.img[0][ix]) = ha;
+            *reinterpret_cast<half2v*>(&L.img[1][ix]) = la;
+            *reinterpret_cast<half2v*>(&L.img[2][ix]) = hb;
+            *reinterpret_cast<half2v*>(&L.img[3][ix]) = lb;
+          }
+        }
+        ++conv_next;
+      }
+    }
+    if (skip) {                                  // the tile of j0 goes to the block kernel; the stream restarts behind it
+      push_tile(Ta + (j0 >> 10));
+      j0 = tend;
+      mode = 0;
+      wave_lds_fence();
+      if (j0 < nJ) load_records(j0);
+      continue;
+    }
+    S2_MARK(2);
+    // ---- 4. the bank over the centres ws .. ws + 127 ----
+    wave_lds_fence();
+    S2_MARK(3);
+    const int offs = ws - wbase - 31;            // = 8 (mod 8) by construction: 16-byte aligned fragments
+    if (mode == 1) {
+      bank_image<false>(L, fr, offs, l, 0);
+    } else {
+      bank_image<true>(L, fr, offs, l, 0);
+      bank_image<true>(L, fr, offs, l, 1);
+    }
+    wave_lds_fence();
+    S2_MARK(4);
+    // ---- 5. outputs ----
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int sl = ci[r] ^ ((ci[r] >> 3) & 7);
+      const int rc = l < nok[r] ? ((c[r] - wbase) & (kRing - 1)) : 2;
+      const float* xp = &L.ring[rc];
+      const float xm2 = xp[-2], xm1 = xp[-1], x0 = xp[0], xp1 = xp[1], xp2 = xp[2];
+      const float sr = s[r], q = sr * sr, q64 = 64.0f * q;
+      const float E1 = xp1 + xm1, D1 = xp1 - xm1, E2 = xp2 + xm2, D2 = xp2 - xm2;
+      float res;
+      if (mode == 1) {
+        const float4v row = L.qa[sl];
+        const unsigned w2 = __float_as_uint(L.qx[sl][0]);
+        const float e = fmaf(q, fmaf(q64, h_lo(w2), row[2]), row[0]), d = fmaf(q, fmaf(q64, h_hi(w2), row[3]), row[1]);
+        float en = 0.0f, dn = 0.0f;
+        if (!(PAR_S2_EXP & 2)) {
+          const float R1 = fast_rcp(fmaf(q, T32::B[1], T32::A[1])), R2 = fast_rcp(fmaf(q, T32::B[2], T32::A[2]));
+          en = fmaf(E2, R2, -(E1 * R1));
+          dn = fmaf(D2 + D2, R2, -(D1 * R1));
+        }
+        const float et = fmaf(e, kBank2ScaleInv, en), dt = fmaf(d, kBank2ScaleInv, dn);
+        res = sinpi_poly(q) * fmaf(-sr, fmaf(sr, et, dt), x0 * 0.318309886f);
+      } else {
+        const float f = fc[r], g = gg[r];
+        // near taps with the lane's own cut-off: numerators sin(pi fc (n -+ s)) = -(-1)^n sin(pi g n +- phi), phi = pi fc s
+        const float h = f * sr, zh = h * h;
+        const float sph = sinpi_poly(zh);
+        const float sinphi = h * sph, cosphi = cospi_half(h);
+        const float zg = g * g;
+        const float S1 = g * fmaf(zg, fmaf(zg, 2.55016404f, -5.16771278f), 3.14159265f);
+        const float C1 = fmaf(zg, fmaf(zg, 4.05871213f, -4.93480220f), 1.0f);
+        const float S2 = 2.0f * S1 * C1, C2 = fmaf(-2.0f * S1, S1, 1.0f);
+        float accM = 0.0f, accP = 0.0f;
+        if (!(PAR_S2_EXP & 2)) {
+          const float R1 = fast_rcp(fmaf(q, T32::B[1], T32::A[1])), R2 = fast_rcp(fmaf(q, T32::B[2], T32::A[2]));
+          const float sc1 = S1 * cosphi, cs1 = C1 * sinphi, sc2 = S2 * cosphi, cs2 = C2 * sinphi;
+          const float G1 = xp1 * (sc1 + cs1), H1 = xm1 * (sc1 - cs1);
+          const float G2 = -xp2 * (sc2 + cs2), H2 = -xm2 * (sc2 - cs2);
+          accM = fmaf(G2 - H2, R2, (G1 - H1) * R1);
+          accP = fmaf(2.0f * (G2 + H2), R2, (G1 + H1) * R1);
+        }
+        const float near = fmaf(x0 * f, sph * 0.318309886f, fmaf(sr, accM, accP));
+        // far taps: psi / pi = s - g0 (K + s), K = the centre's window index (the images' phase origin is the window's)
+        const float Kf = (float)(c[r] - wbase);
+        const float ph = g0 * Kf, pl = fmaf(g0, Kf, -ph);
+        const float rn = rintf(ph);
+        const float t = (sr - (ph - rn)) - fmaf(g0, sr, pl);
+        const float rm = rintf(t);
+        const float v = t - rm;
+        const bool neg = (((int)rn + (int)rm) & 1) != 0;
+        float cps = cospi_half(v), sps = sinpi_half(v);
+        cps = neg ? -cps : cps;
+        sps = neg ? -sps : sps;
+        const float4v rowa = L.qa[sl], rowb = L.qb[sl];
+        const float4v Xf = L.qx[sl];
+        const uint2 X = make_uint2(__float_as_uint(Xf[0]), __float_as_uint(Xf[1]));
+        const unsigned Y = __float_as_uint(L.qy[sl]);
+        const float eA = fmaf(q, fmaf(q64, h_lo(X.x), rowa[2]), rowa[0]), dA = fmaf(q, fmaf(q64, h_hi(X.x), rowa[3]), rowa[1]);
+        const float eB = fmaf(q, fmaf(q64, h_lo(X.y), rowb[2]), rowb[0]), dB = fmaf(q, fmaf(q64, h_hi(X.y), rowb[3]), rowb[1]);
+        const float UA = fmaf(sr, eA, dA) * kBank2ScaleInv, UB = fmaf(sr, eB, dB) * kBank2ScaleInv;
+        const float HA = Xf[2], HB = Xf[3];
+        const float s1k = sr * 0.0009765625f;
+        const float H1A = fmaf(-s1k, HA, h_lo(Y)), H1B = fmaf(-s1k, HB, h_hi(Y));                 // H1 / 1024
+        const float eps = g0 - g;                                    // fc - fc0
+        float far = -fmaf(cps, UA, sps * UB);
+        far = fmaf(eps, fmaf(cps, HB, -(sps * HA)), far);
+        far = fmaf(1608.49544f * eps * eps, fmaf(cps, H1A, sps * H1B), far);                      // 1024 pi / 2
+        res = near + far;
+      }
+      res_p[r] = res;
+      nok_p[r] = nok[r];
+    }
+    j_p = (unsigned)j0;
+    j0 = jn;
+    S2_MARK(5);
+#if PAR_S2_EXP & 64
+    ph_[6] += 1;
+#endif
+  }
+#if PAR_S2_EXP & 64
+  if (l == 0)
+    for (int k = 0; k < 8; ++k) g_s2_phase[(size_t)blockIdx.x * 8 + k] = ph_[k];
+#endif
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+    if (l < nok_p[r] && !(PAR_S2_EXP & 4)) outW[j_p + 64u * r + (unsigned)l] = res_p[r];
+}
+
+int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
+                       hipStream_t s) {
+  (void)device;
+  S2Args a;
+  a.len_out = len_out;
+  a.sig = sig;
+  a.len_in = len_in;
+  a.out = out;
+  a.hdr = fa.hdr;
+  a.rec = fa.rec;
+  a.rec2 = fa.rec2;
+  a.redo_count = fa.redo_count;
+  a.redo_list = fa.redo_list;
+  a.n_full = len_out / kSincTileOutputs;
+  a.n_tiles = ceil_div(len_out, kSincTileOutputs);
+  const int64_t grid = ceil_div(a.n_full, (int64_t)PAR_S2_TILES);
+  if (grid > 0) hipLaunchKernelGGL(k_sinc_stream, dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  else if (a.n_tiles > 0) {
+    // nothing but a partial tile: the caller's block kernel handles short files (launch_sinc_fused never comes here)
+  }
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
+}  // namespace par
+
+#if PAR_S2_EXP & 64
+extern "C" int par_debug_s2_phase_buffer(unsigned long long* dev_buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(par::g_s2_phase), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -1473,7 +1473,8 @@ int par_find_delay_f64(int device, const double* a, int64_t na, const double* b,
     PAR_HIP_CHECK(hipMemcpyAsync(&nc, n_cand, sizeof(int), hipMemcpyDeviceToHost, s));
     PAR_HIP_CHECK(hipMemcpyAsync(&top, arg, sizeof(top), hipMemcpyDeviceToHost, s));
     PAR_HIP_CHECK(hipStreamSynchronize(s));
-    if (nc > 0 && nc <= kXcCand) {                       // more rivals than slots: a plateau, the transform's top stands
+    if (nc > 0 && nc < kXcCand) {                        // the top goes into slot nc: nc + 1 entries must fit the kXcCand slots;
+                                                         // as many rivals as slots or more: a plateau, the transform's top stands
       long long lags[kXcCand + 1];
       double ex[kXcCand + 1];
       PAR_HIP_CHECK(hipMemcpyAsync(lags, cand, nc * sizeof(long long), hipMemcpyDeviceToHost, s));

@@ -4,6 +4,7 @@
 // chunk boundaries are K_sinc tile boundaries); this is the "higher-level slot" of resampling.run
 // (reference util/resampling.py:184, :225-227).
 #include "par_common.h"
+#include "pos_plan.h"
 #include <map>
 #include <vector>
 
@@ -127,6 +128,16 @@ int par_varispeed_fused_f32(int device, const double* speeds, int64_t m, const v
                             int NT, float* out, int64_t out_stride, void* stream) {
   return varispeed_fused_impl("par_varispeed_fused_f32", device, speeds, m, work, aux, max_out, len_out, sig, nullptr,
                               sig_stride, len_in, NT, out, nullptr, out_stride, stream);
+}
+
+int par_fused_redo_tiles(int device, const void* aux, int64_t max_out, int64_t m, int* tiles, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(aux && tiles && m >= 2 && max_out >= 2, PAR_ERR_ARG, "par_fused_redo_tiles: bad argument");
+  PAR_HIP_CHECK(hipSetDevice(device));
+  const FusedAux av = fused_aux_view(const_cast<void*>(aux), max_out, m);
+  PAR_HIP_CHECK(hipMemcpyAsync(tiles, av.redo_count, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)));
+  PAR_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  return PAR_OK;
 }
 
 // Two channels of one file in one launch (same positions, same strides): position regeneration, prologue and tap

@@ -32,6 +32,22 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
+def block_relerr(a, b, block=4096, floor_db=-80.0):
+    """max over `block`-sample blocks of max|a - b| / max|b| WITHIN the block; blocks whose peak lies below `floor_db` dBFS of the
+    file's peak are skipped.  The norm-wise `relerr` lets a loud passage vouch for a quiet one; this does not."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    k = (len(b) // block) * block
+    if k == 0:
+        return relerr(a, b)
+    pk = np.max(np.abs(b))
+    bw = np.abs(b[:k]).reshape(-1, block).max(1)
+    be = np.abs(a[:k] - b[:k]).reshape(-1, block).max(1)
+    keep = bw > pk * 10.0 ** (floor_db / 20.0)
+    return float(np.max(be[keep] / bw[keep])) if keep.any() else 0.0
+
+
 FUSED_TOL = 2e-6
 
 
@@ -962,6 +978,8 @@ def test_unity_path_matrix_core_bank(par):
             a, b = n // 3 + 4000, 2 * n // 3 - 4000                      # would not do, hi + lo does
             ia, ib = np.searchsorted(pos, [a, b])
             assert relerr(got[ia:ib], want[ia:ib]) < TOL
+        if name in ("noise", "nyquist", "loud next to quiet"):           # every 4096-sample block on its own scale
+            assert block_relerr(got, want) < 2 * TOL, (name, block_relerr(got, want))
     bad = base.copy()
     bad[100_000] = np.nan
     bad[300_001] = np.inf
@@ -978,6 +996,70 @@ def test_unity_path_matrix_core_bank(par):
     want = C.sinc(pos, only_nan, NT, threads=8)
     got = par.resampling.varispeed_fused_dev(plan, t.from_numpy(only_nan).cuda(), NT).cpu().numpy()
     assert np.array_equal(np.isnan(got), np.isnan(want)) and 60 <= np.isnan(want).sum() <= 66
+
+
+def test_streaming_kernel_opt_in(par, monkeypatch):
+    """r04: the streaming form of K_sinc (csrc/sinc2.hip, PAR_SINC_STREAM=1; mono, NT = 32, unit strides): one wave streams over
+    eight tiles, taps |n| >= 3 of BOTH regimes on the matrix cores (fc < 1 through two modulated images), the rest of the file
+    through the block kernel's tile list.  Against the C oracle on a fast, a slow and a mixed tape, norm-wise and per 4096-sample
+    block; the tile list stays short; a NaN sample poisons exactly the reference's window; short and odd-length files work."""
+    import ctypes
+    from oracle import oracle_c as C
+    from pyaudiorestoration_amd import _lib, _dev
+    t = par.torch
+    monkeypatch.setenv("PAR_SINC_STREAM", "1")
+    L = _lib.lib()
+    sr, NT = 192000, 32
+    n = 700_001
+    m = n // 256
+    st = np.linspace(0, n, m)
+    rng = np.random.default_rng(21)
+    tt = np.arange(n)
+    noise = rng.standard_normal(n).astype(np.float32)
+    quiet = noise.copy()
+    quiet[n // 3:2 * n // 3] *= np.float32(1e-3)
+    signals = {"noise": noise, "nyquist": np.cos(np.pi * tt).astype(np.float32), "0.45 fs": np.cos(0.9 * np.pi * tt + 0.2).astype(np.float32),
+               "loud next to quiet": quiet}
+    for cname, sp in (("fast", 1.005 + 0.005 * np.sin(2 * np.pi * 4.4 * st / sr + 0.7)),
+                      ("slow", 0.995 + 0.00499 * np.sin(2 * np.pi * 4.4 * st / sr + 0.7)),
+                      ("mix", 1.0 + 0.01 * np.sin(2 * np.pi * 4.4 * st / sr + 0.7)), ("unit", np.ones(m))):
+        plan = par.resampling.speed_plan_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), n, fused=True)
+        assert plan.fused_ok
+        pos, _ = C.speed_to_pos(st, sp, n)
+        for name, sig in signals.items():
+            want = C.sinc(pos, sig, NT, threads=8)
+            got = par.resampling.varispeed_fused_dev(plan, t.from_numpy(sig).cuda(), NT).cpu().numpy()
+            assert relerr(got, want) < TOL, (cname, name, relerr(got, want))
+            assert block_relerr(got, want) < 2 * TOL, (cname, name, block_relerr(got, want))
+        redo = ctypes.c_int(-1)
+        _lib.check(L.par_fused_redo_tiles(0, _dev.ptr(plan.aux), plan.max_out, plan.m, ctypes.byref(redo), _dev.stream_ptr(0)))
+        assert 1 <= redo.value <= 8, (cname, redo.value)            # the file's two ends + the odd rounding tie
+        if cname == "mix":
+            bad = noise.copy()
+            bad[345_678] = np.nan
+            want = C.sinc(pos, bad, NT, threads=8)
+            got = par.resampling.varispeed_fused_dev(plan, t.from_numpy(bad).cuda(), NT).cpu().numpy()
+            assert np.array_equal(np.isnan(got), np.isnan(want)) and 60 <= np.isnan(want).sum() <= 66
+            ok = ~np.isnan(want)
+            assert relerr(got[ok], want[ok]) < TOL
+            loud = (noise * np.float32(2.0e4)).astype(np.float32)   # int16-scaled material: still float16's range
+            want = C.sinc(pos, loud, NT, threads=8)
+            got = par.resampling.varispeed_fused_dev(plan, t.from_numpy(loud).cuda(), NT).cpu().numpy()
+            assert relerr(got, want) < TOL
+            big = (noise * np.float32(1.0e5)).astype(np.float32)    # beyond it: every tile through the block kernel
+            want = C.sinc(pos, big, NT, threads=8)
+            got = par.resampling.varispeed_fused_dev(plan, t.from_numpy(big).cuda(), NT).cpu().numpy()
+            assert relerr(got, want) < TOL
+    # a file shorter than one wave's range, and one of a few tiles
+    for n_s in (5000, 40_000):
+        m_s = max(4, n_s // 256)
+        st_s = np.linspace(0, n_s, m_s)
+        sp_s = 0.997 + 0.002 * np.sin(np.arange(m_s) * 0.3)
+        plan = par.resampling.speed_plan_dev(t.from_numpy(st_s).cuda(), t.from_numpy(sp_s).cuda(), n_s, fused=True)
+        pos, _ = C.speed_to_pos(st_s, sp_s, n_s)
+        want = C.sinc(pos, noise[:n_s], NT, threads=4)
+        got = par.resampling.varispeed_fused_dev(plan, t.from_numpy(noise[:n_s].copy()).cuda(), NT).cpu().numpy()
+        assert relerr(got, want) < TOL, n_s
 
 
 def test_fused_extreme_curves_and_channels(par):

@@ -163,6 +163,23 @@ def render():
     out.append("};")
     out.append("#endif")
     out.append("")
+    # ---- streaming kernel (sinc2.hip): bank over the taps 3 <= |n| <= 31, rows interleaved (e, d), + the (H, H1') pair
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import sinc2_model as M2
+    fr2 = M2.bank_fragments().reshape(-1, 2)
+    w2 = (fr2[:, 0].astype(np.uint32) | (fr2[:, 1].astype(np.uint32) << 16))
+    out.append("// Constant A fragments of the streaming kernel's bank (tools/sinc2_model.py, bank_fragments): taps 3 <= |n| <= 31 as")
+    out.append("// minimax polynomials in q (quadratic to n = %d, linear to 25, constant beyond), rows m = 2 i + (0: e, 1: d);" % max(n for n in M2.DEGS if M2.DEGS[n] == 2))
+    out.append("// [13 fragments][64 lanes][8 halves]: 0-2 (e0 d0) hi, 3-4 (e1 d1) hi, 5-7 (e0 d0) lo x %g, 8-9 (e2 d2) hi, 10-12 (H H1'); e/d x %g." % (M2.LO, M2.SCALE))
+    out.append("constexpr int kBank2Frags = %d;" % len(M2.FRAGS))
+    out.append("constexpr float kBank2ScaleInv = %sf, kBank2LoInv = %sf;" % (repr(1.0 / M2.SCALE), repr(1.0 / M2.LO)))
+    out.append("#ifdef PAR_WANT_BANK2")
+    out.append("__device__ const unsigned int kBank2Frags32[%d] = {" % len(w2))
+    for i in range(0, len(w2), 12):
+        out.append("  " + ", ".join("0x%08xu" % w for w in w2[i:i + 12]) + ",")
+    out.append("};")
+    out.append("#endif")
+    out.append("")
     out += ["}  // namespace par", ""]
     return "\n".join(out)
 
