@@ -245,31 +245,38 @@ def main():
     y = resampling.sinc_wrapper(pos, x, 0, 32)
     save("pipeline", track_times=tr.times, track_freqs=tr.freqs, curve=curve, pos=pos, y=y,
          cfg=np.array([sr, n, n_fft, hop]))
+    PIPE = dict(tr=tr, curve=curve, sr=sr, hop=hop, duration=duration)
 
-    # ------------------------------------- config 4: dropout healer on L2 calls
-    # the glue (dropout_healer_gui.py:111-166) lives in oracle_np.heal_dropouts; here it runs on the
-    # REFERENCE's stft/istft so the fixture pins both the glue's use of them and the spectral numerics.
+    # ------------------------------------- config 4: the dropout healer's OWN glue (r04)
+    # dropout_healer_gui.Canvas.resample_files (:111-166) and the batch-detection branch of .on_mouse_release (:168-242) are
+    # called themselves, as plain functions on a stand-in canvas, with stand-ins for PyQt5 / vispy (oracle/ref_gui.py).  Until
+    # r03 these fixtures came from oracle_np's restatements of the two methods; the arrays did not change by a bit.
     sys.path.insert(0, ROOT)
-    from oracle import oracle_np
+    from oracle import oracle_np, ref_gui
+    D, P, M, W = ref_gui.import_reference_gui(a.ref)
     sr_h = 44100
     xh = (inputs.sine(30000, 1500.0, sr_h, 0.4) + 0.05 * inputs.noise(30000, 60)).astype(np.float32)
     xh[9000:9300] *= 0.05                                   # two synthetic dropouts
     xh[20000:20500] *= 0.1
     marks = [(0.2000, 500.0, 0.2110, 6000.0, 0.5), (0.4500, 800.0, 0.4680, 9000.0, 0.5),
              (0.2050, 1000.0, 0.2150, 3000.0, 1.0)]      # the third overlaps the first (gain clip path)
-    healed = oracle_np.heal_dropouts(xh, sr_h, marks, 512, 32,
-                                     stft_fn=lambda x, n_fft, step: fourier.stft(x, n_fft=n_fft, step=step),
-                                     istft_fn=lambda S, length, hop_length: fourier.istft(S, length=length, hop_length=hop_length))
+    healed, suffix_h = ref_gui.heal_through_reference(D, M, xh[:, None], sr_h, marks, 512, 32)
+    assert suffix_h == "_drops"
+    restated = oracle_np.heal_dropouts(xh, sr_h, marks, 512, 32,
+                                       stft_fn=lambda x, n_fft, step: fourier.stft(x, n_fft=n_fft, step=step),
+                                       istft_fn=lambda S, length, hop_length: fourier.istft(S, length=length, hop_length=hop_length))
+    assert np.array_equal(healed, restated.astype(healed.dtype)), "oracle_np.heal_dropouts no longer restates the reference's glue"
     save("heal", y=healed[:, 0].astype(np.float64), marks=np.array(marks), sr=np.array(sr_h))
 
-    # dropout detector (dropout_healer_gui.py:185-242) on the reference's get_mag
     xd = inputs.detect_input(sr_h)
     md = fourier.get_mag(xd, 512, 32, "blackmanharris", 1)
     det_args = (sr_h, 512, 32, 0.1, 2.6, 3000, 12000)
     vol_d, fb_d = oracle_np.band_volume_db(md, *det_args)
-    found = oracle_np.detect_dropouts(md, *det_args, width_ms=20, sensitivity=5)
+    found = ref_gui.detect_through_reference(D, M, md, sr_h, 512, 32, 0.1, 2.6, 3000, 12000, width_ms=20, sensitivity=5)
+    found_np = oracle_np.detect_dropouts(md, *det_args, width_ms=20, sensitivity=5)
+    assert np.array_equal(np.array(found), np.array(found_np)), "oracle_np.detect_dropouts no longer restates the reference's glue"
     save("detect", vol=vol_d, frame_b=np.array(fb_d), args=np.array(det_args, dtype=np.float64),
-         found=np.array([(a[0], a[1], b[0], b[1]) for a, b in found]))
+         found=np.array([(a_[0], a_[1], b_[0], b_[1]) for a_, b_ in found]))
 
     # ------------------------------ configs 1 and 3 on the reference's own sample files
     # The FLAC files are DATA copied into tests/golden/ (the reference has no tests; these are its demo
@@ -305,6 +312,40 @@ def main():
          c1_n=np.array(len(x1)), c3_shape=np.array(spec3.shape), c3_sum=np.array(spec3.sum()), c3_grid=grid(spec3),
          c3_sr=np.array(sr3), c3_n=np.array(len(x3)), c3_track_times=tr3.times, c3_track_freqs=tr3.freqs, c3_curve=curve3,
          c3_len_pos=np.array(len(pos3)), c3_pos_grid=grid(pos3, 1009), c3_sel=sel, c3_y_sel=y3_sel)
+
+    # ------------------------------ the master curves through the reference's own marker classes, and two .spd projects (r04)
+    # MasterSpeedLine.update / MasterRegLine.update / Canvas.get_speed_curve (util/markers.py:625-708, pyrespeeder_gui.py:133-
+    # 140) run themselves on TraceLine / RegLine objects built by from_cfg, as util/widgets.py:1247-1262 does for a .spd file.
+    c_pilot, _, _ = ref_gui.speed_curve_through_reference(P, M, PIPE["sr"], PIPE["hop"], PIPE["duration"],
+                                                           [[list(PIPE["tr"].times), list(PIPE["tr"].freqs), 0]], [])
+    assert np.array_equal(c_pilot, PIPE["curve"]), "the pilot's master curve is not MasterSpeedLine.update's"
+    assert np.array_equal(ref_gui.speed_curve_through_reference(P, M, sr3, 256, dur3, [[list(tr3.times), list(tr3.freqs), 0]], [])[0],
+                          curve3), "config 3's master curve is not MasterSpeedLine.update's"
+    # two overlapping traces of the 4 kHz pilot (the second one an octave-locked 0.02 up), then a sine regression over them
+    trA = wow.wow_detectors["Peak"](spec3, x3, [(0.2, 4000.0), (2.4, 4000.0)], 1024, 256, sr3, 0.5, "Linear")
+    trB = wow.wow_detectors["Peak Track"](spec3, x3, [(1.9, 4000.0), (4.0, 4000.0)], 1024, 256, sr3, 0.5, "Linear")
+    lines = [[list(map(float, trA.times)), list(map(float, trA.freqs)), 0.0], [list(map(float, trB.times)), list(map(float, trB.freqs)), 0.02]]
+    curve_t, ms_t, _ = ref_gui.speed_curve_through_reference(P, M, sr3, 256, dur3, lines, [], bands=(0.0, 20.0))
+    amp, omega, phase, off = W.trace_sine_reg(curve_t, 0.5, 3.5, None)
+    regs = [[0.5, 3.5, float(amp), float(omega), float(phase), float(off)]]
+    curve_r, _, mr_r = ref_gui.speed_curve_through_reference(P, M, sr3, 256, dur3, lines, regs, bands=(0.0, 20.0))
+    assert not np.array_equal(curve_r, curve_t)
+    from util.config import save_json
+    common = {"fft_size": 1024, "fft_overlap": 4, "fft_zeropad": 1, "mode": "Peak", "tolerance": 0.5, "highpass": 0.0, "lowpass": 20.0,
+              "suffix": "", "sinc_quality": 32, "resampling_mode": "Sinc", "source": "flutter_192.flac"}
+    save_json(os.path.join(a.out, "flutter_192_traces.spd"), dict(common, lines=lines, regs=[]))
+    save_json(os.path.join(a.out, "flutter_192_reg.spd"), dict(common, lines=lines, regs=regs))
+    spd = {}
+    for tag, cv in (("traces", curve_t), ("reg", curve_r)):
+        ps = resampling.speed_to_pos(cv[:, 0] * sr3, cv[:, 1], len(x3))
+        ps = ps[:written_len(cv[:, 0] * sr3, cv[:, 1], len(ps))]
+        starts = (0, 300000, len(ps) - 3001)
+        spd[tag + "_curve"] = cv
+        spd[tag + "_len_pos"] = np.array(len(ps))
+        spd[tag + "_pos_grid"] = grid(ps, 1009)
+        spd[tag + "_sel"] = np.concatenate([np.arange(a0, a0 + 3000) for a0 in starts])
+        spd[tag + "_y_sel"] = np.concatenate([resampling.sinc_wrapper(ps[a0:a0 + 3001], x3[:, 0], 0, 32)[:3000] for a0 in starts])
+    save("spd", reg=np.array(regs[0]), master_traces=ms_t, master_reg=mr_r, **spd)
 
     # ----------------------------------------------- Linear mode + lag curve
     sig = inputs.noise(5000, 50)

@@ -482,6 +482,51 @@ def master_speed_curve(lines, duration, sr, hop, bands=(0, 20)):
 
 # ------------------------------------------------------------- config 4: dropout healer
 
+def master_reg_curve(regs, duration, sr, hop):
+    """MasterRegLine.update + BaseLine.get_linspace (util/markers.py:670-708, 593-597) on RegLine objects as
+    RegLine.__init__ leaves them (:94-119: negative amplitudes folded into the phase).  regs: to_cfg rows."""
+    marker_sr = sr / hop
+    times = np.linspace(0, duration, num=int(duration * marker_sr))
+    objs = []
+    for t0, t1, amplitude, omega, phase, offset in regs:
+        if amplitude < 0:
+            amplitude *= -1
+            phase += np.pi
+        objs.append(dict(t_center=(t0 + t1) / 2, amplitude=amplitude, omega=omega, phase=phase, offset=offset))
+    objs.sort(key=lambda r: r["t_center"])
+    pi2 = 2 * np.pi
+    t_centers, amp_centers, phi_centers = [], [], []
+    for i, reg in enumerate(objs):
+        if i == 0:
+            phi_centers.append(reg["omega"] * times[0] + reg["phase"] % pi2 + reg["offset"] * pi2)
+            t_centers.append(times[0])
+            amp_centers.append(reg["amplitude"])
+        phi_centers.append(reg["omega"] * reg["t_center"] + reg["phase"] % pi2 + reg["offset"] * pi2)
+        t_centers.append(reg["t_center"])
+        amp_centers.append(reg["amplitude"])
+        if i == len(objs) - 1:
+            phi_centers.append(reg["omega"] * times[-1] + reg["phase"] % pi2 + reg["offset"] * pi2)
+            t_centers.append(times[-1])
+            amp_centers.append(reg["amplitude"])
+    out = np.stack((times, 1.5 * np.interp(times, t_centers, amp_centers) * np.sin(np.interp(times, t_centers, phi_centers))), axis=-1)
+    np.power(2, out[:, 1], out[:, 1])
+    return out
+
+
+def project_speed_curve(cfg, duration, sr):
+    """pyrespeeder_gui.Canvas.get_speed_curve (pyrespeeder_gui.py:133-140) for the markers of a .spd project
+    (util/widgets.py:1247-1262): TraceLine.__init__'s log2 speed + offset (util/markers.py:196-214) per line."""
+    hop = cfg["fft_size"] // cfg.get("fft_overlap", 1)
+    if cfg.get("regs"):
+        return master_reg_curve(cfg["regs"], duration, sr, hop)
+    lines = []
+    for times, freqs, offset in cfg["lines"]:
+        speed = np.log2(np.asarray(freqs, dtype=np.float64))
+        speed -= np.mean(speed)
+        lines.append((np.asarray(times, dtype=np.float64), speed + (0 if offset is None else offset)))
+    return master_speed_curve(lines, duration, sr, hop, (cfg.get("highpass", 0), cfg.get("lowpass", 20)))
+
+
 def heal_dropouts(signal, sr, markers, fft_size=512, hop=32, stft_fn=None, istft_fn=None):
     """dropout_healer_gui.Canvas.resample_files (dropout_healer_gui.py:111-166), one pass per channel.
     markers: (a0, a1, b0, b1, surrounding) as DropoutSample.to_cfg() (util/markers.py:368-426).

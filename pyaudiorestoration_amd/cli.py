@@ -5,6 +5,7 @@ resample on that GPU, results are written as <stem>_res<suffix>.wav like resampl
 (util/resampling.py:235-237).  No Qt, no collective communication.
 
     python -m pyaudiorestoration_amd.cli respeed --trail 0.2,4000,4.0,4000 tape1.flac tape2.wav
+    python -m pyaudiorestoration_amd.cli respeed --project tape.spd tape.flac      # traces / regressions saved by the GUI
     python -m pyaudiorestoration_amd.cli resample --curve curve.json tape.wav      # [[t_seconds, speed], ...]
     python -m pyaudiorestoration_amd.cli resample --speed 1.015 tape.wav           # constant correction
     python -m pyaudiorestoration_amd.cli tapesync --project take.tapesync take2.flac
@@ -34,7 +35,7 @@ def _worker(dev, jobs, args, results):
             path = jobs.get_nowait()
         except queue.Empty:
             return None
-        if args.cmd in ("tapesync", "heal"):        # these flows read their source themselves
+        if args.cmd in ("tapesync", "heal") or (args.cmd == "respeed" and args.project):        # these flows read their source themselves
             return path, None
         return path, reader.submit(io_ops.read_file, path)
 
@@ -43,8 +44,8 @@ def _worker(dev, jobs, args, results):
         while nxt is not None:
             (path, pending), nxt = nxt, take()       # the next file starts decoding now
             try:
-                if args.cmd in ("tapesync", "heal"):
-                    flow = pipeline.tapesync if args.cmd == "tapesync" else pipeline.heal_project
+                if args.cmd in ("tapesync", "heal") or (args.cmd == "respeed" and args.project):
+                    flow = {"tapesync": pipeline.tapesync, "heal": pipeline.heal_project, "respeed": pipeline.respeed_project}[args.cmd]
                     flow(args.project, source=path, out_suffix=args.suffix, device=dev)
                     results.append((path, None))
                     continue
@@ -73,7 +74,9 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="pyaudiorestoration_amd.cli")
     sub = ap.add_subparsers(dest="cmd", required=True)
     a = sub.add_parser("respeed", help="trace a pilot tone / hum and remove wow & flutter")
-    a.add_argument("--trail", type=lambda s: [float(v) for v in s.split(",")], required=True, help="t0,f0,t1,f1 (s, Hz)")
+    what = a.add_mutually_exclusive_group(required=True)
+    what.add_argument("--trail", type=lambda s: [float(v) for v in s.split(",")], help="t0,f0,t1,f1 (s, Hz): trace it here")
+    what.add_argument("--project", help=".spd JSON written by the GUI: its traces and regressions make the master curve")
     a.add_argument("--mode", default="Peak", help="tracker name as in wow_detection.wow_detectors")
     a.add_argument("--tolerance", type=float, default=0.5, help="semitones")
     a.add_argument("--fft-size", type=int, default=1024)

@@ -45,6 +45,71 @@ def master_speed_curve(lines, duration, sr, hop, bands=(0, 20)):
     return curve
 
 
+def master_reg_curve(regs, duration, sr, hop):
+    """MasterRegLine.update + get_linspace (util/markers.py:670-708, 593-597): the sine regressions, sorted by their centres,
+    joined by interpolating phase and amplitude between the centres.  regs: rows (t0, t1, amplitude, omega, phase, offset) as
+    RegLine.to_cfg writes them (util/markers.py:175-176).  Returns [[t_seconds, linear_speed], ...]."""
+    marker_sr = sr / hop
+    times = np.linspace(0, duration, num=int(duration * marker_sr))
+    rows = []
+    for t0, t1, amplitude, omega, phase, offset in regs:
+        if amplitude < 0:                            # RegLine.__init__ (:117-119): a negative amplitude is a phase of pi
+            amplitude, phase = -amplitude, phase + np.pi
+        rows.append(((t0 + t1) / 2, amplitude, omega, phase, offset))
+    rows.sort(key=lambda r: r[0])
+    pi2 = 2 * np.pi
+    t_centers, amp_centers, phi_centers = [], [], []
+    for i, (tc, amplitude, omega, phase, offset) in enumerate(rows):
+        if i == 0:
+            phi_centers.append(omega * times[0] + phase % pi2 + offset * pi2)
+            t_centers.append(times[0])
+            amp_centers.append(amplitude)
+        phi_centers.append(omega * tc + phase % pi2 + offset * pi2)
+        t_centers.append(tc)
+        amp_centers.append(amplitude)
+        if i == len(rows) - 1:
+            phi_centers.append(omega * times[-1] + phase % pi2 + offset * pi2)
+            t_centers.append(times[-1])
+            amp_centers.append(amplitude)
+    sine_curve = np.sin(np.interp(times, t_centers, phi_centers))
+    amplitudes_sampled = np.interp(times, t_centers, amp_centers)
+    data = np.stack((times, 1.5 * amplitudes_sampled * sine_curve), axis=-1)       # (:704: "boost it a bit")
+    np.power(2, data[:, 1], data[:, 1])
+    return data
+
+
+def project_speed_curve(cfg, duration, sr):
+    """The speed curve a saved pyrespeeder project (.spd: pyrespeeder_gui.py:17-18 STORE = lines, regs; util/widgets.py:1224-
+    1262) resamples with: Canvas.get_speed_curve (pyrespeeder_gui.py:133-140) -- the regressed curve if the project holds
+    regressions, else the measured one (the traces' mean, band-passed between the project's highpass and lowpass).
+    cfg["lines"]: rows (times, freqs, offset) of TraceLine.to_cfg (util/markers.py:275-276)."""
+    hop = cfg["fft_size"] // cfg.get("fft_overlap", 1)
+    if cfg.get("regs"):
+        return master_reg_curve(cfg["regs"], duration, sr, hop)
+    lines = []
+    for times, freqs, offset in cfg.get("lines", ()):
+        lines.append((np.asarray(times, dtype=np.float64), trace_to_speed(np.asarray(freqs, dtype=np.float64)) + (offset or 0)))
+    if not lines:
+        raise ValueError("project holds neither traces nor regressions")
+    return master_speed_curve(lines, duration, sr, hop, (cfg.get("highpass", 0), cfg.get("lowpass", 20)))
+
+
+def respeed_project(project, source=None, out_suffix=None, device=None):
+    """Run a saved pyrespeeder project headless: `project` is the path of a .spd JSON (fft_size, fft_overlap,
+    highpass, lowpass, lines, regs, source, resampling_mode, sinc_quality, suffix) or the dict itself; `source` overrides
+    the audio path stored in it.  Writes <source>_res<suffix>.wav through resampling.run like Canvas.run_resample
+    (pyrespeeder_gui.py:119-131) and returns the speed curve."""
+    import json
+    from . import io_ops
+    cfg = json.load(open(project)) if isinstance(project, (str, bytes)) or hasattr(project, "__fspath__") else dict(project)
+    path = source or cfg["source"]
+    signal, sr, _ = io_ops.read_file(path)
+    curve = project_speed_curve(cfg, len(signal) / sr, sr)
+    resampling.run((path,), signal_data=((signal, sr),), speed_curve=curve, resampling_mode=cfg.get("resampling_mode", "Sinc"),
+                   sinc_quality=cfg.get("sinc_quality", 50), suffix=cfg.get("suffix", "") if out_suffix is None else out_suffix)
+    return curve
+
+
 def respeed(signal, sr, trail, fft_size=1024, hop=256, zeropad=1, mode="Peak", tolerance_st=0.5, bands=(0, 20),
             sinc_quality=32, resampling_mode="Sinc", device=None):
     """signal: float32 (n,) or (n, ch).  Returns dict with every intermediate the reference's GUI

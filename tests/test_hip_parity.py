@@ -1494,6 +1494,44 @@ def test_headless_cli_respeed_and_resample(par, golden, tmp_path):
     assert len(y3) == len(ref3) and relerr(y3[:, 0], ref3) < TOL
 
 
+def test_headless_cli_respeed_project(par, golden, tmp_path):
+    """8(f)-4 (r04): `cli respeed --project tape.spd` -- a saved pyrespeeder project with two traces, and one with a sine
+    regression on top (then the regressed curve is the one that resamples, pyrespeeder_gui.py:133-140).  The curves against
+    the ones the reference's own marker classes made of the same files (1e-7), the output against the reference's with its
+    exact curve (1e-5), and the CLI end to end."""
+    import json
+    import os
+    import shutil
+    from pyaudiorestoration_amd import cli, io_ops, pipeline
+    from test_oracle_golden import GOLD
+    g = golden["spd"]
+    f = str(tmp_path / "tape.flac")
+    shutil.copy(os.path.join(GOLD, "flutter_192.flac"), f)
+    x, sr, _ = io_ops.read_file(f)
+    for tag in ("traces", "reg"):
+        prj = os.path.join(GOLD, f"flutter_192_{tag}.spd")
+        cfg = json.load(open(prj))
+        curve = pipeline.project_speed_curve(cfg, len(x) / sr, sr)
+        assert curve.shape == g[tag + "_curve"].shape and relerr(curve[:, 1], g[tag + "_curve"][:, 1]) < 1e-7, tag
+        # the reference's exact curve through resampling.run
+        par.resampling.run((f,), signal_data=((x, sr),), speed_curve=np.array(g[tag + "_curve"]), resampling_mode="Sinc",
+                           sinc_quality=32, suffix="_exact_" + tag)
+        y, _, _ = io_ops.read_file(str(tmp_path / f"tape_res_exact_{tag}.wav"))
+        assert len(y) == int(g[tag + "_len_pos"]) and relerr(y[g[tag + "_sel"], 0], g[tag + "_y_sel"]) < TOL, tag
+        # the CLI: project -> curve -> output
+        assert cli.main(["respeed", "--project", prj, "--suffix", "_" + tag, f]) == 0
+        y2, sr2, ch2 = io_ops.read_file(str(tmp_path / f"tape_res_{tag}.wav"))
+        assert sr2 == sr and ch2 == 1 and len(y2) == int(g[tag + "_len_pos"])
+        assert relerr(y2[g[tag + "_sel"], 0], g[tag + "_y_sel"]) < P0_BACKEND_SPREAD, tag
+    # a project without markers is refused, a negative regression amplitude is a phase of pi (RegLine.__init__)
+    with pytest.raises(ValueError):
+        pipeline.project_speed_curve({"fft_size": 1024, "fft_overlap": 4, "lines": [], "regs": []}, 1.0, sr)
+    r = list(map(float, g["reg"]))
+    a = pipeline.master_reg_curve([r], len(x) / sr, sr, 256)
+    b = pipeline.master_reg_curve([[r[0], r[1], -r[2], r[3], r[4] - np.pi, r[5]]], len(x) / sr, sr, 256)
+    assert relerr(a[:, 1], b[:, 1]) < 1e-12
+
+
 # --------------------------------------------------------------------------------- round-2 additions
 def test_stereo_kernel_against_the_oracle(par, golden, tmp_path):
     """The stereo K_sinc form checked against the REFERENCE's arithmetic directly (not against the mono kernel):
