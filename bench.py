@@ -49,17 +49,21 @@ def cpu_baseline(sr, nt, budget_s=15.0):
         st, sp = C.synth_curve(m, seconds, float(sr))
         t0 = time.perf_counter()
         pos, _ = C.speed_to_pos(st, sp, n)
+        tp = time.perf_counter() - t0
         out = C.sinc(pos, sig, nt, threads=cores)
         dt = time.perf_counter() - t0
-        return len(out), dt
+        return len(out), dt, tp
 
-    n1, t1 = run(0.5)                               # probe
+    n1, t1, _ = run(0.5)                            # probe
     rate = n1 / t1
     seconds = max(1.0, min(600.0, budget_s * rate / sr))
-    n2, t2 = run(seconds)
+    n2, t2, tp2 = run(seconds)
     return {"value": round(n2 / t2 / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sinc_only_value": round(n2 / max(t2 - tp2, 1e-9) / 1e6, 3), "speed_to_pos_share": round(tp2 / t2, 3),
             "sample": f"{seconds:.1f} s of the same 192 kHz workload ({n2} output samples, {t2:.1f} s wall): "
-                      f"C speed_to_pos on 1 thread + C sinc on {cores} threads (contiguous chunks like sinc_wrapper_mt)"}
+                      f"C speed_to_pos on 1 thread ({100 * tp2 / t2:.0f} % of the wall time: the reference's own serial loop, "
+                      f"which caps this line) + C sinc on {cores} threads (contiguous chunks like sinc_wrapper_mt; "
+                      f"sinc_only_value = the interpolator alone)"}
 
 
 def stft_secondary(sig, dev, n_fft=1024, hop=256, cpu=True):
@@ -315,6 +319,8 @@ def config5_dry_run(a, ctx):
                           "data": "none (dry run: a sleep per file)", "config": {"workload": "config 5 flow, dry run", "files": a.files,
                                                                                  "channel_samples_per_step": int(total)},
                           "n1_same_workload_value": round(n1, 3), "speedup_vs_n1": round(value / n1, 3),
+                          "speedup_base": "n1_same_workload_value (the archive on one GPU, this run) -- the N = 1 line carries the "
+                                          "same quantity as archive_value",
                           "efficiency": round(value / n1 / ctx.world, 4)}), flush=True)
     ctx.close()
 
@@ -595,7 +601,14 @@ def main():
 
     for _ in range(a.warmup):
         step(False)
-    dt = ctx.timed(lambda: step(True), a.steps)        # barrier+sync | K steps | sync+barrier, MAX over ranks
+    step_marks = []                                    # host clock at the end of every timed step (the steps end in a header
+                                                       # read-back, i.e. a stream synchronisation: the marks are GPU-paced)
+
+    def timed_step():
+        step(True)
+        step_marks.append(time.perf_counter())
+    t_begin = time.perf_counter()
+    dt = ctx.timed(timed_step, a.steps)                # barrier+sync | K steps | sync+barrier, MAX over ranks
     total_per_step = ctx.reduce_sum(len_out.value)     # whole-job output samples per step
     if overlap:                                        # K_sinc durations of the timed steps (events on its own stream)
         for e0, e1 in ev_pairs:
@@ -607,7 +620,15 @@ def main():
             L.par_event_destroy(e1)
 
     if rank == 0:
-        ms_step = dt / a.steps * 1e3
+        ms_step_mean = dt / a.steps * 1e3
+        # per-step times from the marks (the first interval starts at the region's opening barrier); median of them
+        marks = [t_begin] + step_marks
+        per_step = sorted((b - a_) * 1e3 for a_, b in zip(marks[:-1], marks[1:]))
+        if len(per_step) >= 3:
+            per_step_mid = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
+        else:
+            per_step_mid = ms_step_mean
+        ms_step = per_step_mid
         value = total_per_step * a.steps / dt / 1e6
         n_launch = sum(sinc_launches)
         k_ms = sum(sinc_ms) / n_launch                      # average K_sinc launch duration (HIP events)
@@ -628,6 +649,9 @@ def main():
         res = {
             "metric": "Msamples/sec resampled (192 kHz varispeed)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
+            "ms_per_step_mean": round(ms_step_mean, 4),
+            "ms_per_step_note": "ms_per_step = median of the per-step times (SURVEY 8d); ms_per_step_mean = timed region / steps, "
+                                "the figure `value` is computed from",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 taps / f64 positions",
             "data": "synthetic",
             "config": {"workload": f"{a.seconds:g}-s {a.sr} Hz mono float32 varispeed resample, +-1% sinusoidal speed "
@@ -676,6 +700,14 @@ def main():
             res["secondary_config4"] = heal_secondary(dev)
             if hasattr(L, "par_varispeed_fused_stereo_f32"):        # absent only in an older build under PAR_HIP_LIB
                 res["secondary_config5"] = stereo_secondary(dev)
+                # the 1-GPU point of the --gpus N > 1 curve under a stable key: N > 1 lines time the config-5 archive (stereo
+                # files through the batch driver), not this line's mono file -- a scaling reader divides value(N) by THIS
+                res["archive_value"] = res["secondary_config5"]["batched_Msamples/s"]
+                res["archive_unit"] = "M channel-samples/s"
+                res["archive_ms_per_file"] = res["secondary_config5"]["batched_ms_per_file"]
+                res["archive_note"] = ("config-5 archive rate of ONE GPU (10-min 192 kHz stereo files through the batch driver, the "
+                                       "code path of --gpus N > 1): the base of the 1/2/4/8-GPU curve is archive_value here and "
+                                       "n1_same_workload_value in the N > 1 lines, never this line's `value`")
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(a.sr, a.nt)
         print(json.dumps(res), flush=True)

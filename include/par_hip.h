@@ -84,7 +84,8 @@ int par_stft_big_f32(int device, const float* x, int64_t n, int64_t x_stride, in
  *   frames   device f32 scratch of par_istft_scratch_floats(n_frames, n_fft, hop) floats; that is 0 (pass NULL)
  *            when the frames are overlap-added in LDS and never stored (n_fft <= 2048 and the overlap-add span of
  *            one workgroup fits 64 KB), else [n_frames][n_fft] (n_fft >= 4096: a frame fills the workgroup alone and the
- *            fused form would re-transform n_fft/hop frames per hop of output)
+ *            fused form would re-transform n_fft/hop frames per hop of output); n_fft > 8192 (to 2^21: the GUI's FFT sizes go
+ *            to 2^20, util/widgets.py:334-351): the frame array plus two complex arrays of the four-step transform
  *   y        device f32[y_len]; y[t] = ola[t + skip] / sumsq[t + skip] (0 beyond the ola length),
  *            skip = n_fft/2 and y_len = `length` reproduce fix_length(y[n_fft//2:], length) (:430-435).
  */

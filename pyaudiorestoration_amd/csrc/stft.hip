@@ -946,6 +946,39 @@ __global__ __launch_bounds__(FftGeom<LOGH>::Threads) void k_istft_frames(const f
   }
 }
 
+// ISTFT of frames above 8192 points (r04): the irfft of one frame through the four-step complex transform K_stft uses for
+// frames of that size (big_fft_c2c), `batch` frames at a time.
+//   k_ibig_pack    A[b][k] = conj(Z[k]),  Z[k] = ((X[k] + conj X[H-k]) + i e^(i pi k / H) (X[k] - conj X[H-k])) / 2   (k < H)
+//   big_fft_c2c    V = FFT_H(A);  z = conj(V) / H  is the packed frame: y[2 i] = Re z[i], y[2 i + 1] = Im z[i]
+//   k_ibig_unpack  frames[f][n] = window[n] y[n] sqrt(n_fft)      (util/fourier.py:359, :401), then k_istft_ola as below
+__global__ __launch_bounds__(256) void k_ibig_pack(const float2* __restrict__ spec, int64_t frame0, int64_t batch, int64_t H,
+                                                   float2* __restrict__ A) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= batch * H) return;
+  const int64_t b = t / H, k = t - b * H;
+  const float2* X = spec + (frame0 + b) * (H + 1);
+  float2 a = X[k], c = X[H - k];
+  if (k == 0) {                                    // numpy's irfft ignores the imaginary parts of the DC and Nyquist bins
+    a.y = 0.0f;
+    c.y = 0.0f;
+  }
+  c = cconj(c);
+  double sn, cs;
+  sincospi((double)k / (double)H, &sn, &cs);       // e^(+i pi k / H)
+  const float2 ev = cadd(a, c), df = csub(a, c);
+  const float2 od = make_float2((float)(cs * df.x - sn * df.y), (float)(cs * df.y + sn * df.x));
+  A[t] = make_float2(0.5f * (ev.x - od.y), -0.5f * (ev.y + od.x));          // conj((ev + i od) / 2)
+}
+
+__global__ __launch_bounds__(256) void k_ibig_unpack(const float2* __restrict__ V, int64_t frame0, int64_t batch, int64_t H,
+                                                     const float* __restrict__ window, float* __restrict__ frames, float scale) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= batch * H) return;
+  const int64_t b = t / H, i = t - b * H;
+  const float2 r = V[t];
+  reinterpret_cast<float2*>(frames)[(frame0 + b) * H + i] = make_float2(r.x * scale * window[2 * i], -r.y * scale * window[2 * i + 1]);
+}
+
 // ISTFT stage 2: gather-form overlap-add + window-sumsquare normalisation (no atomics):
 // y[t] = sum_f frames[f][T - f*hop] / sum_f win^2[T - f*hop],  T = t + skip   (:405-416)
 __global__ __launch_bounds__(256) void k_istft_ola(const float* __restrict__ frames, int64_t n_frames, int n_fft, int hop,
@@ -1171,8 +1204,16 @@ static inline bool istft_is_fused(int n_fft, int hop) {
 
 extern "C" {
 
+// frames per four-step batch of the big ISTFT: two complex arrays of batch x H points beside the frame array
+static int64_t istft_big_batch(int64_t n_frames, int n_fft) {
+  const int64_t H = n_fft / 2, want = (1ll << 22) / H;
+  const int64_t b = want < 1 ? 1 : want;
+  return b < n_frames ? b : n_frames;
+}
+
 int64_t par_istft_scratch_floats(int64_t n_frames, int n_fft, int hop) {
   if (n_frames < 1 || n_fft < 1 || hop < 1) return 0;
+  if (n_fft > 8192) return n_frames * (int64_t)n_fft + 4 * istft_big_batch(n_frames, n_fft) * (int64_t)(n_fft / 2) + 16;
   return par::istft_is_fused(n_fft, hop) ? 0 : n_frames * (int64_t)n_fft;
 }
 
@@ -1530,9 +1571,32 @@ int par_istft_f32(int device, const float* spec, int64_t n_frames, int n_fft, in
   using namespace par;
   PAR_REQUIRE(spec && window && y, PAR_ERR_ARG, "par_istft_f32: null pointer");
   PAR_REQUIRE(n_frames >= 1 && hop >= 1 && y_len >= 0 && skip >= 0, PAR_ERR_ARG, "par_istft_f32: bad sizes");
-  PAR_REQUIRE(n_fft >= 16 && n_fft <= 8192 && (n_fft & (n_fft - 1)) == 0, PAR_ERR_UNSUPPORTED,
-              "par_istft_f32: n_fft=%d is not a power of two in [16, 8192]", n_fft);
+  PAR_REQUIRE(n_fft >= 16 && n_fft <= (1 << 21) && (n_fft & (n_fft - 1)) == 0, PAR_ERR_UNSUPPORTED,
+              "par_istft_f32: n_fft=%d is not a power of two in [16, 2^21]", n_fft);
   PAR_HIP_CHECK(hipSetDevice(device));
+  if (n_fft > 8192) {                              // frames of the four-step size class (the GUI's FFT sizes go to 2^20)
+    PAR_REQUIRE(frames, PAR_ERR_ARG, "par_istft_f32: n_fft=%d needs the scratch of par_istft_scratch_floats", n_fft);
+    const int64_t H = n_fft / 2, B = istft_big_batch(n_frames, n_fft);
+    float2* A = reinterpret_cast<float2*>(frames + ((n_frames * (int64_t)n_fft + 3) & ~3ll));
+    float2* V = A + B * H;
+    const float scale = (float)(sqrt((double)n_fft) / (double)H);
+    for (int64_t f0 = 0; f0 < n_frames; f0 += B) {
+      const int64_t nb = n_frames - f0 < B ? n_frames - f0 : B;
+      hipLaunchKernelGGL(k_ibig_pack, dim3((unsigned)ceil_div(nb * H, 256)), dim3(256), 0, as_stream(stream),
+                         reinterpret_cast<const float2*>(spec), f0, nb, H, A);
+      int rc2 = big_fft_c2c(device, A, V, H, nb, as_stream(stream));
+      if (rc2 != PAR_OK) return rc2;
+      hipLaunchKernelGGL(k_ibig_unpack, dim3((unsigned)ceil_div(nb * H, 256)), dim3(256), 0, as_stream(stream), (const float2*)V,
+                         f0, nb, H, window, frames, scale);
+    }
+    PAR_HIP_CHECK(hipGetLastError());
+    if (y_len > 0) {
+      hipLaunchKernelGGL(k_istft_ola, dim3((unsigned)ceil_div(y_len, 256)), dim3(256), 0, as_stream(stream), frames, n_frames,
+                         n_fft, hop, window, y, y_len, skip);
+      PAR_HIP_CHECK(hipGetLastError());
+    }
+    return PAR_OK;
+  }
   Twiddles tw;
   int rc = get_twiddles(device, n_fft, &tw);
   if (rc != PAR_OK) return rc;

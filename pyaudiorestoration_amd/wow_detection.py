@@ -13,7 +13,8 @@ span).  `fit_sin` / `trace_sine_reg` keep their return contracts.  Everything el
 * Correlation: all frames in one K_track launch sequence (`par_track_corr_f64`): the quadratic-spline resampling as
   a small dense product with the spline's matrix, windowed cross-correlation and parabolic refinement per frame, the
   cumulative sum in order -- the spectrogram stays in HBM;
-* Partials needs librosa + an interactive matplotlib window and is not provided.
+* Partials (`PartialsTracker`): librosa.piptrack's parabolic peak picking on the device (`par_piptrack_f32`), the
+  reference's interactive matplotlib window left out; parity unpinned (librosa is not installed: builder's restatement).
 
 Reference semantics each piece reproduces are cited at the definitions.
 """

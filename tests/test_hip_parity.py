@@ -181,6 +181,26 @@ def test_istft_size_matrix_vs_oracle(par, n_fft, hop):
     assert (L.par_istft_scratch_floats(10, n_fft, hop) != 0) == (hop == 5000 or n_fft >= 4096)
 
 
+@pytest.mark.parametrize("n_fft,hop", [(16384, 4096), (65536, 16384), (1048576, 262144), (32768, 3000)])
+def test_istft_above_8192_points(par, n_fft, hop):
+    """r04: frames of the four-step size class (the GUI's FFT sizes go to 2^20, util/widgets.py:334-351): `istft` accepts what
+    `stft` produces.  irfft through big_fft_c2c + the frame array + the gather overlap-add, against the oracle's istft on a
+    modified spectrogram, and the stft -> istft round trip on the device."""
+    from oracle import oracle_np as O
+    n = 3 * n_fft + 12345
+    x = inputs.noise(n, 7 + (n_fft >> 14))
+    S = O.stft(x, n_fft, hop, "blackmanharris").astype(np.complex64)
+    S[1:n_fft // 8, ::2] *= 0.5
+    for length in (n, None):
+        want = O.istft(S, hop, "blackmanharris", length)
+        got = par.fourier.istft(S, hop_length=hop, length=length)
+        assert got.shape == want.shape and relerr(got, want) < TOL, (n_fft, hop, length, relerr(got, want))
+    xt = par.torch.from_numpy(x).cuda()
+    St = par.fourier.stft(xt, n_fft, hop)                         # four-step forward transform, stays in HBM
+    yt = par.fourier.istft(St, hop_length=hop, length=n)
+    assert relerr(yt.cpu().numpy(), x) < TOL
+
+
 def test_istft_single_frame_without_length_is_empty(par):
     """One frame and no explicit length: the reference trims n_fft/2 from both ends of an n_fft-long overlap-add and
     returns an empty array (found by tools/fuzz_stft.py: the device path used to reject the empty output buffer)."""
@@ -1442,9 +1462,11 @@ def test_bench_contract_line():
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     r = json.loads(lines[0])
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_mean", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "archive_value", "archive_ms_per_file"):
         assert k in r, k
+    assert r["archive_value"] == r["secondary_config5"]["batched_Msamples/s"] > 1000           # the base of the N-GPU curve
+    assert 0 < r["cpu_baseline"]["speed_to_pos_share"] < 1 and r["cpu_baseline"]["sinc_only_value"] >= r["cpu_baseline"]["value"]
     assert r["n_gpus"] == 1 and r["steps"] == 2 and r["scaling"] == "weak" and r["vs_baseline"] is None
     assert r["value"] > 1000 and "workload" in r["config"] and "model" not in r["config"]
     rl = r["roofline"]

@@ -75,8 +75,10 @@ def test_bench_gpus2_starts_its_own_ranks():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["dry_run"] is True and r["steps"] == 2 and r["warmup"] == 1
     assert r["config"]["channel_samples_per_step"] == 42 * 2 * 115_200_000      # every file exactly once per step
-    assert {"n1_same_workload_value", "speedup_vs_n1", "efficiency"} <= set(r)
+    assert {"n1_same_workload_value", "speedup_vs_n1", "efficiency", "speedup_base"} <= set(r)
     assert 1.2 < r["speedup_vs_n1"] < 2.3
+    # the curve's base is the ARCHIVE on one GPU (the N = 1 line's archive_value), never the mono file of that line's `value`
+    assert abs(r["speedup_vs_n1"] - r["value"] / r["n1_same_workload_value"]) < 2e-3 and "archive" in r["speedup_base"]
 
 
 def test_bench_refuses_a_world_that_differs_from_gpus():
