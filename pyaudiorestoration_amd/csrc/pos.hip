@@ -294,7 +294,10 @@ __global__ void __launch_bounds__(256) k_speed_sum(const double* __restrict__ sp
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) h->speed_sum = red[0];
+  if (threadIdx.x == 0) {
+    h->speed_sum = red[0];
+    h->pad2 = 0;                                 // the counter serves k_off_apply_trim next
+  }
 }
 
 // S_i = last element of np.cumsum(1/block_speeds): strictly sequential float64 adds, one lane per segment.
@@ -332,7 +335,7 @@ __device__ __forceinline__ bool long_segment(long long n, long long start, long 
 
 __global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
                                                  int64_t nseg, double* __restrict__ S, double* __restrict__ ck,
-                                                 int64_t ck_len, PlanHeader* __restrict__ h) {
+                                                 int64_t ck_len, PlanHeader* __restrict__ h, int count_long) {
   __shared__ double T[kWave][kCkRound + 1];
   __shared__ long long slot_of[kWave];
   __shared__ int n_ck[kWave];
@@ -353,6 +356,7 @@ __global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, c
       if (long_segment(n, start, i, ck, ck_len)) {      // the k_long_* kernels own this segment (S[i] included)
         is_long = true;
         n = 0;
+        if (count_long) atomicAdd(&h->n_long, 1);
       }
     } else {
       n = 0;
@@ -965,11 +969,10 @@ __global__ void k_publish_ck(PlanHeader* __restrict__ h, int64_t ck_len) {
 // Thread x serves two roles: segment x checks that its checkpoints fit and writes its SegFast record, tile x looks its
 // segment up (upper bound over seg_start: a tile per thread, not a segment per thread -- one segment can cover
 // 10^5..10^6 tiles).
-__global__ void k_tile_seg(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+__device__ __forceinline__ void tile_seg_body(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
                            const double* __restrict__ seg_off, int64_t nseg, const double* __restrict__ ck, int64_t ck_len,
                            int64_t max_tiles, int64_t* __restrict__ tile_seg, SegFast* __restrict__ seg_fast,
-                           long long* __restrict__ tile_st, TileHdr* __restrict__ hdr, PlanHeader* __restrict__ h) {
-  const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                           long long* __restrict__ tile_st, TileHdr* __restrict__ hdr, PlanHeader* __restrict__ h, const int64_t x) {
   const long long len_out = h->len_out;                // written by k_trim / the host path earlier on this stream
   const long long n_tiles = (len_out + kSincTileOutputs - 1) / kSincTileOutputs;
   if (n_tiles + 1 > max_tiles) {
@@ -1039,6 +1042,36 @@ __global__ void k_tile_seg(const double* __restrict__ sp, const int64_t* __restr
       hdr[x] = hd;
     }
   }
+}
+
+__global__ void k_tile_seg(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                           const double* __restrict__ seg_off, int64_t nseg, const double* __restrict__ ck, int64_t ck_len,
+                           int64_t max_tiles, int64_t* __restrict__ tile_seg, SegFast* __restrict__ seg_fast,
+                           long long* __restrict__ tile_st, TileHdr* __restrict__ hdr, PlanHeader* __restrict__ h) {
+  tile_seg_body(sp, seg_start, seg_off, nseg, ck, ck_len, max_tiles, tile_seg, seg_fast, tile_st, hdr, h,
+                (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// ... with k_publish_ck's header update as the epilogue of the last block to finish (r04)
+__global__ void k_tile_seg_publish(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                   const double* __restrict__ seg_off, int64_t nseg, const double* __restrict__ ck, int64_t ck_len,
+                                   int64_t max_tiles, int64_t* __restrict__ tile_seg, SegFast* __restrict__ seg_fast,
+                                   long long* __restrict__ tile_st, TileHdr* __restrict__ hdr, PlanHeader* __restrict__ h,
+                                   int64_t n_items) {
+  __shared__ int is_last;
+  for (int64_t x0 = (int64_t)blockIdx.x * blockDim.x; x0 < n_items; x0 += (int64_t)gridDim.x * blockDim.x)
+    tile_seg_body(sp, seg_start, seg_off, nseg, ck, ck_len, max_tiles, tile_seg, seg_fast, tile_st, hdr, h, x0 + threadIdx.x);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(&h->pad3, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!is_last || threadIdx.x != 0) return;
+  __threadfence();
+  h->pad3 = 0;
+  const int fl = __hip_atomic_load(&h->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  h->ck_len = ck_len;
+  h->ck_valid = (fl & ~kFlagCapAmbiguous) ? 0 : 1;
+  h->flags = fl & ~kFlagCkOverflow;
 }
 
 // ---- block records of the fused resampler (BlockRec, pos_plan.h) ---------------------------------------------------
@@ -1318,6 +1351,206 @@ __global__ void k_off_stitch(const double* __restrict__ S, const PElem* __restri
   h->n_runs = r;
 }
 
+// ---- fused stages of the device plan (r04) ----------------------------------------------------------------------------
+// Until r03 the plan was ~27 launches: every elementwise stage its own kernel around three-kernel scans, and a read-back
+// in the middle.  The elementwise stages now ride inside the scans' own passes (a block's reduce pass only needs the
+// block's elements, its apply pass has the running prefix at hand), single-thread epilogues run in the last block to
+// finish, and the read-back of the long-segment count is gone (a plan that turns out to hold long segments is simply made
+// again with the chunked-cumsum kernels in: sparse curves only, a few hundred segments).  Same arithmetic, bit for bit.
+__device__ __forceinline__ U128 want_fixed(const double* __restrict__ st, const double* __restrict__ sp, int64_t i, bool* bad) {
+  const double period = st[i + 1] - st[i];
+  const double mean = (sp[i] + sp[i + 1]) / 2.0;
+  const double a = period * mean;
+  U128 e{0ull, 0ull};
+  if (!(a >= 0x1p-11 && a < 0x1p62)) {
+    *bad = true;
+  } else {
+    const double ip = floor(a);
+    e.hi = (unsigned long long)ip;
+    e.lo = (unsigned long long)((a - ip) * 0x1p64);     // exact: < 2^64, at most 64 fractional bits
+  }
+  return e;
+}
+
+// lengths, pass 1: a_i in 64.64 fixed point on the fly, block sums; the header is initialised here by block 0 before any
+// flag can be raised?  No: flags are raised by any block, so the header is initialised by k_init_header in front.
+// Also the per-wave partial sums of the speed samples for the reference's buffer bound (k_speed_sum's role).
+__global__ __launch_bounds__(kScanThreads) void k_len_reduce(const double* __restrict__ st, const double* __restrict__ sp,
+                                                              int64_t nseg, U128* __restrict__ bsum, double* __restrict__ partial,
+                                                              PlanHeader* __restrict__ h) {
+  __shared__ U128 smem[kScanThreads / kWave];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  U128 acc = AddU128::identity();
+  bool bad = false;
+  double s = 0.0, c = 0.0;                           // Kahan over this thread's speed samples (m = nseg + 1 of them)
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < nseg) acc = AddU128::combine(acc, want_fixed(st, sp, base + k, &bad));
+    if (base + k <= nseg) {
+      const double y = sp[base + k] - c;
+      const double t = s + y;
+      c = (t - s) - y;
+      s = t;
+    }
+  }
+  if (bad) atomicOr(&h->flags, kFlagRange);
+  U128 total;
+  block_exclusive<AddU128>(acc, smem, &total);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) partial[blockIdx.x * (kScanThreads / kWave) + threadIdx.x / kWave] = s;
+}
+
+// lengths, pass 2 (one block): exclusive scan of the block sums; the speed sum from the per-wave partials
+__global__ __launch_bounds__(kScanThreads) void k_len_top(U128* __restrict__ bsum, int64_t nb, const double* __restrict__ partial,
+                                                           int64_t n_part, PlanHeader* __restrict__ h) {
+  __shared__ U128 smem[kScanThreads / kWave];
+  __shared__ double red[kScanThreads];
+  U128 carry = AddU128::identity();
+  for (int64_t t0 = 0; t0 < nb; t0 += kScanTile) {
+    const int64_t base = t0 + (int64_t)threadIdx.x * kScanItems;
+    U128 v[kScanItems];
+    U128 acc = AddU128::identity();
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      v[k] = (base + k < nb) ? bsum[base + k] : AddU128::identity();
+      acc = AddU128::combine(acc, v[k]);
+    }
+    U128 total;
+    U128 run = AddU128::combine(carry, block_exclusive<AddU128>(acc, smem, &total));
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      if (base + k < nb) bsum[base + k] = run;
+      run = AddU128::combine(run, v[k]);
+    }
+    carry = AddU128::combine(carry, total);
+  }
+  double s = 0.0, c = 0.0;
+  for (int64_t i = threadIdx.x; i < n_part; i += blockDim.x) {
+    const double y = partial[i] - c;
+    const double t = s + y;
+    c = (t - s) - y;
+    s = t;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = kScanThreads / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) h->speed_sum = red[0];
+}
+
+// lengths, pass 3: the running 64.64 sum at every segment -> n_i = round(A_i) - round(A_{i-1}), seg_start (k_seg_lengths)
+__global__ __launch_bounds__(kScanThreads) void k_len_apply(const double* __restrict__ st, const double* __restrict__ sp,
+                                                             int64_t nseg, const U128* __restrict__ bsum,
+                                                             int64_t* __restrict__ seg_start, PlanHeader* __restrict__ h) {
+  __shared__ U128 smem[kScanThreads / kWave];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  U128 v[kScanItems];
+  U128 acc = AddU128::identity();
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (base + k < nseg) ? want_fixed(st, sp, base + k, &bad) : AddU128::identity();
+    acc = AddU128::combine(acc, v[k]);
+  }
+  U128 total;
+  U128 run = AddU128::combine(bsum[blockIdx.x], block_exclusive<AddU128>(acc, smem, &total));
+  int f = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t i = base + k;
+    const U128 prev = run;                          // A_{i-1}
+    run = AddU128::combine(run, v[k]);              // A_i
+    if (i >= nseg) continue;
+    bool amb = false;
+    const unsigned long long Ni = round_fixed(run, &amb);
+    const unsigned long long Np = i > 0 ? round_fixed(prev, &amb) : 0ull;
+    seg_start[i] = (int64_t)Np;
+    if (i == nseg - 1) {
+      seg_start[nseg] = (int64_t)Ni;
+      h->total_written = (int64_t)Ni;
+    }
+    if (amb) f |= kFlagAmbiguous;
+    if (Ni < Np + 2ull) atomicMin(&h->first_bad, (unsigned long long)i);
+  }
+  if (f) atomicOr(&h->flags, f);
+}
+
+// offsets, pass 1: block sums of the plain float64 scan of S (the prediction of the offsets' binades)
+__global__ __launch_bounds__(kScanThreads) void k_offs_reduce(const double* __restrict__ S, int64_t nseg, double* __restrict__ bsum) {
+  __shared__ double smem[kScanThreads / kWave];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (base + k < nseg) acc = acc + S[base + k];
+  double total;
+  block_exclusive<AddF64>(acc, smem, &total);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+// the parity-translation element of step i from the approximate offsets around it (k_off_prepare's body)
+__device__ __forceinline__ PElem off_element(double xa, double xb, double Si, bool* interior_out) {
+  const double lo = 1.0 - 0x1p-30, hi = 1.0 + 0x1p-30;
+  const int e = f64_exponent(xa);
+  bool interior = xa > 0.0 && Si > 0.0 && e > 64 && e < 2046 && f64_exponent(xa * lo) == e &&
+                  f64_exponent(xa * hi) == e && f64_exponent(xb * lo) == e && f64_exponent(xb * hi) == e;
+  PElem p{0, 0, 0, 0};
+  if (interior) {
+    const double t = ldexp(Si, 1075 - e);
+    if (t < 0x1p62) {
+      const double fl = floor(t);
+      const long long q = (long long)fl;
+      const double fr = t - fl;                // exact
+      if (fr > 0.5) p.c0 = p.c1 = q + 1;
+      else if (fr < 0.5) p.c0 = p.c1 = q;
+      else {                                   // exact half: ties-to-even on the SUM's parity
+        p.c0 = q + (q & 1);
+        p.c1 = q + ((q + 1) & 1);
+      }
+    } else {
+      interior = false;
+    }
+  }
+  *interior_out = interior;
+  return p;
+}
+
+// offsets, pass 3 of the float64 scan fused with k_off_prepare: the running sum in front of and behind every step is the
+// approximate offset there (a PREDICTION of its binade, verified later by k_off_apply: any accurate association of the
+// sum serves), from which the step's parity-translation element follows -- or the step is listed `direct`.
+__global__ __launch_bounds__(kScanThreads) void k_offs_elements(const double* __restrict__ S, const double* __restrict__ st,
+                                                                 int64_t nseg, const double* __restrict__ bsum_f,
+                                                                 PElem* __restrict__ el, long long* __restrict__ direct,
+                                                                 PlanHeader* __restrict__ h) {
+  __shared__ double smem_f[kScanThreads / kWave];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  double v[kScanItems];
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (base + k < nseg) ? S[base + k] : 0.0;
+    acc = acc + v[k];
+  }
+  double total;
+  double run = bsum_f[blockIdx.x] + block_exclusive<AddF64>(acc, smem_f, &total);     // sum of the steps in front of `base`
+  const double st0 = st[0];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t i = base + k;
+    const double xa = st0 + run;
+    run = run + v[k];
+    if (i >= nseg) continue;
+    bool interior;
+    PElem p = off_element(xa, st0 + run, v[k], &interior);
+    if (!interior) mark_direct(i, direct, h);
+    el[i] = p;
+  }
+}
+
 // offsets for every segment, verification of the binade prediction, end-trim detection (:129)
 __global__ void k_off_apply(const double* __restrict__ sp, const PElem* __restrict__ E, const RunEntry* __restrict__ runs,
                             int64_t nseg, double n_in, double* __restrict__ seg_off, PlanHeader* __restrict__ h) {
@@ -1345,11 +1578,10 @@ __global__ void k_off_apply(const double* __restrict__ sp, const PElem* __restri
   if (first <= n_in && n_in <= xn) atomicMin(&h->trim_seg, (unsigned long long)i);
 }
 
-// np.argmin |pos - n_in| inside the trim segment (first occurrence), header finalisation
-__global__ void k_trim(const double* __restrict__ st, const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
-                       const double* __restrict__ seg_off, int64_t m, double n_in, const double* __restrict__ ck,
-                       int64_t ck_len, PlanHeader* __restrict__ h) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// np.argmin |pos - n_in| inside the trim segment (first occurrence), header finalisation (one thread)
+__device__ __forceinline__ void trim_body(const double* __restrict__ st, const double* __restrict__ sp,
+                                          const int64_t* __restrict__ seg_start, const double* __restrict__ seg_off, int64_t m,
+                                          double n_in, const double* __restrict__ ck, int64_t ck_len, PlanHeader* __restrict__ h) {
   const int64_t nseg = m - 1;
   // int(np.mean(speeds) * (st[-1]-st[0]) * 1.01)  (:108)
   // speed_sum (k_speed_sum) and numpy's pairwise sum each sit within ~2.5e-15 (relative) of the true sum.  Only
@@ -1397,6 +1629,53 @@ __global__ void k_trim(const double* __restrict__ st, const double* __restrict__
     h->written = h->total_written;
   }
   h->len_out = len;
+}
+
+__global__ void k_trim(const double* __restrict__ st, const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                       const double* __restrict__ seg_off, int64_t m, double n_in, const double* __restrict__ ck,
+                       int64_t ck_len, PlanHeader* __restrict__ h) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  trim_body(st, sp, seg_start, seg_off, m, n_in, ck, ck_len, h);
+}
+
+// k_off_apply with k_trim as the epilogue of the last block to finish (r04).  Grid-stride over the segments with at most 512
+// blocks: every block ends with ONE atomic on the header's counter, and thousands of them serialise on that word (measured:
+// 0.4 ms for the 10 548 blocks of a 2.7 M-segment curve).
+__global__ __launch_bounds__(256) void k_off_apply_trim(const double* __restrict__ st, const double* __restrict__ sp,
+                                                        const PElem* __restrict__ E, const RunEntry* __restrict__ runs,
+                                                        const int64_t* __restrict__ seg_start, int64_t nseg, double n_in,
+                                                        double* __restrict__ seg_off, const double* __restrict__ ck,
+                                                        int64_t ck_len, PlanHeader* __restrict__ h) {
+  __shared__ int is_last;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nseg; i += (int64_t)gridDim.x * blockDim.x) {
+    const int nr = h->n_runs;
+    int lo = 0, hi = nr - 1;                     // last run with start <= i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (runs[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const long long a = runs[lo].start;
+    const double xa = runs[lo].x;
+    const double xi = (i == a) ? xa : apply_elem(E[i - 1], xa);
+    const bool is_direct = runs[lo + 1].start == i + 1;      // step i ends its run
+    const double xn = is_direct ? runs[lo + 1].x : apply_elem(E[i], xa);
+    seg_off[i] = xi;
+    if (i == nseg - 1) seg_off[nseg] = xn;
+    if (!is_direct) {
+      const int e = f64_exponent(xa);
+      if (f64_exponent(xi) != e || f64_exponent(xn) != e) atomicOr(&h->flags, kFlagVerify);
+    }
+    const double first = 1.0 / sp[i] + xi;       // k = 0: bs = 0/(n-1)*ds + s0 = s0
+    if (first <= n_in && n_in <= xn) atomicMin(&h->trim_seg, (unsigned long long)i);
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(&h->pad2, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!is_last || threadIdx.x != 0) return;
+  __threadfence();                               // acquire: the other blocks' seg_off and header atomics
+  h->pad2 = 0;
+  trim_body(st, sp, seg_start, seg_off, nseg + 1, n_in, ck, ck_len, h);
 }
 
 // pos[start_i + k] = cumsum_k + offset_i  (:125).  One lane per segment; each wave transposes 64 x 16
@@ -1665,22 +1944,31 @@ extern "C" {
 size_t par_speed_plan_bytes(int64_t m) { return par::plan_bytes(m < 2 ? 2 : m); }
 
 // Per-segment reciprocal sums (+ checkpoints): one lane per ordinary segment, the chunked exact path for long ones.
+// mode 0: count the long segments, read the count back and run the chunked-cumsum kernels if there are any (the serial-path
+//         plans: a stream synchronisation in the middle);
+// mode 1: k_seg_sum counts its long segments itself and nothing else happens here -- the caller finds the count in the
+//         header it reads at the end of the plan and, if it is not zero, makes the plan again in mode 2;
+// mode 2: the chunked-cumsum kernels unconditionally.
 static int launch_seg_sums(const double* speeds, const par::PlanView& pv, int64_t nseg, double* ck, int64_t ck_len,
-                            int64_t max_out, int64_t m, hipStream_t s) {
+                            int64_t max_out, int64_t m, hipStream_t s, int mode = 0) {
   using namespace par;
   const unsigned g256 = (unsigned)ceil_div(nseg, 256);
-  if (ck) hipLaunchKernelGGL(k_count_long, dim3(g256), dim3(256), 0, s, pv.seg_start, nseg, (const double*)ck, ck_len, pv.hdr);
+  if (ck && mode == 0) hipLaunchKernelGGL(k_count_long, dim3(g256), dim3(256), 0, s, pv.seg_start, nseg, (const double*)ck, ck_len, pv.hdr);
   hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.S, ck,
-                     ck_len, pv.hdr);
-  if (!ck) return PAR_OK;
+                     ck_len, pv.hdr, mode != 0 ? 1 : 0);
+  if (!ck || mode == 1) return PAR_OK;
+  if (mode == 2) goto long_kernels;
   // Curves without a long segment (every dense curve) skip the nine chunked-cumsum launches: one 4-byte read-back,
   // issued behind k_seg_sum so the GPU stays busy while the host waits.  (It is not only the launches: under a
   // concurrent K_sinc the side stream is served well for about a millisecond and then starves until K_sinc
   // drains -- measured --, so a plan that is to hide under the previous file's K_sinc has to be short.)
-  int n_long = 0;
-  PAR_HIP_CHECK(hipMemcpyAsync(&n_long, &pv.hdr->n_long, sizeof(int), hipMemcpyDeviceToHost, s));
-  PAR_HIP_CHECK(hipStreamSynchronize(s));
-  if (n_long == 0) return PAR_OK;
+  {
+    int n_long = 0;
+    PAR_HIP_CHECK(hipMemcpyAsync(&n_long, &pv.hdr->n_long, sizeof(int), hipMemcpyDeviceToHost, s));
+    PAR_HIP_CHECK(hipStreamSynchronize(s));
+    if (n_long == 0) return PAR_OK;
+  }
+long_kernels:
   const long long G = max_out / kLongChunk + m + 8;                 // bound on the global chunk slots
   const long long GW = G / kWinSlotDiv + 8;                         // ... and on the global window slots
   const unsigned gc = (unsigned)ceil_div(G, 256), gs = (unsigned)(nseg < 2048 ? nseg : 2048),
@@ -1738,16 +2026,21 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
   // recurrence is redone serially on the host in the reference's own float64 order, everything else -- the O(len_out)
   // reciprocal sums, offsets, trim, checkpoints -- stays on the device.
   bool host_made_lengths = false;
+  bool with_long = false;                       // the plan holds long segments: found out from the header of the first go
   for (int attempt = 0; attempt < 2 && !need_host; ++attempt) {
     const unsigned g256 = (unsigned)ceil_div(nseg, 256);
+    const unsigned nbs = (unsigned)ceil_div(nseg, kScanTile), nbm = (unsigned)ceil_div(m, kScanTile);
+    double* scratch_f = pv.xs;                  // per-wave speed partials, later the float64 scan's block sums (xs itself is gone)
     hipLaunchKernelGGL(k_init_header, dim3(1), dim3(1), 0, s, pv.hdr, m);
     int rc;
     if (attempt == 0) {
-      U128* fix = reinterpret_cast<U128*>(pv.scan);
-      hipLaunchKernelGGL(k_seg_want, dim3(g256), dim3(256), 0, s, sampletimes, speeds, nseg, fix, pv.hdr);
-      rc = inclusive_scan<AddU128>(fix, nseg, reinterpret_cast<U128*>(pv.bsum), s);
-      if (rc != PAR_OK) return rc;
-      hipLaunchKernelGGL(k_seg_lengths, dim3(g256), dim3(256), 0, s, fix, nseg, pv.seg_start, pv.hdr);
+      // lengths: the 64.64 fixed-point scan with k_seg_want / k_seg_lengths / k_speed_sum inside its passes (3 launches)
+      U128* bsum = reinterpret_cast<U128*>(pv.bsum);
+      hipLaunchKernelGGL(k_len_reduce, dim3(nbm), dim3(kScanThreads), 0, s, sampletimes, speeds, nseg, bsum, scratch_f, pv.hdr);
+      hipLaunchKernelGGL(k_len_top, dim3(1), dim3(kScanThreads), 0, s, bsum, (int64_t)nbs, (const double*)scratch_f,
+                         (int64_t)nbm * (kScanThreads / kWave), pv.hdr);
+      hipLaunchKernelGGL(k_len_apply, dim3(nbs), dim3(kScanThreads), 0, s, sampletimes, speeds, nseg, (const U128*)bsum,
+                         pv.seg_start, pv.hdr);
     } else {
       bool lengths_ok = false;
       rc = host_lengths(pv, sampletimes, speeds, m, s, &lengths_ok);
@@ -1757,35 +2050,43 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
         break;
       }
       host_made_lengths = true;
+      hipLaunchKernelGGL(k_speed_sum, dim3((unsigned)(m / 4096 + 1)), dim3(256), 0, s, speeds, m,
+                         reinterpret_cast<double*>(pv.bsum), pv.hdr);
     }
-    hipLaunchKernelGGL(k_speed_sum, dim3((unsigned)(m / 4096 + 1)), dim3(256), 0, s, speeds, m,
-                       reinterpret_cast<double*>(pv.bsum), pv.hdr);     // bsum is idle between two scans
-    rc = launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s);
+    rc = launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s, with_long ? 2 : 1);
     if (rc != PAR_OK) return rc;
-    PAR_HIP_CHECK(hipMemcpyAsync(pv.xs, pv.S, nseg * sizeof(double), hipMemcpyDeviceToDevice, s));
-    rc = inclusive_scan<AddF64>(pv.xs, nseg, reinterpret_cast<double*>(pv.bsum), s);
-    if (rc != PAR_OK) return rc;
+    // offsets: float64 scan of S (its apply pass makes the parity-translation elements), heads, ComposeP scan (its apply
+    // pass ends with the stitch), then the offsets themselves with the trim as epilogue: 8 launches
     PElem* el = reinterpret_cast<PElem*>(pv.scan);
-    hipLaunchKernelGGL(k_off_prepare, dim3(g256), dim3(256), 0, s, pv.S, pv.xs, sampletimes, nseg, el, pv.direct, pv.hdr);
+    hipLaunchKernelGGL(k_offs_reduce, dim3(nbs), dim3(kScanThreads), 0, s, (const double*)pv.S, nseg, scratch_f);
+    hipLaunchKernelGGL(k_scan_top<AddF64>, dim3(1), dim3(kScanThreads), 0, s, scratch_f, (int64_t)nbs);
+    hipLaunchKernelGGL(k_offs_elements, dim3(nbs), dim3(kScanThreads), 0, s, (const double*)pv.S, sampletimes, nseg,
+                       (const double*)scratch_f, el, pv.direct, pv.hdr);
     hipLaunchKernelGGL(k_off_heads, dim3((kMaxDirect + 255) / 256), dim3(256), 0, s, el, nseg, pv.direct, pv.hdr);
-    rc = inclusive_scan<ComposeP>(el, nseg, reinterpret_cast<PElem*>(pv.bsum), s);
-    if (rc != PAR_OK) return rc;
+    hipLaunchKernelGGL(k_scan_reduce<ComposeP>, dim3(nbs), dim3(kScanThreads), 0, s, (const PElem*)el, nseg,
+                       reinterpret_cast<PElem*>(pv.bsum));
+    hipLaunchKernelGGL(k_scan_top<ComposeP>, dim3(1), dim3(kScanThreads), 0, s, reinterpret_cast<PElem*>(pv.bsum), (int64_t)nbs);
+    hipLaunchKernelGGL(k_scan_apply<ComposeP>, dim3(nbs), dim3(kScanThreads), 0, s, el, nseg, (const PElem*)pv.bsum);
     hipLaunchKernelGGL(k_off_stitch, dim3(1), dim3(1), 0, s, pv.S, el, sampletimes, nseg, pv.direct, pv.runs, pv.hdr);
-    hipLaunchKernelGGL(k_off_apply, dim3(g256), dim3(256), 0, s, speeds, el, pv.runs, nseg, (double)n_in, pv.seg_off,
-                       pv.hdr);
-    hipLaunchKernelGGL(k_trim, dim3(1), dim3(1), 0, s, sampletimes, speeds, pv.seg_start, pv.seg_off, m, (double)n_in,
+    hipLaunchKernelGGL(k_off_apply_trim, dim3(g256 < 512u ? g256 : 512u), dim3(256), 0, s, sampletimes, speeds, (const PElem*)el,
+                       (const RunEntry*)pv.runs, (const int64_t*)pv.seg_start, nseg, (double)n_in, pv.seg_off,
                        (const double*)ck, ck_len, pv.hdr);
     if (aux) {
-      hipLaunchKernelGGL(k_tile_seg, dim3((unsigned)ceil_div(std::max<int64_t>(nseg, max_tiles), 256)), dim3(256), 0, s,
+      const int64_t n_items = std::max<int64_t>(nseg, max_tiles);
+      hipLaunchKernelGGL(k_tile_seg_publish, dim3((unsigned)std::min<int64_t>(ceil_div(n_items, 256), 512)), dim3(256), 0, s,
                          speeds, pv.seg_start, pv.seg_off, nseg, (const double*)ck, ck_len, max_tiles,
                          reinterpret_cast<int64_t*>(ck + ck_len), reinterpret_cast<SegFast*>(ck + ck_len + max_tiles),
-                         fused_aux_view(aux, max_out, m).tile_st, fused_aux_view(aux, max_out, m).hdr, pv.hdr);
-      hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
+                         fused_aux_view(aux, max_out, m).tile_st, fused_aux_view(aux, max_out, m).hdr, pv.hdr, n_items);
       launch_block_rec(speeds, pv, nseg, aux, max_out, m, s);
     }
     PAR_HIP_CHECK(hipGetLastError());
     PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
     PAR_HIP_CHECK(hipStreamSynchronize(s));
+    if (h.n_long > 0 && !with_long) {           // sparse curve: once more, with the chunked exact cumsum of its long segments
+      with_long = true;
+      --attempt;
+      continue;
+    }
     if (h.flags & kFlagCapAmbiguous) {
       // Only the buffer bound is in doubt: settle int(mean * span * 1.01) with numpy's own pairwise order on the host
       // (one D2H of the speed samples); everything else the device computed stands.
