@@ -29,12 +29,13 @@
 #include "sinc_taps_gen.h"
 #include "sinc_common.h"
 #include <limits.h>
+#include <type_traits>
 
 #ifndef PAR_S2_TILES
 #define PAR_S2_TILES 8          // tiles per wave
 #endif
 #ifndef PAR_S2_WAVES
-#define PAR_S2_WAVES 3          // waves per SIMD the kernel is built for (registers <= 512 / this)
+#define PAR_S2_WAVES 2          // waves per SIMD the kernel is built for (registers <= 512 / this)
 #endif
 #ifndef PAR_S2_EXP
 #define PAR_S2_EXP 0            // timing builds, never shipped: 1 no MFMAs, 2 no near taps, 4 no stores, 8 no conversion, 16 unity maths on every pass
@@ -61,11 +62,14 @@ struct S2Lds {
   float4v qx[kPass];                             // .x = e2|d2 of x / A (halves), .y = e2|d2 of B, .z = H(A), .w = H(B) (float32 bits)
   uint4 recs[16];                                // block records of the pass: [0..7] first pieces, [8..15] second pieces
   float qy[kPass];                             // H1'(A) | H1'(B) (halves)
+#ifdef PAR_S2_LDS_PAD
+  char pad[PAR_S2_LDS_PAD];                      // (occupancy experiments)
+#endif
 };
 static_assert(offsetof(S2Lds, img) % 16 == 0 && offsetof(S2Lds, qa) % 16 == 0, "16-byte aligned fragments");
 
 #if PAR_S2_EXP & 64
-__device__ unsigned long long* g_s2_phase;       // [waves][8] cycle sums per phase (timing builds only)
+__device__ unsigned long long* g_s2_phase;       // [waves][16] cycle sums per phase (timing builds only)
 #define S2_MARK(k)                                              \
   do {                                                          \
     const unsigned long long now_ = __builtin_readcyclecounter(); \
@@ -101,8 +105,11 @@ __device__ __forceinline__ float sinpi_poly(float z) {       // sin(pi x) / x as
 
 // hi part of the float16 split.  The matrix cores flush subnormal float16 operands to zero (measured: a modulated image lost
 // its samples below 6.1e-5 near the modulator's zero crossings, 2e-5 of the peak): below float16's normal range the hi part is
-// zero and the lo part (x 4096) carries the value.
+// zero and the lo part (x 4096) carries the value.  (Switching the wave to flush float16 subnormals, MODE.FP_DENORM[3:2] = 0,
+// would make the conversions do this for free -- tools/exp/denorm_mode.hip -- but the bank's packed e2 / d2 halves of a quiet
+// passage ARE subnormal and must survive: 7.7e-5 of the block's peak on the 'loud next to quiet' test with the mode set.)
 __device__ __forceinline__ _Float16 hi16(float x) { return (_Float16)(fabsf(x) < 6.103515625e-05f ? 0.0f : x); }
+#define S2_HI(x) hi16(x)
 
 __device__ __forceinline__ unsigned pack_h2(float a, float b) {
   const half2v h = {(_Float16)a, (_Float16)b};
@@ -181,53 +188,31 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ __forceinline__ int clamp64(int n) { return n < 0 ? 0 : (n > 64 ? 64 : n); }
 __device__ __forceinline__ unsigned long long prefix(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }   // 0 <= n <= 64
 
-struct S2Place {                                 // what placement hands to the rest of the pass
-  int c[2];                                      // window centres, relative to A0
-  float s[2], ep[2];                             // sub-sample shift; max(period - 1, 0)
-  unsigned long long bad_here, bad_next, gen;    // lanes outside the record model / tie margin (this tile, next tile); lanes with fc < 1
+// Placement of one row (64 consecutive outputs, lane l) from its block records (pos_plan.h BlockRec): window centre relative
+// to A0, sub-sample shift, max(period - 1, 0); `bad` = the lane's block leaves the plain record model (a slow piece, the cubic
+// term) or its centre lies within the reference's own rounding of a tie -- such tiles go to the block kernel.
+struct S2Row {
+  int c;
+  float s, ep;
+  bool bad;
 };
-
-// Placement of the pass's outputs j0 + 64 r + l from their block records (pos_plan.h BlockRec).  EDGE = false: the whole pass
-// lies inside one tile and inside the wave's range (7 passes of 8) -- no lane sets, one anchor.
-template <bool EDGE>
-__device__ __forceinline__ void s2_place(const uint4 (&ra)[2], const uint4 (&rb)[2], const int u, const int l, const float tolf,
-                                         const int dA0, const int dA1, const int (&nv)[2], const int (&nt)[2], S2Place& P) {
-  const int uc = u - kRec / 2;
-  const float uf = (float)uc, u2f = uf * uf, tw1 = fmaf(2.0f, uf, 1.0f);
-  const bool any_cubic = __ballot(((ra[0].x | ra[1].x) & kRecCubic) != 0u) != 0ull;
-  P.bad_here = P.bad_next = P.gen = 0ull;
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const unsigned m = ra[r].x;
-    const bool second = (unsigned)u > (m & 31u);
-    const uint4 q = second ? rb[r] : ra[r];
-    const float F = __uint_as_float(q.y), e1 = __uint_as_float(q.z), e2 = __uint_as_float(q.w);
-    const bool last = (unsigned)u == ((m >> kRecLastShift) & 63u);
-    float frac = fmaf(u2f, e2, fmaf(uf, e1, F));
-    float e = fmaf(e2, last ? tw1 - 2.0f : tw1, e1);             // period to the next position, minus 1
-    if (any_cubic && (m & kRecCubic)) {          // steeper ramps: e3 = (4/3) e2^2 / (1 + e1)
-      const float e3 = 1.33333333f * e2 * e2 * (1.0f - e1);
-      frac = fmaf(u2f * uf, e3, frac);
-      e = fmaf(e3, fmaf(3.0f, u2f, fmaf(last ? -3.0f : 3.0f, uf, 1.0f)), e);
-    }
-    const float ri = rintf(frac);
-    const float sh = frac - ri;
-    const int dA = EDGE ? (l < nt[r] ? dA0 : dA1) : dA0;
-    P.c[r] = dA + ((int)q.x >> 16) + uc + (int)ri;
-    P.s[r] = sh;
-    P.ep[r] = fmaxf(e, 0.0f);
-    // a block outside the record model (either piece), or a centre within the reference's own rounding of a tie
-    const unsigned long long bad = __ballot((m & (kRecSlow0 | kRecSlow1)) != 0u || !(fabsf(fabsf(sh) - 0.5f) > tolf));
-    const unsigned long long gen = __ballot(1.0f + P.ep[r] != 1.0f);
-    if (EDGE) {
-      P.bad_here |= bad & prefix(nv[r] < nt[r] ? nv[r] : nt[r]);
-      P.bad_next |= bad & prefix(nv[r]) & ~prefix(nt[r]);
-      P.gen |= gen & prefix(nv[r]);
-    } else {
-      P.bad_here |= bad;
-      P.gen |= gen;
-    }
-  }
+__device__ __forceinline__ S2Row s2_place_row(const uint4 ra, const uint4 rb, const int u, const int cbase, const float uf,
+                                              const float u2f, const float tw1, const float tw0, const float tolf) {
+  const unsigned m = ra.x;
+  const bool second = (unsigned)u > (m & 31u);
+  const float F = __uint_as_float(second ? rb.y : ra.y), e1 = __uint_as_float(second ? rb.z : ra.z),
+              e2 = __uint_as_float(second ? rb.w : ra.w);
+  const int irel = (int)(second ? rb.x : ra.x) >> 16;
+  const bool last = (unsigned)u == ((m >> kRecLastShift) & 63u);
+  const float frac = fmaf(u2f, e2, fmaf(uf, e1, F));
+  const float e = fmaf(e2, last ? tw0 : tw1, e1);               // period to the next position, minus 1
+  const float ri = rintf(frac);
+  S2Row o;
+  o.s = frac - ri;
+  o.c = cbase + irel + (int)ri;
+  o.ep = __builtin_amdgcn_fmed3f(e, 0.0f, 3.0e38f);             // max(e, 0) in one instruction
+  o.bad = (m & (kRecSlow0 | kRecSlow1 | kRecCubic)) != 0u || !(fabsf(fabsf(o.s) - 0.5f) > tolf);
+  return o;
 }
 
 __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Args a) {
@@ -269,8 +254,7 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
   int j0 = 0;                                    // next output
   int wbase = 0, conv_next = 0, dma_next = 0, dma_bad = INT_MAX, mode = 0;   // mode: 0 none, 1 plain image (fc = 1), 2 modulated images
   float g0 = 0.0f;
-  // tile state: refreshed when j0 crosses a tile border
-  int tend = 0, dA0 = 0, dA1 = 0, fl0 = 0, fl1 = 0;
+  int tend = 0, dA0 = 0, dA1 = 0, fl0 = 0, fl1 = 0;      // tile state: refreshed when j0 crosses a tile border
   // results of the previous pass: stored one pass late, behind the wait for this pass's records -- gfx950 counts loads and
   // stores in ONE counter, and a wave that waits for a load it issued behind a store waits for the store as well
   float res_p[2] = {0.0f, 0.0f};
@@ -306,103 +290,86 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
   };
   // the file's last, partial tile belongs to the block kernel
   if (blockIdx.x == 0 && a.n_full < a.n_tiles) push_tile(a.n_full);
+  const int lbank = ((l & 15) * 8 + (l >> 4) * 8) * 2;            // this lane's byte offset inside a fragment row of the images
 
 #if PAR_S2_EXP & 64
-  unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_ = __builtin_readcyclecounter();
+  unsigned long long ph_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_ = __builtin_readcyclecounter();
 #endif
-  while (j0 < nJ) {
-    S2_MARK(7);
-    j0 = __builtin_amdgcn_readfirstlane(j0);     // (the compiler does not see that the loop's state is wave-uniform)
-    wbase = __builtin_amdgcn_readfirstlane(wbase);
-    conv_next = __builtin_amdgcn_readfirstlane(conv_next);
-    dma_next = __builtin_amdgcn_readfirstlane(dma_next);
-    dma_bad = __builtin_amdgcn_readfirstlane(dma_bad);
-    mode = __builtin_amdgcn_readfirstlane(mode);
-    tend = __builtin_amdgcn_readfirstlane(tend);
-    if (j0 >= tend) {                            // a new tile: its anchor and flags, and those of the tile behind it
-      const int Tt = j0 >> 10;
-      tend = (Tt + 1) << 10;
-      dA0 = __builtin_amdgcn_readlane(hd_dA, Tt);
-      dA1 = __builtin_amdgcn_readlane(hd_dA, Tt + 1);
-      fl0 = __builtin_amdgcn_readlane(hd_fl, Tt);
-      fl1 = __builtin_amdgcn_readlane(hd_fl, Tt + 1);
-    }
+  // One pass.  EDGE = false: all 128 outputs lie inside one tile and inside the wave's range (7 passes of 8): no lane sets.
+  auto pass = [&](auto edge_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
     // ---- 1. placement ----
-    // everything this pass reads from LDS that came by direct load (its records, its newest chunk) set out a pass ago;
-    // nothing younger is in flight (the stores of the pass before leave BEHIND this wait)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    wave_lds_fence();
-    const int u = (j0 + l) & (kRec - 1);         // the same for both rows
+    const int t5 = (j0 & (kRec - 1)) + l;
+    const int u = t5 & (kRec - 1);               // the same for both rows (64 = 2 blocks)
     uint4 ra[2], rb[2];
     {
-      const int b = (int)(((unsigned)(j0 + l) >> kRecShift) - ((unsigned)j0 >> kRecShift));      // 0 .. 2 (row 1: + 2)
-      ra[0] = L.recs[b];
-      rb[0] = L.recs[8 + b];
-      ra[1] = L.recs[b + 2];
-      rb[1] = L.recs[10 + b];
+      const uint4* rp = &L.recs[t5 >> kRecShift];                  // blocks 0 .. 2 of the pass (row 1: + 2)
+      ra[0] = rp[0];
+      rb[0] = rp[8];
+      ra[1] = rp[2];
+      rb[1] = rp[10];
     }
-    S2Place P;
-    int nv[2] = {64, 64};                        // valid lanes of row r: l < nv[r]
-    const bool interior = j0 + kPass <= tend && j0 + kPass <= nJ;
-    if (interior) {
-      const int nt[2] = {64, 64};
-      s2_place<false>(ra, rb, u, l, tolf, dA0, dA1, nv, nt, P);
-    } else {
-      const int jlim = ((fl1 & 1) && tend < nJ) ? tend : nJ;     // a tile out of range ends the pass at its border
-      int nt[2];                                 // lanes of this tile: l < nt[r]
+    int nv[2] = {64, 64}, nt[2] = {64, 64};      // valid lanes of row r: l < nv[r]; lanes of this tile: l < nt[r]
+    if (EDGE) {
+      const int jlim = ((fl1 & 1) && tend < nJ) ? tend : nJ;       // a tile out of range ends the pass at its border
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         nv[r] = clamp64(jlim - j0 - 64 * r);
         nt[r] = clamp64(tend - j0 - 64 * r);
       }
-      s2_place<true>(ra, rb, u, l, tolf, dA0, dA1, nv, nt, P);
-      if (P.bad_next != 0ull) {                  // bad lanes of the next tile end the pass at the border
+    }
+    const int uc = u - kRec / 2;
+    const float uf = (float)uc, u2f = uf * uf, tw1 = fmaf(2.0f, uf, 1.0f), tw0 = tw1 - 2.0f;
+    S2Row R[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) R[r] = s2_place_row(ra[r], rb[r], u, (EDGE ? (l < nt[r] ? dA0 : dA1) : dA0) + uc, uf, u2f, tw1, tw0, tolf);
+    unsigned long long bad_here, gen;
+    if (EDGE) {
+      const unsigned long long b0 = __ballot(R[0].bad) & prefix(nv[0]), b1 = __ballot(R[1].bad) & prefix(nv[1]);
+      bad_here = (b0 & prefix(nt[0])) | (b1 & prefix(nt[1]));
+      if (((b0 & ~prefix(nt[0])) | (b1 & ~prefix(nt[1]))) != 0ull) {   // bad lanes of the next tile end the pass at the border
         nv[0] = nv[0] < nt[0] ? nv[0] : nt[0];
         nv[1] = nv[1] < nt[1] ? nv[1] : nt[1];
       }
+      gen = (__ballot(1.0f + R[0].ep != 1.0f) & prefix(nv[0])) | (__ballot(1.0f + R[1].ep != 1.0f) & prefix(nv[1]));
+    } else {
+      bad_here = __ballot(R[0].bad || R[1].bad);
+      gen = __ballot(1.0f + R[0].ep != 1.0f || 1.0f + R[1].ep != 1.0f);
     }
-    int (&c)[2] = P.c;
-    float (&s)[2] = P.s;
-    float (&ep)[2] = P.ep;
-    // bad lanes of THIS tile send it to the block kernel
-    bool skip = (fl0 & 1) || P.bad_here != 0ull;
+    bool skip = (fl0 & 1) || bad_here != 0ull;
     S2_MARK(0);
     // the previous pass's outputs leave now: the records this pass waited for were issued before them
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int r = 0; r < 2; ++r)
       if (l < nok_p[r] && !(PAR_S2_EXP & 4)) outW[j_p + 64u * r + (unsigned)l] = res_p[r];
-    nok_p[0] = nok_p[1] = 0;
     asm volatile("" ::: "memory");
-    const int c0 = __builtin_amdgcn_readfirstlane(c[0]);
-    const int ws = c0 & ~7;
+    const int ws = __builtin_amdgcn_readfirstlane(R[0].c) & ~7;
     // which outputs this pass finishes (centres inside [ws, ws + 128): a prefix of the valid lanes) -- and with that where the
     // next pass starts: its records set out NOW, a whole pass ahead of their use
     int ci[2], nok[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      ci[r] = c[r] - ws;
+      ci[r] = R[r].c - ws;
       const unsigned long long in = __ballot(ci[r] < kPass);
-      nok[r] = interior ? __popcll(in) : __popcll(in & prefix(nv[r]));
-      ci[r] = l < nok[r] ? ci[r] : 0;
+      nok[r] = EDGE ? __popcll(in & prefix(nv[r])) : __popcll(in);
+      ci[r] = ci[r] < 0 ? 0 : (ci[r] > kPass - 1 ? kPass - 1 : ci[r]);         // lanes outside read a harmless slot
     }
     const int jn = j0 + nok[0] + nok[1];
     wave_lds_fence();                            // every lane has read this pass's records
     if (!skip) load_records(jn);
     // ---- 2. the stream: mode, window, conversion ----
-    unsigned long long gen = P.gen;
-    if (!interior) gen = (__ballot(1.0f + ep[0] != 1.0f) & prefix(nv[0])) | (__ballot(1.0f + ep[1] != 1.0f) & prefix(nv[1]));
-    const bool all_unity = (gen == 0ull) | ((PAR_S2_EXP & 16) != 0);
-    const int want = all_unity ? 1 : 2;
+    const int want = (gen == 0ull || (PAR_S2_EXP & 16)) ? 1 : 2;
     float fc[2] = {1.0f, 1.0f}, gg[2] = {0.0f, 0.0f};
     bool restart = mode != want || ws - wbase > (1 << 20);
     if (want == 2) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        fc[r] = fast_rcp(1.0f + ep[r]);
-        gg[r] = ep[r] * fc[r];                   // 1 - fc
+        fc[r] = fast_rcp(1.0f + R[r].ep);
+        gg[r] = R[r].ep * fc[r];                 // 1 - fc
       }
-      const unsigned long long far_off = (__ballot(!(fabsf(g0 - gg[0]) <= kEpsTol)) & prefix(nv[0])) | (__ballot(!(fabsf(g0 - gg[1]) <= kEpsTol)) & prefix(nv[1]));
+      const unsigned long long far_off = EDGE ? (__ballot(!(fabsf(g0 - gg[0]) <= kEpsTol)) & prefix(nv[0])) | (__ballot(!(fabsf(g0 - gg[1]) <= kEpsTol)) & prefix(nv[1]))
+                                              : __ballot(!(fabsf(g0 - gg[0]) <= kEpsTol) || !(fabsf(g0 - gg[1]) <= kEpsTol));
       restart = restart || far_off != 0ull;
     }
     if (!skip && restart) {
@@ -418,20 +385,21 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
       dma_next = 0;                              // (the fetch below is the only exposed one of the stream: rare)
     }
     S2_MARK(1);
-    const int need_hi = ws + 160 - wbase;        // last window index the bank's non-zero coefficients meet
-    // chunks up to need_hi / 128 are converted below; the one behind them sets out now, a pass ahead.  (Its ring slot held the
+    const int need_c = (ws + 160 - wbase) >> 7;  // the bank's non-zero coefficients reach window index ws + 160 - wbase: chunks <= need_c
+    // chunks up to need_c are converted below; the one behind them sets out now, a pass ahead.  (Its ring slot held the
     // chunk four back, which ends before ws - 2: no near tap of this or a later pass reads it.)
-    if (!skip && dma_next <= need_hi / kPass + 1) {
-      const bool late = dma_next <= need_hi / kPass;             // only right behind a restart / a jump
-      while (dma_next <= need_hi / kPass + 1) chunk_dma(dma_next++);
+    if (!skip && dma_next <= need_c + 1) {
+      const bool late = dma_next <= need_c;      // only right behind a restart / a jump
+      while (dma_next <= need_c + 1) chunk_dma(dma_next++);
       if (late) {
         __builtin_amdgcn_s_waitcnt(0x0F70);
         wave_lds_fence();
       }
     }
+    S2_MARK(8);
     if (!skip) {
 #pragma unroll 1
-      while (conv_next * kPass <= need_hi) {
+      while (conv_next <= need_c) {
         if (conv_next >= dma_bad) {
           skip = true;
           break;
@@ -447,28 +415,34 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
           skip = true;
           break;
         }
-        if (ix < 8) *reinterpret_cast<float2*>(&L.ring_tail[ix]) = xx;
-        if (ix == kRing - 2) *reinterpret_cast<float2*>(&L.ring_head[2]) = xx;
+        S2_MARK(9);
+        // mirrors of the ring's two ends for the near taps (a chunk fills a quarter of the ring: wave-uniform tests)
+        if ((conv_next & 3) == 0 && l < 4) *reinterpret_cast<float2*>(&L.ring_tail[ix]) = xx;
+        if ((conv_next & 3) == 3 && l == kWave - 1) *reinterpret_cast<float2*>(&L.ring_head[2]) = xx;
         if (!(PAR_S2_EXP & 8)) {
           if (mode == 1) {
-            const half2v h = {hi16(x0), hi16(x1)};
+            const half2v h = {S2_HI(x0), S2_HI(x1)};                   // (hi16: what the matrix cores will see)
             const half2v lo = {(_Float16)((x0 - (float)h[0]) * 4096.0f), (_Float16)((x1 - (float)h[1]) * 4096.0f)};
             *reinterpret_cast<half2v*>(&L.img[0][ix]) = h;
             *reinterpret_cast<half2v*>(&L.img[1][ix]) = lo;
           } else {
+            // modulated images x_k sin / cos(pi g0 k): g0 k / 2 in revolutions as hi + lo (fma), reduced to (-1/2, 1/2],
+            // then the hardware sine / cosine (v_sin_f32 / v_cos_f32: 1.2e-7 absolute, tools/exp/hw_sincos.hip)
+            const float gh = 0.5f * g0;
             float ya[2], yb[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
               const float x = t ? x1 : x0;
               const float kf = (float)(wi + t);
-              const float ph = g0 * kf, pl = fmaf(g0, kf, -ph);       // g0 k as hi + lo: the phase is good to ~1e-8 turns
-              const float rn = rintf(ph);
-              const float rr = (ph - rn) + pl;
-              const float sg = ((int)rn & 1) ? -x : x;
-              ya[t] = sg * sinpi_half(rr);
-              yb[t] = sg * cospi_half(rr);
+              const float ph = gh * kf, pl = fmaf(gh, kf, -ph);
+              const float rv = (ph - rintf(ph)) + pl;
+              ya[t] = x * __builtin_amdgcn_sinf(rv);
+              yb[t] = x * __builtin_amdgcn_cosf(rv);
+              // (the products must be ROUNDED float32 values: left to contraction, the compiler derives lo from
+              // half(x sin) of the exact product but stores half(float(x sin)) -- a double rounding apart, 5e-5 of the peak)
+              asm volatile("" : "+v"(ya[t]), "+v"(yb[t]));
             }
-            const half2v ha = {hi16(ya[0]), hi16(ya[1])}, hb = {hi16(yb[0]), hi16(yb[1])};
+            const half2v ha = {S2_HI(ya[0]), S2_HI(ya[1])}, hb = {S2_HI(yb[0]), S2_HI(yb[1])};
             const half2v la = {(_Float16)((ya[0] - (float)ha[0]) * 4096.0f), (_Float16)((ya[1] - (float)ha[1]) * 4096.0f)};
             const half2v lb = {(_Float16)((yb[0] - (float)hb[0]) * 4096.0f), (_Float16)((yb[1] - (float)hb[1]) * 4096.0f)};
             *reinterpret_cast<half2v*>(&L.img[0][ix]) = ha;
@@ -478,15 +452,17 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
           }
         }
         ++conv_next;
+        S2_MARK(10);
       }
     }
     if (skip) {                                  // the tile of j0 goes to the block kernel; the stream restarts behind it
       push_tile(Ta + (j0 >> 10));
+      nok_p[0] = nok_p[1] = 0;
       j0 = tend;
       mode = 0;
       wave_lds_fence();
       if (j0 < nJ) load_records(j0);
-      continue;
+      return;
     }
     S2_MARK(2);
     // ---- 4. the bank over the centres ws .. ws + 127 ----
@@ -505,10 +481,10 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int sl = ci[r] ^ ((ci[r] >> 3) & 7);
-      const int rc = l < nok[r] ? ((c[r] - wbase) & (kRing - 1)) : 2;
+      const int rc = (ws - wbase + ci[r]) & (kRing - 1);
       const float* xp = &L.ring[rc];
       const float xm2 = xp[-2], xm1 = xp[-1], x0 = xp[0], xp1 = xp[1], xp2 = xp[2];
-      const float sr = s[r], q = sr * sr, q64 = 64.0f * q;
+      const float sr = R[r].s, q = sr * sr, q64 = 64.0f * q;
       const float E1 = xp1 + xm1, D1 = xp1 - xm1, E2 = xp2 + xm2, D2 = xp2 - xm2;
       float res;
       if (mode == 1) {
@@ -527,11 +503,9 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
         const float f = fc[r], g = gg[r];
         // near taps with the lane's own cut-off: numerators sin(pi fc (n -+ s)) = -(-1)^n sin(pi g n +- phi), phi = pi fc s
         const float h = f * sr, zh = h * h;
-        const float sph = sinpi_poly(zh);
-        const float sinphi = h * sph, cosphi = cospi_half(h);
-        const float zg = g * g;
-        const float S1 = g * fmaf(zg, fmaf(zg, 2.55016404f, -5.16771278f), 3.14159265f);
-        const float C1 = fmaf(zg, fmaf(zg, 4.05871213f, -4.93480220f), 1.0f);
+        const float sph = sinpi_poly(zh);                            // sin(phi) / h: the centre tap needs the quotient
+        const float sinphi = h * sph, cosphi = __builtin_amdgcn_cosf(0.5f * h);
+        const float S1 = __builtin_amdgcn_sinf(0.5f * g), C1 = __builtin_amdgcn_cosf(0.5f * g);
         const float S2 = 2.0f * S1 * C1, C2 = fmaf(-2.0f * S1, S1, 1.0f);
         float accM = 0.0f, accP = 0.0f;
         if (!(PAR_S2_EXP & 2)) {
@@ -543,23 +517,19 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
           accP = fmaf(2.0f * (G2 + H2), R2, (G1 + H1) * R1);
         }
         const float near = fmaf(x0 * f, sph * 0.318309886f, fmaf(sr, accM, accP));
-        // far taps: psi / pi = s - g0 (K + s), K = the centre's window index (the images' phase origin is the window's)
-        const float Kf = (float)(c[r] - wbase);
-        const float ph = g0 * Kf, pl = fmaf(g0, Kf, -ph);
-        const float rn = rintf(ph);
-        const float t = (sr - (ph - rn)) - fmaf(g0, sr, pl);
-        const float rm = rintf(t);
-        const float v = t - rm;
-        const bool neg = (((int)rn + (int)rm) & 1) != 0;
-        float cps = cospi_half(v), sps = sinpi_half(v);
-        cps = neg ? -cps : cps;
-        sps = neg ? -sps : sps;
+        // far taps: psi / (2 pi) = (s (1 - g0) - g0 K) / 2, K = the centre's window index (the images' phase origin is the
+        // window's): g0 K / 2 as hi + lo, reduced, then the hardware cosine / sine
+        const float gh = 0.5f * g0;
+        const float Kf = (float)(ws - wbase + ci[r]);
+        const float ph = gh * Kf, pl = fmaf(gh, Kf, -ph);
+        const float tv = fmaf(sr, 0.5f - gh, -(ph - rintf(ph))) - pl;
+        const float cps = __builtin_amdgcn_cosf(tv), sps = __builtin_amdgcn_sinf(tv);
         const float4v rowa = L.qa[sl], rowb = L.qb[sl];
         const float4v Xf = L.qx[sl];
-        const uint2 X = make_uint2(__float_as_uint(Xf[0]), __float_as_uint(Xf[1]));
+        const unsigned Xa = __float_as_uint(Xf[0]), Xb = __float_as_uint(Xf[1]);
         const unsigned Y = __float_as_uint(L.qy[sl]);
-        const float eA = fmaf(q, fmaf(q64, h_lo(X.x), rowa[2]), rowa[0]), dA = fmaf(q, fmaf(q64, h_hi(X.x), rowa[3]), rowa[1]);
-        const float eB = fmaf(q, fmaf(q64, h_lo(X.y), rowb[2]), rowb[0]), dB = fmaf(q, fmaf(q64, h_hi(X.y), rowb[3]), rowb[1]);
+        const float eA = fmaf(q, fmaf(q64, h_lo(Xa), rowa[2]), rowa[0]), dA = fmaf(q, fmaf(q64, h_hi(Xa), rowa[3]), rowa[1]);
+        const float eB = fmaf(q, fmaf(q64, h_lo(Xb), rowb[2]), rowb[0]), dB = fmaf(q, fmaf(q64, h_hi(Xb), rowb[3]), rowb[1]);
         const float UA = fmaf(sr, eA, dA) * kBank2ScaleInv, UB = fmaf(sr, eB, dB) * kBank2ScaleInv;
         const float HA = Xf[2], HB = Xf[3];
         const float s1k = sr * 0.0009765625f;
@@ -579,10 +549,35 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
 #if PAR_S2_EXP & 64
     ph_[6] += 1;
 #endif
+  };
+
+  while (j0 < nJ) {
+    S2_MARK(7);
+    j0 = __builtin_amdgcn_readfirstlane(j0);     // (the compiler does not see that the loop's state is wave-uniform)
+    wbase = __builtin_amdgcn_readfirstlane(wbase);
+    conv_next = __builtin_amdgcn_readfirstlane(conv_next);
+    dma_next = __builtin_amdgcn_readfirstlane(dma_next);
+    dma_bad = __builtin_amdgcn_readfirstlane(dma_bad);
+    mode = __builtin_amdgcn_readfirstlane(mode);
+    tend = __builtin_amdgcn_readfirstlane(tend);
+    if (j0 >= tend) {                            // a new tile: its anchor and flags, and those of the tile behind it
+      const int Tt = j0 >> 10;
+      tend = (Tt + 1) << 10;
+      dA0 = __builtin_amdgcn_readlane(hd_dA, Tt);
+      dA1 = __builtin_amdgcn_readlane(hd_dA, Tt + 1);
+      fl0 = __builtin_amdgcn_readlane(hd_fl, Tt);
+      fl1 = __builtin_amdgcn_readlane(hd_fl, Tt + 1);
+    }
+    // everything this pass reads from LDS that came by direct load (its records, its newest chunk) set out a pass ago;
+    // nothing younger is in flight (the stores of the pass before leave BEHIND this wait)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    wave_lds_fence();
+    if (j0 + kPass <= tend && j0 + kPass <= nJ) pass(std::false_type{});
+    else pass(std::true_type{});
   }
 #if PAR_S2_EXP & 64
   if (l == 0)
-    for (int k = 0; k < 8; ++k) g_s2_phase[(size_t)blockIdx.x * 8 + k] = ph_[k];
+    for (int k = 0; k < 16; ++k) g_s2_phase[(size_t)blockIdx.x * 16 + k] = ph_[k];
 #endif
 #pragma unroll
   for (int r = 0; r < 2; ++r)

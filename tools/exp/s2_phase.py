@@ -11,7 +11,7 @@ n = int(sr * seconds); m = int(seconds * sr / 256)
 sig = torch.empty(n, dtype=torch.float32, device="cuda")
 _lib.check(L.par_synth_signal_f32(dev, _dev.ptr(sig), 0, n, float(sr), 0x5EED, s))
 t = np.linspace(0, seconds, m)
-names = ["records wait + placement", "pending stores + mode", "conversion (+DMA issue)", "count + record loads", "bank (MFMA)", "outputs", "passes", "loop overhead"]
+names = ["records wait + placement", "pending stores + mode", "conversion (+DMA issue)", "count + record loads", "bank (MFMA)", "outputs", "passes", "loop overhead", "  conv: DMA issue", "  conv: ring read + checks", "  conv: convert + write", "", "", "", "", ""]
 for name, sp in (("slow", 0.995 + 0.005 * np.sin(2 * np.pi * 0.55 * t + 0.7)), ("fast", 1.005 + 0.005 * np.sin(2 * np.pi * 0.55 * t + 0.7))):
     st_t = torch.from_numpy(t * sr).cuda(); sp_t = torch.from_numpy(sp).cuda()
     cap = int(n * 1.02) + 1024
@@ -22,18 +22,18 @@ for name, sp in (("slow", 0.995 + 0.005 * np.sin(2 * np.pi * 0.55 * t + 0.7)), (
     _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(st_t), _dev.ptr(sp_t), m, n, _dev.ptr(work), nb, _dev.ptr(aux), ab, cap,
                                              ctypes.byref(lo), ctypes.byref(tr), 0, None, ctypes.byref(ok), s))
     waves = (lo.value // 1024 + 7) // 8 + 1
-    buf = torch.zeros(waves * 8, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(waves * 16, dtype=torch.int64, device="cuda")
     L.par_debug_s2_phase_buffer.argtypes = [ctypes.c_void_p]
     assert L.par_debug_s2_phase_buffer(_dev.ptr(buf)) == 0
     for _ in range(2):
         _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(sp_t), m, _dev.ptr(work), _dev.ptr(aux), cap, lo.value, _dev.ptr(sig), 1, n, nt, _dev.ptr(out), 1, s))
     torch.cuda.synchronize()
-    b = buf.cpu().numpy().reshape(-1, 8).astype(np.float64)
+    b = buf.cpu().numpy().reshape(-1, 16).astype(np.float64)
     b = b[b[:, 6] > 0]
     passes = b[:, 6].sum()
     print(f"{name} tape: {len(b)} waves, {passes / len(b):.1f} passes per wave, {lo.value / passes:.1f} outputs per pass")
     tot = 0.0
-    for k in (7, 0, 1, 2, 3, 4, 5):
+    for k in (7, 0, 1, 8, 9, 10, 2, 3, 4, 5):
         c = b[:, k].sum() / passes
         tot += c
         print(f"   {names[k]:28s} {c:8.1f} cycles per pass")
