@@ -536,7 +536,12 @@ def main():
         # Software pipeline over the files of a batch (one file per step): K_sinc of file k on the main stream,
         # the whole plan of file k+1 (25 small latency-bound kernels + one header read-back) on a side stream
         # underneath it.  Every step still executes one full plan and one full K_sinc; nothing is cached.
-        side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PAR_SIDE_PRIO", "0")))
+        if os.environ.get("PAR_SIDE_CUS") or os.environ.get("PAR_SIDE_LOW"):      # experiment: a confined / low-priority plan stream
+            hs = ctypes.c_void_p()
+            _lib.check(L.par_stream_create(dev, int(os.environ.get("PAR_SIDE_LOW", "0")), int(os.environ.get("PAR_SIDE_CUS", "0")), ctypes.byref(hs)))
+            side = torch.cuda.ExternalStream(hs.value, device=dev)
+        else:
+            side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PAR_SIDE_PRIO", "0")))
         side_ptr = ctypes.c_void_p(side.cuda_stream)
         slot_free = [None, None]                        # main-stream event: K_sinc that read this slot is done
         state = {"k": 0, "len": plan_fused(0, sp_)}    # pipeline prologue: plan of the first file

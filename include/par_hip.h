@@ -44,6 +44,11 @@ int par_event_destroy(void* ev);
 int par_event_record(void* ev, void* stream);
 int par_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
 int par_stream_sync(int device, void* stream);
+/* A side stream for the plan of the next file (resampling.varispeed_batch_dev, bench.py): cu_count > 0 confines its kernels
+ * to the first cu_count compute units (hipExtStreamCreateWithCUMask), otherwise low_priority != 0 asks for the device's
+ * least stream priority.  Wrap the handle with torch.cuda.ExternalStream; destroy it with par_stream_destroy. */
+int par_stream_create(int device, int low_priority, int cu_count, void** stream);
+int par_stream_destroy(void* stream);
 
 /* ---- S0-S4: STFT / magnitude ---------------------------------------------------
  * Replaces the backend slot of util/fourier.py:67-75, i.e. a callable

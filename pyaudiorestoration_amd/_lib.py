@@ -30,6 +30,8 @@ SIGNATURES = {
     "par_event_record": (c_int, [c_vp, c_vp]),
     "par_event_elapsed_ms": (c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_float)]),
     "par_stream_sync": (c_int, [c_int, c_vp]),
+    "par_stream_create": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_vp)]),
+    "par_stream_destroy": (c_int, [c_vp]),
     "par_stft_frames": (c_i64, [c_i64, c_int, c_int]),
     "par_stft_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_int, c_i64, c_vp]),
     "par_istft_scratch_floats": (c_i64, [c_i64, c_int, c_int]),

@@ -50,6 +50,31 @@ int par_event_elapsed_ms(void* start, void* stop, float* ms) {
   PAR_HIP_CHECK(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
   return PAR_OK;
 }
+int par_stream_create(int device, int low_priority, int cu_count, void** stream) {
+  PAR_REQUIRE(stream, PAR_ERR_ARG, "par_stream_create: null");
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipStream_t st;
+  if (cu_count > 0) {
+    // the first cu_count compute units of the device's numbering (hipExtStreamCreateWithCUMask: bit i of the mask = CU i)
+    hipDeviceProp_t prop;
+    PAR_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    const int total = prop.multiProcessorCount;
+    PAR_REQUIRE(cu_count <= total, PAR_ERR_ARG, "par_stream_create: cu_count above the device's compute units");
+    std::vector<uint32_t> mask((total + 31) / 32, 0u);
+    for (int i = 0; i < cu_count; ++i) mask[i >> 5] |= 1u << (i & 31);
+    PAR_HIP_CHECK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+  } else {
+    int least = 0, greatest = 0;
+    PAR_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    PAR_HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, low_priority ? least : 0));
+  }
+  *stream = st;
+  return PAR_OK;
+}
+int par_stream_destroy(void* stream) {
+  PAR_HIP_CHECK(hipStreamDestroy(par::as_stream(stream)));
+  return PAR_OK;
+}
 int par_stream_sync(int device, void* stream) {
   PAR_HIP_CHECK(hipSetDevice(device));
   PAR_HIP_CHECK(hipStreamSynchronize(par::as_stream(stream)));

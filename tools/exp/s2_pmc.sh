@@ -8,10 +8,10 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_V
   python - $OUT/pmc_${tag}_results.db <<'PY'
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
-rows = c.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection where kernel_name like '%k_sinc_stream%' group by 1, 2").fetchall()
+rows = c.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection where kernel_name like '%" + __import__('os').environ.get('KPAT','k_sinc_stream') + "%' group by 1, 2").fetchall()
 # per-dispatch values in order: 3 tapes x 11 launches
 for k, n, cnt, a in rows:
-    vals = [r[0] for r in c.execute("select value from counters_collection where kernel_name like '%k_sinc_stream%' and counter_name=? order by dispatch_id", (n,)).fetchall()]
+    vals = [r[0] for r in c.execute("select value from counters_collection where kernel_name like '%" + __import__('os').environ.get('KPAT','k_sinc_stream') + "%' and counter_name=? order by dispatch_id", (n,)).fetchall()]
     per = len(vals) // 3
     t = [sum(vals[i * per:(i + 1) * per]) / per for i in range(3)]
     print(f"{n:28s} slow {t[0]:.4g}  fast {t[1]:.4g}  mix {t[2]:.4g}   per-output x64 (INSTS): slow {t[0]*64/115.2e6:.1f} fast {t[1]*64/115.2e6:.1f}")
