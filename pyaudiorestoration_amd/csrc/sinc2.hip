@@ -584,8 +584,571 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
     if (l < nok_p[r] && !(PAR_S2_EXP & 4)) outW[j_p + 64u * r + (unsigned)l] = res_p[r];
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// K_sinc, pipelined streaming form (r04, second shape).  Same mathematics and the same worker (one wave, kTilesPerWave
+// tiles, constants resident in registers) as k_sinc_stream above; what changes is the ORDER OF WORK.  k_sinc_stream runs a
+// pass as a chain -- records -> placement -> conversion -> bank -> gather -- with a wait for LDS or memory between every two
+// links: at the two waves per SIMD its registers allow, a wave issued one instruction every ~12 cycles (tools/exp/s2_phase.py:
+// 4 360 cycles per 128 outputs for ~350 instructions).  Here the links of one iteration belong to DIFFERENT passes:
+//     iteration k:   OUT(k)        gather + near taps + stores of the pass placed and banked in iteration k - 1
+//                    PLACE(k + 1)  from records that set out in iteration k - 2
+//                    BANK(k + 1)   over the centres PLACE(k + 1) just named, from image chunks converted in iterations <= k - 1
+//                    CONV          the next 128-sample chunk of the ring (fetched in iteration k - 2) -> float16 images
+//                    FETCH         chunk + 2 of the ring and the records of pass k + 3 set out (direct-to-LDS loads)
+// so nothing an iteration reads from LDS was written in the same iteration: ONE wave-level fence per iteration, one
+// s_waitcnt vmcnt(5) (everything but the previous iteration's five memory operations has landed), no branch in the body.
+// The ring holds 8 chunks of float32 samples (near taps) and 4 of the float16 images; the bank is single-buffered (an
+// iteration's gathers precede its bank writes in program order, LDS serves a wave's operations in order).
+// Whatever is not the plain case -- the first pass of a run, a pass that meets a flagged tile or block, the end of the
+// wave's range, a change of tap regime or of g0, a conversion window that has drifted out of its slack -- leaves the loop
+// and is done by start_run(): the same stages, one after the other with full waits, which also primes the loop again.
+#ifndef PAR_S3_UNITY_WAVES
+#define PAR_S3_UNITY_WAVES 3
+#endif
+constexpr int kRingF = 1024;                      // float32 samples in the ring (8 chunks)
+constexpr int kRingH = 512;                       // samples per float16 image (4 chunks)
+
+template <bool GENK>                              // GENK: the kernel carries the fc < 1 path (two modulated images, wider bank rows)
+struct S3LdsT {
+  float ring_head[4];                            // [2], [3] mirror ring[1022], ring[1023]
+  float ring[kRingF];
+  float ring_tail[8];                            // mirrors ring[0 .. 7]
+  _Float16 img[GENK ? 4 : 2][kRingH];            // x (or A) hi, lo x 4096; B hi, lo x 4096
+  float4v qa[kPass];                             // bank rows {e0, d0, e1, d1} of x / A, slot = ci ^ ((ci >> 3) & 7)
+  float4v qb[GENK ? kPass : 1];                  // of B
+  float4v qx[GENK ? kPass : 1];                  // .x = e2|d2 of x / A (halves), .y = e2|d2 of B, .z = H(A), .w = H(B)
+  float qy[kPass];                               // GENK: H1'(A) | H1'(B) (halves); else: e2|d2 of x (halves)
+  uint4 recs[4][16];                             // block records of four passes: [0..7] first pieces, [8..15] second pieces
+};
+static_assert(offsetof(S3LdsT<true>, img) % 16 == 0 && offsetof(S3LdsT<true>, qa) % 16 == 0 && offsetof(S3LdsT<true>, recs) % 16 == 0, "16-byte aligned");
+static_assert(offsetof(S3LdsT<false>, img) % 16 == 0 && offsetof(S3LdsT<false>, qa) % 16 == 0 && offsetof(S3LdsT<false>, recs) % 16 == 0, "16-byte aligned");
+
+struct S3Pass {                                  // a placed pass: 128 candidate outputs j .. j + 127 (two per lane)
+  int c[2];                                      // window centre relative to A0
+  float s[2], ep[2];                             // shift, max(period - 1, 0)
+  int nok[2];                                    // lanes of row r the pass finishes: l < nok[r]   (wave-uniform)
+  int j, ws;                                     // first output (relative to Ja), first bank centre (wave-uniform)
+};
+
+template <bool GEN, class LDS>
+__device__ __forceinline__ void bank_image3(LDS& L, const half8v (&fr)[kBank2Frags], const int offs, const int l, const int sel) {
+  const int bb = l & 15, g = l >> 4;
+  const int i0 = offs + 8 * bb + 8 * g;
+  half8v xh[3], xl[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    const int ix = (i0 + 32 * ks) & (kRingH - 1);
+    xh[ks] = *reinterpret_cast<const half8v*>(&L.img[2 * sel][ix]);
+    xl[ks] = *reinterpret_cast<const half8v*>(&L.img[2 * sel + 1][ix]);
+  }
+  float4v e0 = {0.0f, 0.0f, 0.0f, 0.0f}, lo = e0, e1 = e0, x1 = e0, e2 = e0, hh = e0;
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[ks], xh[ks], e0, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[5 + ks], xh[ks], lo, 0, 0, 0);
+    if (ks < 2) e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[3 + ks], xh[ks], e1, 0, 0, 0);
+    if (GEN) hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[10 + ks], xh[ks], hh, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[ks], xl[ks], lo, 0, 0, 0);
+    if (ks < 2) {
+      x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[3 + ks], xl[ks], x1, 0, 0, 0);
+      e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[8 + ks], xh[ks], e2, 0, 0, 0);
+    }
+  }
+  const float4v v0 = e0 + lo * kBank2LoInv, v1 = e1 + x1 * kBank2LoInv;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int sl = (8 * bb + 2 * g + p) ^ (bb & 7);
+    const float4v row = {v0[2 * p], v0[2 * p + 1], v1[2 * p], v1[2 * p + 1]};
+    const unsigned e2d2 = pack_h2(e2[2 * p] * 0.015625f, e2[2 * p + 1] * 0.015625f);
+    if (GEN) {
+      (sel ? L.qb : L.qa)[sl] = row;
+      float* qx = reinterpret_cast<float*>(&L.qx[sl]);
+      qx[sel] = __uint_as_float(e2d2);
+      qx[2 + sel] = hh[2 * p];
+      reinterpret_cast<_Float16*>(&L.qy[sl])[sel] = (_Float16)(hh[2 * p + 1] * 0.0009765625f);
+    } else {
+      L.qa[sl] = row;
+      L.qy[sl] = __uint_as_float(e2d2);
+    }
+  }
+}
+
+// the outputs of one row of a placed pass (bank and ring in LDS): MODE 1 fc = 1, MODE 2 modulated images
+template <int MODE, class LDS>
+__device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const float sr, const float epr, const int wsK, const float g0) {
+  using T32 = TapTab<32>;
+  const int sl = ci ^ ((ci >> 3) & 7);
+  const int rc = (wsK + ci) & (kRingF - 1);
+  const float* xp = &L.ring[rc];
+  const float xm2 = xp[-2], xm1 = xp[-1], x0 = xp[0], xp1 = xp[1], xp2 = xp[2];
+  const float q = sr * sr, q64 = 64.0f * q;
+  const float R1 = fast_rcp(fmaf(q, T32::B[1], T32::A[1])), R2 = fast_rcp(fmaf(q, T32::B[2], T32::A[2]));
+  if (MODE == 1) {
+    const float E1 = xp1 + xm1, D1 = xp1 - xm1, E2 = xp2 + xm2, D2 = xp2 - xm2;
+    const float4v row = L.qa[sl];
+    const unsigned w2 = __float_as_uint(L.qy[sl]);
+    const float e = fmaf(q, fmaf(q64, h_lo(w2), row[2]), row[0]), d = fmaf(q, fmaf(q64, h_hi(w2), row[3]), row[1]);
+    const float en = fmaf(E2, R2, -(E1 * R1));
+    const float dn = fmaf(D2 + D2, R2, -(D1 * R1));
+    const float et = fmaf(e, kBank2ScaleInv, en), dt = fmaf(d, kBank2ScaleInv, dn);
+    return sinpi_poly(q) * fmaf(-sr, fmaf(sr, et, dt), x0 * 0.318309886f);
+  } else {
+    const float f = fast_rcp(1.0f + epr), g = epr * f;               // fc, 1 - fc
+    const float h = f * sr, zh = h * h;
+    const float sph = sinpi_poly(zh);
+    const float sinphi = h * sph, cosphi = __builtin_amdgcn_cosf(0.5f * h);
+    const float S1 = __builtin_amdgcn_sinf(0.5f * g), C1 = __builtin_amdgcn_cosf(0.5f * g);
+    const float S2 = 2.0f * S1 * C1, C2 = fmaf(-2.0f * S1, S1, 1.0f);
+    const float sc1 = S1 * cosphi, cs1 = C1 * sinphi, sc2 = S2 * cosphi, cs2 = C2 * sinphi;
+    const float G1 = xp1 * (sc1 + cs1), H1 = xm1 * (sc1 - cs1);
+    const float G2 = -xp2 * (sc2 + cs2), H2 = -xm2 * (sc2 - cs2);
+    const float accM = fmaf(G2 - H2, R2, (G1 - H1) * R1);
+    const float accP = fmaf(2.0f * (G2 + H2), R2, (G1 + H1) * R1);
+    const float near = fmaf(x0 * f, sph * 0.318309886f, fmaf(sr, accM, accP));
+    const float gh = 0.5f * g0;
+    const float Kf = (float)(wsK + ci);
+    const float ph = gh * Kf, pl = fmaf(gh, Kf, -ph);
+    const float tv = fmaf(sr, 0.5f - gh, -(ph - rintf(ph))) - pl;
+    const float cps = __builtin_amdgcn_cosf(tv), sps = __builtin_amdgcn_sinf(tv);
+    const float4v rowa = L.qa[sl], rowb = L.qb[sl];
+    const float4v Xf = L.qx[sl];
+    const unsigned Xa = __float_as_uint(Xf[0]), Xb = __float_as_uint(Xf[1]);
+    const unsigned Y = __float_as_uint(L.qy[sl]);
+    const float eA = fmaf(q, fmaf(q64, h_lo(Xa), rowa[2]), rowa[0]), dA = fmaf(q, fmaf(q64, h_hi(Xa), rowa[3]), rowa[1]);
+    const float eB = fmaf(q, fmaf(q64, h_lo(Xb), rowb[2]), rowb[0]), dB = fmaf(q, fmaf(q64, h_hi(Xb), rowb[3]), rowb[1]);
+    const float UA = fmaf(sr, eA, dA) * kBank2ScaleInv, UB = fmaf(sr, eB, dB) * kBank2ScaleInv;
+    const float HA = Xf[2], HB = Xf[3];
+    const float s1k = sr * 0.0009765625f;
+    const float H1A = fmaf(-s1k, HA, h_lo(Y)), H1B = fmaf(-s1k, HB, h_hi(Y));
+    const float eps = g0 - g;
+    float far = -fmaf(cps, UA, sps * UB);
+    far = fmaf(eps, fmaf(cps, HB, -(sps * HA)), far);
+    far = fmaf(1608.49544f * eps * eps, fmaf(cps, H1A, sps * H1B), far);
+    return near + far;
+  }
+}
+
+// one chunk of the ring -> float16 images (and the ring's mirrors); returns false when float16 does not suit the chunk
+template <int MODE, class LDS>
+__device__ __forceinline__ bool s3_convert(LDS& L, const int chunk, const int l, const float g0) {
+  const int wi = chunk * kPass + 2 * l;
+  const int ix = wi & (kRingF - 1), ih = wi & (kRingH - 1);
+  const float2 xx = *reinterpret_cast<const float2*>(&L.ring[ix]);
+  const float x0 = xx.x, x1 = xx.y;
+  const float am = fmaxf(fabsf(x0), fabsf(x1));
+  const bool ok = !(__ballot(!(fabsf(x0) < 32768.0f) || !(fabsf(x1) < 32768.0f)) != 0ull ||
+                    (__ballot(am >= kQuiet) == 0ull && __ballot(am > 0.0f) != 0ull));
+  if ((chunk & 7) == 0 && l < 4) *reinterpret_cast<float2*>(&L.ring_tail[ix]) = xx;
+  if ((chunk & 7) == 7 && l == kWave - 1) *reinterpret_cast<float2*>(&L.ring_head[2]) = xx;
+  if (MODE == 1) {
+    const half2v h = {S2_HI(x0), S2_HI(x1)};
+    const half2v lo = {(_Float16)((x0 - (float)h[0]) * 4096.0f), (_Float16)((x1 - (float)h[1]) * 4096.0f)};
+    *reinterpret_cast<half2v*>(&L.img[0][ih]) = h;
+    *reinterpret_cast<half2v*>(&L.img[1][ih]) = lo;
+  } else {
+    const float gh = 0.5f * g0;
+    float ya[2], yb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float x = t ? x1 : x0;
+      const float kf = (float)(wi + t);
+      const float ph = gh * kf, pl = fmaf(gh, kf, -ph);
+      const float rv = (ph - rintf(ph)) + pl;
+      ya[t] = x * __builtin_amdgcn_sinf(rv);
+      yb[t] = x * __builtin_amdgcn_cosf(rv);
+      asm volatile("" : "+v"(ya[t]), "+v"(yb[t]));
+    }
+    const half2v ha = {S2_HI(ya[0]), S2_HI(ya[1])}, hb = {S2_HI(yb[0]), S2_HI(yb[1])};
+    const half2v la = {(_Float16)((ya[0] - (float)ha[0]) * 4096.0f), (_Float16)((ya[1] - (float)ha[1]) * 4096.0f)};
+    const half2v lb = {(_Float16)((yb[0] - (float)hb[0]) * 4096.0f), (_Float16)((yb[1] - (float)hb[1]) * 4096.0f)};
+    *reinterpret_cast<half2v*>(&L.img[0][ih]) = ha;
+    *reinterpret_cast<half2v*>(&L.img[1][ih]) = la;
+    *reinterpret_cast<half2v*>(&L.img[2][ih]) = hb;
+    *reinterpret_cast<half2v*>(&L.img[3][ih]) = lb;
+  }
+  return ok;
+}
+
+// GENK = true: both tap regimes (two waves per SIMD: 15.5 KB of LDS and the fc < 1 path's registers).  GENK = false: fc = 1
+// passes only, tiles that hold an fc < 1 pass go to the block kernel's list (three waves per SIMD).
+template <bool GENK>
+__global__ __launch_bounds__(kWave, GENK ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_pipe(const S2Args a) {
+  __shared__ S3LdsT<GENK> L;
+  const int l = threadIdx.x;
+  const int64_t Ta = (int64_t)blockIdx.x * PAR_S2_TILES;
+  if (Ta >= a.n_full) return;
+  const int64_t Tb = Ta + PAR_S2_TILES < a.n_full ? Ta + PAR_S2_TILES : a.n_full;
+  const int64_t Ja = Ta * kSincTileOutputs, Jb = Tb * kSincTileOutputs;
+  half8v fr[kBank2Frags];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(kBank2Frags32) + l;
+#pragma unroll
+    for (int f = 0; f < kBank2Frags; ++f) fr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
+  }
+  long long A0;
+  int hd_dA, hd_fl;
+  {
+    const int64_t Ti = Ta + l < a.n_tiles ? Ta + l : a.n_tiles - 1;
+    const TileHdr h = a.hdr[l <= PAR_S2_TILES ? Ti : Ta];
+    A0 = __shfl(h.anchor, 0, kWave);
+    const long long d = h.anchor - A0;
+    hd_fl = h.flags | ((d > -0x40000000ll && d < 0x40000000ll) ? 0 : 1);
+    hd_dA = (int)d;
+  }
+  {
+    uint4* z = reinterpret_cast<uint4*>(&L.img[0][0]);
+    const uint4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(L.img) / 16 / kWave); ++i) z[i * kWave + l] = zero;
+  }
+  const float tolf = (float)((fabs((double)A0) + 2.0e7) * 1.2e-16 + 2.0e-10) + 2.0e-7f;
+  const int nJ = (int)(Jb - Ja);
+  float* const outW = a.out + Ja;
+  const uint4* const recW = reinterpret_cast<const uint4*>(a.rec) + (Ja >> kRecShift);
+  const uint4* const rec2W = reinterpret_cast<const uint4*>(a.rec2) + (Ja >> kRecShift);
+  const int blk_max = (int)(((a.len_out + kRec - 1) >> kRecShift) - (Ja >> kRecShift)) - 1;      // last block with a record, relative
+
+  // ---- stream state (wave-uniform) ----
+  int j0 = 0;                                    // first output not yet placed into a finished pass
+  int wbase = 0, conv_next = 0, conv_lo = 0, dma_next = 0, dma_bad = INT_MAX, mode = 0, pk = 0;
+  float g0 = 0.0f;
+  int rbA = 0, rbB = 0, rbC = 0;                 // first block (relative) of the record buffers of passes pk + 1, pk + 2, pk + 3
+
+  auto fetch_records = [&](int buf, int blk0) {  // 8 first pieces + 8 second pieces from block blk0 on -> recs[buf]
+    if (l < 16) {
+      int b = blk0 + (l & 7);
+      b = b < blk_max ? b : blk_max;
+      b = b < 0 ? 0 : b;
+      dma_dwordx4((l < 8 ? recW : rec2W) + b, &L.recs[buf][0]);
+    }
+  };
+  auto chunk_dma = [&](int k) {                  // chunk k = input samples [wbase + 128 k, + 128) relative to A0 -> ring slot k & 7
+    long long lo = A0 + wbase + (long long)kPass * k;
+    if (!(lo >= 0 && lo + kPass <= (long long)a.len_in)) {
+      dma_bad = k < dma_bad ? k : dma_bad;
+      lo = lo < 0 ? 0 : (long long)a.len_in - kPass;       // (any readable address: the chunk is never used)
+      lo = lo < 0 ? 0 : lo;
+    }
+    const float* gp = a.sig + lo + l;
+    float* dst = &L.ring[(k & 7) * kPass];
+    dma_dword(gp, dst);
+    dma_dword(gp + kWave, dst + kWave);
+  };
+  auto push_tile = [&](int64_t T) {
+    if (l == 0) {
+      const int slot = atomicAdd(a.redo_count, 1);
+      a.redo_list[slot] = (int)T;
+    }
+  };
+  if (blockIdx.x == 0 && a.n_full < a.n_tiles) push_tile(a.n_full);
+
+  // placement of the pass that starts at output j from record buffer `buf` (first block rb); the lanes' tile anchors
+  struct Placed {
+    S2Row R[2];
+    int nt[2];
+    int fl0, fl1, tend;
+  };
+  auto place = [&](int j, int buf, int rb) {
+    Placed P;
+    const int T = j >> 10;
+    P.tend = (T + 1) << 10;
+    const int dA0 = __builtin_amdgcn_readlane(hd_dA, T), dA1 = __builtin_amdgcn_readlane(hd_dA, T + 1);
+    P.fl0 = __builtin_amdgcn_readlane(hd_fl, T);
+    P.fl1 = __builtin_amdgcn_readlane(hd_fl, T + 1);
+    const int t5 = (j & (kRec - 1)) + l;
+    const int u = t5 & (kRec - 1);
+    const int bi = ((j >> kRecShift) - rb + (t5 >> kRecShift)) & 7;
+    const uint4* rp = &L.recs[buf][0];
+    const uint4 ra0 = rp[bi], rb0 = rp[8 + bi], ra1 = rp[(bi + 2) & 7], rb1 = rp[8 + ((bi + 2) & 7)];
+    const int uc = u - kRec / 2;
+    const float uf = (float)uc, u2f = uf * uf, tw1 = fmaf(2.0f, uf, 1.0f), tw0 = tw1 - 2.0f;
+    P.nt[0] = clamp64(P.tend - j);
+    P.nt[1] = clamp64(P.tend - j - 64);
+    P.R[0] = s2_place_row(ra0, rb0, u, (l < P.nt[0] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
+    P.R[1] = s2_place_row(ra1, rb1, u, (l < P.nt[1] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
+    return P;
+  };
+
+  S3Pass P;                                      // the pass OUT works on next (placed, its bank in LDS)
+  P.nok[0] = P.nok[1] = 0;
+  P.j = P.ws = 0;
+  P.c[0] = P.c[1] = 0;
+  P.s[0] = P.s[1] = P.ep[0] = P.ep[1] = 0.0f;
+
+  auto out_pass = [&](auto mode_tag, const S3Pass& Q, float (&res)[2]) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    const int wsK = Q.ws - wbase;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      int ci = Q.c[r] - Q.ws;
+      ci = ci < 0 ? 0 : (ci > kPass - 1 ? kPass - 1 : ci);
+      res[r] = s3_out_row<MODE>(L, ci, Q.s[r], Q.ep[r], wsK, g0);
+    }
+  };
+  auto store_pass = [&](const S3Pass& Q, const float (&res)[2]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (l < Q.nok[r] && !(PAR_S2_EXP & 4)) outW[(unsigned)Q.j + 64u * r + (unsigned)l] = res[r];
+  };
+
+  // ---- the cold path: places, converts for, banks and -- unless it is a full pass the loop can take -- finishes the pass
+  // at j0, everything in order with full waits.  Returns true with P = a full pass ready for the loop (records of the two
+  // passes behind it and the ring's next two chunks landed), false when the range is done.
+#if PAR_S2_EXP & 128
+#define S3_COUNT(k) do { if (l == 0) atomicAdd(a.redo_count + (k), 1); } while (0)
+#else
+#define S3_COUNT(k) do { } while (0)
+#endif
+  auto start_run = [&]() -> bool {
+    for (;;) {
+      if (j0 >= nJ) return false;
+      S3_COUNT(1);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      wave_lds_fence();
+      const int buf = pk & 3;
+      fetch_records(buf, j0 >> kRecShift);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      wave_lds_fence();
+      const Placed Q = place(j0, buf, j0 >> kRecShift);
+      const int tend = Q.tend;
+      // lane sets: valid lanes (inside the range), lanes of this tile
+      int nv[2] = {clamp64(nJ - j0), clamp64(nJ - j0 - 64)};
+      const unsigned long long b0 = __ballot(Q.R[0].bad) & prefix(nv[0]), b1 = __ballot(Q.R[1].bad) & prefix(nv[1]);
+      const unsigned long long bad_here = (b0 & prefix(Q.nt[0])) | (b1 & prefix(Q.nt[1]));
+      const bool bad_next = ((b0 & ~prefix(Q.nt[0])) | (b1 & ~prefix(Q.nt[1])) | (unsigned long long)((Q.fl1 & 1) && tend < nJ)) != 0ull;
+      if (bad_next) {                             // the pass ends at the tile border
+        nv[0] = nv[0] < Q.nt[0] ? nv[0] : Q.nt[0];
+        nv[1] = nv[1] < Q.nt[1] ? nv[1] : Q.nt[1];
+      }
+      bool skip = (Q.fl0 & 1) || bad_here != 0ull;
+      const unsigned long long gen = (__ballot(1.0f + Q.R[0].ep != 1.0f) & prefix(nv[0])) | (__ballot(1.0f + Q.R[1].ep != 1.0f) & prefix(nv[1]));
+      const int ws = __builtin_amdgcn_readfirstlane(Q.R[0].c) & ~7;
+      S3Pass N;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        N.c[r] = Q.R[r].c;
+        N.s[r] = Q.R[r].s;
+        N.ep[r] = Q.R[r].ep;
+        const unsigned long long in = __ballot(Q.R[r].c - ws < kPass);
+        N.nok[r] = __popcll(in & prefix(nv[r]));
+      }
+      N.j = j0;
+      N.ws = ws;
+      const int want = gen == 0ull ? 1 : 2;
+      if (!GENK && want == 2) skip = true;        // (this kernel leaves fc < 1 passes to the block kernel)
+      float gg[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) gg[r] = N.ep[r] * fast_rcp(1.0f + N.ep[r]);
+      auto far_off = [&](float gref) {
+        return ((__ballot(!(fabsf(gref - gg[0]) <= kEpsTol)) & prefix(nv[0])) | (__ballot(!(fabsf(gref - gg[1]) <= kEpsTol)) & prefix(nv[1]))) != 0ull;
+      };
+      if (!skip) {
+        bool rebuild = mode != want || (want == 2 && far_off(g0));
+        // the ring: restarted at the first pass of the wave and after a jump the fetched chunks do not cover
+        const int lo_need = ws - 39 - wbase;      // window index of the first image sample the bank reads
+        if (mode == 0 || lo_need < kPass * (dma_next - 8) + kPass || lo_need < 0 || lo_need > kPass * dma_next || ws - wbase > (1 << 20)) {
+          __builtin_amdgcn_s_waitcnt(0x0F70);     // (nothing may still be on its way into the old ring)
+          wbase = ws - 39;
+          dma_next = 0;
+          dma_bad = INT_MAX;
+          rebuild = true;
+        }
+        const int wsK = ws - wbase;
+        if (rebuild) {
+          mode = want;
+          if (want == 2) {
+            g0 = __shfl(gg[0], nJ - j0 > 32 ? 32 : 0, kWave);
+            if (far_off(g0)) skip = true;         // a ramp too steep for one g0
+          }
+          conv_lo = conv_next = (wsK - 39) >> 7;
+        }
+        // slack of the conversion window.  The loop checks the pass BEHIND this one (its bank needs the image to reach
+        // 161 samples beyond its first centre, one pass = 120 .. 136 centres further on) and converts one chunk per
+        // iteration: fc = 1 passes advance by <= 128 centres (the converted stretch drifts ahead of them: start low),
+        // fc < 1 passes by >= 128 (start as far ahead as the four-chunk image ring allows)
+        const int conv_target = want == 1 ? (wsK + 300 + 127) >> 7 : (wsK + 465) >> 7;
+        const int need_lo = (wsK - 39) >> 7;      // first image chunk the bank of this pass reads
+        if (conv_next < need_lo) conv_lo = conv_next = need_lo;
+        int conv_end = conv_target > conv_next ? conv_target : conv_next;
+        if (need_lo < conv_lo || need_lo < conv_end - 4) {        // the image ring (4 chunks) has moved past it: converted again
+          conv_lo = conv_next = need_lo;
+          conv_end = conv_target > need_lo ? conv_target : need_lo;
+        }
+        while (dma_next < conv_end + 2) chunk_dma(dma_next++);
+        // records of the two passes behind this one set out now (exact start of the next pass, a guess for the one behind)
+        const int jn = j0 + N.nok[0] + N.nok[1];
+        rbA = jn >> kRecShift;
+        rbB = (jn + 120) >> kRecShift;
+        fetch_records((pk + 1) & 3, rbA);
+        fetch_records((pk + 2) & 3, rbB);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        wave_lds_fence();
+        if (!skip) {
+#pragma unroll 1
+          while (conv_next < conv_end) {
+            if (conv_next >= dma_bad) {
+              skip = true;
+              break;
+            }
+            bool ok;
+            if constexpr (GENK) ok = mode == 1 ? s3_convert<1>(L, conv_next, l, g0) : s3_convert<2>(L, conv_next, l, g0);
+            else ok = s3_convert<1>(L, conv_next, l, g0);
+            if (!ok) {
+              skip = true;
+              break;
+            }
+            ++conv_next;
+          }
+        }
+        if (!skip && conv_next + 1 >= dma_bad) skip = true;      // the loop would convert a chunk that was never fetched
+      }
+      if (skip) {
+        push_tile(Ta + (j0 >> 10));
+        j0 = tend;
+        mode = 0;
+        continue;
+      }
+      wave_lds_fence();
+      const int offs = ws - wbase - 31;
+      if (!GENK || mode == 1) {
+        bank_image3<false>(L, fr, offs, l, 0);
+      } else if constexpr (GENK) {
+        bank_image3<true>(L, fr, offs, l, 0);
+        bank_image3<true>(L, fr, offs, l, 1);
+      }
+      wave_lds_fence();
+      j0 += N.nok[0] + N.nok[1];
+      ++pk;
+      rbC = (j0 + 240) >> kRecShift;
+      const bool full = N.nok[1] >= 1 && N.nok[0] + N.nok[1] >= 120;
+      if (full) {
+        P = N;
+        return true;
+      }
+      float res[2];
+      if (!GENK || mode == 1) out_pass(std::integral_constant<int, 1>{}, N, res);
+      else if constexpr (GENK) out_pass(std::integral_constant<int, 2>{}, N, res);
+      store_pass(N, res);
+    }
+  };
+
+#if PAR_S2_EXP & 64
+  unsigned long long s3t_[4] = {0, 0, 0, 0}, s3last_ = __builtin_readcyclecounter();
+  const unsigned long long s3start_ = s3last_;
+#endif
+  // ---- the loop: see the head of this kernel.  Leaves with P finished and j0 at a pass start_run() has to look at.
+  auto hot = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    for (;;) {
+      j0 = __builtin_amdgcn_readfirstlane(j0);
+      wbase = __builtin_amdgcn_readfirstlane(wbase);
+      conv_next = __builtin_amdgcn_readfirstlane(conv_next);
+      dma_next = __builtin_amdgcn_readfirstlane(dma_next);
+      dma_bad = __builtin_amdgcn_readfirstlane(dma_bad);
+      pk = __builtin_amdgcn_readfirstlane(pk);
+      g0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(g0)));
+      rbA = __builtin_amdgcn_readfirstlane(rbA);
+      rbB = __builtin_amdgcn_readfirstlane(rbB);
+      rbC = __builtin_amdgcn_readfirstlane(rbC);
+#if PAR_S2_EXP & 64
+      const unsigned long long tA_ = __builtin_readcyclecounter();
+#endif
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+#if PAR_S2_EXP & 64
+      const unsigned long long tB_ = __builtin_readcyclecounter();
+      s3t_[0] += tB_ - tA_;
+      s3t_[1] += tA_ - s3last_;
+      s3last_ = tB_;
+      s3t_[2] += 1;
+#endif
+      wave_lds_fence();
+      // PLACE(pk): the pass behind P
+      const Placed Q = place(j0, pk & 3, rbA);
+      const unsigned long long bad = __ballot(Q.R[0].bad || Q.R[1].bad);
+      const unsigned long long gen = __ballot(1.0f + Q.R[0].ep != 1.0f || 1.0f + Q.R[1].ep != 1.0f);
+      const int ws = __builtin_amdgcn_readfirstlane(Q.R[0].c) & ~7;
+      S3Pass N;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        N.c[r] = Q.R[r].c;
+        N.s[r] = Q.R[r].s;
+        N.ep[r] = Q.R[r].ep;
+        N.nok[r] = __popcll(__ballot(Q.R[r].c - ws < kPass));
+      }
+      N.j = j0;
+      N.ws = ws;
+      const int wsK = ws - wbase;
+      const int d = kPass * conv_next - wsK;      // image converted up to d samples beyond the first bank centre
+      bool ok = ((Q.fl0 | Q.fl1) & 1) == 0 && bad == 0ull && j0 + kPass <= nJ && N.nok[1] >= 1 && N.nok[0] + N.nok[1] >= 120 &&
+                (MODE == 1 ? gen == 0ull : gen != 0ull) && d >= 161 && d <= 473 && conv_next + 1 < dma_bad &&
+                (unsigned)((j0 >> kRecShift) - rbA) <= 1u;
+      if (MODE == 2) {
+        const float g_0 = N.ep[0] * fast_rcp(1.0f + N.ep[0]), g_1 = N.ep[1] * fast_rcp(1.0f + N.ep[1]);
+        ok = ok && __ballot(!(fabsf(g0 - g_0) <= kEpsTol) || !(fabsf(g0 - g_1) <= kEpsTol)) == 0ull;
+      }
+      // BANK(pk) over [ws, ws + 128): image samples converted in earlier iterations
+      // OUT(P) first in program order: its gathers must precede the bank's row writes
+      float res[2];
+      out_pass(mode_tag, P, res);
+      const int offs = wsK - 31;
+      bank_image3<MODE == 2>(L, fr, offs, l, 0);
+      if constexpr (MODE == 2) bank_image3<true>(L, fr, offs, l, 1);
+      // CONV: one chunk per iteration
+      const bool cok = s3_convert<MODE>(L, conv_next, l, g0);
+      // FETCH + stores: records of pass pk + 2, chunk conv_next + 2, then P's outputs (five memory operations, in this order)
+      fetch_records((pk + 2) & 3, rbC);
+      chunk_dma(dma_next);
+      store_pass(P, res);
+      wave_lds_fence();
+      ++conv_next;
+      ++dma_next;
+      if (!cok) mode = 0;                         // (start_run converts again and sends the tile to the block kernel)
+      S3_COUNT(2);
+#if PAR_S2_EXP & 128
+      if (!(ok && cok)) {
+        if (((Q.fl0 | Q.fl1) & 1) != 0 || bad != 0ull) S3_COUNT(3);
+        else if (!(j0 + kPass <= nJ)) S3_COUNT(4);
+        else if (!(N.nok[1] >= 1 && N.nok[0] + N.nok[1] >= 120)) S3_COUNT(5);
+        else if (!(MODE == 1 ? gen == 0ull : gen != 0ull)) S3_COUNT(6);
+        else if (!(d >= 161 && d <= 473)) S3_COUNT(7);
+        else if (!(conv_next < dma_bad)) S3_COUNT(9);
+        else if (!((unsigned)((j0 >> kRecShift) - rbA) <= 1u)) S3_COUNT(11);
+        else if (!cok) S3_COUNT(10);
+        else S3_COUNT(8);
+      }
+#endif
+      if (!(ok && cok)) return;
+      // N becomes P
+      P = N;
+      j0 += N.nok[0] + N.nok[1];
+      ++pk;
+      rbA = rbB;
+      rbB = rbC;
+      rbC = (j0 + 240) >> kRecShift;
+    }
+  };
+
+  while (start_run()) {
+    if (!GENK || mode == 1) hot(std::integral_constant<int, 1>{});
+    else if constexpr (GENK) hot(std::integral_constant<int, 2>{});
+    // P has been finished by the loop; the pass at j0 needs the cold path
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+#if PAR_S2_EXP & 64
+  if (l == 0) {
+    unsigned long long* o = g_s2_phase + (size_t)blockIdx.x * 16;
+    o[0] = s3t_[0];                                // cycles in the loop's memory wait (includes two clock reads)
+    o[1] = s3t_[1];                                // cycles between the end of one wait and the start of the next
+    o[2] = s3t_[2];                                // iterations
+    o[3] = __builtin_readcyclecounter() - s3start_;      // the wave's whole life behind its set-up
+    o[6] = s3t_[2];
+  }
+#endif
+}
+
 int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
-                       hipStream_t s) {
+                       hipStream_t s, int variant) {
   (void)device;
   S2Args a;
   a.len_out = len_out;
@@ -600,7 +1163,9 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
   a.n_full = len_out / kSincTileOutputs;
   a.n_tiles = ceil_div(len_out, kSincTileOutputs);
   const int64_t grid = ceil_div(a.n_full, (int64_t)PAR_S2_TILES);
-  if (grid > 0) hipLaunchKernelGGL(k_sinc_stream, dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  if (grid > 0 && variant == 1) hipLaunchKernelGGL(k_sinc_stream, dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  else if (grid > 0 && variant == 2) hipLaunchKernelGGL(k_sinc_pipe<true>, dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  else if (grid > 0) hipLaunchKernelGGL(k_sinc_pipe<false>, dim3((unsigned)grid), dim3(kWave), 0, s, a);
   else if (a.n_tiles > 0) {
     // nothing but a partial tile: the caller's block kernel handles short files (launch_sinc_fused never comes here)
   }

@@ -47,7 +47,8 @@ struct FusedArgs {
 };
 
 // Streaming kernel (sinc2.hip): mono, NT = 32, unit strides.  Tiles it does not take are appended to fa.redo_list.
+// variant 1: k_sinc_stream (one pass after the other), 2: k_sinc_pipe (stages of different passes in one iteration)
 int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
-                       hipStream_t s);
+                       hipStream_t s, int variant);
 
 }  // namespace par

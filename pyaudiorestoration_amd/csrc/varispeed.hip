@@ -140,6 +140,17 @@ int par_fused_redo_tiles(int device, const void* aux, int64_t max_out, int64_t m
   return PAR_OK;
 }
 
+// experiment builds of the streaming kernel (-DPAR_S2_EXP=128) count passes by kind in the 16 words behind the redo count
+int par_debug_fused_counters(int device, const void* aux, int64_t max_out, int64_t m, int* words16, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(aux && words16 && m >= 2 && max_out >= 2, PAR_ERR_ARG, "par_debug_fused_counters: bad argument");
+  PAR_HIP_CHECK(hipSetDevice(device));
+  const FusedAux av = fused_aux_view(const_cast<void*>(aux), max_out, m);
+  PAR_HIP_CHECK(hipMemcpyAsync(words16, av.redo_count, 16 * sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)));
+  PAR_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  return PAR_OK;
+}
+
 // Two channels of one file in one launch (same positions, same strides): position regeneration, prologue and tap
 // weights are computed once for both.
 int par_varispeed_fused_stereo_f32(int device, const double* speeds, int64_t m, const void* work, const void* aux,
