@@ -609,7 +609,9 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
 constexpr int kRingF = 1024;                      // float32 samples in the ring (8 chunks)
 constexpr int kRingH = 512;                       // samples per float16 image (4 chunks)
 
-template <bool GENK>                              // GENK: the kernel carries the fc < 1 path (two modulated images, wider bank rows)
+// GENK: the kernel carries the fc < 1 path in its modulated-image form (two images, wider bank rows).  MOM: in its moment form
+// (one image; seven moment filters per centre beside the fc = 1 bank).
+template <bool GENK, bool MOM = false>
 struct S3LdsT {
   float ring_head[4];                            // [2], [3] mirror ring[1022], ring[1023]
   float ring[kRingF];
@@ -619,8 +621,12 @@ struct S3LdsT {
   float4v qb[GENK ? kPass : 1];                  // of B
   float4v qx[GENK ? kPass : 1];                  // .x = e2|d2 of x / A (halves), .y = e2|d2 of B, .z = H(A), .w = H(B)
   float qy[kPass];                               // GENK: H1'(A) | H1'(B) (halves); else: e2|d2 of x (halves)
+  float4v qm0[MOM ? kPass : 1];                  // moment rows {m0, m1, m2, m3} (same slots as qa)
+  float4v qm1[MOM ? kPass : 1];                  // {m4, m5, m6, -}
   uint4 recs[4][16];                             // block records of four passes: [0..7] first pieces, [8..15] second pieces
 };
+typedef S3LdsT<false, true> S3LdsMom;
+static_assert(offsetof(S3LdsMom, qm0) % 16 == 0 && offsetof(S3LdsMom, recs) % 16 == 0, "16-byte aligned");
 static_assert(offsetof(S3LdsT<true>, img) % 16 == 0 && offsetof(S3LdsT<true>, qa) % 16 == 0 && offsetof(S3LdsT<true>, recs) % 16 == 0, "16-byte aligned");
 static_assert(offsetof(S3LdsT<false>, img) % 16 == 0 && offsetof(S3LdsT<false>, qa) % 16 == 0 && offsetof(S3LdsT<false>, recs) % 16 == 0, "16-byte aligned");
 
@@ -674,7 +680,55 @@ __device__ __forceinline__ void bank_image3(LDS& L, const half8v (&fr)[kBank2Fra
   }
 }
 
-// the outputs of one row of a placed pass (bank and ring in LDS): MODE 1 fc = 1, MODE 2 modulated images
+// fc = 1 bank AND the seven moment filters of the fc < 1 correction over the same 128 centres, from the same signal fragments
+// (fm: kBank3Frags32, sinc_taps_gen.h): 15 + 18 MFMAs.
+template <class LDS>
+__device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Frags], const half8v (&fm)[kBank3Frags], const int offs, const int l) {
+  const int bb = l & 15, g = l >> 4;
+  const int i0 = offs + 8 * bb + 8 * g;
+  half8v xh[3], xl[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    const int ix = (i0 + 32 * ks) & (kRingH - 1);
+    xh[ks] = *reinterpret_cast<const half8v*>(&L.img[0][ix]);
+    xl[ks] = *reinterpret_cast<const half8v*>(&L.img[1][ix]);
+  }
+  const float4v z = {0.0f, 0.0f, 0.0f, 0.0f};
+  float4v e0 = z, lo = z, e1 = z, x1 = z, e2 = z, a01 = z, l01 = z, a23 = z, a45 = z, a6 = z;
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[ks], xh[ks], e0, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[5 + ks], xh[ks], lo, 0, 0, 0);
+    a01 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fm[ks], xh[ks], a01, 0, 0, 0);
+    l01 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fm[3 + ks], xh[ks], l01, 0, 0, 0);
+    a23 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fm[6 + ks], xh[ks], a23, 0, 0, 0);
+    a45 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fm[9 + ks], xh[ks], a45, 0, 0, 0);
+    a6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fm[12 + ks], xh[ks], a6, 0, 0, 0);
+    if (ks < 2) e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[3 + ks], xh[ks], e1, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[ks], xl[ks], lo, 0, 0, 0);
+    l01 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fm[ks], xl[ks], l01, 0, 0, 0);
+    if (ks < 2) {
+      x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[3 + ks], xl[ks], x1, 0, 0, 0);
+      e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[8 + ks], xh[ks], e2, 0, 0, 0);
+    }
+  }
+  const float4v v0 = e0 + lo * kBank2LoInv, v1 = e1 + x1 * kBank2LoInv, m01 = a01 + l01 * kBank2LoInv;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int sl = (8 * bb + 2 * g + p) ^ (bb & 7);
+    const float4v row = {v0[2 * p], v0[2 * p + 1], v1[2 * p], v1[2 * p + 1]};
+    L.qa[sl] = row;
+    L.qy[sl] = __uint_as_float(pack_h2(e2[2 * p] * 0.015625f, e2[2 * p + 1] * 0.015625f));
+    const float4v r0 = {m01[2 * p], m01[2 * p + 1], a23[2 * p], a23[2 * p + 1]};
+    const float4v r1 = {a45[2 * p], a45[2 * p + 1], a6[2 * p], 0.0f};
+    L.qm0[sl] = r0;
+    L.qm1[sl] = r1;
+  }
+}
+
+// the outputs of one row of a placed pass (bank and ring in LDS): MODE 1 fc = 1, MODE 2 modulated images, MODE 3 fc = 1 + the
+// moment correction  -g (cos(pi s) Re Q - sin(pi s) Im Q),  Q = sum_i M_i (i 32 G)^i (alpha_i + i beta_i),  G = pi g, w = G s,
+// alpha_i = 1/(i! (i+1)) - w^2 / (2 i! (i+3)),  beta_i = -w / (i! (i+2))   (tools/sinc3_model.py: 1e-7 for g <= 0.0101)
 template <int MODE, class LDS>
 __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const float sr, const float epr, const int wsK, const float g0) {
   using T32 = TapTab<32>;
@@ -684,7 +738,7 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
   const float xm2 = xp[-2], xm1 = xp[-1], x0 = xp[0], xp1 = xp[1], xp2 = xp[2];
   const float q = sr * sr, q64 = 64.0f * q;
   const float R1 = fast_rcp(fmaf(q, T32::B[1], T32::A[1])), R2 = fast_rcp(fmaf(q, T32::B[2], T32::A[2]));
-  if (MODE == 1) {
+  if (MODE == 1 || MODE == 3) {
     const float E1 = xp1 + xm1, D1 = xp1 - xm1, E2 = xp2 + xm2, D2 = xp2 - xm2;
     const float4v row = L.qa[sl];
     const unsigned w2 = __float_as_uint(L.qy[sl]);
@@ -692,7 +746,32 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
     const float en = fmaf(E2, R2, -(E1 * R1));
     const float dn = fmaf(D2 + D2, R2, -(D1 * R1));
     const float et = fmaf(e, kBank2ScaleInv, en), dt = fmaf(d, kBank2ScaleInv, dn);
-    return sinpi_poly(q) * fmaf(-sr, fmaf(sr, et, dt), x0 * 0.318309886f);
+    const float spq = sinpi_poly(q);                                  // sin(pi s) / s
+    const float unity = spq * fmaf(-sr, fmaf(sr, et, dt), x0 * 0.318309886f);
+    if (MODE == 1) return unity;
+    const float4v M0 = L.qm0[sl], M1 = L.qm1[sl];
+    const float g = epr * fast_rcp(1.0f + epr);                        // 1 - fc
+    const float G = 3.14159265f * g, w = G * sr, w2m = w * w, G32 = 32.0f * G;
+    float re, im;
+    // i = 6 (beta_6 and the w^2 terms of i >= 3 are below 1e-8 of the peak)
+    re = M1[2] * 1.98412698e-4f;                                       // 1 / (6! 7)
+    im = 0.0f;
+#define S3_MOM_STEP(Mi, A0, A1, B0)                                   \
+    {                                                                 \
+      const float al_ = fmaf(w2m, -(A1), (A0)), be_ = w * -(B0);      \
+      const float nre_ = fmaf(-G32, im, (Mi) * al_), nim_ = fmaf(G32, re, (Mi) * be_); \
+      re = nre_;                                                      \
+      im = nim_;                                                      \
+    }
+    S3_MOM_STEP(M1[1], 1.38888889e-3f, 0.0f, 1.19047619e-3f)          // i = 5: 1/(5! 6), -, 1/(5! 7)
+    S3_MOM_STEP(M1[0], 8.33333333e-3f, 0.0f, 6.94444444e-3f)          // i = 4: 1/(4! 5), -, 1/(4! 6)
+    S3_MOM_STEP(M0[3], 4.16666667e-2f, 0.0f, 3.33333333e-2f)          // i = 3: 1/(3! 4), -, 1/(3! 5)
+    S3_MOM_STEP(M0[2], 1.66666667e-1f, 5.0e-2f, 1.25e-1f)             // i = 2: 1/(2! 3), 1/(2 2! 5), 1/(2! 4)
+    S3_MOM_STEP(M0[1], 0.5f, 0.125f, 3.33333333e-1f)                  // i = 1: 1/2, 1/(2 4), 1/3
+    S3_MOM_STEP(M0[0], 1.0f, 1.66666667e-1f, 0.5f)                    // i = 0: 1, 1/(2 3), 1/2
+#undef S3_MOM_STEP
+    const float S = sr * spq, C = __builtin_amdgcn_cosf(0.5f * sr);
+    return fmaf(-g, fmaf(C, re, -(S * im)), unity);
   } else {
     const float f = fast_rcp(1.0f + epr), g = epr * f;               // fc, 1 - fc
     const float h = f * sr, zh = h * h;
@@ -772,9 +851,13 @@ __device__ __forceinline__ bool s3_convert(LDS& L, const int chunk, const int l,
 
 // GENK = true: both tap regimes (two waves per SIMD: 15.5 KB of LDS and the fc < 1 path's registers).  GENK = false: fc = 1
 // passes only, tiles that hold an fc < 1 pass go to the block kernel's list (three waves per SIMD).
-template <bool GENK>
-__global__ __launch_bounds__(kWave, GENK ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_pipe(const S2Args a) {
-  __shared__ S3LdsT<GENK> L;
+// MOM = true (GENK = false): fc < 1 passes as fc = 1 + the moment correction (one image, no g0, no restarts; valid for
+// 1 - fc <= kGMaxMom, steeper tiles go to the block kernel).
+constexpr float kEpMaxMom = 0.0125f / (1.0f - 0.0125f);      // period - 1 at 1 - fc = 0.0125
+template <bool GENK, bool MOM>
+__global__ __launch_bounds__(kWave, (GENK || MOM) ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_pipe(const S2Args a) {
+  static_assert(!(GENK && MOM), "one form of the fc < 1 path per kernel");
+  __shared__ S3LdsT<GENK, MOM> L;
   const int l = threadIdx.x;
   const int64_t Ta = (int64_t)blockIdx.x * PAR_S2_TILES;
   if (Ta >= a.n_full) return;
@@ -785,6 +868,12 @@ __global__ __launch_bounds__(kWave, GENK ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_p
     const uint4* src = reinterpret_cast<const uint4*>(kBank2Frags32) + l;
 #pragma unroll
     for (int f = 0; f < kBank2Frags; ++f) fr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
+  }
+  half8v fm[kBank3Frags];                       // (used by the MOM kernel only)
+  if constexpr (MOM) {
+    const uint4* src = reinterpret_cast<const uint4*>(kBank3Frags32) + l;
+#pragma unroll
+    for (int f = 0; f < kBank3Frags; ++f) fm[f] = __builtin_bit_cast(half8v, src[f * kWave]);
   }
   long long A0;
   int hd_dA, hd_fl;
@@ -812,7 +901,8 @@ __global__ __launch_bounds__(kWave, GENK ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_p
   // ---- stream state (wave-uniform) ----
   int j0 = 0;                                    // first output not yet placed into a finished pass
   int wbase = 0, conv_next = 0, conv_lo = 0, dma_next = 0, dma_bad = INT_MAX, mode = 0, pk = 0;
-  float g0 = 0.0f;
+  int regime = 1;                                // the loop the current pass belongs to: 1 fc = 1, 2 modulated images, 3 moment correction
+  float g0 = 0.0f;                               // (mode: the form of the images in LDS -- 0 none, 1 the signal itself, 2 modulated)
   int rbA = 0, rbB = 0, rbC = 0;                 // first block (relative) of the record buffers of passes pk + 1, pk + 2, pk + 3
 
   auto fetch_records = [&](int buf, int blk0) {  // 8 first pieces + 8 second pieces from block blk0 on -> recs[buf]
@@ -867,6 +957,10 @@ __global__ __launch_bounds__(kWave, GENK ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_p
     P.nt[1] = clamp64(P.tend - j - 64);
     P.R[0] = s2_place_row(ra0, rb0, u, (l < P.nt[0] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
     P.R[1] = s2_place_row(ra1, rb1, u, (l < P.nt[1] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
+    if (MOM) {                                   // the moment correction covers 1 - fc <= 0.0125
+      P.R[0].bad = P.R[0].bad || !(P.R[0].ep <= kEpMaxMom);
+      P.R[1].bad = P.R[1].bad || !(P.R[1].ep <= kEpMaxMom);
+    }
     return P;
   };
 
@@ -936,7 +1030,8 @@ __global__ __launch_bounds__(kWave, GENK ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_p
       N.j = j0;
       N.ws = ws;
       const int want = gen == 0ull ? 1 : 2;
-      if (!GENK && want == 2) skip = true;        // (this kernel leaves fc < 1 passes to the block kernel)
+      if (!GENK && !MOM && want == 2) skip = true;        // (this kernel leaves fc < 1 passes to the block kernel)
+      const int img_want = MOM ? 1 : want;        // the moment form works on the signal's own image
       float gg[2];
 #pragma unroll
       for (int r = 0; r < 2; ++r) gg[r] = N.ep[r] * fast_rcp(1.0f + N.ep[r]);
@@ -944,7 +1039,7 @@ __global__ __launch_bounds__(kWave, GENK ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_p
         return ((__ballot(!(fabsf(gref - gg[0]) <= kEpsTol)) & prefix(nv[0])) | (__ballot(!(fabsf(gref - gg[1]) <= kEpsTol)) & prefix(nv[1]))) != 0ull;
       };
       if (!skip) {
-        bool rebuild = mode != want || (want == 2 && far_off(g0));
+        bool rebuild = mode != img_want || (img_want == 2 && far_off(g0));
         // the ring: restarted at the first pass of the wave and after a jump the fetched chunks do not cover
         const int lo_need = ws - 39 - wbase;      // window index of the first image sample the bank reads
         if (mode == 0 || lo_need < kPass * (dma_next - 8) + kPass || lo_need < 0 || lo_need > kPass * dma_next || ws - wbase > (1 << 20)) {
@@ -955,9 +1050,10 @@ __global__ __launch_bounds__(kWave, GENK ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_p
           rebuild = true;
         }
         const int wsK = ws - wbase;
+        regime = MOM ? (want == 1 ? 1 : 3) : want;
         if (rebuild) {
-          mode = want;
-          if (want == 2) {
+          mode = img_want;
+          if (img_want == 2) {
             g0 = __shfl(gg[0], nJ - j0 > 32 ? 32 : 0, kWave);
             if (far_off(g0)) skip = true;         // a ramp too steep for one g0
           }
@@ -1011,7 +1107,10 @@ __global__ __launch_bounds__(kWave, GENK ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_p
       }
       wave_lds_fence();
       const int offs = ws - wbase - 31;
-      if (!GENK || mode == 1) {
+      if constexpr (MOM) {
+        if (regime == 3) bank_image3m(L, fr, fm, offs, l);
+        else bank_image3<false>(L, fr, offs, l, 0);
+      } else if (!GENK || mode == 1) {
         bank_image3<false>(L, fr, offs, l, 0);
       } else if constexpr (GENK) {
         bank_image3<true>(L, fr, offs, l, 0);
@@ -1027,7 +1126,9 @@ __global__ __launch_bounds__(kWave, GENK ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_p
         return true;
       }
       float res[2];
-      if (!GENK || mode == 1) out_pass(std::integral_constant<int, 1>{}, N, res);
+      if (MOM && regime == 3) {
+        if constexpr (MOM) out_pass(std::integral_constant<int, 3>{}, N, res);
+      } else if (!GENK || mode == 1) out_pass(std::integral_constant<int, 1>{}, N, res);
       else if constexpr (GENK) out_pass(std::integral_constant<int, 2>{}, N, res);
       store_pass(N, res);
     }
@@ -1092,10 +1193,14 @@ __global__ __launch_bounds__(kWave, GENK ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_p
       float res[2];
       out_pass(mode_tag, P, res);
       const int offs = wsK - 31;
-      bank_image3<MODE == 2>(L, fr, offs, l, 0);
-      if constexpr (MODE == 2) bank_image3<true>(L, fr, offs, l, 1);
+      if constexpr (MODE == 3) {
+        bank_image3m(L, fr, fm, offs, l);
+      } else {
+        bank_image3<MODE == 2>(L, fr, offs, l, 0);
+        if constexpr (MODE == 2) bank_image3<true>(L, fr, offs, l, 1);
+      }
       // CONV: one chunk per iteration
-      const bool cok = s3_convert<MODE>(L, conv_next, l, g0);
+      const bool cok = s3_convert<MODE == 2 ? 2 : 1>(L, conv_next, l, g0);
       // FETCH + stores: records of pass pk + 2, chunk conv_next + 2, then P's outputs (five memory operations, in this order)
       fetch_records((pk + 2) & 3, rbC);
       chunk_dma(dma_next);
@@ -1130,7 +1235,9 @@ __global__ __launch_bounds__(kWave, GENK ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_p
   };
 
   while (start_run()) {
-    if (!GENK || mode == 1) hot(std::integral_constant<int, 1>{});
+    if (MOM && regime == 3) {
+      if constexpr (MOM) hot(std::integral_constant<int, 3>{});
+    } else if (!GENK || mode == 1) hot(std::integral_constant<int, 1>{});
     else if constexpr (GENK) hot(std::integral_constant<int, 2>{});
     // P has been finished by the loop; the pass at j0 needs the cold path
   }
@@ -1164,8 +1271,9 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
   a.n_tiles = ceil_div(len_out, kSincTileOutputs);
   const int64_t grid = ceil_div(a.n_full, (int64_t)PAR_S2_TILES);
   if (grid > 0 && variant == 1) hipLaunchKernelGGL(k_sinc_stream, dim3((unsigned)grid), dim3(kWave), 0, s, a);
-  else if (grid > 0 && variant == 2) hipLaunchKernelGGL(k_sinc_pipe<true>, dim3((unsigned)grid), dim3(kWave), 0, s, a);
-  else if (grid > 0) hipLaunchKernelGGL(k_sinc_pipe<false>, dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  else if (grid > 0 && variant == 2) hipLaunchKernelGGL((k_sinc_pipe<true, false>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  else if (grid > 0 && variant == 3) hipLaunchKernelGGL((k_sinc_pipe<false, false>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  else if (grid > 0) hipLaunchKernelGGL((k_sinc_pipe<false, true>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
   else if (a.n_tiles > 0) {
     // nothing but a partial tile: the caller's block kernel handles short files (launch_sinc_fused never comes here)
   }

@@ -180,6 +180,19 @@ def render():
     out.append("};")
     out.append("#endif")
     out.append("")
+    fr3 = M2.moment_fragments().reshape(-1, 2)
+    w3 = (fr3[:, 0].astype(np.uint32) | (fr3[:, 1].astype(np.uint32) << 16))
+    out.append("// Constant A fragments of the moment filters m_i = sum_n (-1)^n win_n (n / 32)^i x[c + n], i = 0 .. 6, all taps |n| <= 31")
+    out.append("// (tools/sinc2_model.py, moment_fragments; the fc < 1 correction of tools/sinc3_model.py): [15 fragments][64 lanes][8 halves]:")
+    out.append("// 0-2 (m0 m1) hi, 3-5 (m0 m1) lo x %g, 6-8 (m2 m3), 9-11 (m4 m5), 12-14 (m6 -)." % M2.LO)
+    out.append("constexpr int kBank3Frags = %d;" % len(M2.MOM_FRAGS))
+    out.append("#ifdef PAR_WANT_BANK2")
+    out.append("__device__ const unsigned int kBank3Frags32[%d] = {" % len(w3))
+    for i in range(0, len(w3), 12):
+        out.append("  " + ", ".join("0x%08xu" % w for w in w3[i:i + 12]) + ",")
+    out.append("};")
+    out.append("#endif")
+    out.append("")
     out += ["}  // namespace par", ""]
     return "\n".join(out)
 

@@ -139,6 +139,39 @@ def bank_fragments():
     return out.view(np.uint16)
 
 
+# ---- moment filters of the fc < 1 correction (tools/sinc3_model.py, NOTES r04): m_i = sum_n (-1)^n win_n (n / 32)^i x[c + n] over ALL
+# taps |n| <= 31, i = 0 .. 6.  Same fragment geometry as the bank: pairs (m0 m1), (m2 m3), (m4 m5), (m6 -); fragments 0-2 (m0 m1)
+# hi slices 0-2, 3-5 (m0 m1) coefficient lo x 4096, 6-8 (m2 m3), 9-11 (m4 m5), 12-14 (m6 -).  Coefficients below float16's normal
+# range are zero to the matrix cores (their whole contribution is < 2e-9 of the peak: sinc3_model.py).
+MOMENTS = 7
+MOM_FRAGS = ((0, 1, 0, 0), (0, 1, 1, 0), (0, 1, 2, 0), (0, 1, 0, 1), (0, 1, 1, 1), (0, 1, 2, 1),
+             (2, 3, 0, 0), (2, 3, 1, 0), (2, 3, 2, 0), (4, 5, 0, 0), (4, 5, 1, 0), (4, 5, 2, 0), (6, -1, 0, 0), (6, -1, 1, 0), (6, -1, 2, 0))
+
+
+def mom_coef(i, n):
+    if i < 0 or abs(n) >= NT:
+        return 0.0
+    sg = -1.0 if (abs(n) & 1) else 1.0
+    return sg * win_n(abs(n)) * (n / 32.0) ** i
+
+
+def moment_fragments():
+    out = np.zeros((len(MOM_FRAGS), 64, 8), dtype=np.float16)
+    for fr, (fe, fd, ks, lo) in enumerate(MOM_FRAGS):
+        for lane in range(64):
+            m, g = lane & 15, lane >> 4
+            i, fsel = m >> 1, m & 1
+            for j in range(8):
+                n = 32 * ks + 8 * g + j - 31 - i
+                cf = mom_coef(fd if fsel else fe, n) if -NT < n < NT else 0.0
+                hi = np.float16(cf if abs(cf) >= 2.0 ** -14 else 0.0)
+                out[fr, lane, j] = np.float16((cf - float(hi)) * LO) if lo else hi
+    # the lo fragments must themselves be normal float16 values or zero (the matrix cores flush the rest): those below are dropped
+    sub = (np.abs(out.astype(np.float64)) < 2.0 ** -14) & (out != 0)
+    out[sub] = 0
+    return out.view(np.uint16)
+
+
 def h16(x):
     """float16 as the matrix cores see it: subnormals flush to zero"""
     v = np.asarray(x, dtype=np.float64).astype(np.float16).astype(np.float64)
