@@ -615,16 +615,25 @@ template <bool GENK, bool MOM = false>
 struct S3LdsT {
   float ring_head[4];                            // [2], [3] mirror ring[1022], ring[1023]
   float ring[kRingF];
-  float ring_tail[8];                            // mirrors ring[0 .. 7]
+  float ring_tail[4];                            // mirrors ring[0 .. 3]
   _Float16 img[GENK ? 4 : 2][kRingH];            // x (or A) hi, lo x 4096; B hi, lo x 4096
   float4v qa[kPass];                             // bank rows {e0, d0, e1, d1} of x / A, slot = ci ^ ((ci >> 3) & 7)
   float4v qb[GENK ? kPass : 1];                  // of B
   float4v qx[GENK ? kPass : 1];                  // .x = e2|d2 of x / A (halves), .y = e2|d2 of B, .z = H(A), .w = H(B)
-  float qy[kPass];                               // GENK: H1'(A) | H1'(B) (halves); else: e2|d2 of x (halves)
-  float4v qm0[MOM ? kPass : 1];                  // moment rows {m0, m1, m2, m3} (same slots as qa)
-  float4v qm1[MOM ? kPass : 1];                  // {m4, m5, m6, -}
+  float qy[MOM ? 1 : kPass];                     // GENK: H1'(A) | H1'(B) (halves); else: e2|d2 of x (halves); MOM: in qm0
+  float4v qm0[MOM ? kPass : 1];                  // moment rows {m0, m1, m2, e2|d2 of x (halves)} (same slots as qa)
+  uint2 qm1[MOM ? kPass : 1];                    // {m3 | m4, m5 | m6} as halves / 64 (their terms are <= 8e-4 of the correction's first)
   uint4 recs[4][16];                             // block records of four passes: [0..7] first pieces, [8..15] second pieces
 };
+// e2 | d2 of the fc = 1 bank: its own array, or word 3 of the moment row
+template <class LDS> __device__ __forceinline__ float& s3_e2d2(LDS& L, int sl) {
+  if constexpr (sizeof(L.qm0) > 16) return reinterpret_cast<float*>(&L.qm0[sl])[3];
+  else return L.qy[sl];
+}
+template <class LDS> __device__ __forceinline__ float s3_e2d2(const LDS& L, int sl) {
+  if constexpr (sizeof(L.qm0) > 16) return reinterpret_cast<const float*>(&L.qm0[sl])[3];
+  else return L.qy[sl];
+}
 typedef S3LdsT<false, true> S3LdsMom;
 static_assert(offsetof(S3LdsMom, qm0) % 16 == 0 && offsetof(S3LdsMom, recs) % 16 == 0, "16-byte aligned");
 static_assert(offsetof(S3LdsT<true>, img) % 16 == 0 && offsetof(S3LdsT<true>, qa) % 16 == 0 && offsetof(S3LdsT<true>, recs) % 16 == 0, "16-byte aligned");
@@ -675,15 +684,34 @@ __device__ __forceinline__ void bank_image3(LDS& L, const half8v (&fr)[kBank2Fra
       reinterpret_cast<_Float16*>(&L.qy[sl])[sel] = (_Float16)(hh[2 * p + 1] * 0.0009765625f);
     } else {
       L.qa[sl] = row;
-      L.qy[sl] = __uint_as_float(e2d2);
+      s3_e2d2(L, sl) = __uint_as_float(e2d2);
     }
   }
 }
 
 // fc = 1 bank AND the seven moment filters of the fc < 1 correction over the same 128 centres, from the same signal fragments
 // (fm: kBank3Frags32, sinc_taps_gen.h): 15 + 18 MFMAs.
-template <class LDS>
-__device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Frags], const half8v (&fm)[kBank3Frags], const int offs, const int l) {
+// ctab: the workgroup's table of constant fragments in LDS, fragment f of lane l at ctab[64 f + l]: 0-9 the fc = 1 bank's
+// (kBank2Frags32's first ten), 10-24 the moment filters' (kBank3Frags32).  MOMENTS = false: the fc = 1 bank alone.
+constexpr int kCtabUnity = 10;
+#ifndef PAR_S3_MOM_FR_REGS
+#define PAR_S3_MOM_FR_REGS 5                       // how many of the fc = 1 bank's ten fragments stay in registers (the rest, and the moment filters', come from the table)
+#endif
+#ifndef PAR_S3_SCHED_BARRIERS
+#define PAR_S3_SCHED_BARRIERS 0                    // 1: the bank's two halves and the loop's stages are not interleaved by the compiler (fewer live registers)
+#endif
+__device__ __forceinline__ void s3_sched_fence() {
+#if PAR_S3_SCHED_BARRIERS
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+#ifndef PAR_S3_MOM_WAVES
+#define PAR_S3_MOM_WAVES 1                         // waves per workgroup of the moment kernel; 1: no table, all 25 fragments in registers
+#endif
+constexpr int kMomFrRegs = PAR_S3_MOM_WAVES == 1 ? kCtabUnity : PAR_S3_MOM_FR_REGS;
+template <bool MOMENTS, class LDS>
+__device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Frags], const half8v (&fmr)[kBank3Frags],
+                                             const uint4* __restrict__ ctab, const int offs, const int l) {
   const int bb = l & 15, g = l >> 4;
   const int i0 = offs + 8 * bb + 8 * g;
   half8v xh[3], xl[3];
@@ -693,36 +721,57 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
     xh[ks] = *reinterpret_cast<const half8v*>(&L.img[0][ix]);
     xl[ks] = *reinterpret_cast<const half8v*>(&L.img[1][ix]);
   }
+  const uint4* ct = ctab + l;
+  auto frag = [&](int f) {
+    if (f < kMomFrRegs) return fr[f];
+    if (PAR_S3_MOM_WAVES == 1) return fmr[f - kCtabUnity];
+    return __builtin_bit_cast(half8v, ct[64 * (f - kMomFrRegs)]);
+  };
   const float4v z = {0.0f, 0.0f, 0.0f, 0.0f};
-  float4v e0 = z, lo = z, e1 = z, x1 = z, e2 = z, a01 = z, l01 = z, a23 = z, a45 = z, a6 = z;
+  float4v e0 = z, lo = z, e1 = z, x1 = z, e2 = z;
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
-    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[ks], xh[ks], e0, 0, 0, 0);
-    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[5 + ks], xh[ks], lo, 0, 0, 0);
-    a01 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fm[ks], xh[ks], a01, 0, 0, 0);
-    l01 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fm[3 + ks], xh[ks], l01, 0, 0, 0);
-    a23 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fm[6 + ks], xh[ks], a23, 0, 0, 0);
-    a45 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fm[9 + ks], xh[ks], a45, 0, 0, 0);
-    a6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fm[12 + ks], xh[ks], a6, 0, 0, 0);
-    if (ks < 2) e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[3 + ks], xh[ks], e1, 0, 0, 0);
-    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[ks], xl[ks], lo, 0, 0, 0);
-    l01 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fm[ks], xl[ks], l01, 0, 0, 0);
+    const half8v f0 = frag(ks);
+    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, xh[ks], e0, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag(5 + ks), xh[ks], lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, xl[ks], lo, 0, 0, 0);
     if (ks < 2) {
-      x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[3 + ks], xl[ks], x1, 0, 0, 0);
-      e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[8 + ks], xh[ks], e2, 0, 0, 0);
+      const half8v f1 = frag(3 + ks);
+      e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, xh[ks], e1, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, xl[ks], x1, 0, 0, 0);
+      e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag(8 + ks), xh[ks], e2, 0, 0, 0);
     }
   }
-  const float4v v0 = e0 + lo * kBank2LoInv, v1 = e1 + x1 * kBank2LoInv, m01 = a01 + l01 * kBank2LoInv;
+  const float4v v0 = e0 + lo * kBank2LoInv, v1 = e1 + x1 * kBank2LoInv;
+  float4v a01 = z, l01 = z, a23 = z, a45 = z, a6 = z;
+  s3_sched_fence();
+  if (MOMENTS) {
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      const half8v f01 = frag(kCtabUnity + ks);
+      a01 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f01, xh[ks], a01, 0, 0, 0);
+      l01 = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag(kCtabUnity + 3 + ks), xh[ks], l01, 0, 0, 0);
+      l01 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f01, xl[ks], l01, 0, 0, 0);
+      a23 = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag(kCtabUnity + 6 + ks), xh[ks], a23, 0, 0, 0);
+      a45 = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag(kCtabUnity + 9 + ks), xh[ks], a45, 0, 0, 0);
+      a6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag(kCtabUnity + 12 + ks), xh[ks], a6, 0, 0, 0);
+    }
+  }
+  const float4v m01 = a01 + l01 * kBank2LoInv;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int sl = (8 * bb + 2 * g + p) ^ (bb & 7);
     const float4v row = {v0[2 * p], v0[2 * p + 1], v1[2 * p], v1[2 * p + 1]};
     L.qa[sl] = row;
-    L.qy[sl] = __uint_as_float(pack_h2(e2[2 * p] * 0.015625f, e2[2 * p + 1] * 0.015625f));
-    const float4v r0 = {m01[2 * p], m01[2 * p + 1], a23[2 * p], a23[2 * p + 1]};
-    const float4v r1 = {a45[2 * p], a45[2 * p + 1], a6[2 * p], 0.0f};
-    L.qm0[sl] = r0;
-    L.qm1[sl] = r1;
+    const float e2d2 = __uint_as_float(pack_h2(e2[2 * p] * 0.015625f, e2[2 * p + 1] * 0.015625f));
+    if (MOMENTS) {
+      const float4v r0 = {m01[2 * p], m01[2 * p + 1], a23[2 * p], e2d2};
+      L.qm0[sl] = r0;
+      const uint2 r1 = {pack_h2(a23[2 * p + 1] * 0.015625f, a45[2 * p] * 0.015625f), pack_h2(a45[2 * p + 1] * 0.015625f, a6[2 * p] * 0.015625f)};
+      L.qm1[sl] = r1;
+    } else {
+      s3_e2d2(L, sl) = e2d2;
+    }
   }
 }
 
@@ -741,7 +790,14 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
   if (MODE == 1 || MODE == 3) {
     const float E1 = xp1 + xm1, D1 = xp1 - xm1, E2 = xp2 + xm2, D2 = xp2 - xm2;
     const float4v row = L.qa[sl];
-    const unsigned w2 = __float_as_uint(L.qy[sl]);
+    float4v M0 = {0.0f, 0.0f, 0.0f, 0.0f};
+    unsigned w2;
+    if (MODE == 3) {
+      M0 = L.qm0[sl];
+      w2 = __float_as_uint(M0[3]);
+    } else {
+      w2 = __float_as_uint(s3_e2d2(L, sl));
+    }
     const float e = fmaf(q, fmaf(q64, h_lo(w2), row[2]), row[0]), d = fmaf(q, fmaf(q64, h_hi(w2), row[3]), row[1]);
     const float en = fmaf(E2, R2, -(E1 * R1));
     const float dn = fmaf(D2 + D2, R2, -(D1 * R1));
@@ -749,12 +805,13 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
     const float spq = sinpi_poly(q);                                  // sin(pi s) / s
     const float unity = spq * fmaf(-sr, fmaf(sr, et, dt), x0 * 0.318309886f);
     if (MODE == 1) return unity;
-    const float4v M0 = L.qm0[sl], M1 = L.qm1[sl];
+    const uint2 Mh = L.qm1[sl];
+    const float m3 = 64.0f * h_lo(Mh.x), m4 = 64.0f * h_hi(Mh.x), m5 = 64.0f * h_lo(Mh.y), m6 = 64.0f * h_hi(Mh.y);
     const float g = epr * fast_rcp(1.0f + epr);                        // 1 - fc
     const float G = 3.14159265f * g, w = G * sr, w2m = w * w, G32 = 32.0f * G;
     float re, im;
     // i = 6 (beta_6 and the w^2 terms of i >= 3 are below 1e-8 of the peak)
-    re = M1[2] * 1.98412698e-4f;                                       // 1 / (6! 7)
+    re = m6 * 1.98412698e-4f;                                          // 1 / (6! 7)
     im = 0.0f;
 #define S3_MOM_STEP(Mi, A0, A1, B0)                                   \
     {                                                                 \
@@ -763,9 +820,9 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
       re = nre_;                                                      \
       im = nim_;                                                      \
     }
-    S3_MOM_STEP(M1[1], 1.38888889e-3f, 0.0f, 1.19047619e-3f)          // i = 5: 1/(5! 6), -, 1/(5! 7)
-    S3_MOM_STEP(M1[0], 8.33333333e-3f, 0.0f, 6.94444444e-3f)          // i = 4: 1/(4! 5), -, 1/(4! 6)
-    S3_MOM_STEP(M0[3], 4.16666667e-2f, 0.0f, 3.33333333e-2f)          // i = 3: 1/(3! 4), -, 1/(3! 5)
+    S3_MOM_STEP(m5, 1.38888889e-3f, 0.0f, 1.19047619e-3f)             // i = 5: 1/(5! 6), -, 1/(5! 7)
+    S3_MOM_STEP(m4, 8.33333333e-3f, 0.0f, 6.94444444e-3f)             // i = 4: 1/(4! 5), -, 1/(4! 6)
+    S3_MOM_STEP(m3, 4.16666667e-2f, 0.0f, 3.33333333e-2f)             // i = 3: 1/(3! 4), -, 1/(3! 5)
     S3_MOM_STEP(M0[2], 1.66666667e-1f, 5.0e-2f, 1.25e-1f)             // i = 2: 1/(2! 3), 1/(2 2! 5), 1/(2! 4)
     S3_MOM_STEP(M0[1], 0.5f, 0.125f, 3.33333333e-1f)                  // i = 1: 1/2, 1/(2 4), 1/3
     S3_MOM_STEP(M0[0], 1.0f, 1.66666667e-1f, 0.5f)                    // i = 0: 1, 1/(2 3), 1/2
@@ -818,7 +875,7 @@ __device__ __forceinline__ bool s3_convert(LDS& L, const int chunk, const int l,
   const float am = fmaxf(fabsf(x0), fabsf(x1));
   const bool ok = !(__ballot(!(fabsf(x0) < 32768.0f) || !(fabsf(x1) < 32768.0f)) != 0ull ||
                     (__ballot(am >= kQuiet) == 0ull && __ballot(am > 0.0f) != 0ull));
-  if ((chunk & 7) == 0 && l < 4) *reinterpret_cast<float2*>(&L.ring_tail[ix]) = xx;
+  if ((chunk & 7) == 0 && l < 2) *reinterpret_cast<float2*>(&L.ring_tail[ix]) = xx;
   if ((chunk & 7) == 7 && l == kWave - 1) *reinterpret_cast<float2*>(&L.ring_head[2]) = xx;
   if (MODE == 1) {
     const half2v h = {S2_HI(x0), S2_HI(x1)};
@@ -854,27 +911,51 @@ __device__ __forceinline__ bool s3_convert(LDS& L, const int chunk, const int l,
 // MOM = true (GENK = false): fc < 1 passes as fc = 1 + the moment correction (one image, no g0, no restarts; valid for
 // 1 - fc <= kGMaxMom, steeper tiles go to the block kernel).
 constexpr float kEpMaxMom = 0.0125f / (1.0f - 0.0125f);      // period - 1 at 1 - fc = 0.0125
+// PAR_S3_MOM_WAVES > 1 (experiment): the MOM kernel as a workgroup of that many waves that never meet again after its head --
+// each streams over its own eight tiles with its own piece of LDS -- sharing a table of constant fragments in LDS (the moment
+// filters' 15 and 10 - PAR_S3_MOM_FR_REGS of the fc = 1 bank's), which frees up to 100 VGPRs: 11 waves = 2.75 per SIMD at 168
+// VGPRs without spills.  Measured (fc < 1 / fc = 1 tapes): 96 / 137 Gsamples/s at 11 waves, 94 / 146 at 8, against 104.5 / 154
+// for one-wave workgroups with all 25 fragments in registers: a workgroup that owns the whole LDS of its compute unit starts
+// and ends as one (table load, cold start of every stream, the stragglers' tail: nothing else can start meanwhile).
 template <bool GENK, bool MOM>
-__global__ __launch_bounds__(kWave, (GENK || MOM) ? 2 : PAR_S3_UNITY_WAVES) void k_sinc_pipe(const S2Args a) {
+struct S3Shared {
+  uint4 fmtab[(MOM && PAR_S3_MOM_WAVES > 1) ? (kCtabUnity - kMomFrRegs + kBank3Frags) * kWave : 1];
+  S3LdsT<GENK, MOM> per[MOM ? PAR_S3_MOM_WAVES : 1];
+};
+template <bool GENK, bool MOM>
+__global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S3_MOM_WAVES > 1) ? 1 : ((GENK || MOM) ? 2 : PAR_S3_UNITY_WAVES)) void k_sinc_pipe(const S2Args a) {
   static_assert(!(GENK && MOM), "one form of the fc < 1 path per kernel");
-  __shared__ S3LdsT<GENK, MOM> L;
-  const int l = threadIdx.x;
-  const int64_t Ta = (int64_t)blockIdx.x * PAR_S2_TILES;
+  constexpr int NW = MOM ? PAR_S3_MOM_WAVES : 1;
+  __shared__ S3Shared<GENK, MOM> SH;
+  const int l = threadIdx.x & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  S3LdsT<GENK, MOM>& L = SH.per[wv];
+  if constexpr (MOM && NW > 1) {
+    const uint4* src2 = reinterpret_cast<const uint4*>(kBank2Frags32);
+    const uint4* src3 = reinterpret_cast<const uint4*>(kBank3Frags32);
+    constexpr int kU = (kCtabUnity - kMomFrRegs) * kWave;
+    for (int i = threadIdx.x; i < kU + kBank3Frags * kWave; i += kWave * NW)
+      SH.fmtab[i] = i < kU ? src2[i + kMomFrRegs * kWave] : src3[i - kU];
+    __syncthreads();
+  }
+  const int64_t stream_id = (int64_t)blockIdx.x * NW + wv;
+  const int64_t Ta = stream_id * PAR_S2_TILES;
   if (Ta >= a.n_full) return;
   const int64_t Tb = Ta + PAR_S2_TILES < a.n_full ? Ta + PAR_S2_TILES : a.n_full;
   const int64_t Ja = Ta * kSincTileOutputs, Jb = Tb * kSincTileOutputs;
-  half8v fr[kBank2Frags];
-  {
+  half8v fr[kBank2Frags];                        // (the MOM kernel reads its constants from the table instead)
+  if constexpr (!MOM || kMomFrRegs > 0) {
     const uint4* src = reinterpret_cast<const uint4*>(kBank2Frags32) + l;
 #pragma unroll
     for (int f = 0; f < kBank2Frags; ++f) fr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
   }
-  half8v fm[kBank3Frags];                       // (used by the MOM kernel only)
-  if constexpr (MOM) {
+  half8v fmr[kBank3Frags];                       // the moment filters' fragments (one-wave form of the MOM kernel only)
+  if constexpr (MOM && NW == 1) {
     const uint4* src = reinterpret_cast<const uint4*>(kBank3Frags32) + l;
 #pragma unroll
-    for (int f = 0; f < kBank3Frags; ++f) fm[f] = __builtin_bit_cast(half8v, src[f * kWave]);
+    for (int f = 0; f < kBank3Frags; ++f) fmr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
   }
+  const uint4* const fm = SH.fmtab;
   long long A0;
   int hd_dA, hd_fl;
   {
@@ -931,7 +1012,7 @@ __global__ __launch_bounds__(kWave, (GENK || MOM) ? 2 : PAR_S3_UNITY_WAVES) void
       a.redo_list[slot] = (int)T;
     }
   };
-  if (blockIdx.x == 0 && a.n_full < a.n_tiles) push_tile(a.n_full);
+  if (stream_id == 0 && a.n_full < a.n_tiles) push_tile(a.n_full);
 
   // placement of the pass that starts at output j from record buffer `buf` (first block rb); the lanes' tile anchors
   struct Placed {
@@ -1108,8 +1189,8 @@ __global__ __launch_bounds__(kWave, (GENK || MOM) ? 2 : PAR_S3_UNITY_WAVES) void
       wave_lds_fence();
       const int offs = ws - wbase - 31;
       if constexpr (MOM) {
-        if (regime == 3) bank_image3m(L, fr, fm, offs, l);
-        else bank_image3<false>(L, fr, offs, l, 0);
+        if (regime == 3) bank_image3m<true>(L, fr, fmr, fm, offs, l);
+        else bank_image3m<false>(L, fr, fmr, fm, offs, l);
       } else if (!GENK || mode == 1) {
         bank_image3<false>(L, fr, offs, l, 0);
       } else if constexpr (GENK) {
@@ -1193,8 +1274,10 @@ __global__ __launch_bounds__(kWave, (GENK || MOM) ? 2 : PAR_S3_UNITY_WAVES) void
       float res[2];
       out_pass(mode_tag, P, res);
       const int offs = wsK - 31;
-      if constexpr (MODE == 3) {
-        bank_image3m(L, fr, fm, offs, l);
+      if constexpr (MOM) {
+        s3_sched_fence();
+        bank_image3m<MODE == 3>(L, fr, fmr, fm, offs, l);
+        s3_sched_fence();
       } else {
         bank_image3<MODE == 2>(L, fr, offs, l, 0);
         if constexpr (MODE == 2) bank_image3<true>(L, fr, offs, l, 1);
@@ -1244,7 +1327,7 @@ __global__ __launch_bounds__(kWave, (GENK || MOM) ? 2 : PAR_S3_UNITY_WAVES) void
   __builtin_amdgcn_s_waitcnt(0x0F70);
 #if PAR_S2_EXP & 64
   if (l == 0) {
-    unsigned long long* o = g_s2_phase + (size_t)blockIdx.x * 16;
+    unsigned long long* o = g_s2_phase + (size_t)stream_id * 16;
     o[0] = s3t_[0];                                // cycles in the loop's memory wait (includes two clock reads)
     o[1] = s3t_[1];                                // cycles between the end of one wait and the start of the next
     o[2] = s3t_[2];                                // iterations
@@ -1273,7 +1356,8 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
   if (grid > 0 && variant == 1) hipLaunchKernelGGL(k_sinc_stream, dim3((unsigned)grid), dim3(kWave), 0, s, a);
   else if (grid > 0 && variant == 2) hipLaunchKernelGGL((k_sinc_pipe<true, false>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
   else if (grid > 0 && variant == 3) hipLaunchKernelGGL((k_sinc_pipe<false, false>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
-  else if (grid > 0) hipLaunchKernelGGL((k_sinc_pipe<false, true>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  else if (grid > 0)
+    hipLaunchKernelGGL((k_sinc_pipe<false, true>), dim3((unsigned)ceil_div(grid, (int64_t)PAR_S3_MOM_WAVES)), dim3(kWave * PAR_S3_MOM_WAVES), 0, s, a);
   else if (a.n_tiles > 0) {
     // nothing but a partial tile: the caller's block kernel handles short files (launch_sinc_fused never comes here)
   }

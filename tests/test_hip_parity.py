@@ -1018,12 +1018,13 @@ def test_unity_path_matrix_core_bank(par):
     assert np.array_equal(np.isnan(got), np.isnan(want)) and 60 <= np.isnan(want).sum() <= 66
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3"])
+@pytest.mark.parametrize("variant", ["1", "2", "3", "4"])
 def test_streaming_kernel_opt_in(par, monkeypatch, variant):
     """r04: the streaming forms of K_sinc (csrc/sinc2.hip, opt-in through PAR_SINC_STREAM; mono, NT = 32, unit strides): one wave
     streams over eight tiles, taps |n| >= 3 of BOTH regimes on the matrix cores (fc < 1 through two modulated images), the rest
     of the file through the block kernel's tile list.  1: k_sinc_stream (a pass at a time), 2: k_sinc_pipe (stages of different
-    passes in one iteration), 3: k_sinc_pipe for fc = 1 passes only, fc < 1 tiles to the block kernel.  Against the C oracle on
+    passes in one iteration), 3: k_sinc_pipe for fc = 1 passes only, fc < 1 tiles to the block kernel, 4: k_sinc_pipe with the
+    fc < 1 taps in their moment form (fc = 1 bank + seven moment filters on one image).  Against the C oracle on
     a fast, a slow and a mixed tape, norm-wise and per 4096-sample block; the tile list stays short; a NaN sample poisons exactly
     the reference's window; short and odd-length files work."""
     import ctypes
