@@ -708,7 +708,12 @@ __device__ __forceinline__ void s3_sched_fence() {
 #ifndef PAR_S3_MOM_WAVES
 #define PAR_S3_MOM_WAVES 1                         // waves per workgroup of the moment kernel; 1: no table, all 25 fragments in registers
 #endif
+#ifndef PAR_S3_MOM_FM_REGS
+#define PAR_S3_MOM_FM_REGS 15                      // one-wave form: how many of the moment filters' 15 fragments stay in registers (the rest in the wave's LDS)
+#endif
 constexpr int kMomFrRegs = PAR_S3_MOM_WAVES == 1 ? kCtabUnity : PAR_S3_MOM_FR_REGS;
+constexpr int kMomFmRegs = PAR_S3_MOM_WAVES == 1 ? PAR_S3_MOM_FM_REGS : 0;
+constexpr int kMomTabFrags = (kCtabUnity - kMomFrRegs) + (kBank3Frags - kMomFmRegs);
 template <bool MOMENTS, class LDS>
 __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Frags], const half8v (&fmr)[kBank3Frags],
                                              const uint4* __restrict__ ctab, const int offs, const int l) {
@@ -724,8 +729,9 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
   const uint4* ct = ctab + l;
   auto frag = [&](int f) {
     if (f < kMomFrRegs) return fr[f];
-    if (PAR_S3_MOM_WAVES == 1) return fmr[f - kCtabUnity];
-    return __builtin_bit_cast(half8v, ct[64 * (f - kMomFrRegs)]);
+    if (f < kCtabUnity) return __builtin_bit_cast(half8v, ct[64 * (f - kMomFrRegs)]);
+    if (f - kCtabUnity < kMomFmRegs) return fmr[f - kCtabUnity];
+    return __builtin_bit_cast(half8v, ct[64 * ((kCtabUnity - kMomFrRegs) + (f - kCtabUnity - kMomFmRegs))]);
   };
   const float4v z = {0.0f, 0.0f, 0.0f, 0.0f};
   float4v e0 = z, lo = z, e1 = z, x1 = z, e2 = z;
@@ -919,23 +925,31 @@ constexpr float kEpMaxMom = 0.0125f / (1.0f - 0.0125f);      // period - 1 at 1 
 // and ends as one (table load, cold start of every stream, the stragglers' tail: nothing else can start meanwhile).
 template <bool GENK, bool MOM>
 struct S3Shared {
-  uint4 fmtab[(MOM && PAR_S3_MOM_WAVES > 1) ? (kCtabUnity - kMomFrRegs + kBank3Frags) * kWave : 1];
+  uint4 fmtab[(MOM && kMomTabFrags > 0) ? kMomTabFrags * kWave : 1];
   S3LdsT<GENK, MOM> per[MOM ? PAR_S3_MOM_WAVES : 1];
 };
+#ifndef PAR_S3_NUM_VGPR
+#define PAR_S3_NUM_VGPR 0                           // experiment: cap the kernels' VGPRs below what the launch bounds allow
+#endif
+#if PAR_S3_NUM_VGPR
+#define S3_VGPR_CAP __attribute__((amdgpu_num_vgpr(PAR_S3_NUM_VGPR)))
+#else
+#define S3_VGPR_CAP
+#endif
 template <bool GENK, bool MOM>
-__global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S3_MOM_WAVES > 1) ? 1 : ((GENK || MOM) ? 2 : PAR_S3_UNITY_WAVES)) void k_sinc_pipe(const S2Args a) {
+__global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S3_MOM_WAVES > 1) ? 1 : ((GENK || MOM) ? 2 : PAR_S3_UNITY_WAVES)) S3_VGPR_CAP void k_sinc_pipe(const S2Args a) {
   static_assert(!(GENK && MOM), "one form of the fc < 1 path per kernel");
   constexpr int NW = MOM ? PAR_S3_MOM_WAVES : 1;
   __shared__ S3Shared<GENK, MOM> SH;
   const int l = threadIdx.x & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   S3LdsT<GENK, MOM>& L = SH.per[wv];
-  if constexpr (MOM && NW > 1) {
+  if constexpr (MOM && kMomTabFrags > 0) {
     const uint4* src2 = reinterpret_cast<const uint4*>(kBank2Frags32);
     const uint4* src3 = reinterpret_cast<const uint4*>(kBank3Frags32);
     constexpr int kU = (kCtabUnity - kMomFrRegs) * kWave;
-    for (int i = threadIdx.x; i < kU + kBank3Frags * kWave; i += kWave * NW)
-      SH.fmtab[i] = i < kU ? src2[i + kMomFrRegs * kWave] : src3[i - kU];
+    for (int i = threadIdx.x; i < kMomTabFrags * kWave; i += kWave * NW)
+      SH.fmtab[i] = i < kU ? src2[i + kMomFrRegs * kWave] : src3[i - kU + kMomFmRegs * kWave];
     __syncthreads();
   }
   const int64_t stream_id = (int64_t)blockIdx.x * NW + wv;
@@ -950,10 +964,10 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
     for (int f = 0; f < kBank2Frags; ++f) fr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
   }
   half8v fmr[kBank3Frags];                       // the moment filters' fragments (one-wave form of the MOM kernel only)
-  if constexpr (MOM && NW == 1) {
+  if constexpr (MOM && kMomFmRegs > 0) {
     const uint4* src = reinterpret_cast<const uint4*>(kBank3Frags32) + l;
 #pragma unroll
-    for (int f = 0; f < kBank3Frags; ++f) fmr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
+    for (int f = 0; f < kMomFmRegs; ++f) fmr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
   }
   const uint4* const fm = SH.fmtab;
   long long A0;

@@ -102,11 +102,16 @@ __global__ void k_track_peak_fixed(const float* __restrict__ mag, int bins, int6
 }
 
 // Peak / Peak Track on band magnitudes re-evaluated from the SIGNAL in float64 (r03).  The reference's numpy backend hands
-// its trackers float64 containers (util/fourier.py:136-157: float32 frames -> pocketfft -> / np.float64(sqrt(n_fft)));
+// its trackers float64 CONTAINERS (util/fourier.py:136-157: float32 frames -> pocketfft -> / np.float64(sqrt(n_fft))) whose
+// values carry pocketfft's single-precision rounding (numpy >= 2); this kernel evaluates the exact DFT of the same float32
+// frame, which is not bit-parity with either backend but sits inside their spread (profiles/r03_p0_sensitivity.txt).
 // K_stft's magnitudes are float32 and a few 1e-8 relative noisier than one float32 rounding, which the config-3 chain
 // (running-sum positions, a window centre that jumps at half-integers) amplifies to 3.7e-5 of the output peak
 // (profiles/r02_p0_sensitivity.txt).  Only the band [NL, NU) and the two neighbours of its peak matter to the tracker:
-// <= a dozen bins x n_fft samples per frame, a windowed direct DFT in float64 -- ~0.03 GFLOP on config 3.
+// <= a dozen bins x n_fft samples per frame, a windowed direct DFT in float64 -- ~0.03 GFLOP on config 3.  A thread's samples
+// lie 256 apart: it takes its first twiddle from sincospi and turns it by exp(-2 pi i 256 k / N) from there (one sincospi
+// pair per thread and bin instead of one per sample: ADVICE r03); wide bands on long transforms are refused by the caller
+// (wow_detection._trace_refined: bins x n_fft x frames above 2e10 takes the spectrogram path).
 // One 256-thread workgroup per frame.  The frame is the reference's: reflect-padded by n_fft/2, sample x window rounded to
 // float32 (segment_array, util/fourier.py:160-166), zero-extended to n_fft * zeropad, spectrum / sqrt(n_fft), + 1e-7.
 constexpr int kRefineMaxBins = 2048;
@@ -116,6 +121,9 @@ __device__ __forceinline__ double refined_mag(const float* __restrict__ x, int64
   double re = 0.0, im = 0.0;
   const int64_t base = frame * hop - n_fft / 2;
   const int64_t m = 2 * (n - 1);
+  double sn, cs, rs, rc;                                     // twiddle of this thread's current sample; its step per 256 samples
+  sincospi(2.0 * (double)(((long long)k * threadIdx.x) % N) / (double)N, &sn, &cs);
+  sincospi(2.0 * (double)(((long long)k * blockDim.x) % N) / (double)N, &rs, &rc);
   for (int q = threadIdx.x; q < n_fft; q += blockDim.x) {
     int64_t j = base + q;
     if (j < 0 || j >= n) {                                   // np.pad(..., mode='reflect')
@@ -123,11 +131,11 @@ __device__ __forceinline__ double refined_mag(const float* __restrict__ x, int64
       if (j >= n) j = m - j;
     }
     const float xw = x[j * xs] * win[q];                     // float32 product, like the reference's frame matrix
-    const long long r = ((long long)k * q) % N;
-    double sn, cs;
-    sincospi(2.0 * (double)r / (double)N, &sn, &cs);
     re += (double)xw * cs;
     im -= (double)xw * sn;
+    const double c2 = cs * rc - sn * rs;                     // (<= n_fft / 256 turns: 1e-15 of drift at 16384 points)
+    sn = sn * rc + cs * rs;
+    cs = c2;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

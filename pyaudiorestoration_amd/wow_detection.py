@@ -180,6 +180,12 @@ class Track:
         n_fft, zp = int(rf["n_fft"]), int(rf.get("zeropad", 1))
         if n_fft * zp != self.fft_size or x_t.ndim != 1:
             return False
+        # the float64 band re-evaluation is a direct DFT: bins x n_fft per frame.  A wide tolerance on a long, zero-padded
+        # transform would turn milliseconds into seconds: such traces read the spectrogram instead
+        f_hi = float(np.max(self.freqs)) if len(self.freqs) else 0.0
+        band_bins = max(4.0, f_hi * (2.0 ** self.tolerance - 2.0 ** -self.tolerance) * self.fft_size / float(self.sr)) + 2.0
+        if band_bins * n_fft * len(self.freqs) > 2.0e10:
+            return False
         stride = x_t.stride(0)
         f_t = _dev.to_dev(self.freqs, torch.float64, dev)
         status = _dev.empty(1, torch.int32, dev)
