@@ -285,6 +285,7 @@ def test_sinc_golden(par, golden):
     bsig = inputs.bench_signal(0, 96000, 48000)
     yb = par.resampling.sinc_wrapper(gp["bench_pos"], bsig, 0, 32)
     assert relerr(yb, g["bench_y"]) < TOL
+    assert block_relerr(yb, g["bench_y"]) < 2 * TOL            # per 4096-sample block on its own scale
     assert relerr(par.resampling.sinc_wrapper(g["tail_pos"], inputs.noise(1000, 31), 0, 16), g["tail_y"]) < TOL
     sig = inputs.noise(3000, 32)
     pos = np.cumsum(np.full(2500, 1.013)) - 0.4
@@ -325,6 +326,13 @@ def test_sinc_vs_c_oracle_regimes(par, NT):
         ref = C.sinc(pos, sig, NT, threads=8)
         got = par.resampling.sinc_wrapper(pos, sig, 0, NT)
         assert relerr(got, ref) < TOL, (name, NT, relerr(got, ref))
+        assert block_relerr(got, ref) < 2 * TOL, (name, NT, block_relerr(got, ref))
+    # mixed-level material: a passage 60 dB below the rest is judged on its own scale
+    lvl = np.where((np.arange(len(sig)) // 50000) % 2 == 0, 1.0, 1e-3).astype(np.float32)
+    pos = 40.25 + np.cumsum(1 + 0.01 * np.sin(np.arange(n_out) * 2e-3))
+    ref = C.sinc(pos, sig * lvl, NT, threads=8)
+    got = par.resampling.sinc_wrapper(pos, sig * lvl, 0, NT)
+    assert block_relerr(got, ref) < 2 * TOL, ("levels", NT, block_relerr(got, ref))
 
 
 def test_sinc_exact_integer_positions_and_repeats(par):
