@@ -333,7 +333,15 @@ __device__ __forceinline__ bool long_segment(long long n, long long start, long 
   return ck != nullptr && n > kLongSeg && ck_slot0(start, i) + (n + kCk - 1) / kCk <= ck_len;
 }
 
-__global__ __launch_bounds__(64) void k_seg_sum(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+#ifndef PAR_PLAN_VGPR_CAP
+#define PAR_PLAN_VGPR_CAP 0          // experiment: cap the VGPRs of the plan's two widest kernels (k_seg_sum 44, k_scan_top 40)
+#endif
+#if PAR_PLAN_VGPR_CAP
+#define PLAN_VGPR_CAP __attribute__((amdgpu_num_vgpr(PAR_PLAN_VGPR_CAP)))
+#else
+#define PLAN_VGPR_CAP
+#endif
+__global__ __launch_bounds__(64) PLAN_VGPR_CAP void k_seg_sum(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
                                                  int64_t nseg, double* __restrict__ S, double* __restrict__ ck,
                                                  int64_t ck_len, PlanHeader* __restrict__ h, int count_long) {
   __shared__ double T[kWave][kCkRound + 1];

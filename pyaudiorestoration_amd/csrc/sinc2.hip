@@ -623,6 +623,9 @@ struct S3LdsT {
   float qy[MOM ? 1 : kPass];                     // GENK: H1'(A) | H1'(B) (halves); else: e2|d2 of x (halves); MOM: in qm0
   float4v qm0[MOM ? kPass : 1];                  // moment rows {m0, m1, m2, e2|d2 of x (halves)} (same slots as qa)
   uint2 qm1[MOM ? kPass : 1];                    // {m3 | m4, m5 | m6} as halves / 64 (their terms are <= 8e-4 of the correction's first)
+#ifdef PAR_S3_LDS_PAD
+  uint4 pad[PAR_S3_LDS_PAD / 16];                // (occupancy experiments)
+#endif
   uint4 recs[4][16];                             // block records of four passes: [0..7] first pieces, [8..15] second pieces
 };
 // e2 | d2 of the fc = 1 bank: its own array, or word 3 of the moment row
@@ -714,6 +717,10 @@ __device__ __forceinline__ void s3_sched_fence() {
 constexpr int kMomFrRegs = PAR_S3_MOM_WAVES == 1 ? kCtabUnity : PAR_S3_MOM_FR_REGS;
 constexpr int kMomFmRegs = PAR_S3_MOM_WAVES == 1 ? PAR_S3_MOM_FM_REGS : 0;
 constexpr int kMomTabFrags = (kCtabUnity - kMomFrRegs) + (kBank3Frags - kMomFmRegs);
+// The last three moment fragments hold (m6, -): their odd rows are zero filters whose results nobody reads, so the table keeps
+// the even lanes only (lane l reads entry l >> 1: an odd row then carries its neighbour's coefficients, harmlessly) -- half the bytes.
+constexpr int kMomHalf = (kMomFmRegs <= 12 && kMomTabFrags > 0) ? 3 : 0;            // fragments stored at half size
+constexpr int kMomTabWords = (kMomTabFrags - kMomHalf) * kWave + kMomHalf * (kWave / 2);   // uint4 entries of the table
 template <bool MOMENTS, class LDS>
 __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Frags], const half8v (&fmr)[kBank3Frags],
                                              const uint4* __restrict__ ctab, const int offs, const int l) {
@@ -731,7 +738,10 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
     if (f < kMomFrRegs) return fr[f];
     if (f < kCtabUnity) return __builtin_bit_cast(half8v, ct[64 * (f - kMomFrRegs)]);
     if (f - kCtabUnity < kMomFmRegs) return fmr[f - kCtabUnity];
-    return __builtin_bit_cast(half8v, ct[64 * ((kCtabUnity - kMomFrRegs) + (f - kCtabUnity - kMomFmRegs))]);
+    const int tf = (kCtabUnity - kMomFrRegs) + (f - kCtabUnity - kMomFmRegs);      // fragment index inside the table
+    if (kMomHalf && f - kCtabUnity >= kBank3Frags - 3)
+      return __builtin_bit_cast(half8v, ctab[(kMomTabFrags - 3) * kWave + (f - kCtabUnity - (kBank3Frags - 3)) * (kWave / 2) + (l >> 1)]);
+    return __builtin_bit_cast(half8v, ct[64 * tf]);
   };
   const float4v z = {0.0f, 0.0f, 0.0f, 0.0f};
   float4v e0 = z, lo = z, e1 = z, x1 = z, e2 = z;
@@ -925,7 +935,7 @@ constexpr float kEpMaxMom = 0.0125f / (1.0f - 0.0125f);      // period - 1 at 1 
 // and ends as one (table load, cold start of every stream, the stragglers' tail: nothing else can start meanwhile).
 template <bool GENK, bool MOM>
 struct S3Shared {
-  uint4 fmtab[(MOM && kMomTabFrags > 0) ? kMomTabFrags * kWave : 1];
+  uint4 fmtab[(MOM && kMomTabFrags > 0) ? kMomTabWords : 1];
   S3LdsT<GENK, MOM> per[MOM ? PAR_S3_MOM_WAVES : 1];
 };
 #ifndef PAR_S3_NUM_VGPR
@@ -948,8 +958,15 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
     const uint4* src2 = reinterpret_cast<const uint4*>(kBank2Frags32);
     const uint4* src3 = reinterpret_cast<const uint4*>(kBank3Frags32);
     constexpr int kU = (kCtabUnity - kMomFrRegs) * kWave;
-    for (int i = threadIdx.x; i < kMomTabFrags * kWave; i += kWave * NW)
-      SH.fmtab[i] = i < kU ? src2[i + kMomFrRegs * kWave] : src3[i - kU + kMomFmRegs * kWave];
+    constexpr int kFull = (kMomTabFrags - kMomHalf) * kWave;
+    for (int i = threadIdx.x; i < kMomTabWords; i += kWave * NW) {
+      if (i < kFull) {
+        SH.fmtab[i] = i < kU ? src2[i + kMomFrRegs * kWave] : src3[i - kU + kMomFmRegs * kWave];
+      } else {                                    // even lanes of the (m6, -) fragments
+        const int h = i - kFull, f = h / (kWave / 2), e = h % (kWave / 2);
+        SH.fmtab[i] = src3[(kBank3Frags - 3 + f) * kWave + 2 * e];
+      }
+    }
     __syncthreads();
   }
   const int64_t stream_id = (int64_t)blockIdx.x * NW + wv;
