@@ -177,6 +177,17 @@ __device__ __forceinline__ void dma_dwordx4(const void* gptr, const void* lds) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(__builtin_amdgcn_readfirstlane(la)) : "memory", "m0");
 }
 
+// 128 consecutive floats from a wave-uniform address: two direct loads off a scalar base (per-lane byte offset 4 l; the instruction
+// offset advances the global and the LDS address alike)
+__device__ __forceinline__ void dma_chunk128(const float* base, unsigned lane_bytes, const void* lds) {
+  const unsigned la = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds;
+  const unsigned long long b = (unsigned long long)(uintptr_t)base;
+  const unsigned long long bs = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);       // (the value IS wave-uniform)
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1\n\tglobal_load_lds_dword %0, %1 offset:256"
+               ::"v"(lane_bytes), "s"(bs), "s"(__builtin_amdgcn_readfirstlane(la)) : "memory", "m0");
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -196,10 +207,11 @@ struct S2Row {
   float s, ep;
   bool bad;
 };
+template <bool SECOND = true>                    // false: the caller knows that no lane of the row takes its block's second piece
 __device__ __forceinline__ S2Row s2_place_row(const uint4 ra, const uint4 rb, const int u, const int cbase, const float uf,
                                               const float u2f, const float tw1, const float tw0, const float tolf) {
   const unsigned m = ra.x;
-  const bool second = (unsigned)u > (m & 31u);
+  const bool second = SECOND && (unsigned)u > (m & 31u);
   const float F = __uint_as_float(second ? rb.y : ra.y), e1 = __uint_as_float(second ? rb.z : ra.z),
               e2 = __uint_as_float(second ? rb.w : ra.w);
   const int irel = (int)(second ? rb.x : ra.x) >> 16;
@@ -622,7 +634,7 @@ struct S3LdsT {
   float4v qx[GENK ? kPass : 1];                  // .x = e2|d2 of x / A (halves), .y = e2|d2 of B, .z = H(A), .w = H(B)
   float qy[MOM ? 1 : kPass];                     // GENK: H1'(A) | H1'(B) (halves); else: e2|d2 of x (halves); MOM: in qm0
   float4v qm0[MOM ? kPass : 1];                  // moment rows {m0, m1, m2, e2|d2 of x (halves)} (same slots as qa)
-  uint2 qm1[MOM ? kPass : 1];                    // {m3 | m4, m5 | m6} as halves / 64 (their terms are <= 8e-4 of the correction's first)
+  float4v qm1[MOM ? kPass : 1];                  // {m3, m4, m5, m6}
 #ifdef PAR_S3_LDS_PAD
   uint4 pad[PAR_S3_LDS_PAD / 16];                // (occupancy experiments)
 #endif
@@ -783,7 +795,7 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
     if (MOMENTS) {
       const float4v r0 = {m01[2 * p], m01[2 * p + 1], a23[2 * p], e2d2};
       L.qm0[sl] = r0;
-      const uint2 r1 = {pack_h2(a23[2 * p + 1] * 0.015625f, a45[2 * p] * 0.015625f), pack_h2(a45[2 * p + 1] * 0.015625f, a6[2 * p] * 0.015625f)};
+      const float4v r1 = {a23[2 * p + 1], a45[2 * p], a45[2 * p + 1], a6[2 * p]};
       L.qm1[sl] = r1;
     } else {
       s3_e2d2(L, sl) = e2d2;
@@ -821,8 +833,8 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
     const float spq = sinpi_poly(q);                                  // sin(pi s) / s
     const float unity = spq * fmaf(-sr, fmaf(sr, et, dt), x0 * 0.318309886f);
     if (MODE == 1) return unity;
-    const uint2 Mh = L.qm1[sl];
-    const float m3 = 64.0f * h_lo(Mh.x), m4 = 64.0f * h_hi(Mh.x), m5 = 64.0f * h_lo(Mh.y), m6 = 64.0f * h_hi(Mh.y);
+    const float4v Mh = L.qm1[sl];
+    const float m3 = Mh[0], m4 = Mh[1], m5 = Mh[2], m6 = Mh[3];
     const float g = epr * fast_rcp(1.0f + epr);                        // 1 - fc
     const float G = 3.14159265f * g, w = G * sr, w2m = w * w, G32 = 32.0f * G;
     float re, im;
@@ -1017,25 +1029,29 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
   float g0 = 0.0f;                               // (mode: the form of the images in LDS -- 0 none, 1 the signal itself, 2 modulated)
   int rbA = 0, rbB = 0, rbC = 0;                 // first block (relative) of the record buffers of passes pk + 1, pk + 2, pk + 3
 
+  // records: lanes 0-7 fetch first pieces, 8-15 second pieces, one 16-byte direct load each.  (The plan's record arrays end four
+  // tiles behind the file's last block -- fused_blocks(), pos_plan.h -- so the 16 blocks a guess may reach past it are readable.)
+  const uint4* const rec_lane = (l < 8 ? recW : rec2W) + (l & 7);
   auto fetch_records = [&](int buf, int blk0) {  // 8 first pieces + 8 second pieces from block blk0 on -> recs[buf]
-    if (l < 16) {
-      int b = blk0 + (l & 7);
-      b = b < blk_max ? b : blk_max;
-      b = b < 0 ? 0 : b;
-      dma_dwordx4((l < 8 ? recW : rec2W) + b, &L.recs[buf][0]);
-    }
+    if (l < 16) dma_dwordx4(rec_lane + (blk0 < 0 ? 0 : blk0), &L.recs[buf][0]);
   };
-  auto chunk_dma = [&](int k) {                  // chunk k = input samples [wbase + 128 k, + 128) relative to A0 -> ring slot k & 7
-    long long lo = A0 + wbase + (long long)kPass * k;
-    if (!(lo >= 0 && lo + kPass <= (long long)a.len_in)) {
-      dma_bad = k < dma_bad ? k : dma_bad;
-      lo = lo < 0 ? 0 : (long long)a.len_in - kPass;       // (any readable address: the chunk is never used)
-      lo = lo < 0 ? 0 : lo;
-    }
-    const float* gp = a.sig + lo + l;
-    float* dst = &L.ring[(k & 7) * kPass];
-    dma_dword(gp, dst);
-    dma_dword(gp + kWave, dst + kWave);
+  // ring chunks: chunk k = input samples [wbase + 128 k, + 128) relative to A0 -> ring slot k & 7.  Chunks dma_klo .. dma_khi lie
+  // inside the file (set when the ring is restarted); the others are never used (dma_bad) and fetch some readable stretch instead.
+  int dma_klo = 0, dma_khi = -1;
+  const float* ring_src = a.sig;                 // &sig[A0 + wbase]
+  auto ring_restart = [&]() {
+    const long long o = A0 + wbase;
+    ring_src = a.sig + o;
+    const long long klo = o >= 0 ? 0 : (-o + kPass - 1) / kPass, khi = ((long long)a.len_in - o) / kPass - 1;
+    dma_klo = (int)(klo > 0x3fffffff ? 0x3fffffff : klo);
+    dma_khi = (int)(khi > 0x3fffffff ? 0x3fffffff : (khi < -1 ? -1 : khi));
+  };
+  const unsigned lane_bytes = 4u * (unsigned)l;
+  auto chunk_dma = [&](int k) {
+    const bool inside = k >= dma_klo && k <= dma_khi;
+    if (!inside) dma_bad = k < dma_bad ? k : dma_bad;
+    const float* src = inside ? ring_src + (long long)kPass * k : a.sig;      // (a.sig: len_in >= 128 for every file this kernel is launched on)
+    dma_chunk128(src, lane_bytes, &L.ring[(k & 7) * kPass]);
   };
   auto push_tile = [&](int64_t T) {
     if (l == 0) {
@@ -1051,13 +1067,21 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
     int nt[2];
     int fl0, fl1, tend;
   };
+  int tc_T = -1, tc_dA0 = 0, tc_dA1 = 0, tc_fl0 = 0, tc_fl1 = 0;      // anchors and flags of the tile of j and of the one behind it (refreshed once per tile)
   auto place = [&](int j, int buf, int rb) {
     Placed P;
     const int T = j >> 10;
     P.tend = (T + 1) << 10;
-    const int dA0 = __builtin_amdgcn_readlane(hd_dA, T), dA1 = __builtin_amdgcn_readlane(hd_dA, T + 1);
-    P.fl0 = __builtin_amdgcn_readlane(hd_fl, T);
-    P.fl1 = __builtin_amdgcn_readlane(hd_fl, T + 1);
+    if (T != tc_T) {
+      tc_T = T;
+      tc_dA0 = __builtin_amdgcn_readlane(hd_dA, T);
+      tc_dA1 = __builtin_amdgcn_readlane(hd_dA, T + 1);
+      tc_fl0 = __builtin_amdgcn_readlane(hd_fl, T);
+      tc_fl1 = __builtin_amdgcn_readlane(hd_fl, T + 1);
+    }
+    const int dA0 = tc_dA0, dA1 = tc_dA1;
+    P.fl0 = tc_fl0;
+    P.fl1 = tc_fl1;
     const int t5 = (j & (kRec - 1)) + l;
     const int u = t5 & (kRec - 1);
     const int bi = ((j >> kRecShift) - rb + (t5 >> kRecShift)) & 7;
@@ -1067,8 +1091,14 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
     const float uf = (float)uc, u2f = uf * uf, tw1 = fmaf(2.0f, uf, 1.0f), tw0 = tw1 - 2.0f;
     P.nt[0] = clamp64(P.tend - j);
     P.nt[1] = clamp64(P.tend - j - 64);
-    P.R[0] = s2_place_row(ra0, rb0, u, (l < P.nt[0] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
-    P.R[1] = s2_place_row(ra1, rb1, u, (l < P.nt[1] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
+    // a segment starts inside one block in eight: most passes have no second piece to select
+    if (__ballot((unsigned)u > (ra0.x & 31u) || (unsigned)u > (ra1.x & 31u)) == 0ull) {
+      P.R[0] = s2_place_row<false>(ra0, rb0, u, (l < P.nt[0] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
+      P.R[1] = s2_place_row<false>(ra1, rb1, u, (l < P.nt[1] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
+    } else {
+      P.R[0] = s2_place_row(ra0, rb0, u, (l < P.nt[0] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
+      P.R[1] = s2_place_row(ra1, rb1, u, (l < P.nt[1] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
+    }
     if (MOM) {                                   // the moment correction covers 1 - fc <= 0.0125
       P.R[0].bad = P.R[0].bad || !(P.R[0].ep <= kEpMaxMom);
       P.R[1].bad = P.R[1].bad || !(P.R[1].ep <= kEpMaxMom);
@@ -1160,6 +1190,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
           dma_next = 0;
           dma_bad = INT_MAX;
           rebuild = true;
+          ring_restart();
         }
         const int wsK = ws - wbase;
         regime = MOM ? (want == 1 ? 1 : 3) : want;
@@ -1253,17 +1284,18 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
   // ---- the loop: see the head of this kernel.  Leaves with P finished and j0 at a pass start_run() has to look at.
   auto hot = [&](auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
+    // (the cold path left the loop's state in vector registers: it is wave-uniform, and stays so through the loop)
+    j0 = __builtin_amdgcn_readfirstlane(j0);
+    wbase = __builtin_amdgcn_readfirstlane(wbase);
+    conv_next = __builtin_amdgcn_readfirstlane(conv_next);
+    dma_next = __builtin_amdgcn_readfirstlane(dma_next);
+    dma_bad = __builtin_amdgcn_readfirstlane(dma_bad);
+    pk = __builtin_amdgcn_readfirstlane(pk);
+    g0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(g0)));
+    rbA = __builtin_amdgcn_readfirstlane(rbA);
+    rbB = __builtin_amdgcn_readfirstlane(rbB);
+    rbC = __builtin_amdgcn_readfirstlane(rbC);
     for (;;) {
-      j0 = __builtin_amdgcn_readfirstlane(j0);
-      wbase = __builtin_amdgcn_readfirstlane(wbase);
-      conv_next = __builtin_amdgcn_readfirstlane(conv_next);
-      dma_next = __builtin_amdgcn_readfirstlane(dma_next);
-      dma_bad = __builtin_amdgcn_readfirstlane(dma_bad);
-      pk = __builtin_amdgcn_readfirstlane(pk);
-      g0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(g0)));
-      rbA = __builtin_amdgcn_readfirstlane(rbA);
-      rbB = __builtin_amdgcn_readfirstlane(rbB);
-      rbC = __builtin_amdgcn_readfirstlane(rbC);
 #if PAR_S2_EXP & 64
       const unsigned long long tA_ = __builtin_readcyclecounter();
 #endif
@@ -1279,7 +1311,8 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
       // PLACE(pk): the pass behind P
       const Placed Q = place(j0, pk & 3, rbA);
       const unsigned long long bad = __ballot(Q.R[0].bad || Q.R[1].bad);
-      const unsigned long long gen = __ballot(1.0f + Q.R[0].ep != 1.0f || 1.0f + Q.R[1].ep != 1.0f);
+      // some lane with fc < 1: 1 + ep != 1 in float32, i.e. ep > 2^-24 (ep >= 0)
+      const unsigned long long gen = __ballot(fmaxf(Q.R[0].ep, Q.R[1].ep) > 5.9604645e-8f);
       const int ws = __builtin_amdgcn_readfirstlane(Q.R[0].c) & ~7;
       S3Pass N;
 #pragma unroll
@@ -1293,9 +1326,10 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
       N.ws = ws;
       const int wsK = ws - wbase;
       const int d = kPass * conv_next - wsK;      // image converted up to d samples beyond the first bank centre
-      bool ok = ((Q.fl0 | Q.fl1) & 1) == 0 && bad == 0ull && j0 + kPass <= nJ && N.nok[1] >= 1 && N.nok[0] + N.nok[1] >= 120 &&
-                (MODE == 1 ? gen == 0ull : gen != 0ull) && d >= 161 && d <= 473 && conv_next + 1 < dma_bad &&
-                (unsigned)((j0 >> kRecShift) - rbA) <= 1u;
+      // (bitwise: one chain of scalar operations, no branch per term; >= 120 finished outputs imply a full first row)
+      bool ok = (((Q.fl0 | Q.fl1) & 1) == 0) & (bad == 0ull) & (j0 + kPass <= nJ) & (N.nok[0] + N.nok[1] >= 120) &
+                (MODE == 1 ? gen == 0ull : gen != 0ull) & ((unsigned)(d - 161) <= 312u) & (conv_next + 1 < dma_bad) &
+                ((unsigned)((j0 >> kRecShift) - rbA) <= 1u);
       if (MODE == 2) {
         const float g_0 = N.ep[0] * fast_rcp(1.0f + N.ep[0]), g_1 = N.ep[1] * fast_rcp(1.0f + N.ep[1]);
         ok = ok && __ballot(!(fabsf(g0 - g_0) <= kEpsTol) || !(fabsf(g0 - g_1) <= kEpsTol)) == 0ull;
