@@ -54,14 +54,17 @@ int par_stream_create(int device, int low_priority, int cu_count, void** stream)
   PAR_REQUIRE(stream, PAR_ERR_ARG, "par_stream_create: null");
   PAR_HIP_CHECK(hipSetDevice(device));
   hipStream_t st;
-  if (cu_count > 0) {
-    // the first cu_count compute units of the device's numbering (hipExtStreamCreateWithCUMask: bit i of the mask = CU i)
+  if (cu_count != 0) {
+    // cu_count > 0: the first cu_count compute units of the device's numbering; < 0: all BUT the first -cu_count
+    // (hipExtStreamCreateWithCUMask: bit i of the mask = CU i)
     hipDeviceProp_t prop;
     PAR_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     const int total = prop.multiProcessorCount;
-    PAR_REQUIRE(cu_count <= total, PAR_ERR_ARG, "par_stream_create: cu_count above the device's compute units");
+    const int n = cu_count > 0 ? cu_count : -cu_count;
+    PAR_REQUIRE(n <= total && (cu_count > 0 || n < total), PAR_ERR_ARG, "par_stream_create: cu_count outside the device's compute units");
     std::vector<uint32_t> mask((total + 31) / 32, 0u);
-    for (int i = 0; i < cu_count; ++i) mask[i >> 5] |= 1u << (i & 31);
+    for (int i = 0; i < total; ++i)
+      if ((i < n) == (cu_count > 0)) mask[i >> 5] |= 1u << (i & 31);
     PAR_HIP_CHECK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
   } else {
     int least = 0, greatest = 0;
