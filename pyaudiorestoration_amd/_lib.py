@@ -65,6 +65,8 @@ SIGNATURES = {
     "par_fused_redo_tiles": (c_int, [c_int, c_vp, c_i64, c_i64, ctypes.POINTER(c_int), c_vp]),
     "par_varispeed_fused_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64,
                                         c_vp]),
+    "par_varispeed_fused_alone_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64,
+                                              c_vp]),
     "par_varispeed_fused_stereo_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_int,
                                                c_vp, c_vp, c_i64, c_vp]),
     "par_profile_enable": (c_int, [c_int, c_int]),

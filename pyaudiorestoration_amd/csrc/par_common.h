@@ -60,7 +60,7 @@ int launch_sinc(int device, const double* pos, int64_t len_out, int64_t j_begin,
                 int64_t sig_stride, int64_t len_in, int NT, float* out, int64_t out_stride, hipStream_t s);
 int launch_sinc_fused(int device, const double* speeds, int64_t m, const void* work, const void* aux, int64_t max_out,
                       int64_t len_out, const float* sig, const float* sig1, int64_t sig_stride, int64_t len_in, int NT,
-                      float* out, float* out1, int64_t out_stride, hipStream_t s);
+                      float* out, float* out1, int64_t out_stride, hipStream_t s, int form = 0);
 constexpr int64_t kSincTileOutputs = 1024;   // outputs per K_sinc workgroup (chunk boundaries align to it)
 
 }  // namespace par

@@ -1097,6 +1097,41 @@ def test_streaming_kernel_opt_in(par, monkeypatch, variant):
         assert relerr(got, want) < TOL, n_s
 
 
+def test_fused_alone_entry_point(par):
+    """par_varispeed_fused_alone_f32 (r04): the fused resampler for a launch with nothing planned beside it.  Mono NT = 32 unit-stride
+    files go through the streaming kernel in its moment form (the tile diagnostic says so), everything else through the block
+    kernel exactly as par_varispeed_fused_f32; results against the C oracle either way."""
+    import ctypes
+    from oracle import oracle_c as C
+    from pyaudiorestoration_amd import _lib, _dev
+    t = par.torch
+    L = _lib.lib()
+    n, sr = 400_000, 192000
+    m = n // 256
+    st = np.linspace(0, n, m)
+    sp = 1.0 + 0.01 * np.sin(2 * np.pi * 4.4 * st / sr + 0.7)
+    sig = np.random.default_rng(77).standard_normal(n).astype(np.float32)
+    plan = par.resampling.speed_plan_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), n, fused=True)
+    pos, _ = C.speed_to_pos(st, sp, n)
+    redo = ctypes.c_int(-1)
+    for NT, streamed in ((32, True), (50, False), (16, False)):
+        want = C.sinc(pos, sig, NT, threads=8)
+        a = par.resampling.varispeed_fused_dev(plan, t.from_numpy(sig).cuda(), NT, alone=True).cpu().numpy()
+        _lib.check(L.par_fused_redo_tiles(0, _dev.ptr(plan.aux), plan.max_out, plan.m, ctypes.byref(redo), _dev.stream_ptr(0)))
+        b = par.resampling.varispeed_fused_dev(plan, t.from_numpy(sig).cuda(), NT).cpu().numpy()
+        assert relerr(a, want) < TOL and block_relerr(a, want) < 2 * TOL, (NT, relerr(a, want))
+        if streamed:
+            assert 1 <= redo.value <= 8 and relerr(a, b) < 5e-6 and not np.array_equal(a, b)
+        else:
+            assert np.array_equal(a, b)                    # the block kernel either way
+    # a strided channel of an interleaved file: never the streaming kernel
+    st2 = np.stack([sig, sig[::-1]], axis=1).copy()
+    x = t.from_numpy(st2).cuda().reshape(-1)
+    a = par.resampling.varispeed_fused_dev(plan, x[1:], 32, sig_stride=2, len_in=n, alone=True).cpu().numpy()
+    b = par.resampling.varispeed_fused_dev(plan, x[1:], 32, sig_stride=2, len_in=n).cpu().numpy()
+    assert np.array_equal(a, b) and relerr(a, C.sinc(pos, st2[:, 1].copy(), 32, threads=8)) < TOL
+
+
 def test_fused_extreme_curves_and_channels(par):
     """Fused path under stress: fast curves whose tiles overflow the LDS stage (float64 slow path),
     slow curves (many outputs per input), stereo strided views, tiny NT and NT = 100."""
