@@ -562,6 +562,18 @@ def main():
         _lib.check(L.par_event_record(e1, sp_))
         _lib.check(L.par_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
         alone.append(ms.value / 20)
+        # the same reference point for the opt-in streaming kernel in its moment form (par_varispeed_fused_alone_f32, r04): not the
+        # shipped path of the timed step (beside a plan it draws level with the block kernel), reported for the record
+        alone_moment = None
+        if a.nt == 32:
+            for i in range(30):
+                if i == 10:
+                    _lib.check(L.par_event_record(e0, sp_))
+                _lib.check(L.par_varispeed_fused_alone_f32(dev, _dev.ptr(spd), m, _dev.ptr(work[0]), _dev.ptr(aux[0]), cap,
+                                                           state["len"], _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, sp_))
+            _lib.check(L.par_event_record(e1, sp_))
+            _lib.check(L.par_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+            alone_moment = ms.value / 20
         L.par_event_destroy(e0)
         L.par_event_destroy(e1)
 
@@ -683,6 +695,11 @@ def main():
             res["roofline"]["note"] += ("; kernel_ms is measured in the timed region, where the next file's plan kernels "
                                         "share the GPU with K_sinc; kernel_ms_alone / frac_alone = the same launch with the "
                                         "GPU to itself, 20 launches back to back before the timed region")
+            if alone_moment is not None:
+                res["roofline"]["kernel_ms_alone_moment_form"] = round(alone_moment, 4)
+                res["roofline"]["frac_alone_moment_form"] = round(ALGO_BYTES_PER_SAMPLE * samples_per_launch / (alone_moment * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                res["roofline"]["note"] += ("; kernel_ms_alone_moment_form = the same launch through par_varispeed_fused_alone_f32 (streaming "
+                                            "kernel, fc < 1 taps in their moment form: csrc/sinc2.hip) -- opt-in, not the kernel of the timed step")
         # What actually limits the kernel: VALU issue.  Instruction count per output from the committed PMC pass
         # (SQ_INSTS_VALU, profiles/), rate from this run's HIP-event time; ceilings: 2 cycles per wave64 instruction
         # per SIMD at the 2.4 GHz peak clock (MI355X_MICROARCH.md) and the rate a pure v_fma_f32 stream measured

@@ -89,7 +89,11 @@ while time.time() < t_end:
         out_f = R.varispeed_fused_dev(plan, sig_t, NT).cpu().numpy()
         # record-placed outputs: same window centres as the position-array form, shift to ~1e-7 of a sample
         ef = float(np.max(np.abs(out_f - out_a)) / scale)
-        assert ef < (2e-6 if NT <= 64 else 4e-6), (case, "fused vs position-array", ef, n, NT, seg, style)   # float32 sums of 2 NT taps
+        # float32 sums of 2 NT taps in two different orders.  2e-6 holds on level material; where the 30x louder half of the
+        # signal reaches into the window of a quiet output the two orders (and the oracle's) differ by the loud terms' rounding:
+        # seed 204836 (NT = 31 / 32, last outputs in front of the loud half): 3.3e-6 / 4.6e-6 between the two device forms,
+        # the fused one 2.9e-7 / 4.0e-7 from the oracle (tools/exp/dbg_fuzz_case.py)
+        assert ef < 6e-6, (case, "fused vs position-array", ef, n, NT, seg, style)
         errs.append(float(np.max(np.abs(out_f - ref)) / scale))
         worst_f = max(worst_f, ef)
         # stereo form: both channels in one launch == one mono launch each (to float32 rounding)
