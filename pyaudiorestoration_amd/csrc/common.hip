@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int par_version(void) { return 101; }
+int par_version(void) { return 102; }     // 102 (r04): par_varispeed_fused_alone_f32, ISTFT above 8192 points, par_stream_create complement masks
 
 int par_device_count(void) {
   int n = 0;
