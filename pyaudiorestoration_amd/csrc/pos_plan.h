@@ -24,6 +24,11 @@ struct PlanHeader {
   int32_t pad3;
   unsigned long long first_bad;  // first segment with n_i < 2 (~0: none).  Harmless when the trim fires before it: the
                                  // reference stops there and never builds that segment (k_trim decides)
+  int32_t lazy;           // 1: this plan was made WITHOUT the per-sample cumsum (closed-form segment sums, see "lazy plans")
+  int32_t lazy_fail;      // != 0: some segment is outside what the closed form vouches for (or too many candidates): the
+                          //       caller makes the plan again the eager way
+  int32_t n_cand;         // segments whose sum was recomputed exactly (kMaxCand + 1: list overflow)
+  int32_t pad4;
 };
 static_assert(sizeof(PlanHeader) <= 256, "PlanHeader must fit the reserved header bytes");
 constexpr int kFlagAmbiguous = 1;   // a cumulative length is too close to a rounding tie
@@ -34,6 +39,7 @@ constexpr int kFlagDirectOverflow = 16;
 constexpr int kFlagCapAmbiguous = 64; // end_guess within the device sum's error of an integer: the host path decides
 constexpr int kFlagCkOverflow = 32;  // checkpoint buffer too small (plan stays valid; the fused path is refused)
 constexpr int kMaxDirect = 2048;
+constexpr int kMaxCand = 1 << 16;   // lazy plans: segments whose exact sum the offset chain needs after all (~5e3 per 60-min file)
 constexpr unsigned long long kNoTrim = ~0ull;
 
 struct U128 {
@@ -49,6 +55,12 @@ struct RunEntry {
   double x;                         // offset at that segment (bit-exact)
 };
 
+struct Cand {
+  long long i;          // segment
+  double xa, xb;        // the approximate offsets around it (binade prediction of its chain element)
+};
+static_assert(sizeof(Cand) == 24, "plan_bytes counts 24 bytes per candidate");
+
 constexpr size_t kHdrBytes = 256;
 struct PlanView {
   PlanHeader* hdr;
@@ -60,11 +72,12 @@ struct PlanView {
   char* bsum;           // block sums for the scans
   long long* direct;    // [kMaxDirect] indices of direct (binade-crossing) steps
   RunEntry* runs;       // [kMaxDirect + 2]
+  Cand* cand;           // [kMaxCand] lazy plans: candidates for the exact sum
 };
 inline size_t scan_blocks(int64_t n) { return (size_t)((n + 1023) / 1024); }
 inline size_t plan_bytes(int64_t m) {
   return kHdrBytes + (size_t)m * (8 + 8 + 8 + 8 + 32) + (scan_blocks(m) + 8) * 32 + kMaxDirect * 8 +
-         (kMaxDirect + 2) * sizeof(RunEntry) + 256;
+         (kMaxDirect + 2) * sizeof(RunEntry) + 256 + (size_t)kMaxCand * 24;
 }
 inline PlanView plan_view(void* work, int64_t m) {
   char* b = static_cast<char*>(work);
@@ -86,6 +99,8 @@ inline PlanView plan_view(void* work, int64_t m) {
   v.direct = reinterpret_cast<long long*>(b);
   b += kMaxDirect * 8;
   v.runs = reinterpret_cast<RunEntry*>(b);
+  b += ((kMaxDirect + 2) * sizeof(RunEntry) + 255) / 256 * 256;
+  v.cand = reinterpret_cast<Cand*>(b);
   return v;
 }
 
@@ -138,6 +153,45 @@ __device__ __forceinline__ double ramp_recip(double a, const Ramp& r) {
   return r.fast ? recip_unscaled(bs) : 1.0 / bs;
 }
 
+
+// ---------------------------------------------------------------------------------- lazy plans (r05)
+// The reference's position chain needs, per curve segment, S_i = the LAST element of np.cumsum(1 / block_speeds) -- n_i
+// correctly rounded divisions and n_i sequential float64 adds (691 M of each for the 60-min file: the plan's k_seg_sum,
+// 0.4 of the 0.9 ms the plan costs a concurrent K_sinc), plus a checkpoint of the running sum every 8 steps (0.7 GB written)
+// so that K_sinc can redo an output with the reference's own arithmetic.  But the bits of S_i only matter where a rounding
+// DECIDES something:
+//   * the offset chain x_{i+1} = fl(x_i + S_i) rounds to a grid of ulp(x) ~ 1e-7 (at 7e8), S_i's own uncertainty is ~1e-11:
+//     a closed-form S~_i with a rigorous error bound B_i settles the chain element of every segment whose S~_i/ulp lies
+//     farther than B_i from a rounding boundary (k_offs_elements) -- all but ~5e3 of the 2.7 M segments of the 60-min
+//     curve; those CANDIDATES (and the ~50 binade-crossing steps) get the exact sequential sum (k_seg_exact_list) and the
+//     chain is bit-identical to numpy's;
+//   * K_sinc needs rint(p) exact and the shift to ~1e-7: outputs whose closed-form position lies within the bound of a
+//     half-integer (~1 in 10^6) walk the segment's cumsum from its first step with the reference's own arithmetic
+//     (place_exact, sinc.hip); nobody else needs a checkpoint.
+// A plan is lazy only if EVERY segment qualifies: 2 <= n <= kLazyMaxN outputs, speeds in [1/16, 64], |s1 - s0| <= 2^-9 of
+// the smaller one (k_seg_sum_lazy); otherwise the caller makes it again the eager way (sparse, stepped or wild curves).
+constexpr long long kLazyMaxN = 1024;
+constexpr int kTileLazy = 4;         // TileHdr.flags: the plan holds no cumsum checkpoints
+// sum_{k=0}^{K-1} 1 / (s0 + step k): expansion about the midpoint speed m (odd powers cancel),
+//   (K/m) [1 + t (K^2-1)/12 (1 + t (3K^2-7)/20)],  t = (step/m)^2;  next term < K (step K / 2m)^6 / 7 < 1.5e-19 K here.
+__device__ __forceinline__ double lazy_prefix(double s0, double step, double K) {
+#pragma clang fp contract(off)
+  const double m = __builtin_fma(step, 0.5 * (K - 1.0), s0);
+  const double rc = 1.0 / m;
+  const double z = rc * step, t = z * z, K2 = K * K;
+  const double corr = t * (K2 - 1.0) * (1.0 / 12.0) * (1.0 + t * (3.0 * K2 - 7.0) * 0.05);
+  return K * rc * (1.0 + corr);
+}
+// |lazy_prefix - numpy's sequentially rounded cumsum after K terms|: K adds each within 2^-53 of a running sum <= j / smin
+// (0.5 K^2), every term within 2.01 * 2^-53 / smin of 1 / (s0 + step k) (three roundings of the ramp value, one of the
+// reciprocal), ~6 ulp of the closed form's own evaluation (12 K); the rest is margin.
+__device__ __forceinline__ double lazy_bound(double K, double smin) {
+  return (0.55 * K * K + 16.0 * K + 64.0) * 0x1p-53 / smin;
+}
+__device__ __forceinline__ bool lazy_segment_ok(long long n, double s0, double s1) {
+  const double lo = s0 < s1 ? s0 : s1, hi = s0 < s1 ? s1 : s0;
+  return n >= 2 && n <= kLazyMaxN && lo >= 0.0625 && hi <= 64.0 && (hi - lo) <= 0x1p-9 * lo;    // false for NaN
+}
 
 // ---------------------------------------------------------------------------- cumsum checkpoints
 // The fused resampler regenerates positions inside K_sinc from per-segment checkpoints of the running
