@@ -525,11 +525,15 @@ def main():
     trimmed = ctypes.c_int(0)
     ok = ctypes.c_int(0)
 
+    plan_force = 8 if os.environ.get("PAR_PLAN_EAGER") else 0      # A/B knob: the eager plan (per-sample cumsum + checkpoints)
+    state_plan = {"lazy": False}
+
     def plan_fused(slot, stream_ptr):
         _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(st), _dev.ptr(spd), m, n_in, _dev.ptr(work[slot]), nbytes,
                                                  _dev.ptr(aux[slot]), aux_bytes, cap, ctypes.byref(len_out),
-                                                 ctypes.byref(trimmed), 0, None, ctypes.byref(ok), stream_ptr))
-        assert ok.value == 1 and 2 <= len_out.value <= cap
+                                                 ctypes.byref(trimmed), plan_force, None, ctypes.byref(ok), stream_ptr))
+        assert ok.value in (1, 2) and 2 <= len_out.value <= cap      # 2: a lazy plan (csrc/pos_plan.h), what this curve gets
+        state_plan["lazy"] = ok.value == 2
         return len_out.value
 
     if overlap:

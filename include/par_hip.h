@@ -206,7 +206,14 @@ int par_varispeed_resample_f32(int device, const double* speeds, int64_t m, cons
  * par_speed_to_pos_fill + par_sinc_resample_f32, 16 B/sample less HBM traffic.  *fused_ok (optional) reports
  * whether the checkpoints of every needed segment fit in aux; only then may par_varispeed_fused_f32 be called
  * (with the same work/aux/max_out and the returned len_out -- it does not read the plan back, so that it never
- * synchronises); otherwise callers use the position-array path (the plan itself stays valid). */
+ * synchronises); otherwise callers use the position-array path (the plan itself stays valid).
+ * LAZY plans (r05, csrc/pos_plan.h): on a dense, gentle curve (every segment 2..1024 outputs, speeds in [1/16, 64] changing
+ * by <= 2^-9 of themselves across it) the plan skips the per-sample cumsum: segment sums in closed form with a rigorous error
+ * bound, the exact sequential sum only for the few thousand segments where that bound could change a rounding of the offset
+ * chain, and K_sinc walks a segment's cumsum with the reference's own arithmetic only for the ~1 output in 10^6 whose
+ * position lies within the bound of a half-integer.  Offsets, len_out, trim and every window centre are bit-identical to
+ * the eager plan's; *fused_ok comes back 2 and aux then holds NO checkpoints (par_speed_to_pos_fill_fused must not be used).
+ * Curves that do not qualify are planned the eager way (*fused_ok 1).  force_host | 8 asks for the eager plan outright. */
 size_t par_fused_aux_bytes(int64_t max_out, int64_t m);
 int par_speed_to_pos_plan_fused(int device, const double* sampletimes, const double* speeds, int64_t m, int64_t n_in,
                                 void* work, size_t work_bytes, void* aux, size_t aux_bytes, int64_t max_out,

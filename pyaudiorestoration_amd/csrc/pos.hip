@@ -186,8 +186,12 @@ static int inclusive_scan(typename Op::T* data, int64_t n, typename Op::T* bsum,
 }
 
 // ------------------------------------------------------------------------- stage kernels
-__global__ void k_init_header(PlanHeader* h, int64_t m) {
+__global__ void k_init_header(PlanHeader* h, int64_t m, int lazy) {
   h->m = m;
+  h->lazy = lazy;
+  h->lazy_fail = 0;
+  h->n_cand = 0;
+  h->pad4 = 0;
   h->len_out = 0;
   h->total_written = 0;
   h->trim_seg = kNoTrim;
@@ -977,10 +981,75 @@ __global__ void k_publish_ck(PlanHeader* __restrict__ h, int64_t ck_len) {
 // Thread x serves two roles: segment x checks that its checkpoints fit and writes its SegFast record, tile x looks its
 // segment up (upper bound over seg_start: a tile per thread, not a segment per thread -- one segment can cover
 // 10^5..10^6 tiles).
+// closed-form placement record of segment x (sinc.hip place_fast).  `fast` bounds what the closed form leaves out: the
+// fourth-order remainder of the <= kCk-term reciprocal sum is < 400 step^4 / smin^5, kept below 2e-10.
+__device__ __forceinline__ SegFast seg_fast_record(const double* __restrict__ sp, const double* __restrict__ seg_off, long long x,
+                                                   long long n) {
+  const double s0 = sp[x], s1 = sp[x + 1], off = seg_off[x];
+  SegFast f;
+  const bool off_ok = fabs(off) < 4.0e18;            // also false for NaN
+  const double ro = off_ok ? rint(off) : 0.0;
+  f.foff = off_ok ? off - ro : 0.0;
+  f.A = (long long)ro;
+  f.n = n < 0x7fffffffll ? (int)n : 0x7fffffff;
+  f.step = n >= 2 ? (s1 - s0) / (double)(n - 1) : 0.0;
+  const double smin = s0 < s1 ? s0 : s1, smax = s0 < s1 ? s1 : s0;
+  f.fast = off_ok && n >= 2 && n < 0x7fffffffll && smin >= 0.0625 && smax <= 64.0 &&
+           fabs(f.step) <= 6.0e-4 * smin * sqrt(sqrt(smin));
+  // level 2 (BlockRec with the cubic term): over the 32 centred steps of a block (|d| <= 16, up to 33 with the steps behind
+  // the checkpoint) the quartic term of the reciprocal sum, z^3 d^4 / 4 with z = step / speed, stays < 1e-8 samples
+  // level 3 (the block quadratic alone): the cubic term z^2 d^3 / 3 <= 1365 z^2 stays < 1e-8
+  if (f.fast && fabs(f.step) <= 5.0e-5 * smin) f.fast = fabs(f.step) <= 2.7e-6 * smin ? 3 : 2;
+  return f;
+}
+
+// entry x of the tile tables: tile x (x < n_tiles: its first output is `sample`) or the extra entry [n_tiles] (the segment
+// that holds the LAST output); lo = the segment that contains `sample`
+__device__ __forceinline__ void tile_entry(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                           const double* __restrict__ seg_off, int64_t nseg, const double* __restrict__ ck,
+                                           int64_t ck_len, int64_t* __restrict__ tile_seg, long long* __restrict__ tile_st,
+                                           TileHdr* __restrict__ hdr, const long long x, const long long n_tiles,
+                                           const long long sample, const long long lo, const bool lazy) {
+  tile_seg[x] = lo;
+  // boundaries the tile's blocks may meet, for k_block_rec's lookup
+  for (int q = 0; q < kTileStarts; ++q) tile_st[x * kTileStarts + q] = lo + q <= nseg ? seg_start[lo + q] : LLONG_MAX;
+  // tile header: the anchor every window centre of the tile is relative to -- an even integer within ~8 samples of the
+  // tile's first position (the checkpoint below it; block records keep a 16-bit offset from it)
+  if (x < n_tiles) {
+    const long long start = seg_start[lo], k = sample - start, b = k >> 3;
+    static_assert(kCk == 8, "k >> 3");
+    const double off = seg_off[lo];
+    const bool off_ok = fabs(off) < 4.0e18;
+    const double ro = off_ok ? rint(off) : 0.0;
+    const long long slot = ck_slot0(start, lo) + b;
+    // (lazy plans have no checkpoints: the closed-form position of the tile's first output serves as well)
+    const double ckv = lazy ? (lazy_segment_ok(seg_start[lo + 1] - start, sp[lo], sp[lo + 1])
+                                   ? lazy_prefix(sp[lo], (sp[lo + 1] - sp[lo]) / (double)(seg_start[lo + 1] - start - 1), (double)(k + 1))
+                                   : 0.0)
+                            : ((b && slot < ck_len) ? ck[slot] : 0.0);
+    const double rel = (off_ok ? off - ro : 0.0) + ckv;
+    const bool ok = off_ok && fabs(rel) < 1.0e15 && ro > -0x1p61 && ro < 0x1p61;
+    TileHdr hd;
+    hd.anchor = ok ? ((long long)ro + (long long)rint(rel)) & ~1ll : 0ll;
+    hd.c_last = 0;
+    hd.iT = lo;
+    hd.mn_rel = 0;
+    // bit 1: some segment under the tile (or the one behind it: the last output's period reaches there) touches
+    // speed >= 1, i.e. the tile may hold fc = 1 outputs.  A hint only: K_sinc's matrix-core path is taken by workgroups
+    // whose tile carries it, everything else computes the same numbers on the vector path.
+    bool may_unity = false;
+    for (long long q = lo; q < nseg && seg_start[q] <= sample + kSincTileOutputs; ++q)
+      may_unity = may_unity || !(sp[q] < kUnityHintBelow) || !(sp[q + 1] < kUnityHintBelow);
+    hd.flags = (ok ? 0 : 1) | (may_unity ? kTileMayUnity : 0) | (lazy ? kTileLazy : 0);
+    hdr[x] = hd;
+  }
+}
+
 __device__ __forceinline__ void tile_seg_body(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
                            const double* __restrict__ seg_off, int64_t nseg, const double* __restrict__ ck, int64_t ck_len,
                            int64_t max_tiles, int64_t* __restrict__ tile_seg, SegFast* __restrict__ seg_fast,
-                           long long* __restrict__ tile_st, TileHdr* __restrict__ hdr, PlanHeader* __restrict__ h, const int64_t x) {
+                           long long* __restrict__ tile_st, TileHdr* __restrict__ hdr, PlanHeader* __restrict__ h, const int64_t x,
+                           const bool lazy = false) {
   const long long len_out = h->len_out;                // written by k_trim / the host path earlier on this stream
   const long long n_tiles = (len_out + kSincTileOutputs - 1) / kSincTileOutputs;
   if (n_tiles + 1 > max_tiles) {
@@ -989,27 +1058,9 @@ __device__ __forceinline__ void tile_seg_body(const double* __restrict__ sp, con
   }
   if (x < nseg) {
     const long long a = seg_start[x], b = seg_start[x + 1];
-    if (b > a && a < len_out && ck_slot0(a, x) + (b - a + kCk - 1) / kCk > ck_len)
+    if (!lazy && b > a && a < len_out && ck_slot0(a, x) + (b - a + kCk - 1) / kCk > ck_len)
       atomicOr(&h->flags, kFlagCkOverflow);             // a needed segment has no checkpoints: fused path refused
-    // closed-form placement record (sinc.hip place_fast).  `fast` bounds what the closed form leaves out: the
-    // fourth-order remainder of the <= kCk-term reciprocal sum is < 400 step^4 / smin^5, kept below 2e-10.
-    const long long n = b - a;
-    const double s0 = sp[x], s1 = sp[x + 1], off = seg_off[x];
-    SegFast f;
-    const bool off_ok = fabs(off) < 4.0e18;            // also false for NaN
-    const double ro = off_ok ? rint(off) : 0.0;
-    f.foff = off_ok ? off - ro : 0.0;
-    f.A = (long long)ro;
-    f.n = n < 0x7fffffffll ? (int)n : 0x7fffffff;
-    f.step = n >= 2 ? (s1 - s0) / (double)(n - 1) : 0.0;
-    const double smin = s0 < s1 ? s0 : s1, smax = s0 < s1 ? s1 : s0;
-    f.fast = off_ok && n >= 2 && n < 0x7fffffffll && smin >= 0.0625 && smax <= 64.0 &&
-             fabs(f.step) <= 6.0e-4 * smin * sqrt(sqrt(smin));
-    // level 2 (BlockRec with the cubic term): over the 32 centred steps of a block (|d| <= 16, up to 33 with the steps behind
-    // the checkpoint) the quartic term of the reciprocal sum, z^3 d^4 / 4 with z = step / speed, stays < 1e-8 samples
-    // level 3 (the block quadratic alone): the cubic term z^2 d^3 / 3 <= 1365 z^2 stays < 1e-8
-    if (f.fast && fabs(f.step) <= 5.0e-5 * smin) f.fast = fabs(f.step) <= 2.7e-6 * smin ? 3 : 2;
-    seg_fast[x] = f;
+    seg_fast[x] = seg_fast_record(sp, seg_off, x, b - a);
   }
   if (x > n_tiles || len_out <= 0) return;
   // entry [n_tiles] is extra: the segment that holds the LAST output
@@ -1019,37 +1070,7 @@ __device__ __forceinline__ void tile_seg_body(const double* __restrict__ sp, con
     const long long mid = (lo + hi + 1) >> 1;
     if (seg_start[mid] <= sample) lo = mid; else hi = mid - 1;
   }
-  if (lo < nseg) {
-    tile_seg[x] = lo;
-    // boundaries the tile's blocks may meet, for k_block_rec's lookup
-    for (int q = 0; q < kTileStarts; ++q) tile_st[x * kTileStarts + q] = lo + q <= nseg ? seg_start[lo + q] : LLONG_MAX;
-    // tile header: the anchor every window centre of the tile is relative to -- an even integer within ~8 samples of the
-    // tile's first position (the checkpoint below it; block records keep a 16-bit offset from it)
-    if (x < n_tiles) {
-      const long long start = seg_start[lo], k = sample - start, b = k >> 3;
-      static_assert(kCk == 8, "k >> 3");
-      const double off = seg_off[lo];
-      const bool off_ok = fabs(off) < 4.0e18;
-      const double ro = off_ok ? rint(off) : 0.0;
-      const long long slot = ck_slot0(start, lo) + b;
-      const double ckv = (b && slot < ck_len) ? ck[slot] : 0.0;
-      const double rel = (off_ok ? off - ro : 0.0) + ckv;
-      const bool ok = off_ok && fabs(rel) < 1.0e15 && ro > -0x1p61 && ro < 0x1p61;
-      TileHdr hd;
-      hd.anchor = ok ? ((long long)ro + (long long)rint(rel)) & ~1ll : 0ll;
-      hd.c_last = 0;
-      hd.iT = lo;
-      hd.mn_rel = 0;
-      // bit 1: some segment under the tile (or the one behind it: the last output's period reaches there) touches
-      // speed >= 1, i.e. the tile may hold fc = 1 outputs.  A hint only: K_sinc's matrix-core path is taken by workgroups
-      // whose tile carries it, everything else computes the same numbers on the vector path.
-      bool may_unity = false;
-      for (long long q = lo; q < nseg && seg_start[q] <= sample + kSincTileOutputs; ++q)
-        may_unity = may_unity || !(sp[q] < kUnityHintBelow) || !(sp[q + 1] < kUnityHintBelow);
-      hd.flags = (ok ? 0 : 1) | (may_unity ? kTileMayUnity : 0);
-      hdr[x] = hd;
-    }
-  }
+  if (lo < nseg) tile_entry(sp, seg_start, seg_off, nseg, ck, ck_len, tile_seg, tile_st, hdr, x, n_tiles, sample, lo, lazy);
 }
 
 __global__ void k_tile_seg(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
@@ -1065,10 +1086,12 @@ __global__ void k_tile_seg_publish(const double* __restrict__ sp, const int64_t*
                                    const double* __restrict__ seg_off, int64_t nseg, const double* __restrict__ ck, int64_t ck_len,
                                    int64_t max_tiles, int64_t* __restrict__ tile_seg, SegFast* __restrict__ seg_fast,
                                    long long* __restrict__ tile_st, TileHdr* __restrict__ hdr, PlanHeader* __restrict__ h,
-                                   int64_t n_items) {
+                                   int64_t n_items, int lazy) {
   __shared__ int is_last;
+  if (lazy && h->lazy_fail) return;                     // the plan is being made again the eager way
   for (int64_t x0 = (int64_t)blockIdx.x * blockDim.x; x0 < n_items; x0 += (int64_t)gridDim.x * blockDim.x)
-    tile_seg_body(sp, seg_start, seg_off, nseg, ck, ck_len, max_tiles, tile_seg, seg_fast, tile_st, hdr, h, x0 + threadIdx.x);
+    tile_seg_body(sp, seg_start, seg_off, nseg, ck, ck_len, max_tiles, tile_seg, seg_fast, tile_st, hdr, h, x0 + threadIdx.x,
+                  lazy != 0);
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) is_last = atomicAdd(&h->pad3, 1) == (int)gridDim.x - 1;
@@ -1078,8 +1101,29 @@ __global__ void k_tile_seg_publish(const double* __restrict__ sp, const int64_t*
   h->pad3 = 0;
   const int fl = __hip_atomic_load(&h->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   h->ck_len = ck_len;
-  h->ck_valid = (fl & ~kFlagCapAmbiguous) ? 0 : 1;
+  h->ck_valid = (fl & ~kFlagCapAmbiguous) ? 0 : (lazy ? 2 : 1);     // 2: K_sinc may run, but there are no checkpoints to fill from
   h->flags = fl & ~kFlagCkOverflow;
+}
+
+// Lazy plans: a thread per SEGMENT writes its SegFast record and the entries of the tiles whose first output it holds (n <= kLazyMaxN
+// <= one tile: at most two of them) -- no bisection per tile (22 dependent loads each), no grid cap, no epilogue: k_trim_lazy has
+// published ck_valid already.
+__global__ __launch_bounds__(256) void k_tile_seg_lazy(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                                       const double* __restrict__ seg_off, int64_t nseg,
+                                                       int64_t* __restrict__ tile_seg, SegFast* __restrict__ seg_fast,
+                                                       long long* __restrict__ tile_st, TileHdr* __restrict__ hdr,
+                                                       const PlanHeader* __restrict__ h) {
+  if (h->ck_valid != 2) return;
+  const long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= nseg) return;
+  const long long len_out = h->len_out;
+  const long long n_tiles = (len_out + kSincTileOutputs - 1) / kSincTileOutputs;
+  const long long a = seg_start[x], b = seg_start[x + 1];
+  seg_fast[x] = seg_fast_record(sp, seg_off, x, b - a);
+  if (b <= a || a >= len_out) return;
+  for (long long T = (a + kSincTileOutputs - 1) / kSincTileOutputs; T * kSincTileOutputs < b && T < n_tiles; ++T)
+    tile_entry(sp, seg_start, seg_off, nseg, nullptr, 0, tile_seg, tile_st, hdr, T, n_tiles, T * kSincTileOutputs, x, true);
+  if (len_out - 1 < b) tile_entry(sp, seg_start, seg_off, nseg, nullptr, 0, tile_seg, tile_st, hdr, n_tiles, n_tiles, len_out - 1, x, true);
 }
 
 // ---- block records of the fused resampler (BlockRec, pos_plan.h) ---------------------------------------------------
@@ -1225,8 +1269,14 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
   const long long b = k >> 3;
   const int uk = (int)(k & 7);
   static_assert(kCk == 8, "k >> 3");
-  const double ckv = b ? ck[slot0 + b] : 0.0;
-  const BlockPoly q0 = block_poly(sf.foff, sf.step, sp0, kd, uk, ckv, sf.fast != 0);
+  BlockPoly q0;
+  if (hd.flags & kTileLazy) {        // no checkpoints: the cumsum in front of step k in closed form from the segment's first step
+    const double rc = recip_nr(__builtin_fma(sf.step, kd + 16.0, sp0));
+    q0 = piece_poly(sf.foff + lazy_prefix(sp0, sf.step, kd), rc, rc * sf.step, -16);
+  } else {
+    const double ckv = b ? ck[slot0 + b] : 0.0;
+    q0 = block_poly(sf.foff, sf.step, sp0, kd, uk, ckv, sf.fast != 0);
+  }
   const double r0 = rint(q0.a0);
   const long long rel0 = sf.A + (long long)(int)r0 - hd.anchor;   // |a0| >= 1e9 saturates: such a block is flagged and never placed from Irel
   const bool range0 = fabs(q0.a0) < 1.0e9 && sf.A > -(1ll << 61) && sf.A < (1ll << 61) && irel_ok(rel0) && !(hd.flags & 1);
@@ -1257,6 +1307,146 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
   o.e1 = (float)q0.a1m1;
   o.e2 = (float)q0.a2;
   rec[g] = o;
+}
+
+// Lazy plans: the records of the blocks whose first output lies in 64 consecutive segments, by ONE WAVE -- the segments' data
+// staged in LDS, then a lane per block (the blocks of consecutive segments are consecutive: coalesced 16-byte stores), its
+// segment found by a 6-step search of the staged starts.  The cumsum in front of a block in closed form from the segment's
+// first step (no checkpoint, no dependent global load), and the second piece of the block a segment ends in (k_block_rec2's
+// job) by the same lane.  Same records as k_block_rec + k_block_rec2 up to the closed form's 1e-12; flags identical.
+// (A thread per segment looping over its ~8 blocks: 486 us for the 60-min curve -- 128-byte strides between the lanes of a
+// store; a thread per block with the tile tables' lookup as in k_block_rec + k_block_rec2: 230 + 130 us.)
+constexpr int kRecLazySegs = 64;
+// (records need ~1e-10, not numpy's bits: this kernel's arithmetic may contract into FMAs, unlike the rest of the file)
+__device__ __forceinline__ double recip_nr_c(double b) {
+#pragma clang fp contract(fast)
+  double x = __builtin_amdgcn_rcp(b);
+  x = x + x * (1.0 - b * x);
+  return x + x * (1.0 - b * x);
+}
+__device__ __forceinline__ BlockPoly piece_poly_c(double base, double rc, double z, int d0) {
+#pragma clang fp contract(fast)
+  const double rp = -(rc * z), cz = rc * z * z, dd0 = (double)d0;
+  const double s2m = (dd0 - 1.0) * dd0 * (2.0 * dd0 - 1.0) * (1.0 / 6.0);
+  BlockPoly q;
+  q.a0 = ((base + rc * (1.0 - dd0)) + 0.5 * rp * (dd0 - dd0 * dd0)) - cz * s2m;
+  q.a1m1 = ((rc - 1.0) + 0.5 * rp) + cz * (1.0 / 6.0);
+  q.a2 = 0.5 * rp + 0.5 * cz;
+  return q;
+}
+__device__ __forceinline__ double lazy_prefix_nr(double s0, double step, double K) {     // lazy_prefix to ~1e-15 relative
+#pragma clang fp contract(fast)
+  const double rc = recip_nr_c(__builtin_fma(step, 0.5 * (K - 1.0), s0));
+  const double z = rc * step, t = z * z, K2 = K * K;
+  return K * rc * (1.0 + t * (K2 - 1.0) * (1.0 / 12.0) * (1.0 + t * (3.0 * K2 - 7.0) * 0.05));
+}
+__global__ __launch_bounds__(256) void k_block_rec_lazy(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                                        int64_t nseg, const SegFast* __restrict__ seg_fast,
+                                                        const TileHdr* __restrict__ hdr, BlockRec* __restrict__ rec,
+                                                        BlockRec2* __restrict__ rec2, const PlanHeader* __restrict__ h) {
+  __shared__ SegFast s_sf[4][kRecLazySegs + 1];
+  __shared__ double s_sp[4][kRecLazySegs + 2];
+  __shared__ int s_a[4][kRecLazySegs + 1];                       // segment starts relative to the wave's first one
+  if (h->ck_valid != 2) return;
+  const int l = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+  const long long i0 = ((long long)blockIdx.x * 4 + w) * kRecLazySegs;
+  if (i0 >= nseg) return;
+  const long long len_out = h->len_out;
+  const long long a0 = seg_start[i0];
+  if (a0 >= len_out) return;
+  const int nsw = (int)(nseg - i0 < kRecLazySegs ? nseg - i0 : kRecLazySegs);      // segments of this wave
+  {
+    const long long il = i0 + l < nseg ? i0 + l : nseg;           // entries past the curve repeat the end (never selected)
+    const long long d = seg_start[il] - a0;
+    s_a[w][l] = d < 0x7fffffffll ? (int)d : 0x7fffffff;
+    s_sf[w][l] = seg_fast[il < nseg ? il : nseg - 1];
+    s_sp[w][l] = sp[il];
+    if (l == 0) {
+      const long long ie = i0 + kRecLazySegs < nseg ? i0 + kRecLazySegs : nseg;
+      const long long de = seg_start[ie] - a0;
+      s_a[w][kRecLazySegs] = de < 0x7fffffffll ? (int)de : 0x7fffffff;
+      s_sf[w][kRecLazySegs] = seg_fast[ie < nseg ? ie : nseg - 1];
+      s_sp[w][kRecLazySegs] = sp[ie];
+      s_sp[w][kRecLazySegs + 1] = sp[ie + 1 <= nseg ? ie + 1 : nseg];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const long long b_end = a0 + s_a[w][nsw];                      // first output behind the wave's segments
+  const long long lim = b_end < len_out ? b_end : len_out;
+  const long long G0 = (a0 + kRec - 1) >> kRecShift, G1 = (lim + kRec - 1) >> kRecShift;
+  long long Tc = -1;
+  TileHdr hd;
+  hd.anchor = 0;
+  hd.flags = 0;
+  for (long long g = G0 + l; g < G1; g += kWave) {
+    const long long jb = g << kRecShift;
+    const int jr = (int)(jb - a0);
+    int lo = 0, hi = nsw - 1;                                     // last staged segment with start <= jb
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (lo < hi) {
+        if (s_a[w][mid] <= jr) lo = mid; else hi = mid - 1;
+      }
+    }
+    const long long i = i0 + lo;
+    const long long a = a0 + s_a[w][lo], b = a0 + s_a[w][lo + 1];
+    const SegFast sf = s_sf[w][lo];
+    const bool has_next = i + 1 < nseg;
+    const SegFast s1 = s_sf[w][has_next ? lo + 1 : lo];
+    const double sp0 = s_sp[w][lo], sp1 = s_sp[w][has_next ? lo + 1 : lo];
+    const long long T = jb / kSincTileOutputs;
+    if (T != Tc) {
+      hd = hdr[T];
+      Tc = T;
+    }
+    const long long j0 = T * kSincTileOutputs;
+    const double kd = (double)(jb - a);
+    const long long d = b - jb;
+    const int rem = d < kRec + 1 ? (int)d : kRec + 1;
+    const double rc = recip_nr_c(__builtin_fma(sf.step, kd + 16.0, sp0));
+    const BlockPoly q0 = piece_poly_c(sf.foff + lazy_prefix_nr(sp0, sf.step, kd), rc, rc * sf.step, -16);
+    const double r0 = rint(q0.a0);
+    const long long rel0 = sf.A + (long long)(int)r0 - hd.anchor;
+    const bool range0 = fabs(q0.a0) < 1.0e9 && sf.A > -(1ll << 61) && sf.A < (1ll << 61) && irel_ok(rel0) && !(hd.flags & 1);
+    const unsigned ustar = rem < kRec ? (unsigned)rem : (unsigned)kRec;
+    const long long ul = j0 + kSincTileOutputs >= len_out ? len_out - 1 - jb : -1;      // the file's last output: slow path
+    const unsigned slow0 = !(sf.fast >= 2 && range0 && fabs(q0.a1m1) <= 0.03125) || (ul >= 0 && ul < (long long)ustar);
+    unsigned slow1 = 0u, end1 = 0u, cubic = sf.fast == 2;
+    if (ustar < (unsigned)kRec) {                               // segment i + 1 starts at u = ustar
+      const int need = kRec - (int)ustar;
+      end1 = s1.n == need;
+      slow1 = !(has_next && s1.fast >= 2 && s1.n >= need && s1.A > -(1ll << 61) && s1.A < (1ll << 61) && sp1 >= 0.971 &&
+                sp1 <= 1.031) ||
+              (ul >= (long long)ustar && ul < kRec);
+      cubic |= s1.fast == 2;
+      if (has_next && b < len_out) {                            // its piece of this block (k_block_rec2)
+        const int us = (int)ustar;
+        const double rc1 = recip_nr_c(__builtin_fma(s1.step, (double)(16 - us), sp1));
+        const BlockPoly b1 = piece_poly_c(s1.foff, rc1, rc1 * s1.step, us - 16);
+        const double r1 = rint(b1.a0);
+        const long long rel = s1.A + (long long)r1 - hd.anchor;
+        BlockRec2 o2;
+        o2.w0 = (unsigned)((int)rel << 16);
+        o2.F = (float)(b1.a0 - r1);
+        o2.e1 = (float)b1.a1m1;
+        o2.e2 = (float)b1.a2;
+        rec2[g] = o2;
+        if (!(fabs(b1.a0) < 1.0e9 && irel_ok(rel))) slow1 = 1u;
+      }
+    }
+    const bool e0 = (ustar < (unsigned)kRec) || rem == kRec;
+    if (end1) slow1 = 1u;
+    BlockRec o;
+    o.w0 = ((unsigned)((int)rel0 << 16)) | (ustar - 1u) | (e0 ? kRecE0 : 0u) | (end1 ? kRecE1 : 0u) | (slow0 ? kRecSlow0 : 0u) |
+           (slow1 ? kRecSlow1 : 0u) | (cubic ? kRecCubic : 0u) | ((e0 ? ustar - 1u : 63u) << kRecLastShift);
+    o.F = (float)(q0.a0 - r0);
+    o.e1 = (float)q0.a1m1;
+    o.e2 = (float)q0.a2;
+    rec[g] = o;
+  }
 }
 
 __device__ __forceinline__ void mark_direct(long long i, long long* direct, PlanHeader* h) {
@@ -1327,6 +1517,7 @@ __global__ void k_off_stitch(const double* __restrict__ S, const PElem* __restri
                              int64_t nseg, long long* __restrict__ direct, RunEntry* __restrict__ runs,
                              PlanHeader* __restrict__ h) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (h->lazy && h->lazy_fail) return;         // (a failed lazy pass may have listed thousands of direct steps)
   int nd = h->n_direct;
   if (nd > kMaxDirect) nd = kMaxDirect;
   for (int a = 1; a < nd; ++a) {               // insertion sort (nd is tiny)
@@ -1530,10 +1721,14 @@ __device__ __forceinline__ PElem off_element(double xa, double xb, double Si, bo
 // offsets, pass 3 of the float64 scan fused with k_off_prepare: the running sum in front of and behind every step is the
 // approximate offset there (a PREDICTION of its binade, verified later by k_off_apply: any accurate association of the
 // sum serves), from which the step's parity-translation element follows -- or the step is listed `direct`.
+// Lazy plans (cand != nullptr): S holds closed-form sums good to lazy_bound(); a step whose element that uncertainty could
+// change -- S/ulp within the bound of a rounding boundary -- or that is not an interior step is listed for the exact sum.
 __global__ __launch_bounds__(kScanThreads) void k_offs_elements(const double* __restrict__ S, const double* __restrict__ st,
                                                                  int64_t nseg, const double* __restrict__ bsum_f,
                                                                  PElem* __restrict__ el, long long* __restrict__ direct,
-                                                                 PlanHeader* __restrict__ h) {
+                                                                 PlanHeader* __restrict__ h, Cand* __restrict__ cand,
+                                                                 const double* __restrict__ sp,
+                                                                 const int64_t* __restrict__ seg_start) {
   __shared__ double smem_f[kScanThreads / kWave];
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
   double v[kScanItems];
@@ -1556,14 +1751,75 @@ __global__ __launch_bounds__(kScanThreads) void k_offs_elements(const double* __
     PElem p = off_element(xa, st0 + run, v[k], &interior);
     if (!interior) mark_direct(i, direct, h);
     el[i] = p;
+    if (cand != nullptr) {
+      bool listed = !interior;
+      if (interior) {
+        const int e = f64_exponent(xa);
+        const double t = ldexp(v[k], 1075 - e);
+        const double fr = t - floor(t);
+        const double s0 = sp[i], s1 = sp[i + 1];
+        const double bu = ldexp(lazy_bound((double)(seg_start[i + 1] - seg_start[i]), s0 < s1 ? s0 : s1), 1075 - e);
+        listed = !(fabs(fr - 0.5) > bu);
+      }
+      if (listed) {
+        const int slot = atomicAdd(&h->n_cand, 1);
+        if (slot < kMaxCand) cand[slot] = Cand{(long long)i, xa, st0 + run};
+      }
+    }
   }
+}
+
+
+// ---- lazy plans (pos_plan.h): closed-form segment sums, exact sums only where the offset chain's rounding needs them ------
+// One thread per segment: S~_i by the closed form, or the verdict that the curve is not one for a lazy plan.
+__global__ __launch_bounds__(256) void k_seg_sum_lazy(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                                      int64_t nseg, double* __restrict__ S, PlanHeader* __restrict__ h) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg) return;
+  const long long n = seg_start[i + 1] - seg_start[i];
+  const double s0 = sp[i], s1 = sp[i + 1];
+  double v = 0.0;
+  if (lazy_segment_ok(n, s0, s1)) {
+    v = lazy_prefix(s0, (s1 - s0) / (double)(n - 1), (double)n);
+  } else {
+    // a degenerate segment (n < 2) behind the trim never exists for the reference; in front of it the plan is refused
+    // anyway.  Either way the eager plan words the verdict.
+    atomicOr(&h->lazy_fail, 1);
+  }
+  S[i] = v;
+}
+
+// One lane per candidate: the reference's own sequential sum, then the segment's chain element once more.
+__global__ __launch_bounds__(64) void k_seg_exact_list(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                                                       int64_t nseg, double* __restrict__ S, PElem* __restrict__ el,
+                                                       const Cand* __restrict__ cand, long long* __restrict__ direct,
+                                                       PlanHeader* __restrict__ h) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  int nc = h->n_cand;
+  if (nc > kMaxCand) {                                   // list overflow: not a curve for a lazy plan after all
+    if (slot == 0) atomicOr(&h->lazy_fail, 2);
+    return;
+  }
+  if (slot >= nc || h->lazy_fail) return;
+  const Cand c = cand[slot];
+  const long long i = c.i;
+  const long long n = seg_start[i + 1] - seg_start[i];
+  const Ramp r = make_ramp(sp[i], sp[i + 1], n);
+  double sum = 0.0;
+  for (long long k = 0; k < n; ++k) sum = sum + ramp_recip((double)k, r);
+  bool was_interior, interior;
+  (void)off_element(c.xa, c.xb, S[i], &was_interior);
+  const PElem p = off_element(c.xa, c.xb, sum, &interior);
+  if (!interior && was_interior) mark_direct(i, direct, h);
+  S[i] = sum;
+  el[i] = p;
 }
 
 // offsets for every segment, verification of the binade prediction, end-trim detection (:129)
 __global__ void k_off_apply(const double* __restrict__ sp, const PElem* __restrict__ E, const RunEntry* __restrict__ runs,
                             int64_t nseg, double n_in, double* __restrict__ seg_off, PlanHeader* __restrict__ h) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nseg) return;
+  if (i >= nseg || (h->lazy && h->lazy_fail)) return;
   const int nr = h->n_runs;
   int lo = 0, hi = nr - 1;                     // last run with start <= i
   while (lo < hi) {
@@ -1646,6 +1902,20 @@ __global__ void k_trim(const double* __restrict__ st, const double* __restrict__
   trim_body(st, sp, seg_start, seg_off, m, n_in, ck, ck_len, h);
 }
 
+// Lazy plans: the trim (it walks the trim segment from its first step: <= kLazyMaxN steps) and, since nothing behind it can
+// raise a flag any more, the verdict the record kernels and the host read: ck_valid = 2 (K_sinc may run; no checkpoints).
+__global__ void k_trim_lazy(const double* __restrict__ st, const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
+                            const double* __restrict__ seg_off, int64_t m, double n_in, int64_t ck_len, int64_t max_tiles,
+                            PlanHeader* __restrict__ h) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (h->lazy_fail) return;
+  trim_body(st, sp, seg_start, seg_off, m, n_in, nullptr, 0, h);
+  const int fl = __hip_atomic_load(&h->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const long long n_tiles = (h->len_out + kSincTileOutputs - 1) / kSincTileOutputs;
+  h->ck_len = ck_len;
+  h->ck_valid = ((fl & ~kFlagCapAmbiguous) || n_tiles + 1 > max_tiles) ? 0 : 2;
+}
+
 // k_off_apply with k_trim as the epilogue of the last block to finish (r04).  Grid-stride over the segments with at most 512
 // blocks: every block ends with ONE atomic on the header's counter, and thousands of them serialise on that word (measured:
 // 0.4 ms for the 10 548 blocks of a 2.7 M-segment curve).
@@ -1655,6 +1925,8 @@ __global__ __launch_bounds__(256) void k_off_apply_trim(const double* __restrict
                                                         double* __restrict__ seg_off, const double* __restrict__ ck,
                                                         int64_t ck_len, PlanHeader* __restrict__ h) {
   __shared__ int is_last;
+  if (h->lazy && h->lazy_fail) return;           // not a curve for a lazy plan: it is being made again the eager way (and the
+                                                 // trim's walk over a segment without checkpoints could take seconds)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nseg; i += (int64_t)gridDim.x * blockDim.x) {
     const int nr = h->n_runs;
     int lo = 0, hi = nr - 1;                     // last run with start <= i
@@ -2028,7 +2300,11 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
   const int64_t max_tiles = aux ? (int64_t)fused_tiles(max_out) : 0;
   PlanHeader h;
   memset(&h, 0, sizeof(h));
-  bool need_host = force_host != 0;
+  bool need_host = (force_host & 3) != 0;
+  // lazy plan (pos_plan.h): closed-form segment sums, exact ones only where a rounding decides -- for the fused resampler on
+  // dense, gentle curves (every segment checked on the device; a curve that is not one is planned again the eager way).
+  // force_host & 8 asks for the eager plan outright (callers that fill positions from the checkpoints).
+  bool lazy = aux != nullptr && !need_host && !(force_host & 8) && n_in / (m - 1) <= kLazyMaxN;
   g_last_plan_flags = 0;
   // attempt 0: everything on the device.  attempt 1 (only after a near-tie in the segment lengths): the O(m) length
   // recurrence is redone serially on the host in the reference's own float64 order, everything else -- the O(len_out)
@@ -2039,7 +2315,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
     const unsigned g256 = (unsigned)ceil_div(nseg, 256);
     const unsigned nbs = (unsigned)ceil_div(nseg, kScanTile), nbm = (unsigned)ceil_div(m, kScanTile);
     double* scratch_f = pv.xs;                  // per-wave speed partials, later the float64 scan's block sums (xs itself is gone)
-    hipLaunchKernelGGL(k_init_header, dim3(1), dim3(1), 0, s, pv.hdr, m);
+    hipLaunchKernelGGL(k_init_header, dim3(1), dim3(1), 0, s, pv.hdr, m, lazy ? 1 : 0);
     int rc;
     if (attempt == 0) {
       // lengths: the 64.64 fixed-point scan with k_seg_want / k_seg_lengths / k_speed_sum inside its passes (3 launches)
@@ -2061,35 +2337,62 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
       hipLaunchKernelGGL(k_speed_sum, dim3((unsigned)(m / 4096 + 1)), dim3(256), 0, s, speeds, m,
                          reinterpret_cast<double*>(pv.bsum), pv.hdr);
     }
-    rc = launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s, with_long ? 2 : 1);
-    if (rc != PAR_OK) return rc;
+    if (lazy) {
+      hipLaunchKernelGGL(k_seg_sum_lazy, dim3(g256), dim3(256), 0, s, speeds, (const int64_t*)pv.seg_start, nseg, pv.S, pv.hdr);
+    } else {
+      rc = launch_seg_sums(speeds, pv, nseg, ck, ck_len, max_out, m, s, with_long ? 2 : 1);
+      if (rc != PAR_OK) return rc;
+    }
     // offsets: float64 scan of S (its apply pass makes the parity-translation elements), heads, ComposeP scan (its apply
     // pass ends with the stitch), then the offsets themselves with the trim as epilogue: 8 launches
     PElem* el = reinterpret_cast<PElem*>(pv.scan);
     hipLaunchKernelGGL(k_offs_reduce, dim3(nbs), dim3(kScanThreads), 0, s, (const double*)pv.S, nseg, scratch_f);
     hipLaunchKernelGGL(k_scan_top<AddF64>, dim3(1), dim3(kScanThreads), 0, s, scratch_f, (int64_t)nbs);
     hipLaunchKernelGGL(k_offs_elements, dim3(nbs), dim3(kScanThreads), 0, s, (const double*)pv.S, sampletimes, nseg,
-                       (const double*)scratch_f, el, pv.direct, pv.hdr);
+                       (const double*)scratch_f, el, pv.direct, pv.hdr, lazy ? pv.cand : (Cand*)nullptr, speeds,
+                       (const int64_t*)pv.seg_start);
+    if (lazy)
+      hipLaunchKernelGGL(k_seg_exact_list, dim3(kMaxCand / 64), dim3(64), 0, s, speeds, (const int64_t*)pv.seg_start, nseg, pv.S,
+                         el, (const Cand*)pv.cand, pv.direct, pv.hdr);
     hipLaunchKernelGGL(k_off_heads, dim3((kMaxDirect + 255) / 256), dim3(256), 0, s, el, nseg, pv.direct, pv.hdr);
     hipLaunchKernelGGL(k_scan_reduce<ComposeP>, dim3(nbs), dim3(kScanThreads), 0, s, (const PElem*)el, nseg,
                        reinterpret_cast<PElem*>(pv.bsum));
     hipLaunchKernelGGL(k_scan_top<ComposeP>, dim3(1), dim3(kScanThreads), 0, s, reinterpret_cast<PElem*>(pv.bsum), (int64_t)nbs);
     hipLaunchKernelGGL(k_scan_apply<ComposeP>, dim3(nbs), dim3(kScanThreads), 0, s, el, nseg, (const PElem*)pv.bsum);
     hipLaunchKernelGGL(k_off_stitch, dim3(1), dim3(1), 0, s, pv.S, el, sampletimes, nseg, pv.direct, pv.runs, pv.hdr);
+    if (lazy) {
+      // full grids without the last-block epilogues (their one atomic per block on a header word is what capped those grids)
+      hipLaunchKernelGGL(k_off_apply, dim3(g256), dim3(256), 0, s, speeds, (const PElem*)el, (const RunEntry*)pv.runs, nseg,
+                         (double)n_in, pv.seg_off, pv.hdr);
+      hipLaunchKernelGGL(k_trim_lazy, dim3(1), dim3(1), 0, s, sampletimes, speeds, (const int64_t*)pv.seg_start,
+                         (const double*)pv.seg_off, m, (double)n_in, ck_len, max_tiles, pv.hdr);
+      const FusedAux av = fused_aux_view(aux, max_out, m);
+      hipLaunchKernelGGL(k_tile_seg_lazy, dim3(g256), dim3(256), 0, s, speeds, (const int64_t*)pv.seg_start,
+                         (const double*)pv.seg_off, nseg, av.tile_seg, av.seg_fast, av.tile_st, av.hdr, (const PlanHeader*)pv.hdr);
+      hipLaunchKernelGGL(k_block_rec_lazy, dim3((unsigned)ceil_div(nseg, 4 * kRecLazySegs)), dim3(256), 0, s, speeds, (const int64_t*)pv.seg_start, nseg,
+                         (const SegFast*)av.seg_fast, (const TileHdr*)av.hdr, av.rec, av.rec2, (const PlanHeader*)pv.hdr);
+    } else {
     hipLaunchKernelGGL(k_off_apply_trim, dim3(g256 < 512u ? g256 : 512u), dim3(256), 0, s, sampletimes, speeds, (const PElem*)el,
                        (const RunEntry*)pv.runs, (const int64_t*)pv.seg_start, nseg, (double)n_in, pv.seg_off,
                        (const double*)ck, ck_len, pv.hdr);
-    if (aux) {
+    }
+    if (aux && !lazy) {
       const int64_t n_items = std::max<int64_t>(nseg, max_tiles);
       hipLaunchKernelGGL(k_tile_seg_publish, dim3((unsigned)std::min<int64_t>(ceil_div(n_items, 256), 512)), dim3(256), 0, s,
                          speeds, pv.seg_start, pv.seg_off, nseg, (const double*)ck, ck_len, max_tiles,
                          reinterpret_cast<int64_t*>(ck + ck_len), reinterpret_cast<SegFast*>(ck + ck_len + max_tiles),
-                         fused_aux_view(aux, max_out, m).tile_st, fused_aux_view(aux, max_out, m).hdr, pv.hdr, n_items);
+                         fused_aux_view(aux, max_out, m).tile_st, fused_aux_view(aux, max_out, m).hdr, pv.hdr, n_items,
+                         lazy ? 1 : 0);
       launch_block_rec(speeds, pv, nseg, aux, max_out, m, s);
     }
     PAR_HIP_CHECK(hipGetLastError());
     PAR_HIP_CHECK(hipMemcpyAsync(&h, pv.hdr, sizeof(h), hipMemcpyDeviceToHost, s));
     PAR_HIP_CHECK(hipStreamSynchronize(s));
+    if (lazy && h.lazy_fail) {                  // not a curve for a lazy plan: once more, with the per-sample cumsum
+      lazy = false;
+      --attempt;
+      continue;
+    }
     if (h.n_long > 0 && !with_long) {           // sparse curve: once more, with the chunked exact cumsum of its long segments
       with_long = true;
       --attempt;
@@ -2126,7 +2429,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
                          speeds, pv.seg_start, pv.seg_off, nseg, (const double*)ck, ck_len, max_tiles,
                          reinterpret_cast<int64_t*>(ck + ck_len), reinterpret_cast<SegFast*>(ck + ck_len + max_tiles),
                          fused_aux_view(aux, max_out, m).tile_st, fused_aux_view(aux, max_out, m).hdr, pv.hdr);
-      if (force_host == 2) hipLaunchKernelGGL(k_inject_verify_fault, dim3(1), dim3(1), 0, s, pv.hdr);
+      if ((force_host & 3) == 2) hipLaunchKernelGGL(k_inject_verify_fault, dim3(1), dim3(1), 0, s, pv.hdr);
       hipLaunchKernelGGL(k_publish_ck, dim3(1), dim3(1), 0, s, pv.hdr, ck_len);
       launch_block_rec(speeds, pv, nseg, aux, max_out, m, s);
       PAR_HIP_CHECK(hipGetLastError());

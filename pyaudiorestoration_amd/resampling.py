@@ -27,11 +27,13 @@ def find_cutoff(array, cutoff):
 class SpeedPlan:
     """Device-resident result of the planning stage of speed_to_pos (segment lengths, offsets, trim)."""
 
-    def __init__(self, speeds_t, m, work, len_out, trimmed, path, dev, aux=None, fused_ok=False, max_out=0):
+    def __init__(self, speeds_t, m, work, len_out, trimmed, path, dev, aux=None, fused_ok=False, max_out=0, lazy=False):
         self.speeds_t, self.m, self.work, self.len_out, self.trimmed, self.path, self.dev = \
             speeds_t, m, work, len_out, trimmed, path, dev
-        # fused_ok: the plan carries cumsum checkpoints for every needed segment (fused K_sinc can run)
-        self.aux, self.fused_ok, self.max_out = aux, fused_ok, max_out
+        # fused_ok: the fused K_sinc can run from this plan.  lazy: it was made without the per-sample cumsum (closed-form
+        # segment sums, exact ones only where a rounding decides: csrc/pos_plan.h) -- same positions and window centres, but
+        # no checkpoints, so par_speed_to_pos_fill_fused cannot fill from it (ask for eager=True then)
+        self.aux, self.fused_ok, self.max_out, self.lazy = aux, fused_ok, max_out, lazy
 
 
 def _max_out_for_bytes(L, nbytes, m):
@@ -58,12 +60,13 @@ def fused_max_out(sampletimes_t, speeds_t):
 
 
 def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_host_chain=False, fused=False,
-                   max_out=None, work=None, aux=None, stream=None):
+                   max_out=None, work=None, aux=None, stream=None, eager=False):
     """Planning stage.  fused=True also stores per-segment cumsum checkpoints (every 8th step) so that
     varispeed_resample_dev can regenerate positions inside K_sinc instead of reading a position array.
     work / aux: caller-owned uint8 device buffers to (re)use; stream: torch stream to plan on (default: current).
     force_host_chain: True/1 = serial host evaluation of the two chains; 2 (tests) = that plus an injected checkpoint
-    verification failure, after which fused_ok must be False."""
+    verification failure, after which fused_ok must be False.
+    eager: always compute the per-sample cumsum and its checkpoints (default: dense gentle curves get a lazy plan)."""
     dev = _dev.device_index(dev if dev is not None else sampletimes_t.device)
     L = _lib.lib()
     m = sampletimes_t.numel()
@@ -82,10 +85,10 @@ def speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force_h
             _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(sampletimes_t), _dev.ptr(speeds_t), m,
                                                      int(num_imput_samples), _dev.ptr(work), work.numel(), _dev.ptr(aux_),
                                                      aux_.numel(), max_out_, ctypes.byref(len_out), ctypes.byref(trimmed),
-                                                     int(force_host_chain), ctypes.byref(path), ctypes.byref(ok),
-                                                     s_ptr))
+                                                     int(force_host_chain) | (8 if eager else 0), ctypes.byref(path),
+                                                     ctypes.byref(ok), s_ptr))
             return SpeedPlan(speeds_t, m, work, len_out.value, bool(trimmed.value), path.value, dev, aux_, bool(ok.value),
-                             max_out_)
+                             max_out_, lazy=ok.value == 2)
 
         if max_out is None and aux is not None:
             # A batch hands the previous item's buffer back: size the plan to what that buffer holds instead of running
@@ -119,12 +122,12 @@ def speed_to_pos_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force
     checkpoints let the fill run in parallel over 8-sample blocks instead of one lane per segment."""
     m = sampletimes_t.numel()
     sparse = m >= 2 and int(num_imput_samples) // max(m - 1, 1) > 16384
-    plan = speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev, force_host_chain, fused=sparse)
+    plan = speed_plan_dev(sampletimes_t, speeds_t, num_imput_samples, dev, force_host_chain, fused=sparse, eager=True)
     if info is not None:
         info.update(path=plan.path, trimmed=plan.trimmed)
     pos = _dev.empty(plan.len_out, torch.float64, plan.dev)
     L = _lib.lib()
-    if sparse and plan.fused_ok:
+    if sparse and plan.fused_ok and not plan.lazy:
         _lib.check(L.par_speed_to_pos_fill_fused(plan.dev, _dev.ptr(speeds_t), plan.m, _dev.ptr(plan.work), _dev.ptr(plan.aux),
                                                  plan.max_out, _dev.ptr(pos), plan.len_out, _dev.stream_ptr(plan.dev)))
     else:

@@ -245,8 +245,10 @@ def test_gentle_ramps_reciprocals_from_the_previous_block(par):
             ref, _ = C.speed_to_pos(st, sp, n_in)
             pos = par.resampling.speed_to_pos(st, sp, n_in)
             assert len(pos) == len(ref) and np.array_equal(pos, ref), (scale, hop)
-            plan = par.resampling.speed_plan_dev(torch.from_numpy(st).cuda(), torch.from_numpy(sp).cuda(), n_in, fused=True)
+            plan = par.resampling.speed_plan_dev(torch.from_numpy(st).cuda(), torch.from_numpy(sp).cuda(), n_in, fused=True,
+                                                 eager=True)
             if plan.fused_ok:
+                assert not plan.lazy
                 buf = torch.empty(plan.len_out, dtype=torch.float64, device="cuda")
                 from pyaudiorestoration_amd import _dev, _lib
                 _lib.check(_lib.lib().par_speed_to_pos_fill_fused(0, _dev.ptr(plan.speeds_t), plan.m, _dev.ptr(plan.work),
@@ -2084,3 +2086,112 @@ def test_correlation_on_the_device(par, golden):
         assert abs(abs(d) - 37.3) < 0.05
     with pytest.raises(IndexError):
         C.find_delay(np.array([0.0, 0.0, 0.0, 1.0]), np.array([0.0, 1.0]))   # peak on the last lag: parabolic() reads f[x+1]
+
+
+# ---- lazy plans (r05; csrc/pos_plan.h) -----------------------------------------------------------------------------
+def _plan_arrays(plan):
+    """(header words, seg_start, seg_off, S) of a device plan (layout: csrc/pos_plan.h plan_view)."""
+    import torch
+    raw = plan.work.cpu().numpy()
+    m = plan.m
+    hdr = raw[:256].view(np.int32)
+    off = 256
+    seg_start = raw[off:off + 8 * m].view(np.int64)
+    seg_off = raw[off + 8 * m:off + 16 * m].view(np.float64)
+    S = raw[off + 16 * m:off + 24 * m].view(np.float64)
+    return hdr, seg_start.copy(), seg_off.copy(), S.copy()
+
+
+def _lazy_bound(n, smin):
+    return (0.55 * n * n + 16.0 * n + 64.0) * 2.0 ** -53 / smin
+
+
+def test_lazy_plan_equals_eager_plan(par):
+    """A lazy plan (closed-form segment sums + exact sums for the candidates of the offset chain) must reproduce the eager
+    plan's offsets, lengths and trim bit for bit; its closed-form sums must sit inside the bound the candidate test relies on;
+    curves it does not vouch for must come back eager; and the fused resampler must produce the same output from either."""
+    import torch
+    from oracle import oracle_c as C
+    R = par.resampling
+    rng = np.random.default_rng(77)
+    cases = []
+    sc = inputs.bench_speed_curve(30.0, 192000)
+    cases.append(("bench30", sc[:, 0] * 192000, sc[:, 1], int(192000 * 30.0), True))
+    sc = inputs.bench_speed_curve(4.0, 48000, hop=64, depth=0.02, rate_hz=3.0)
+    cases.append(("flutter", sc[:, 0] * 48000, sc[:, 1], int(48000 * 4.0), True))
+    for scale, m, hop in ((1.0, 6000, 256), (0.07, 3000, 256), (50.0, 800, 256), (0.9, 5000, 64), (3.3, 2000, 1000), (1.0, 300, 7)):
+        st = np.arange(m) * float(hop)
+        sp = scale * (1.0 + 0.01 * np.sin(np.arange(m) * 0.013 + 0.4) + 1e-7 * rng.standard_normal(m))
+        ok = 0.0625 <= sp.min() and sp.max() <= 64.0 and hop * sp.max() * 1.01 <= 1024
+        cases.append((f"gentle{scale}/{hop}", st, sp, int(st[-1] * float(np.mean(sp)) * 0.97), ok))
+    st = np.arange(4000) * 256.0
+    sp = 1.0 + 0.01 * np.sin(np.arange(4000) * 0.013)
+    sp2 = sp.copy()
+    sp2[1234] *= 1.03                                                      # one steep segment: the whole plan goes eager
+    cases.append(("one-steep", st, sp2, int(st[-1] * 0.97), False))
+    cases.append(("no-trim", st, sp, int(st[-1] * 1.2), True))            # the trim never fires
+    st5 = np.arange(40) * 5000.0                                           # segments of ~5000 outputs: too long for the closed form
+    cases.append(("long-segs", st5, 1.0 + 0.002 * np.sin(np.arange(40) * 0.3), int(st5[-1] * 0.97), False))
+    worst = 0.0
+    n_cand_seen = 0
+    for name, st, sp, n_in, want_lazy in cases:
+        st_t, sp_t = torch.from_numpy(np.ascontiguousarray(st, dtype=np.float64)).cuda(), torch.from_numpy(np.ascontiguousarray(sp, dtype=np.float64)).cuda()
+        eager = R.speed_plan_dev(st_t, sp_t, n_in, fused=True, eager=True)
+        he, ss_e, so_e, S_e = _plan_arrays(eager)
+        lazy = R.speed_plan_dev(st_t, sp_t, n_in, fused=True)
+        hl, ss_l, so_l, S_l = _plan_arrays(lazy)
+        assert eager.fused_ok and not eager.lazy and lazy.fused_ok, name
+        assert lazy.lazy == want_lazy, (name, lazy.lazy, hl[26:29])
+        assert (lazy.len_out, lazy.trimmed, lazy.path) == (eager.len_out, eager.trimmed, eager.path), name
+        assert np.array_equal(ss_e, ss_l), name
+        nseg = lazy.m - 1
+        assert np.array_equal(so_e.view(np.int64), so_l.view(np.int64)), (name, "offset chain differs from the eager plan's")
+        ref, _ = C.speed_to_pos(np.asarray(st, dtype=np.float64), np.asarray(sp, dtype=np.float64), n_in)
+        assert lazy.len_out == len(ref), name
+        if lazy.lazy:
+            n = np.diff(ss_l)[:nseg].astype(np.float64)
+            smin = np.minimum(sp[:-1], sp[1:])
+            ratio = np.abs(S_l[:nseg] - S_e[:nseg]) / _lazy_bound(n, smin)
+            worst = max(worst, float(ratio.max()))
+            assert ratio.max() < 0.5, (name, "closed-form sum outside half its bound", float(ratio.max()))
+            n_cand_seen += int(hl[28])
+            assert 0 <= hl[28] <= 65536 and hl[27] == 0, name
+        sig = inputs.bench_signal(0, int(n_in), 48000)
+        sig_t = torch.from_numpy(sig).cuda()
+        for NT in (32, 50):
+            a = R.varispeed_fused_dev(eager, sig_t, NT).cpu().numpy()
+            b = R.varispeed_fused_dev(lazy, sig_t, NT).cpu().numpy()
+            want = C.sinc(ref, sig, NT, threads=8)
+            pk = float(np.max(np.abs(want)))
+            assert np.max(np.abs(a - b)) <= FUSED_TOL * pk, (name, NT, "lazy vs eager output")
+            assert np.max(np.abs(b - want)) <= TOL * pk, (name, NT)
+    assert n_cand_seen > 0          # the exact-sum list was exercised
+    print(f"lazy plans: worst |closed form - exact sum| / bound = {worst:.3f}, candidates seen {n_cand_seen}")
+
+
+def test_lazy_plan_near_ties_take_the_exact_walk(par):
+    """Window centres of a lazy plan's fused output against rint() of the oracle's exact positions, on curves built so that many
+    positions land within 1e-9 of a half-integer (speed exactly 1 after a half-sample start offset is not possible through a
+    curve, so: speed 2/3 and 2 give positions on thirds and halves), plus the bench curve, through the debug slot of the fused
+    kernel's placement (the output of a unit-ramp signal x[i] = i IS the position to ~1e-3, so rint errors show as jumps)."""
+    import torch
+    from oracle import oracle_c as C
+    R = par.resampling
+    for speed, hop, m in ((2.0, 64, 3000), (0.5, 256, 2000), (2.0 / 3.0, 300, 1500), (1.0, 256, 3000)):
+        st = np.arange(m) * float(hop)
+        sp = np.full(m, speed)
+        sp[1::2] *= 1.0 + 2.0 ** -30                                       # not a constant curve: segments differ by an ulp-ish ramp
+        n_in = int(st[-1] * speed * 0.98)
+        st_t, sp_t = torch.from_numpy(st).cuda(), torch.from_numpy(sp).cuda()
+        lazy = R.speed_plan_dev(st_t, sp_t, n_in, fused=True)
+        eager = R.speed_plan_dev(st_t, sp_t, n_in, fused=True, eager=True)
+        assert lazy.fused_ok and lazy.lazy, speed
+        ref, _ = C.speed_to_pos(st, sp, n_in)
+        assert lazy.len_out == len(ref) == eager.len_out
+        sig = inputs.noise(n_in, seed=5)
+        sig_t = torch.from_numpy(sig).cuda()
+        want = C.sinc(ref, sig, 32, threads=8)
+        got = R.varispeed_fused_dev(lazy, sig_t, 32).cpu().numpy()
+        pk = float(np.max(np.abs(want)))
+        # a wrong window centre on white noise moves the output by ~1e-1 of the peak at half-integer positions
+        assert np.max(np.abs(got - want)) <= TOL * pk, (speed, float(np.max(np.abs(got - want)) / pk))
