@@ -35,14 +35,42 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_SAMPLE = 8.0    # 4 B signal read + 4 B output write
 
 
+def usable_cores():
+    """(cores this process may run on, cores the box reports): the scheduler affinity mask, further limited by the cgroup's CPU
+    quota when there is one (cpu.max / cfs_quota_us); os.cpu_count() alone reports the HOST's cores inside a limited container
+    ("cores: 256" for a rate worth ~17 of them)."""
+    reported = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = reported
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, reported
+
+
 def cpu_baseline(sr, nt, budget_s=15.0):
     """Oracle C port (oracle/par_oracle.c) on the host cores: speed_to_pos (1 thread, serial like the
-    reference) + sinc_mt (one contiguous chunk per core, like sinc_wrapper_mt)."""
+    reference) + sinc_mt (one contiguous chunk per usable core, like sinc_wrapper_mt's one per os.cpu_count(),
+    util/resampling.py:33-46)."""
     import numpy as np
     from oracle import oracle_c as C
-    cores = os.cpu_count() or 1
+    cores, reported = usable_cores()
 
-    def run(seconds):
+    def run(seconds, threads):
         n = int(sr * seconds)
         sig = C.synth_signal(0, n, float(sr))
         m = int(seconds * sr / 256)
@@ -50,20 +78,26 @@ def cpu_baseline(sr, nt, budget_s=15.0):
         t0 = time.perf_counter()
         pos, _ = C.speed_to_pos(st, sp, n)
         tp = time.perf_counter() - t0
-        out = C.sinc(pos, sig, nt, threads=cores)
+        out = C.sinc(pos, sig, nt, threads=threads)
         dt = time.perf_counter() - t0
         return len(out), dt, tp
 
-    n1, t1, _ = run(0.5)                            # probe
-    rate = n1 / t1
+    n1, t1, tp1 = run(0.5, 1)                        # probe = the per-core rate of the interpolator (one thread)
+    per_core = n1 / max(t1 - tp1, 1e-9)
+    use = cores
+    rate = per_core * min(cores, 8)                  # sizes the sample only (a conservative guess of the N-thread rate)
     seconds = max(1.0, min(600.0, budget_s * rate / sr))
-    n2, t2, tp2 = run(seconds)
-    return {"value": round(n2 / t2 / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sinc_only_value": round(n2 / max(t2 - tp2, 1e-9) / 1e6, 3), "speed_to_pos_share": round(tp2 / t2, 3),
+    n2, t2, tp2 = run(seconds, use)
+    sinc_rate = n2 / max(t2 - tp2, 1e-9)
+    return {"value": round(n2 / t2 / 1e6, 3), "unit": "Msamples/s", "cores": use, "cores_usable": cores, "cores_reported": reported,
+            "kind": "port", "per_core_Msamples/s": round(per_core / 1e6, 3),
+            "sinc_only_value": round(sinc_rate / 1e6, 3), "sinc_only_parallel_efficiency": round(sinc_rate / (per_core * use), 3),
+            "speed_to_pos_share": round(tp2 / t2, 3),
             "sample": f"{seconds:.1f} s of the same 192 kHz workload ({n2} output samples, {t2:.1f} s wall): "
                       f"C speed_to_pos on 1 thread ({100 * tp2 / t2:.0f} % of the wall time: the reference's own serial loop, "
-                      f"which caps this line) + C sinc on {cores} threads (contiguous chunks like sinc_wrapper_mt; "
-                      f"sinc_only_value = the interpolator alone)"}
+                      f"which caps this line) + C sinc on {use} threads = the cores this process may use (affinity mask and cgroup "
+                      f"quota; the box reports {reported}), contiguous chunks like sinc_wrapper_mt; sinc_only_value = the interpolator "
+                      f"alone, per_core_Msamples/s = the same on ONE thread (0.5-s probe)"}
 
 
 def stft_secondary(sig, dev, n_fft=1024, hop=256, cpu=True):
@@ -465,6 +499,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="serial steps (plan, then K_sinc); default: the plan of file k+1 runs on a side stream under K_sinc of file k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--block-kernel", action="store_true", help="A/B: the block kernel instead of the streaming kernel (par_debug_sinc_kernel(0))")
     ap.add_argument("--config5", action="store_true", help="time the 512-file stereo archive (default when --gpus > 1)")
     ap.add_argument("--files", type=int, default=512, help="files of the config-5 archive")
     ap.add_argument("--ring", type=int, default=6, help="resident synthetic stereo files per GPU in the config-5 mode")
@@ -511,7 +546,13 @@ def main():
     out = torch.empty(cap, dtype=torch.float32, device=f"cuda:{dev}")
     fused = not a.no_fused
     overlap = fused and not a.no_overlap
-    n_slots = 2 if overlap else 1                      # plan buffers are double-buffered when steps are pipelined
+    # Pipelined steps: the plan of file k + depth is made on a side stream while K_sinc of files k .. k + depth - 1 run / wait on the
+    # main stream (depth + 1 plan buffers).  Depth 1 (until r04): K_sinc of file k + 1 can only be launched once its plan's header
+    # has been read back, i.e. behind whatever part of that plan did not fit beside K_sinc of file k.
+    # (measured r05: depths 1..4 give the same step -- beside the streaming kernel the plan only runs in the gap between two
+    # launches however early it is queued -- so the default stays the double-buffered depth 1 of the product's batch driver)
+    depth = max(1, int(os.environ.get("PAR_BENCH_DEPTH", "1"))) if overlap else 0
+    n_slots = depth + 1 if overlap else 1
     work = [torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{dev}") for _ in range(n_slots)]
     if fused:       # cumsum checkpoints + tile map: positions are regenerated inside K_sinc, never stored
         aux_bytes = int(L.par_fused_aux_bytes(cap, m))
@@ -526,6 +567,13 @@ def main():
     ok = ctypes.c_int(0)
 
     plan_force = 8 if os.environ.get("PAR_PLAN_EAGER") else 0      # A/B knob: the eager plan (per-sample cumsum + checkpoints)
+    block_kernel = a.block_kernel or bool(os.environ.get("PAR_BENCH_BLOCK_KERNEL"))
+    if block_kernel:
+        L.par_debug_sinc_kernel(0)                                 # A/B knob: the block kernel for the mono NT = 32 file too
+    streaming = fused and a.nt == 32 and not block_kernel          # what par_varispeed_fused_f32 launches for this workload
+    kernel_symbols = (["k_sinc_pipe<false, true>", "k_sinc_fused_list"] if streaming else
+                      [f"k_sinc_fused<1, {a.nt if a.nt in (32, 50) else 0}, 4>"] if fused else
+                      [f"k_sinc_pos<{a.nt if a.nt in (32, 50) else 0}>"])
     state_plan = {"lazy": False}
 
     def plan_fused(slot, stream_ptr):
@@ -547,8 +595,11 @@ def main():
         else:
             side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PAR_SIDE_PRIO", "0")))
         side_ptr = ctypes.c_void_p(side.cuda_stream)
-        slot_free = [None, None]                        # main-stream event: K_sinc that read this slot is done
-        state = {"k": 0, "len": plan_fused(0, sp_)}    # pipeline prologue: plan of the first file
+        slot_free = [None] * n_slots                    # main-stream event: K_sinc that read this slot is done
+        lens = [0] * n_slots
+        for q in range(depth):                          # pipeline prologue: plans of the first `depth` files
+            lens[q] = plan_fused(q, sp_)
+        state = {"k": 0, "len": lens[0]}
         ev_pairs = []
         # reference point outside the timed region: K_sinc with the GPU to itself (no plan underneath), launched back to
         # back like the timed steps -- 30 launches, the last 20 timed.  (A single launch on an idle GPU, which is what this
@@ -566,31 +617,19 @@ def main():
         _lib.check(L.par_event_record(e1, sp_))
         _lib.check(L.par_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
         alone.append(ms.value / 20)
-        # the same reference point for the opt-in streaming kernel in its moment form (par_varispeed_fused_alone_f32, r04): not the
-        # shipped path of the timed step (beside a plan it draws level with the block kernel), reported for the record
-        alone_moment = None
-        if a.nt == 32:
-            for i in range(30):
-                if i == 10:
-                    _lib.check(L.par_event_record(e0, sp_))
-                _lib.check(L.par_varispeed_fused_alone_f32(dev, _dev.ptr(spd), m, _dev.ptr(work[0]), _dev.ptr(aux[0]), cap,
-                                                           state["len"], _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, sp_))
-            _lib.check(L.par_event_record(e1, sp_))
-            _lib.check(L.par_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
-            alone_moment = ms.value / 20
         L.par_event_destroy(e0)
         L.par_event_destroy(e1)
 
         def step(timed):
             k = state["k"]
-            cur, nxt = k % 2, (k + 1) % 2
+            cur, nxt = k % n_slots, (k + depth) % n_slots
             e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
             if timed:
                 _lib.check(L.par_event_create(ctypes.byref(e0)))
                 _lib.check(L.par_event_create(ctypes.byref(e1)))
                 _lib.check(L.par_event_record(e0, sp_))
             _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(spd), m, _dev.ptr(work[cur]), _dev.ptr(aux[cur]), cap,
-                                                 state["len"], _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, sp_))
+                                                 lens[cur], _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, sp_))
             if timed:
                 _lib.check(L.par_event_record(e1, sp_))
                 ev_pairs.append((e0, e1))
@@ -598,7 +637,8 @@ def main():
             slot_free[cur].record(torch.cuda.current_stream(dev))
             if slot_free[nxt] is not None:
                 side.wait_event(slot_free[nxt])          # the K_sinc that last read slot `nxt` must be finished
-            state["len"] = plan_fused(nxt, side_ptr)    # returns after the side stream drained (header read-back)
+            lens[nxt] = plan_fused(nxt, side_ptr)       # returns after the side stream drained (header read-back)
+            state["len"] = lens[nxt]
             state["k"] = k + 1
     else:
         _lib.check(L.par_profile_enable(dev, 1))         # HIP events around every K_sinc launch, on its own stream
@@ -661,10 +701,12 @@ def main():
         digest = _build.source_digest()                 # the kernel sources this run was built from
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if ("fused" in tr.get("kernel", "")) == bool(fused):          # the committed PMC pass measured this form
+            same = tr.get("kernel_symbols") == kernel_symbols      # the committed PMC pass measured the kernel(s) launched here
+            if same:
                 traffic = round(tr["hbm_bytes_per_sample"] * samples_per_launch / (k_ms * 1e-3) / 1e9, 2)
-                traffic_src = {"file": "profiles/pmc_traffic.json", "from": tr.get("source"), "source_digest": tr.get("source_digest"),
-                               "running_digest": digest, "stale": tr.get("source_digest") != digest}
+            traffic_src = {"file": "profiles/pmc_traffic.json", "from": tr.get("source"), "kernel_symbols": tr.get("kernel_symbols"),
+                           "source_digest": tr.get("source_digest"), "running_digest": digest,
+                           "stale": tr.get("source_digest") != digest or not same}
         except Exception:
             pass
         res = {
@@ -673,16 +715,21 @@ def main():
             "ms_per_step_mean": round(ms_step_mean, 4),
             "ms_per_step_note": "ms_per_step = median of the per-step times (SURVEY 8d); ms_per_step_mean = timed region / steps, "
                                 "the figure `value` is computed from",
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 taps / f64 positions",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 near taps, far taps (|n| >= 3) as float16 hi + lo x 2^-12 filter banks on v_mfma_f32_16x16x32_f16 with f32 "
+                      "accumulation / f64 positions" if streaming else
+                      "f32 taps (fc = 1 far taps f16 hi + lo on MFMA) / f64 positions" if fused and a.nt == 32 else "f32 taps / f64 positions"),
             "data": "synthetic",
             "config": {"workload": f"{a.seconds:g}-s {a.sr} Hz mono float32 varispeed resample, +-1% sinusoidal speed "
                                    f"curve (0.55 Hz, hop 256), {2 * a.nt}-tap Hann sinc; one file per GPU",
                        "samples_in_per_gpu": n_in, "samples_out_per_gpu": int(len_out.value), "NT": a.nt,
-                       "step": ("plan (device scans, cumsum checkpoints, block records) + fused K_sinc (outputs placed from 16-byte block records, no position array)" if fused else "plan (device scans) + K_pos fill (float64 position array) + K_sinc") + "; inputs resident in HBM"
-                               + ("; batch pipelining: the plan of file k+1 runs on a side stream under K_sinc of file k (every step = one full plan + one full K_sinc)" if overlap else "")},
+                       "plan": ("lazy (closed-form segment sums, exact ones for the offset chain's candidates: csrc/pos_plan.h)" if state_plan["lazy"] else "eager (per-sample cumsum + checkpoints)") if fused else "position array",
+                       "step": ("plan (device scans, block records) + fused K_sinc (outputs placed from 16-byte block records, no position array)" if fused else "plan (device scans) + K_pos fill (float64 position array) + K_sinc") + "; inputs resident in HBM"
+                               + (f"; batch pipelining: the plan of file k+{depth} runs on a side stream while K_sinc of the files before it run (every step = one full plan + one full K_sinc)" if overlap else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "source": traffic_src,
-                         "kernel": "k_sinc", "limited_by": "valu",
+                         "kernel": "k_sinc", "kernel_symbols": kernel_symbols, "limited_by": "valu",
+                         "warm_launches_before_timed": (30 if overlap else 0) + a.warmup,
                          "kernel_ms": round(k_ms, 4), "launches_per_step": n_launch // len(sinc_ms),
                          "samples_per_launch": int(samples_per_launch),
                          "note": "achieved = 8 algorithmic B/output sample (4 B in + 4 B out) / HIP-event K_sinc time; "
@@ -699,17 +746,14 @@ def main():
             res["roofline"]["note"] += ("; kernel_ms is measured in the timed region, where the next file's plan kernels "
                                         "share the GPU with K_sinc; kernel_ms_alone / frac_alone = the same launch with the "
                                         "GPU to itself, 20 launches back to back before the timed region")
-            if alone_moment is not None:
-                res["roofline"]["kernel_ms_alone_moment_form"] = round(alone_moment, 4)
-                res["roofline"]["frac_alone_moment_form"] = round(ALGO_BYTES_PER_SAMPLE * samples_per_launch / (alone_moment * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                res["roofline"]["note"] += ("; kernel_ms_alone_moment_form = the same launch through par_varispeed_fused_alone_f32 (streaming "
-                                            "kernel, fc < 1 taps in their moment form: csrc/sinc2.hip) -- opt-in, not the kernel of the timed step")
         # What actually limits the kernel: VALU issue.  Instruction count per output from the committed PMC pass
         # (SQ_INSTS_VALU, profiles/), rate from this run's HIP-event time; ceilings: 2 cycles per wave64 instruction
         # per SIMD at the 2.4 GHz peak clock (MI355X_MICROARCH.md) and the rate a pure v_fma_f32 stream measured
         # (tools/ubench.hip, profiles/r01_ubench_gfx950.txt).
         try:
             vp = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu.json")))
+            if vp.get("kernel_symbols") != kernel_symbols:          # counters of some other kernel: say nothing rather than that
+                raise KeyError("pmc_valu.json describes " + str(vp.get("kernel_symbols")))
             ipo = vp["valu_lane_instr_per_output"]
             ach = ipo * samples_per_launch / (k_ms * 1e-3) / 1e12
             res["roofline_valu"] = {"limited_by": "valu", "valu_lane_instr_per_output": round(ipo, 1),
@@ -717,6 +761,7 @@ def main():
                                     "ceiling_measured_fma_stream_Tlaneops": vp.get("fma_stream_Tlaneops", 58.76),
                                     "frac_of_spec": round(ach / 78.64, 4),
                                     "frac_of_measured": round(ach / vp.get("fma_stream_Tlaneops", 58.76), 4),
+                                    "kernel_symbols": kernel_symbols,
                                     "source": vp.get("source", "profiles/"), "source_digest": vp.get("source_digest"),
                                     "running_digest": digest, "stale": vp.get("source_digest") != digest}
         except Exception:

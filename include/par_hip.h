@@ -223,18 +223,22 @@ int par_varispeed_fused_f32(int device, const double* speeds, int64_t m, const v
                             int64_t max_out, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in,
                             int NT, float* out, int64_t out_stride, void* stream);
 
-/* par_varispeed_fused_f32 for a launch that has the GPU to itself -- the caller queues no plan of a next file beside it (a single
- * file, the last file of a batch; reference: one file at a time, util/resampling.py:168).  Same arguments, same results within
- * the contract's tolerance (every window centre is the reference's).  Mono NT = 32 files on unit strides of at least four
- * 1024-output tiles take the streaming kernel in its moment form (csrc/sinc2.hip: 8 % faster than the block kernel when nothing
- * runs beside it, no faster when a plan does); everything else takes par_varispeed_fused_f32's kernels. */
-int par_varispeed_fused_alone_f32(int device, const double* speeds, int64_t m, const void* work, const void* aux,
-                                  int64_t max_out, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in,
-                                  int NT, float* out, int64_t out_stride, void* stream);
+/* Which kernel runs: mono NT = 32 files on unit strides of at least four 1024-output tiles and 4096 input samples take the
+ * streaming kernel (csrc/sinc2.hip: one wave per eight tiles, the taps |n| >= 3 of both tap regimes as fixed filter banks on the
+ * matrix cores, fc < 1 through seven moment filters) and hand the tiles it does not cover -- blocks outside the record model,
+ * window-centre ties, input float16 does not suit, the file's ends -- to the block kernel (csrc/sinc.hip) through a tile list in
+ * `aux`; everything else (stereo, other NT, strided views, short files) takes the block kernel.  Results agree within the
+ * contract's tolerance and every window centre is the reference's either way.  K_sinc WRITES that list into `aux`: one
+ * par_varispeed_fused_* launch per plan at a time (two launches of one plan on different streams would race on it). */
+
+/* Process-wide choice of that kernel, for tests and A/B sessions: form -1 = the default above, 0 = the block kernel for
+ * everything.  Returns the previous setting. */
+int par_debug_sinc_kernel(int form);
 
 /* Diagnostic: how many 1024-output tiles of the LAST par_varispeed_fused_f32 launch on this aux buffer the streaming kernel
  * (mono, NT = 32, unit strides) handed to the block kernel (blocks outside the record model, window-centre ties, input that
- * float16 does not suit, the file's ends).  Synchronises the stream.  0 when the streaming kernel did not run. */
+ * float16 does not suit, the file's ends).  Synchronises the stream.  0 when the streaming kernel did not run (the plan
+ * zeroes the count). */
 int par_fused_redo_tiles(int device, const void* aux, int64_t max_out, int64_t m, int* tiles, void* stream);
 
 /* Stereo form: two channels of ONE file (same positions; sig0/sig1 and out0/out1 share the strides -- e.g. the two

@@ -308,7 +308,11 @@ def main():
     y3_sel = np.concatenate([resampling.sinc_wrapper(pos3[a0:a0 + 3001], x3[:, 0], 0, 32)[:3000]
                              for a0 in (0, 400000)] +
                             [resampling.sinc_wrapper(pos3[len(pos3) - 3000:], x3[:, 0], 0, 32)])
-    save("samples", c1_shape=np.array(m1.shape), c1_sum=np.array(m1.sum()), c1_grid=grid(m1), c1_sr=np.array(sr1),
+    # the WHOLE config-3 output of the reference, every 8th sample kept (r05: the end-to-end test counts the samples beyond
+    # the 1e-5 contract instead of bounding the max; 101 k samples = 400 KB)
+    y3_full = resampling.sinc_wrapper(pos3, x3[:, 0], 0, 32)
+    y3_dense = y3_full[5::8].copy()
+    save("samples", c3_y_dense=y3_dense, c3_y_peak=np.array(np.max(np.abs(y3_full))), c1_shape=np.array(m1.shape), c1_sum=np.array(m1.sum()), c1_grid=grid(m1), c1_sr=np.array(sr1),
          c1_n=np.array(len(x1)), c3_shape=np.array(spec3.shape), c3_sum=np.array(spec3.sum()), c3_grid=grid(spec3),
          c3_sr=np.array(sr3), c3_n=np.array(len(x3)), c3_track_times=tr3.times, c3_track_freqs=tr3.freqs, c3_curve=curve3,
          c3_len_pos=np.array(len(pos3)), c3_pos_grid=grid(pos3, 1009), c3_sel=sel, c3_y_sel=y3_sel)

@@ -62,11 +62,10 @@ SIGNATURES = {
     "par_speed_to_pos_plan_fused": (c_int, [c_int, c_vp, c_vp, c_i64, c_i64, c_vp, c_sz, c_vp, c_sz, c_i64,
                                             ctypes.POINTER(c_i64), ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int),
                                             ctypes.POINTER(c_int), c_vp]),
+    "par_debug_sinc_kernel": (c_int, [c_int]),
     "par_fused_redo_tiles": (c_int, [c_int, c_vp, c_i64, c_i64, ctypes.POINTER(c_int), c_vp]),
     "par_varispeed_fused_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64,
                                         c_vp]),
-    "par_varispeed_fused_alone_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64,
-                                              c_vp]),
     "par_varispeed_fused_stereo_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_int,
                                                c_vp, c_vp, c_i64, c_vp]),
     "par_profile_enable": (c_int, [c_int, c_int]),

@@ -2316,6 +2316,7 @@ static int plan_impl(int device, const double* sampletimes, const double* speeds
     const unsigned nbs = (unsigned)ceil_div(nseg, kScanTile), nbm = (unsigned)ceil_div(m, kScanTile);
     double* scratch_f = pv.xs;                  // per-wave speed partials, later the float64 scan's block sums (xs itself is gone)
     hipLaunchKernelGGL(k_init_header, dim3(1), dim3(1), 0, s, pv.hdr, m, lazy ? 1 : 0);
+    if (aux) PAR_HIP_CHECK(hipMemsetAsync(fused_aux_view(aux, max_out, m).redo_count, 0, 64, s));   // K_sinc's tile list: empty until a launch fills it
     int rc;
     if (attempt == 0) {
       // lengths: the 64.64 fixed-point scan with k_seg_want / k_seg_lengths / k_speed_sum inside its passes (3 launches)

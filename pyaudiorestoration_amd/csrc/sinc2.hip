@@ -37,6 +37,10 @@
 #ifndef PAR_S2_WAVES
 #define PAR_S2_WAVES 2          // waves per SIMD the kernel is built for (registers <= 512 / this)
 #endif
+#ifndef PAR_S2_VARIANTS
+#define PAR_S2_VARIANTS 0       // 1 (experiment builds, tools/exp/s2_variant.sh): also compile the r04 variants 1-3 (k_sinc_stream, k_sinc_pipe<true, false>,
+                                // k_sinc_pipe<false, false>; PAR_SINC_STREAM=1..3).  The product library holds ONE streaming kernel: the moment form.
+#endif
 #ifndef PAR_S2_EXP
 #define PAR_S2_EXP 0            // timing builds, never shipped: 1 no MFMAs, 2 no near taps, 4 no stores, 8 no conversion, 16 unity maths on every pass
 #endif
@@ -52,6 +56,7 @@ constexpr int kPass = 128;                       // centres per pass = outputs t
 constexpr float kEpsTol = 1.5e-4f;               // |fc - fc0| a pass admits (second-order treatment: tools/sinc2_model.py)
 constexpr float kQuiet = 0.0001220703125f;       // 2^-13: a chunk whose loudest sample is below this (and not 0) leaves float16's range
 
+#if PAR_S2_VARIANTS
 struct S2Lds {
   float ring_head[4];                            // [2], [3] mirror ring[510], ring[511]
   float ring[kRing];
@@ -67,6 +72,7 @@ struct S2Lds {
 #endif
 };
 static_assert(offsetof(S2Lds, img) % 16 == 0 && offsetof(S2Lds, qa) % 16 == 0, "16-byte aligned fragments");
+#endif
 
 #if PAR_S2_EXP & 64
 __device__ unsigned long long* g_s2_phase;       // [waves][16] cycle sums per phase (timing builds only)
@@ -118,6 +124,7 @@ __device__ __forceinline__ unsigned pack_h2(float a, float b) {
 __device__ __forceinline__ float h_lo(unsigned w) { return (float)__builtin_bit_cast(half2v, w)[0]; }
 __device__ __forceinline__ float h_hi(unsigned w) { return (float)__builtin_bit_cast(half2v, w)[1]; }
 
+#if PAR_S2_VARIANTS
 // the bank of one image over the pass's 128 centres: element k = 32 ks + 8 g + j of block bb is image sample offs + 8 bb + k
 template <bool GEN>
 __device__ __forceinline__ void bank_image(S2Lds& L, const half8v (&fr)[kBank2Frags], const int offs, const int l, const int sel) {
@@ -163,6 +170,7 @@ __device__ __forceinline__ void bank_image(S2Lds& L, const half8v (&fr)[kBank2Fr
     }
   }
 }
+#endif
 
 // Direct-to-LDS loads as inline assembly: LDS address = M0 + 4 (or 16) x lane.  Through the compiler's builtin every later LDS
 // read that might alias the destination gets an s_waitcnt vmcnt(0) in front of it -- the very latency the stream is built to
@@ -227,6 +235,7 @@ __device__ __forceinline__ S2Row s2_place_row(const uint4 ra, const uint4 rb, co
   return o;
 }
 
+#if PAR_S2_VARIANTS     // r04 variant 1 (a pass as a chain of stages): experiment builds only, superseded by k_sinc_pipe
 __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Args a) {
   using T32 = TapTab<32>;
   __shared__ S2Lds L;
@@ -596,6 +605,7 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
     if (l < nok_p[r] && !(PAR_S2_EXP & 4)) outW[j_p + 64u * r + (unsigned)l] = res_p[r];
 }
 
+#endif  // PAR_S2_VARIANTS
 
 // ------------------------------------------------------------------------------------------------------------------------
 // K_sinc, pipelined streaming form (r04, second shape).  Same mathematics and the same worker (one wave, kTilesPerWave
@@ -1418,10 +1428,15 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
   a.n_full = len_out / kSincTileOutputs;
   a.n_tiles = ceil_div(len_out, kSincTileOutputs);
   const int64_t grid = ceil_div(a.n_full, (int64_t)PAR_S2_TILES);
+#if PAR_S2_VARIANTS
   if (grid > 0 && variant == 1) hipLaunchKernelGGL(k_sinc_stream, dim3((unsigned)grid), dim3(kWave), 0, s, a);
   else if (grid > 0 && variant == 2) hipLaunchKernelGGL((k_sinc_pipe<true, false>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
   else if (grid > 0 && variant == 3) hipLaunchKernelGGL((k_sinc_pipe<false, false>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
-  else if (grid > 0)
+  else
+#else
+  (void)variant;
+#endif
+  if (grid > 0)
     hipLaunchKernelGGL((k_sinc_pipe<false, true>), dim3((unsigned)ceil_div(grid, (int64_t)PAR_S3_MOM_WAVES)), dim3(kWave * PAR_S3_MOM_WAVES), 0, s, a);
   else if (a.n_tiles > 0) {
     // nothing but a partial tile: the caller's block kernel handles short files (launch_sinc_fused never comes here)

@@ -100,7 +100,7 @@ int par_varispeed_resample_f32(int device, const double* speeds, int64_t m, cons
 // in `aux`); K_sinc regenerates each tile's float64 positions in LDS, bit-identical to the materialised path.
 static int varispeed_fused_impl(const char* who, int device, const double* speeds, int64_t m, const void* work, const void* aux,
                                 int64_t max_out, int64_t len_out, const float* sig, const float* sig1, int64_t sig_stride,
-                                int64_t len_in, int NT, float* out, float* out1, int64_t out_stride, void* stream, int form = 0) {
+                                int64_t len_in, int NT, float* out, float* out1, int64_t out_stride, void* stream, int form = -1) {
   using namespace par;
   PAR_REQUIRE(speeds && work && aux && sig && out && m >= 2, PAR_ERR_ARG, "%s: null pointer", who);
   PAR_REQUIRE(len_out >= 2 && len_out <= max_out, PAR_ERR_ARG, "%s: len_out=%lld outside [2, max_out=%lld]", who,
@@ -138,16 +138,6 @@ int par_fused_redo_tiles(int device, const void* aux, int64_t max_out, int64_t m
   PAR_HIP_CHECK(hipMemcpyAsync(tiles, av.redo_count, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)));
   PAR_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
   return PAR_OK;
-}
-
-// The same call for a launch that has the GPU to itself (no plan of a next file queued beside it): mono NT = 32 files on unit
-// strides then go through the streaming kernel in its moment form (sinc2.hip) -- same results within the contract's tolerance,
-// every window centre the reference's -- everything else through the block kernel as in par_varispeed_fused_f32.
-int par_varispeed_fused_alone_f32(int device, const double* speeds, int64_t m, const void* work, const void* aux,
-                                  int64_t max_out, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in,
-                                  int NT, float* out, int64_t out_stride, void* stream) {
-  return varispeed_fused_impl("par_varispeed_fused_alone_f32", device, speeds, m, work, aux, max_out, len_out, sig, nullptr,
-                              sig_stride, len_in, NT, out, nullptr, out_stride, stream, 4);
 }
 
 // experiment builds of the streaming kernel (-DPAR_S2_EXP=128) count passes by kind in the 16 words behind the redo count

@@ -136,23 +136,22 @@ def speed_to_pos_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force
     return pos
 
 
-def varispeed_fused_dev(plan, sig_t, NT, out_t=None, sig_stride=1, len_in=None, out_stride=1, alone=False):
-    """Sinc interpolation of one channel straight from a fused SpeedPlan: K_sinc regenerates each tile's
-    float64 positions in LDS (no position array in HBM).  Same output as the two-step path.
-    alone: nothing else is queued on the GPU beside this launch (no plan of a next file): par_varispeed_fused_alone_f32, which
-    sends mono NT = 32 unit-stride files through the streaming kernel (same results within the contract's tolerance)."""
+def varispeed_fused_dev(plan, sig_t, NT, out_t=None, sig_stride=1, len_in=None, out_stride=1):
+    """Sinc interpolation of one channel straight from a fused SpeedPlan: K_sinc places every output itself from the plan's
+    block records (no position array in HBM).  Same output as the two-step path within the contract's tolerance, every window
+    centre the reference's.  Mono NT = 32 on unit strides takes the streaming kernel, everything else the block kernel
+    (include/par_hip.h)."""
     if not plan.fused_ok:
-        raise ValueError("plan has no valid checkpoints: build it with speed_plan_dev(..., fused=True)")
+        raise ValueError("plan cannot feed the fused resampler: build it with speed_plan_dev(..., fused=True)")
     dev = plan.dev
     L = _lib.lib()
     if len_in is None:
         len_in = sig_t.numel() // sig_stride
     if out_t is None:
         out_t = _dev.empty(plan.len_out * out_stride, torch.float32, dev)
-    fn = L.par_varispeed_fused_alone_f32 if alone else L.par_varispeed_fused_f32
-    _lib.check(fn(dev, _dev.ptr(plan.speeds_t), plan.m, _dev.ptr(plan.work), _dev.ptr(plan.aux),
-                  plan.max_out, plan.len_out, _dev.ptr(sig_t), sig_stride, len_in, int(NT),
-                  _dev.ptr(out_t), out_stride, _dev.stream_ptr(dev)))
+    _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(plan.speeds_t), plan.m, _dev.ptr(plan.work), _dev.ptr(plan.aux),
+                                         plan.max_out, plan.len_out, _dev.ptr(sig_t), sig_stride, len_in, int(NT),
+                                         _dev.ptr(out_t), out_stride, _dev.stream_ptr(dev)))
     return out_t
 
 
@@ -171,8 +170,8 @@ def varispeed_fused_stereo_dev(plan, sig0_t, sig1_t, NT, out0_t, out1_t, sig_str
     return out0_t, out1_t
 
 
-def _resample_item(plan, item, NT, dev, alone=False):
-    """K_sinc launch(es) of one planned work item on the current stream (alone: no plan of a next item runs beside them): (.., sig_t[, sig_stride, len_in]) with a 1-D
+def _resample_item(plan, item, NT, dev):
+    """K_sinc launch(es) of one planned work item on the current stream: (.., sig_t[, sig_stride, len_in]) with a 1-D
     sig_t, or an interleaved (n, ch) sig_t whose channel pairs share one stereo launch (an odd last channel goes
     alone).  A plan without valid checkpoints takes the position-array path."""
     sig_t = item[2]
@@ -200,7 +199,7 @@ def _resample_item(plan, item, NT, dev, alone=False):
     stride = item[3] if len(item) > 3 else 1
     len_in = item[4] if len(item) > 4 else sig_t.numel() // stride
     if plan.fused_ok:
-        return varispeed_fused_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in, alone=alone)
+        return varispeed_fused_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)
     return varispeed_resample_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)[0]
 
 

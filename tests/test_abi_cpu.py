@@ -288,3 +288,40 @@ def test_lag_curve_from_tapesync_markers():
         assert abs(cubic[i, 1] - 0.01 * cubic[i, 0] ** 2) < 1e-9       # a cubic reproduces the parabola exactly
     one = pipeline.lag_curve_from_markers([(3.0, 0, 3.0, 0, 0.25, 1.0)], 10.0, 48000, 256)
     assert np.all(one[:, 1] == 0.25)
+
+
+def test_pmc_summary_picks_the_timed_kernel():
+    """tools/summarise_profiles.pick_counters: the counters quoted on the bench line are those of the kernel(s) the line says a
+    timed launch consists of -- not of whichever K_sinc kernel sorts last (the opt-in moment kernel's rows had
+    overwritten the timed block kernel's)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("summarise_profiles", os.path.join(root, "tools", "summarise_profiles.py"))
+    S = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(S)
+    rows = {("void par::k_sinc_fused<1, 32, 4>(long, float const*, float const*)", "FETCH_SIZE"): 1993364.0,
+            ("void par::k_sinc_fused<1, 32, 4>(long, float const*, float const*)", "SQ_INSTS_VALU"): 3.281e9,
+            ("void par::k_sinc_fused<2, 32, 4>(long, float const*, float const*)", "FETCH_SIZE"): 5.0e5,
+            ("void par::k_sinc_pipe<false, true>(par::S2Args)", "FETCH_SIZE"): 1855254.0,
+            ("void par::k_sinc_pipe<false, true>(par::S2Args)", "SQ_INSTS_VALU"): 1.944e9,
+            ("par::k_sinc_fused_list(long, float const*, long)", "FETCH_SIZE"): 1000.0,
+            ("par::k_sinc_fused_list(long, float const*, long)", "SQ_INSTS_VALU"): 1.0e6}
+    v, missing = S.pick_counters(rows, ["k_sinc_fused<1, 32, 4>"])
+    assert not missing and v == {"FETCH_SIZE": 1993364.0, "SQ_INSTS_VALU": 3.281e9}
+    v, missing = S.pick_counters(rows, ["k_sinc_pipe<false, true>", "k_sinc_fused_list"])
+    assert not missing and v["FETCH_SIZE"] == 1856254.0 and abs(v["SQ_INSTS_VALU"] - 1.945e9) < 1.0
+    v, missing = S.pick_counters(rows, ["k_sinc_stream"])
+    assert missing == ["k_sinc_stream"] and v == {}
+
+
+def test_usable_cores_never_exceed_the_affinity_mask():
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    usable, reported = bench.usable_cores()
+    assert 1 <= usable <= reported
+    if hasattr(os, "sched_getaffinity"):
+        assert usable <= len(os.sched_getaffinity(0))
