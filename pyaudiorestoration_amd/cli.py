@@ -46,24 +46,30 @@ def _worker(dev, jobs, args, results):
             try:
                 if args.cmd in ("tapesync", "heal") or (args.cmd == "respeed" and args.project):
                     flow = {"tapesync": pipeline.tapesync, "heal": pipeline.heal_project, "respeed": pipeline.respeed_project}[args.cmd]
-                    flow(args.project, source=path, out_suffix=args.suffix, device=dev)
+                    if args.cmd == "respeed":       # --suffix / --quality / --resampling override the project's own only when given
+                        flow(args.project, source=path, out_suffix=args.suffix, device=dev, sinc_quality=args.quality,
+                             resampling_mode=getattr(args, "resampling", None))
+                    else:
+                        flow(args.project, source=path, out_suffix=args.suffix, device=dev)
                     results.append((path, None))
                     continue
                 signal, sr, ch = pending.result()
+                quality = 50 if args.quality is None else args.quality          # the GUI's default (util/widgets.py:998-1000)
+                suffix = args.suffix or ""
                 if args.cmd == "respeed":
                     t0, f0, t1, f1 = args.trail
                     r = pipeline.respeed(signal, sr, [(t0, f0), (t1, f1)], args.fft_size, args.hop, 1, args.mode,
-                                         args.tolerance, (0, args.lowpass), args.quality, device=dev)
+                                         args.tolerance, (0, args.lowpass), quality, device=dev)
                     out = r["output"].cpu().numpy()
-                    io_ops.write_wav_float(f"{os.path.splitext(path)[0]}_res{args.suffix}.wav", out, sr)
-                    np.save(f"{os.path.splitext(path)[0]}_speed{args.suffix}.npy", r["speed_curve"])
+                    io_ops.write_wav_float(f"{os.path.splitext(path)[0]}_res{suffix}.wav", out, sr)
+                    np.save(f"{os.path.splitext(path)[0]}_speed{suffix}.npy", r["speed_curve"])
                 else:
                     if args.speed is not None:          # constant correction: a two-point curve over the whole file
                         curve = np.array([[0.0, args.speed], [len(signal) / sr, args.speed]], dtype=np.float64)
                     else:
                         curve = np.asarray(json.load(open(args.curve)), dtype=np.float64)
                     resampling.run((path,), signal_data=((signal, sr),), speed_curve=curve, resampling_mode=args.resampling,
-                                   sinc_quality=args.quality, suffix=args.suffix)
+                                   sinc_quality=quality, suffix=suffix)
                 results.append((path, None))
             except Exception as e:                      # keep the other files going; report at the end
                 logging.exception(f"{path} failed")
@@ -92,8 +98,8 @@ def main(argv=None):
     d = sub.add_parser("heal", help="inpaint the marked dropouts of a saved dropout-healer project (.drop)")
     d.add_argument("--project", required=True, help=".drop JSON written by the GUI")
     for p in (a, b, c, d):
-        p.add_argument("--quality", type=int, default=50, help="sinc_quality (NT); GUI default 50")
-        p.add_argument("--suffix", default="")
+        p.add_argument("--quality", type=int, default=None, help="sinc_quality (NT); default: the project's, else the GUI's 50")
+        p.add_argument("--suffix", default=None, help="output suffix; default: the project's, else none")
         p.add_argument("--gpus", type=int, default=0, help="GPUs to use (0 = all visible)")
         p.add_argument("files", nargs="+")
     args = ap.parse_args(argv)

@@ -368,7 +368,13 @@ __global__ __launch_bounds__(64) PLAN_VGPR_CAP void k_seg_sum(const double* __re
       if (long_segment(n, start, i, ck, ck_len)) {      // the k_long_* kernels own this segment (S[i] included)
         is_long = true;
         n = 0;
-        if (count_long) atomicAdd(&h->n_long, 1);
+        if (count_long) {
+          atomicAdd(&h->n_long, 1);
+          S[i] = 0.0;
+          // first go of a sparse curve (mode 1): the plan is made again with the chunked cumsum, so the rest of THIS pass is void --
+          // the kernels behind see the mark and leave at once instead of scanning undefined sums
+          if (count_long == 1) atomicOr(&h->lazy_fail, 4);
+        }
       }
     } else {
       n = 0;
@@ -1088,7 +1094,7 @@ __global__ void k_tile_seg_publish(const double* __restrict__ sp, const int64_t*
                                    long long* __restrict__ tile_st, TileHdr* __restrict__ hdr, PlanHeader* __restrict__ h,
                                    int64_t n_items, int lazy) {
   __shared__ int is_last;
-  if (lazy && h->lazy_fail) return;                     // the plan is being made again the eager way
+  if (h->lazy_fail) return;                             // the plan is being made again (eager, or with the chunked cumsum)
   for (int64_t x0 = (int64_t)blockIdx.x * blockDim.x; x0 < n_items; x0 += (int64_t)gridDim.x * blockDim.x)
     tile_seg_body(sp, seg_start, seg_off, nseg, ck, ck_len, max_tiles, tile_seg, seg_fast, tile_st, hdr, h, x0 + threadIdx.x,
                   lazy != 0);
@@ -1517,7 +1523,7 @@ __global__ void k_off_stitch(const double* __restrict__ S, const PElem* __restri
                              int64_t nseg, long long* __restrict__ direct, RunEntry* __restrict__ runs,
                              PlanHeader* __restrict__ h) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (h->lazy && h->lazy_fail) return;         // (a failed lazy pass may have listed thousands of direct steps)
+  if (h->lazy_fail) return;         // (a failed lazy pass may have listed thousands of direct steps)
   int nd = h->n_direct;
   if (nd > kMaxDirect) nd = kMaxDirect;
   for (int a = 1; a < nd; ++a) {               // insertion sort (nd is tiny)
@@ -1819,7 +1825,7 @@ __global__ __launch_bounds__(64) void k_seg_exact_list(const double* __restrict_
 __global__ void k_off_apply(const double* __restrict__ sp, const PElem* __restrict__ E, const RunEntry* __restrict__ runs,
                             int64_t nseg, double n_in, double* __restrict__ seg_off, PlanHeader* __restrict__ h) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nseg || (h->lazy && h->lazy_fail)) return;
+  if (i >= nseg || h->lazy_fail) return;
   const int nr = h->n_runs;
   int lo = 0, hi = nr - 1;                     // last run with start <= i
   while (lo < hi) {
@@ -1925,7 +1931,7 @@ __global__ __launch_bounds__(256) void k_off_apply_trim(const double* __restrict
                                                         double* __restrict__ seg_off, const double* __restrict__ ck,
                                                         int64_t ck_len, PlanHeader* __restrict__ h) {
   __shared__ int is_last;
-  if (h->lazy && h->lazy_fail) return;           // not a curve for a lazy plan: it is being made again the eager way (and the
+  if (h->lazy_fail) return;           // not a curve for a lazy plan: it is being made again the eager way (and the
                                                  // trim's walk over a segment without checkpoints could take seconds)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nseg; i += (int64_t)gridDim.x * blockDim.x) {
     const int nr = h->n_runs;
@@ -2235,7 +2241,7 @@ static int launch_seg_sums(const double* speeds, const par::PlanView& pv, int64_
   const unsigned g256 = (unsigned)ceil_div(nseg, 256);
   if (ck && mode == 0) hipLaunchKernelGGL(k_count_long, dim3(g256), dim3(256), 0, s, pv.seg_start, nseg, (const double*)ck, ck_len, pv.hdr);
   hipLaunchKernelGGL(k_seg_sum, dim3((unsigned)ceil_div(nseg, 64)), dim3(64), 0, s, speeds, pv.seg_start, nseg, pv.S, ck,
-                     ck_len, pv.hdr, mode != 0 ? 1 : 0);
+                     ck_len, pv.hdr, mode);
   if (!ck || mode == 1) return PAR_OK;
   if (mode == 2) goto long_kernels;
   // Curves without a long segment (every dense curve) skip the nine chunked-cumsum launches: one 4-byte read-back,

@@ -25,8 +25,9 @@ struct PlanHeader {
   unsigned long long first_bad;  // first segment with n_i < 2 (~0: none).  Harmless when the trim fires before it: the
                                  // reference stops there and never builds that segment (k_trim decides)
   int32_t lazy;           // 1: this plan was made WITHOUT the per-sample cumsum (closed-form segment sums, see "lazy plans")
-  int32_t lazy_fail;      // != 0: some segment is outside what the closed form vouches for (or too many candidates): the
-                          //       caller makes the plan again the eager way
+  int32_t lazy_fail;      // != 0: this pass is void and the kernels behind the mark leave at once -- 1 / 2: some segment is outside
+                          //       what the closed form vouches for / too many candidates (the caller makes the plan again the
+                          //       eager way); 4: the first go of a sparse curve met a long segment (again, with the chunked cumsum)
   int32_t n_cand;         // segments whose sum was recomputed exactly (kMaxCand + 1: list overflow)
   int32_t pad4;
 };

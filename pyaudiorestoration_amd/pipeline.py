@@ -51,6 +51,8 @@ def master_reg_curve(regs, duration, sr, hop):
     RegLine.to_cfg writes them (util/markers.py:175-176).  Returns [[t_seconds, linear_speed], ...]."""
     marker_sr = sr / hop
     times = np.linspace(0, duration, num=int(duration * marker_sr))
+    if len(times) == 0:                              # a file shorter than one hop: the reference indexes times[0] (IndexError)
+        raise ValueError(f"file too short for a speed curve: duration {duration} s at {marker_sr} markers/s")
     rows = []
     for t0, t1, amplitude, omega, phase, offset in regs:
         if amplitude < 0:                            # RegLine.__init__ (:117-119): a negative amplitude is a phase of pi
@@ -94,19 +96,29 @@ def project_speed_curve(cfg, duration, sr):
     return master_speed_curve(lines, duration, sr, hop, (cfg.get("highpass", 0), cfg.get("lowpass", 20)))
 
 
-def respeed_project(project, source=None, out_suffix=None, device=None):
+def respeed_project(project, source=None, out_suffix=None, device=None, sinc_quality=None, resampling_mode=None):
     """Run a saved pyrespeeder project headless: `project` is the path of a .spd JSON (fft_size, fft_overlap,
     highpass, lowpass, lines, regs, source, resampling_mode, sinc_quality, suffix) or the dict itself; `source` overrides
-    the audio path stored in it.  Writes <source>_res<suffix>.wav through resampling.run like Canvas.run_resample
-    (pyrespeeder_gui.py:119-131) and returns the speed curve."""
+    the audio path stored in it; out_suffix / sinc_quality / resampling_mode override the project's own settings (None: the
+    project's).  Writes <source>_res<suffix>.wav through resampling.run like Canvas.run_resample (pyrespeeder_gui.py:119-131)
+    and returns the speed curve."""
     import json
     from . import io_ops
-    cfg = json.load(open(project)) if isinstance(project, (str, bytes)) or hasattr(project, "__fspath__") else dict(project)
+    if isinstance(project, (str, bytes)) or hasattr(project, "__fspath__"):
+        with open(project) as fh:
+            cfg = json.load(fh)
+    else:
+        cfg = dict(project)
     path = source or cfg["source"]
     signal, sr, _ = io_ops.read_file(path)
     curve = project_speed_curve(cfg, len(signal) / sr, sr)
-    resampling.run((path,), signal_data=((signal, sr),), speed_curve=curve, resampling_mode=cfg.get("resampling_mode", "Sinc"),
-                   sinc_quality=cfg.get("sinc_quality", 50), suffix=cfg.get("suffix", "") if out_suffix is None else out_suffix)
+    # resampling.run works on the CURRENT device: make `device` that one for the duration of the call (ADVICE r04: the argument
+    # was accepted and ignored, which only worked because the CLI's worker thread had called set_device itself)
+    with torch.cuda.device(_dev.device_index(device)):
+        resampling.run((path,), signal_data=((signal, sr),), speed_curve=curve,
+                       resampling_mode=resampling_mode or cfg.get("resampling_mode", "Sinc"),
+                       sinc_quality=sinc_quality or cfg.get("sinc_quality", 50),
+                       suffix=cfg.get("suffix", "") if out_suffix is None else out_suffix)
     return curve
 
 
