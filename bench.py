@@ -546,13 +546,12 @@ def main():
     out = torch.empty(cap, dtype=torch.float32, device=f"cuda:{dev}")
     fused = not a.no_fused
     overlap = fused and not a.no_overlap
-    # Pipelined steps: the plan of file k + depth is made on a side stream while K_sinc of files k .. k + depth - 1 run / wait on the
-    # main stream (depth + 1 plan buffers).  Depth 1 (until r04): K_sinc of file k + 1 can only be launched once its plan's header
-    # has been read back, i.e. behind whatever part of that plan did not fit beside K_sinc of file k.
-    # (measured r05: depths 1..4 give the same step -- beside the streaming kernel the plan only runs in the gap between two
-    # launches however early it is queued -- so the default stays the double-buffered depth 1 of the product's batch driver)
-    depth = max(1, int(os.environ.get("PAR_BENCH_DEPTH", "1"))) if overlap else 0
-    n_slots = depth + 1 if overlap else 1
+    # Pipelined steps: K_sinc launches follow one another on the main stream; the plans of the next `depth` files are made by as
+    # many planner threads, each on its own side stream (resampling.varispeed_batch_dev is the same driver for callers' items).
+    # The streaming kernel leaves a plan no room beside it: plans advance in the gap behind a K_sinc -- `depth` of them together,
+    # being latency-bound -- so there is one such gap per `depth` files.  Depth 1 = the double-buffered pipeline of r02-r04.
+    depth = max(1, int(os.environ.get("PAR_BENCH_DEPTH", "4"))) if overlap else 0
+    n_slots = 2 * depth if overlap else 1
     work = [torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{dev}") for _ in range(n_slots)]
     if fused:       # cumsum checkpoints + tile map: positions are regenerated inside K_sinc, never stored
         aux_bytes = int(L.par_fused_aux_bytes(cap, m))
@@ -588,18 +587,29 @@ def main():
         # Software pipeline over the files of a batch (one file per step): K_sinc of file k on the main stream,
         # the whole plan of file k+1 (25 small latency-bound kernels + one header read-back) on a side stream
         # underneath it.  Every step still executes one full plan and one full K_sinc; nothing is cached.
-        if os.environ.get("PAR_SIDE_CUS") or os.environ.get("PAR_SIDE_LOW"):      # experiment: a confined / low-priority plan stream
-            hs = ctypes.c_void_p()
-            _lib.check(L.par_stream_create(dev, int(os.environ.get("PAR_SIDE_LOW", "0")), int(os.environ.get("PAR_SIDE_CUS", "0")), ctypes.byref(hs)))
-            side = torch.cuda.ExternalStream(hs.value, device=dev)
-        else:
-            side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PAR_SIDE_PRIO", "0")))
-        side_ptr = ctypes.c_void_p(side.cuda_stream)
+        import collections
+        from concurrent.futures import ThreadPoolExecutor
+        sides = [torch.cuda.Stream(device=dev, priority=int(os.environ.get("PAR_SIDE_PRIO", "0"))) for _ in range(depth)]
         slot_free = [None] * n_slots                    # main-stream event: K_sinc that read this slot is done
-        lens = [0] * n_slots
-        for q in range(depth):                          # pipeline prologue: plans of the first `depth` files
-            lens[q] = plan_fused(q, sp_)
-        state = {"k": 0, "len": lens[0]}
+        pool = ThreadPoolExecutor(max_workers=depth)
+
+        def plan_job(j):                                # the whole plan of file j (ctypes releases the GIL: planners run together)
+            slot, stream = j % n_slots, sides[j % depth]
+            if slot_free[slot] is not None:
+                stream.wait_event(slot_free[slot])      # the K_sinc that last read this slot must be finished
+            lo, tr, okv = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int(0)
+            _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(st), _dev.ptr(spd), m, n_in, _dev.ptr(work[slot]), nbytes,
+                                                     _dev.ptr(aux[slot]), aux_bytes, cap, ctypes.byref(lo), ctypes.byref(tr),
+                                                     plan_force, None, ctypes.byref(okv), ctypes.c_void_p(stream.cuda_stream)))
+            assert okv.value in (1, 2) and 2 <= lo.value <= cap
+            state_plan["lazy"] = okv.value == 2
+            return lo.value                             # (the call returned after its stream drained: header read-back)
+
+        futs = collections.deque(pool.submit(plan_job, j) for j in range(depth))    # pipeline prologue: the first `depth` plans
+        for f in futs:
+            f.result()
+        state = {"k": 0, "len": futs[0].result()}
+        len_out.value = state["len"]
         ev_pairs = []
         # reference point outside the timed region: K_sinc with the GPU to itself (no plan underneath), launched back to
         # back like the timed steps -- 30 launches, the last 20 timed.  (A single launch on an idle GPU, which is what this
@@ -622,23 +632,23 @@ def main():
 
         def step(timed):
             k = state["k"]
-            cur, nxt = k % n_slots, (k + depth) % n_slots
+            cur = k % n_slots
+            n_out = futs.popleft().result()             # the plan of file k
             e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
             if timed:
                 _lib.check(L.par_event_create(ctypes.byref(e0)))
                 _lib.check(L.par_event_create(ctypes.byref(e1)))
                 _lib.check(L.par_event_record(e0, sp_))
             _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(spd), m, _dev.ptr(work[cur]), _dev.ptr(aux[cur]), cap,
-                                                 lens[cur], _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, sp_))
+                                                 n_out, _dev.ptr(sig), 1, n_in, a.nt, _dev.ptr(out), 1, sp_))
             if timed:
                 _lib.check(L.par_event_record(e1, sp_))
                 ev_pairs.append((e0, e1))
-            slot_free[cur] = torch.cuda.Event()
-            slot_free[cur].record(torch.cuda.current_stream(dev))
-            if slot_free[nxt] is not None:
-                side.wait_event(slot_free[nxt])          # the K_sinc that last read slot `nxt` must be finished
-            lens[nxt] = plan_fused(nxt, side_ptr)       # returns after the side stream drained (header read-back)
-            state["len"] = lens[nxt]
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            slot_free[cur] = ev
+            futs.append(pool.submit(plan_job, k + depth))    # one plan per step: that of the file `depth` places on
+            len_out.value = n_out
             state["k"] = k + 1
     else:
         _lib.check(L.par_profile_enable(dev, 1))         # HIP events around every K_sinc launch, on its own stream
@@ -670,6 +680,10 @@ def main():
         step_marks.append(time.perf_counter())
     t_begin = time.perf_counter()
     dt = ctx.timed(timed_step, a.steps)                # barrier+sync | K steps | sync+barrier, MAX over ranks
+    if overlap:                                        # (their GPU work ended inside the timed region's closing synchronise)
+        for f in futs:
+            f.result()
+        pool.shutdown(wait=True)
     total_per_step = ctx.reduce_sum(len_out.value)     # whole-job output samples per step
     if overlap:                                        # K_sinc durations of the timed steps (events on its own stream)
         for e0, e1 in ev_pairs:
@@ -689,7 +703,9 @@ def main():
             per_step_mid = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
         else:
             per_step_mid = ms_step_mean
-        ms_step = per_step_mid
+        # pipelined steps end when the host has QUEUED them, and plans become ready in bursts of `depth`: the marks are not
+        # per-step GPU times any more and the region's mean is the step time; the serial modes keep the median of the marks
+        ms_step = ms_step_mean if overlap else per_step_mid
         value = total_per_step * a.steps / dt / 1e6
         n_launch = sum(sinc_launches)
         k_ms = sum(sinc_ms) / n_launch                      # average K_sinc launch duration (HIP events)
@@ -713,8 +729,8 @@ def main():
             "metric": "Msamples/sec resampled (192 kHz varispeed)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
             "ms_per_step_mean": round(ms_step_mean, 4),
-            "ms_per_step_note": "ms_per_step = median of the per-step times (SURVEY 8d); ms_per_step_mean = timed region / steps, "
-                                "the figure `value` is computed from",
+            "ms_per_step_note": "ms_per_step = timed region / steps, the figure `value` is computed from (pipelined steps are queued "
+                                "ahead of the GPU, so host marks per step say nothing; --no-overlap reports the median of its per-step times)",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 near taps, far taps (|n| >= 3) as float16 hi + lo x 2^-12 filter banks on v_mfma_f32_16x16x32_f16 with f32 "
                       "accumulation / f64 positions" if streaming else
@@ -725,7 +741,8 @@ def main():
                        "samples_in_per_gpu": n_in, "samples_out_per_gpu": int(len_out.value), "NT": a.nt,
                        "plan": ("lazy (closed-form segment sums, exact ones for the offset chain's candidates: csrc/pos_plan.h)" if state_plan["lazy"] else "eager (per-sample cumsum + checkpoints)") if fused else "position array",
                        "step": ("plan (device scans, block records) + fused K_sinc (outputs placed from 16-byte block records, no position array)" if fused else "plan (device scans) + K_pos fill (float64 position array) + K_sinc") + "; inputs resident in HBM"
-                               + (f"; batch pipelining: the plan of file k+{depth} runs on a side stream while K_sinc of the files before it run (every step = one full plan + one full K_sinc)" if overlap else "")},
+                               + (f"; batch pipelining: K_sinc launches back to back, the plans of the next {depth} files by {depth} planner threads on side streams (every step = one full plan + one full K_sinc)" if overlap else ""),
+                       "planners": depth},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "source": traffic_src,
                          "kernel": "k_sinc", "kernel_symbols": kernel_symbols, "limited_by": "valu",

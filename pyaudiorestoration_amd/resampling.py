@@ -203,71 +203,84 @@ def _resample_item(plan, item, NT, dev):
     return varispeed_resample_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)[0]
 
 
-def varispeed_batch_dev(items, NT, dev=None):
+def varispeed_batch_dev(items, NT, dev=None, planners=None):
     """Software-pipelined fused resampling of a batch of device-resident work items on one GPU (the per-GPU
-    inner loop of a file batch): while K_sinc of item k runs on the current stream, the whole plan
-    of item k+1 -- ~25 small latency-bound kernels and a header read-back -- runs on a side stream underneath
-    it.  Plan buffers are double-buffered; an event keeps a slot from being re-planned before the K_sinc that
-    reads it has finished.
+    inner loop of a file batch).  K_sinc launches follow one another on the current stream; the plans
+    of the next `planners` items -- each ~20 small latency-bound kernels and a header read-back, 0.6 ms on an idle
+    GPU -- are made by as many planner threads, each on its own side stream.  Beside the block kernel a plan runs
+    under the K_sinc in front of it; the streaming kernel (mono NT = 32) leaves it no room, so plans only advance
+    in the gap behind a K_sinc -- where `planners` of them then advance TOGETHER (they are latency-, not
+    throughput-bound): one gap per `planners` files instead of one per file (r05: 4.92 -> 4.6 ms per 60-min file).
+    Plan buffers form a ring of 2 x planners slots; an event keeps a slot from being re-planned before the K_sinc
+    that reads it has finished.  planners=1 is the double-buffered pipeline of r02-r04.
 
     items: iterable of (sampletimes_t, speeds_t, sig_t) or (sampletimes_t, speeds_t, sig_t, sig_stride, len_in)
     with float64 / float32 device tensors; a 2-D sig_t is an interleaved (n, ch) file whose channels share the plan
-    (channel pairs go through the stereo launch) and yields an (len_out, ch) output.  Yields (index, out_t, plan) in order; out_t is ready on the current
-    stream (synchronise or keep using that stream).  An item whose plan has no valid checkpoints is resampled
-    through the position-array path."""
+    (channel pairs go through the stereo launch) and yields an (len_out, ch) output.  Up to `planners` items are
+    taken from the iterable ahead of the one being resampled (their tensors stay resident meanwhile).  Yields
+    (index, out_t, plan) in order; out_t is ready on the current stream (synchronise or keep using that stream).
+    An item whose plan cannot feed the fused resampler is resampled through the position-array path."""
+    import collections
+    from concurrent.futures import ThreadPoolExecutor
     dev = _dev.device_index(dev)
+    P = max(1, int(planners if planners is not None else os.environ.get("PAR_PLANNERS", "4")))
+    n_slots = 2 * P
     main = torch.cuda.current_stream(dev)
-    side = torch.cuda.Stream(device=dev)
-    work, aux, free = [None, None], [None, None], [None, None]
+    sides = [torch.cuda.Stream(device=dev) for _ in range(P)]
+    work, aux, free = [None] * n_slots, [None] * n_slots, [None] * n_slots
 
-    def plan_item(item, slot, stream, ready=None):
+    def plan_item(item, j, ready):
+        slot, stream = j % n_slots, sides[j % P]
         st_t, sp_t, sig_t = item[0], item[1], item[2]
         if sig_t.ndim == 2:
             len_in = sig_t.shape[0]
         else:
             len_in = item[4] if len(item) > 4 else sig_t.numel() // (item[3] if len(item) > 3 else 1)
-        if stream is None:
-            plan = speed_plan_dev(st_t, sp_t, len_in, dev, fused=True, work=work[slot], aux=aux[slot])
-        else:
-            stream.wait_event(ready)                       # the item's tensors were produced on the main stream
-            if free[slot] is not None:
-                stream.wait_event(free[slot])              # the K_sinc that last read this slot is done
-            # sizing reductions, (re)allocation and the plan itself all live on the side stream: a .item() there
-            # does not wait for the K_sinc running on the main stream
-            with torch.cuda.stream(stream):
-                plan = speed_plan_dev(st_t, sp_t, len_in, dev, fused=True, work=work[slot], aux=aux[slot], stream=stream)
-            # allocated (or regrown) under the side stream, read by the K_sinc on the main stream: without this a
-            # block freed at generator teardown returns to the side stream's pool while that kernel still runs
-            plan.work.record_stream(main)
-            plan.aux.record_stream(main)
+        stream.wait_event(ready)                       # the item's tensors were produced on the main stream
+        if free[slot] is not None:
+            stream.wait_event(free[slot])              # the K_sinc that last read this slot is done
+        # sizing reductions, (re)allocation and the plan itself all live on the side stream: a .item() there
+        # does not wait for the K_sinc running on the main stream
+        with torch.cuda.stream(stream):
+            plan = speed_plan_dev(st_t, sp_t, len_in, dev, fused=True, work=work[slot], aux=aux[slot], stream=stream)
+        # allocated (or regrown) under the side stream, read by the K_sinc on the main stream: without this a
+        # block freed at generator teardown returns to the side stream's pool while that kernel still runs
+        plan.work.record_stream(main)
+        plan.aux.record_stream(main)
         work[slot], aux[slot] = plan.work, plan.aux        # keep (possibly grown) buffers for reuse
         return plan
 
     it = iter(items)
+    ahead = collections.deque()                          # (index, item, future of its plan), oldest first
+    pool = ThreadPoolExecutor(max_workers=P)
     try:
-        cur_item = next(it)
-    except StopIteration:
-        return
-    plan = plan_item(cur_item, 0, None)
-    k = 0
-    while True:
-        slot = k % 2
-        # fetch the next item BEFORE launching this K_sinc: whatever its producer enqueues on the main stream
-        # (uploads, generators) then precedes the long kernel instead of queueing behind it
-        try:
-            nxt_item = next(it)
-        except StopIteration:
-            nxt_item = None
-        ready = torch.cuda.Event()
-        ready.record(main)
-        out_t = _resample_item(plan, cur_item, NT, dev)
-        free[slot] = torch.cuda.Event()
-        free[slot].record(main)
-        nxt_plan = plan_item(nxt_item, (k + 1) % 2, side, ready) if nxt_item is not None else None
-        yield k, out_t, plan
-        if nxt_item is None:
-            return
-        cur_item, plan, k = nxt_item, nxt_plan, k + 1
+        j, k, done = 0, 0, False
+        while True:
+            # take items BEFORE launching the next K_sinc: whatever their producer enqueues on the main stream (uploads,
+            # generators) then precedes the long kernel instead of queueing behind it
+            while not done and len(ahead) < P:
+                try:
+                    item = next(it)
+                except StopIteration:
+                    done = True
+                    break
+                ready = torch.cuda.Event()
+                ready.record(main)
+                ahead.append((j, item, pool.submit(plan_item, item, j, ready)))
+                j += 1
+            if not ahead:
+                return
+            k, item, fut = ahead.popleft()
+            plan = fut.result()
+            out_t = _resample_item(plan, item, NT, dev)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            free[k % n_slots] = ev
+            yield k, out_t, plan
+    finally:
+        for _, _, fut in ahead:
+            fut.cancel()
+        pool.shutdown(wait=True)
 
 
 # pinned staging / output slots of varispeed_batch_host, kept between calls (page-locking 0.5 GB costs ~0.1 s)
