@@ -1323,6 +1323,9 @@ __global__ __launch_bounds__(256) void k_block_rec(const double* __restrict__ sp
 // (A thread per segment looping over its ~8 blocks: 486 us for the 60-min curve -- 128-byte strides between the lanes of a
 // store; a thread per block with the tile tables' lookup as in k_block_rec + k_block_rec2: 230 + 130 us.)
 constexpr int kRecLazySegs = 64;
+#ifndef PAR_REC_EXP
+#define PAR_REC_EXP 0            // timing builds of k_block_rec_lazy, never shipped: 1 no record stores, 2 no tile-header loads
+#endif
 // (records need ~1e-10, not numpy's bits: this kernel's arithmetic may contract into FMAs, unlike the rest of the file)
 __device__ __forceinline__ double recip_nr_c(double b) {
 #pragma clang fp contract(fast)
@@ -1353,6 +1356,10 @@ __global__ __launch_bounds__(256) void k_block_rec_lazy(const double* __restrict
   __shared__ SegFast s_sf[4][kRecLazySegs + 1];
   __shared__ double s_sp[4][kRecLazySegs + 2];
   __shared__ int s_a[4][kRecLazySegs + 1];                       // segment starts relative to the wave's first one
+  __shared__ unsigned char s_fl[4][kRecLazySegs];                // what a segment's END contributes to the block it ends in (bits below)
+  __shared__ unsigned char s_seg[4][kRecLazySegs * (kLazyMaxN / kRec)];   // block (relative to the wave's first) -> staged segment
+  static_assert(kLazyMaxN % kRec == 0 && kRecLazySegs <= 256, "a segment owns <= kLazyMaxN / kRec block starts; indices fit a byte");
+  constexpr unsigned kF_Slow1 = 1u, kF_End1 = 2u, kF_Cubic1 = 4u;
   if (h->ck_valid != 2) return;
   const int l = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
   const long long i0 = ((long long)blockIdx.x * 4 + w) * kRecLazySegs;
@@ -1361,12 +1368,18 @@ __global__ __launch_bounds__(256) void k_block_rec_lazy(const double* __restrict
   const long long a0 = seg_start[i0];
   if (a0 >= len_out) return;
   const int nsw = (int)(nseg - i0 < kRecLazySegs ? nseg - i0 : kRecLazySegs);      // segments of this wave
+  const long long G0 = (a0 + kRec - 1) >> kRecShift;
+  // ---- a lane per SEGMENT: stage it, name the blocks whose first output it holds, and do the second piece of the block it
+  // ends in (k_block_rec2's job) -- once per segment instead of in a branch every lane of the block loop walks through
   {
     const long long il = i0 + l < nseg ? i0 + l : nseg;           // entries past the curve repeat the end (never selected)
-    const long long d = seg_start[il] - a0;
+    const long long al = seg_start[il];
+    const long long d = al - a0;
     s_a[w][l] = d < 0x7fffffffll ? (int)d : 0x7fffffff;
-    s_sf[w][l] = seg_fast[il < nseg ? il : nseg - 1];
-    s_sp[w][l] = sp[il];
+    const SegFast sfl = seg_fast[il < nseg ? il : nseg - 1];
+    s_sf[w][l] = sfl;
+    const double spl = sp[il];
+    s_sp[w][l] = spl;
     if (l == 0) {
       const long long ie = i0 + kRecLazySegs < nseg ? i0 + kRecLazySegs : nseg;
       const long long de = seg_start[ie] - a0;
@@ -1375,83 +1388,111 @@ __global__ __launch_bounds__(256) void k_block_rec_lazy(const double* __restrict
       s_sp[w][kRecLazySegs] = sp[ie];
       s_sp[w][kRecLazySegs + 1] = sp[ie + 1 <= nseg ? ie + 1 : nseg];
     }
+    unsigned fl = 0u;
+    if (l < nsw) {
+      const long long bl = seg_start[il + 1];
+      // blocks g with al <= 32 g < min(bl, len_out): this segment holds their output u = 0
+      const long long lim_l = bl < len_out ? bl : len_out;
+      const long long g_lo = (al + kRec - 1) >> kRecShift, g_hi = (lim_l + kRec - 1) >> kRecShift;
+      for (long long g = g_lo; g < g_hi; ++g) s_seg[w][g - G0] = (unsigned char)l;
+      // the block this segment ENDS in (segment il + 1 starts at its u = us): that segment's piece of it
+      const int us = (int)(bl & (kRec - 1));
+      const bool has_next = il + 1 < nseg;
+      if (us != 0 && bl > al) {
+        const SegFast s1 = seg_fast[has_next ? il + 1 : il];
+        const double sp1 = sp[has_next ? il + 1 : il];
+        const int need = kRec - us;
+        if (s1.n == need) fl |= kF_End1 | kF_Slow1;
+        if (!(has_next && s1.fast >= 2 && s1.n >= need && s1.A > -(1ll << 61) && s1.A < (1ll << 61) && sp1 >= 0.971 && sp1 <= 1.031))
+          fl |= kF_Slow1;
+        if (s1.fast == 2) fl |= kF_Cubic1;
+        if (has_next && bl < len_out) {
+          const long long gb = bl >> kRecShift;
+          const long long anchor = hdr[(gb << kRecShift) / kSincTileOutputs].anchor;
+          const double rc1 = recip_nr_c(__builtin_fma(s1.step, (double)(16 - us), sp1));
+          const BlockPoly b1 = piece_poly_c(s1.foff, rc1, rc1 * s1.step, us - 16);
+          const double r1 = rint(b1.a0);
+          const long long rel = s1.A + (long long)r1 - anchor;
+          BlockRec2 o2;
+          o2.w0 = (unsigned)((int)rel << 16);
+          o2.F = (float)(b1.a0 - r1);
+          o2.e1 = (float)b1.a1m1;
+          o2.e2 = (float)b1.a2;
+          rec2[gb] = o2;
+          if (!(fabs(b1.a0) < 1.0e9 && irel_ok(rel))) fl |= kF_Slow1;
+        }
+      }
+      s_fl[w][l] = (unsigned char)fl;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const long long b_end = a0 + s_a[w][nsw];                      // first output behind the wave's segments
   const long long lim = b_end < len_out ? b_end : len_out;
-  const long long G0 = (a0 + kRec - 1) >> kRecShift, G1 = (lim + kRec - 1) >> kRecShift;
+  const int nblk = (int)(((lim + kRec - 1) >> kRecShift) - G0);  // blocks of this wave
+  const int jr0 = (int)((G0 << kRecShift) - a0);                 // first block's first output, relative to a0 (0 .. 31)
+  const long long last_tile0 = ((len_out - 1) / kSincTileOutputs) * kSincTileOutputs;   // first output of the file's last tile
   long long Tc = -1;
-  TileHdr hd;
-  hd.anchor = 0;
-  hd.flags = 0;
-  for (long long g = G0 + l; g < G1; g += kWave) {
-    const long long jb = g << kRecShift;
-    const int jr = (int)(jb - a0);
-    int lo = 0, hi = nsw - 1;                                     // last staged segment with start <= jb
-#pragma unroll
-    for (int it = 0; it < 6; ++it) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (lo < hi) {
-        if (s_a[w][mid] <= jr) lo = mid; else hi = mid - 1;
-      }
-    }
-    const long long i = i0 + lo;
-    const long long a = a0 + s_a[w][lo], b = a0 + s_a[w][lo + 1];
+  long long anchor = 0;
+  int hflags = 0;
+  // ---- a lane per BLOCK: the first piece and the flags (32-bit arithmetic relative to the wave's first output)
+  for (int q = l; q < nblk; q += kWave) {
+    const int lo = s_seg[w][q];
+    const int jr = jr0 + (q << kRecShift);                        // the block's first output, relative to a0
+    const long long g = G0 + q, jb = g << kRecShift;
+    const int ar = s_a[w][lo], br = s_a[w][lo + 1];
     const SegFast sf = s_sf[w][lo];
-    const bool has_next = i + 1 < nseg;
-    const SegFast s1 = s_sf[w][has_next ? lo + 1 : lo];
-    const double sp0 = s_sp[w][lo], sp1 = s_sp[w][has_next ? lo + 1 : lo];
+    const double sp0 = s_sp[w][lo];
     const long long T = jb / kSincTileOutputs;
+#if PAR_REC_EXP & 2
+    anchor = jb;
+#else
     if (T != Tc) {
-      hd = hdr[T];
+      const TileHdr hd = hdr[T];
+      anchor = hd.anchor;
+      hflags = hd.flags;
       Tc = T;
     }
-    const long long j0 = T * kSincTileOutputs;
-    const double kd = (double)(jb - a);
-    const long long d = b - jb;
-    const int rem = d < kRec + 1 ? (int)d : kRec + 1;
+#endif
+    const double kd = (double)(jr - ar);
+    const int dseg = br - jr;
+    const int rem = dseg < kRec + 1 ? dseg : kRec + 1;
     const double rc = recip_nr_c(__builtin_fma(sf.step, kd + 16.0, sp0));
     const BlockPoly q0 = piece_poly_c(sf.foff + lazy_prefix_nr(sp0, sf.step, kd), rc, rc * sf.step, -16);
     const double r0 = rint(q0.a0);
-    const long long rel0 = sf.A + (long long)(int)r0 - hd.anchor;
-    const bool range0 = fabs(q0.a0) < 1.0e9 && sf.A > -(1ll << 61) && sf.A < (1ll << 61) && irel_ok(rel0) && !(hd.flags & 1);
+    const long long rel0 = sf.A + (long long)(int)r0 - anchor;
+    const bool range0 = fabs(q0.a0) < 1.0e9 && sf.A > -(1ll << 61) && sf.A < (1ll << 61) && irel_ok(rel0) && !(hflags & 1);
     const unsigned ustar = rem < kRec ? (unsigned)rem : (unsigned)kRec;
-    const long long ul = j0 + kSincTileOutputs >= len_out ? len_out - 1 - jb : -1;      // the file's last output: slow path
-    const unsigned slow0 = !(sf.fast >= 2 && range0 && fabs(q0.a1m1) <= 0.03125) || (ul >= 0 && ul < (long long)ustar);
+    // the file's last output takes the slow path: its u in this block, or -1 (only blocks of the last tile look)
+    const int ul = jb >= last_tile0 ? (int)(len_out - 1 - jb) : -1;
+    const unsigned slow0 = !(sf.fast >= 2 && range0 && fabs(q0.a1m1) <= 0.03125) || (ul >= 0 && ul < (int)ustar);
     unsigned slow1 = 0u, end1 = 0u, cubic = sf.fast == 2;
-    if (ustar < (unsigned)kRec) {                               // segment i + 1 starts at u = ustar
-      const int need = kRec - (int)ustar;
-      end1 = s1.n == need;
-      slow1 = !(has_next && s1.fast >= 2 && s1.n >= need && s1.A > -(1ll << 61) && s1.A < (1ll << 61) && sp1 >= 0.971 &&
-                sp1 <= 1.031) ||
-              (ul >= (long long)ustar && ul < kRec);
-      cubic |= s1.fast == 2;
-      if (has_next && b < len_out) {                            // its piece of this block (k_block_rec2)
-        const int us = (int)ustar;
-        const double rc1 = recip_nr_c(__builtin_fma(s1.step, (double)(16 - us), sp1));
-        const BlockPoly b1 = piece_poly_c(s1.foff, rc1, rc1 * s1.step, us - 16);
-        const double r1 = rint(b1.a0);
-        const long long rel = s1.A + (long long)r1 - hd.anchor;
-        BlockRec2 o2;
-        o2.w0 = (unsigned)((int)rel << 16);
-        o2.F = (float)(b1.a0 - r1);
-        o2.e1 = (float)b1.a1m1;
-        o2.e2 = (float)b1.a2;
-        rec2[g] = o2;
-        if (!(fabs(b1.a0) < 1.0e9 && irel_ok(rel))) slow1 = 1u;
-      }
+    if (ustar < (unsigned)kRec) {                               // segment i + 1 starts at u = ustar: what its lane found
+      const unsigned fl = s_fl[w][lo];
+      end1 = (fl & kF_End1) != 0u;
+      slow1 = ((fl & kF_Slow1) != 0u) || (ul >= (int)ustar && ul < kRec);
+      cubic |= (fl & kF_Cubic1) != 0u;
     }
     const bool e0 = (ustar < (unsigned)kRec) || rem == kRec;
-    if (end1) slow1 = 1u;
     BlockRec o;
     o.w0 = ((unsigned)((int)rel0 << 16)) | (ustar - 1u) | (e0 ? kRecE0 : 0u) | (end1 ? kRecE1 : 0u) | (slow0 ? kRecSlow0 : 0u) |
            (slow1 ? kRecSlow1 : 0u) | (cubic ? kRecCubic : 0u) | ((e0 ? ustar - 1u : 63u) << kRecLastShift);
     o.F = (float)(q0.a0 - r0);
     o.e1 = (float)q0.a1m1;
     o.e2 = (float)q0.a2;
+#if PAR_REC_EXP & 1
+    if (o.w0 == 0x12345678u)
+#endif
+#if PAR_REC_EXP & 4
+    {
+      typedef unsigned u4v __attribute__((ext_vector_type(4)));
+      u4v v = {o.w0, __float_as_uint(o.F), __float_as_uint(o.e1), __float_as_uint(o.e2)};
+      __builtin_nontemporal_store(v, reinterpret_cast<u4v*>(rec + g));
+    }
+#else
     rec[g] = o;
+#endif
   }
 }
 
