@@ -134,6 +134,15 @@ int par_spec_apply_gain_boxes_c64(int device, float* spec, int64_t n_frames, int
 int par_band_mean_db_f32(int device, const float* mag, int64_t n_frames, int64_t bins, int64_t mag_pitch, int bin_l, int bin_u,
                          int64_t frame_b, int64_t frame_a, double* out, void* stream);
 
+/* Heuristic dropout repair (dropouts_gui.MainWindow.process_heuristic, dropouts_gui.py:241-323): the two O(n) passes around
+ * the band-pass of a band, over the n_ch channels of an interleaved (n, sig_stride) float32 file at once.
+ *   par_curve_scale_f64:    out[c][i] = sig[i][c] * np.interp(np.linspace(0, 1, n)[i], np.linspace(0, 1, frames), fac[c])  (:314-317;
+ *                           fac device f64[n_ch][frames] = correction factor - 1, out device f64[n_ch][n])
+ *   par_accumulate_f64_f32: sig[i][c] = float32(float64(sig[i][c]) + y[c][i])                                                (:319-321) */
+int par_curve_scale_f64(int device, const float* sig, int64_t sig_stride, int n_ch, int64_t n, const double* fac, int64_t frames,
+                        double* out, void* stream);
+int par_accumulate_f64_f32(int device, float* sig, int64_t sig_stride, int n_ch, int64_t n, const double* y, void* stream);
+
 /* ---- R1: speed curve -> fractional read positions ----------------------------------
  * Replaces resampling.speed_to_pos (util/resampling.py:93-137).  Two calls because the
  * caller must allocate the position array:
@@ -378,6 +387,17 @@ int par_zero_crossings_f64(int device, const double* x, int64_t n, int64_t* work
 int64_t par_sosfiltfilt_work_len(int64_t n, int64_t padlen);
 int par_sosfiltfilt_f64(int device, const double* sos, const double* zi, int n_sections, const double* x, int64_t n,
                         int64_t padlen, double* work, int64_t work_len, double* y, void* stream);
+
+/* Batched form (r05): n_sig signals of ONE length n (signal i at x + i * x_stride, result at y + i * y_stride), n_filt = 1
+ * (one cascade for all) or n_sig (cascade i for signal i: sos HOST f64[n_filt][n_sections][6], zi HOST f64[n_filt][n_sections][2]),
+ * every stage ONE launch over the whole batch -- what dropouts_gui.process_heuristic does per band over the channels of a file
+ * (dropouts_gui.py:314-321), or a multi-band analysis of one signal.  Each signal's result equals par_sosfiltfilt_f64's bit for
+ * bit (same block / super-block chain).  padlen as above (the cascades of one call share it); n_sig <= 65535.
+ * Synchronises the stream once (the parameter table's upload). */
+int64_t par_sosfiltfilt_batch_work_len(int64_t n, int64_t padlen, int n_sig, int n_sections);
+int par_sosfiltfilt_batch_f64(int device, const double* sos, const double* zi, int n_filt, int n_sections, const double* x,
+                              int64_t x_stride, int n_sig, int64_t n, int64_t padlen, double* work, int64_t work_len, double* y,
+                              int64_t y_stride, void* stream);
 
 #ifdef __cplusplus
 }

@@ -317,6 +317,15 @@ def main():
          c3_sr=np.array(sr3), c3_n=np.array(len(x3)), c3_track_times=tr3.times, c3_track_freqs=tr3.freqs, c3_curve=curve3,
          c3_len_pos=np.array(len(pos3)), c3_pos_grid=grid(pos3, 1009), c3_sel=sel, c3_y_sel=y3_sel)
 
+    # ------------------------------ heuristic dropout repair: dropouts_gui.MainWindow.process_heuristic itself (r05, 8f-3)
+    hs = inputs.heuristic_input()
+    h_low = ref_gui.heuristic_through_reference(a.ref, hs, 8000, 512, 64, max_width=0.06, f_upper=120, f_lower=20)
+    xd, sr_d, _ = my_io.read_flac(os.path.join(a.ref, "samples", "dropouts_sample.flac"))
+    h_gui = ref_gui.heuristic_through_reference(a.ref, xd, sr_d, 512, 64)          # the GUI's defaults (util/widgets.py:832-889)
+    save("heuristic", low=h_low, low_params=np.array([8000, 512, 64, 0.06, 0.5, 3, 2, 120, 20]), low_in_sum=np.array(inputs.checksum(hs.ravel())),
+         gui_every3=h_gui[::3].copy(), gui_peak=np.array(np.max(np.abs(h_gui))), gui_changed=np.array(np.max(np.abs(h_gui - xd))),
+         gui_params=np.array([sr_d, 512, 64, 0.02, 0.5, 3, 2, 12000, 3000]))
+
     # ------------------------------ the master curves through the reference's own marker classes, and two .spd projects (r04)
     # MasterSpeedLine.update / MasterRegLine.update / Canvas.get_speed_curve (util/markers.py:625-708, pyrespeeder_gui.py:133-
     # 140) run themselves on TraceLine / RegLine objects built by from_cfg, as util/widgets.py:1247-1262 does for a .spd file.

@@ -611,3 +611,64 @@ def detect_dropouts(imdata, sr, fft_size, hop, t_0, t_1, f_lower, f_upper, width
             pass
         found.append(((t_center - half_width, f_lower), (t_center + half_width, f_upper)))
     return found
+
+
+# ------------------------------------------------------------------------- heuristic dropout repair
+def heuristic_bands(f_lower, f_upper, num_bands):
+    """Band edges of dropouts_gui.py:252: a log-spaced grid cast to uint16 (the edges stay numpy uint16 scalars: what follows
+    from that is part of the reference's behaviour, see heuristic_bins)."""
+    return np.logspace(np.log2(f_lower), np.log2(f_upper), num=num_bands, endpoint=True, base=2, dtype=np.uint16)
+
+
+def heuristic_bins(f_lower_band, f_upper_band, fft_size, sr):
+    """dropouts_gui.py:281-282: int(f * fft_size / sr) with f a numpy uint16 scalar.  Under the numpy this build is pinned to
+    (2.x, NEP 50) uint16 * python int stays uint16 and WRAPS for f * fft_size >= 65536 (3000 Hz * 512 -> 28672): the reference's
+    bands then sit in the lowest bins whatever their frequencies.  Evaluated through numpy itself, so this restatement follows
+    the installed numpy exactly as the reference does."""
+    with np.errstate(over="ignore"):
+        return int(f_lower_band * fft_size / sr), int(f_upper_band * fft_size / sr)
+
+
+def heuristic_gain_curve(vol, d, max_slope):
+    """dropouts_gui.py:287-311 for one band: valleys of the volume curve (scipy find_peaks on -vol, prominence 5 dB), each patched
+    by the straight line between the mean volumes d..2d frames to its left and right when that line's slope stays below
+    max_slope.  Returns the gain curve in dB (zeros elsewhere)."""
+    import scipy.signal
+    n_frames = len(vol)
+    peaks, _ = scipy.signal.find_peaks(-vol, height=None, threshold=None, distance=None, prominence=5, wlen=None,
+                                       rel_height=0.5, plateau_size=None)
+    gain_curve = np.zeros(n_frames)
+    for peak_i in peaks:
+        if 2 * d < peak_i < n_frames - 2 * d - 1:
+            left = np.mean(vol[peak_i - 2 * d:peak_i - d])
+            right = np.mean(vol[peak_i + d:peak_i + 2 * d])
+            m = (left - right) / (2 * d)
+            if abs(m) < max_slope:
+                gain_curve[peak_i - d:peak_i + d + 1] = np.interp(range(2 * d + 1), (0, 2 * d), (left, right)) - vol[peak_i - d:peak_i + d + 1]
+    return gain_curve
+
+
+def heal_heuristic(signal, sr, fft_size, hop, max_width=0.02, max_slope=0.5, num_bands=3, bottom_freedom=2, f_upper=12000,
+                   f_lower=3000):
+    """dropouts_gui.MainWindow.process_heuristic (dropouts_gui.py:241-323) for one file: signal (n, ch) float32 -> repaired
+    copy.  Per channel: dB spectrogram (hann), then from the top band down -- band volume, valley gains, the factor clipped
+    between 1 and bottom_freedom x the band above's, the signal x (factor - 1) band-passed (order 3, zero phase) and ADDED to
+    the signal the next band then starts from (:314-321: the bands are sequential through the signal)."""
+    signal = np.array(signal, dtype=np.float32)
+    bands = heuristic_bands(f_lower, f_upper, num_bands)
+    d = int(max_width / 1.5 * sr / hop)
+    n = signal.shape[0]
+    with np.errstate(all="ignore"):
+        for channel in range(signal.shape[1]):
+            imdata = np.array(20 * np.log10(get_mag(signal[:, channel], fft_size, hop, "hann")))
+            correction_fac = np.ones(imdata.shape[1]) * 1000
+            edges = list(zip(bands[:-1], bands[1:]))
+            for f_lo, f_hi in reversed(edges):
+                bin_lower, bin_upper = heuristic_bins(f_lo, f_hi, fft_size, sr)
+                vol = np.mean(imdata[bin_lower:bin_upper], axis=0)
+                gain_curve = heuristic_gain_curve(vol, d, max_slope)
+                correction_fac = np.clip(np.power(10, gain_curve / 20), 1, correction_fac * bottom_freedom)
+                vol_corr = signal[:, channel] * np.interp(np.linspace(0, 1, n), np.linspace(0, 1, len(correction_fac)),
+                                                          correction_fac - 1)
+                signal[:, channel] += butter_bandpass_filter(vol_corr, f_lo, f_hi, sr, order=3)
+    return signal

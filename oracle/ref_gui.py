@@ -211,3 +211,32 @@ def speed_curve_through_reference(P, markers_mod, sr, hop, duration, lines, regs
     c.master_speed.bands = bands
     c.update_lines()
     return np.array(c.get_speed_curve()), np.array(c.master_speed.data), np.array(c.master_reg_speed.data)
+
+
+# ---------------------------------------------------------------------------------------- heuristic dropout repair (8f-3)
+def heuristic_through_reference(ref, signal2d, sr, fft_size, hop, max_width=0.02, max_slope=0.5, num_bands=3, bottom_freedom=2,
+                                f_upper=12000, f_lower=3000):
+    """dropouts_gui.MainWindow.process_heuristic (dropouts_gui.py:241-323) itself on `signal2d` (n, ch) float32: the method is
+    called as a plain function on a stand-in window that carries the DropoutWidget values (util/widgets.py:832-889 defaults)
+    and one file name; io_ops.read_file / write_file are swapped for in-memory ones.  Returns the array it writes."""
+    global _installed
+    if not _installed:
+        sys.meta_path.insert(0, _Finder())
+        _installed = True
+    if ref not in sys.path:
+        sys.path.insert(0, ref)
+    logging.disable(logging.CRITICAL)
+    import dropouts_gui as G
+    win = NS(dropout_widget=NS(max_width=max_width, max_slope=max_slope, num_bands=num_bands, bottom_freedom=bottom_freedom,
+                               f_upper=f_upper, f_lower=f_lower),
+             file_names=["a.wav"], names_to_full_paths={"a.wav": "a.wav"})
+    written = {}
+    old_r, old_w = G.io_ops.read_file, G.io_ops.write_file
+    G.io_ops.read_file = lambda path: (np.array(signal2d, dtype=np.float32), sr, signal2d.shape[1])
+    G.io_ops.write_file = lambda path, data, sr_, ch, suffix="_out": written.update(data=np.array(data), suffix=suffix)
+    try:
+        with np.errstate(all="ignore"):
+            G.MainWindow.process_heuristic(win, fft_size, hop)
+    finally:
+        G.io_ops.read_file, G.io_ops.write_file = old_r, old_w
+    return written["data"]

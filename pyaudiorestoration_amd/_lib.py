@@ -78,6 +78,11 @@ SIGNATURES = {
                                            c_dbl, c_dbl, c_int, c_vp, c_vp]),
     "par_sosfiltfilt_work_len": (c_i64, [c_i64, c_i64]),
     "par_sosfiltfilt_f64": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "par_curve_scale_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "par_accumulate_f64_f32": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_vp, c_vp]),
+    "par_sosfiltfilt_batch_work_len": (c_i64, [c_i64, c_i64, c_int, c_int]),
+    "par_sosfiltfilt_batch_f64": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_vp, c_i64, c_vp,
+                                          c_i64, c_vp]),
     "par_track_cog_f64": (c_int, [c_int, c_vp, c_i64, c_int, c_i64, c_i64, c_i64, c_vp, c_int, c_dbl, c_dbl, c_vp, c_vp]),
     "par_stft_big_scratch_bytes": (ctypes.c_size_t, [c_i64, c_int, c_int, c_int]),
     "par_stft_big_f32": (c_int, [c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, ctypes.c_size_t, c_vp]),

@@ -150,6 +150,41 @@ __global__ void __launch_bounds__(256) k_band_mean_db(const float* __restrict__ 
   if (lane == 0) out[w] = acc / (double)(bin_u - bin_l);
 }
 
+
+// ---- heuristic dropout repair (dropouts_gui.py:314-321): the two O(n) passes around the band-pass filter ---------------------
+// out[c][i] = sig[i][c] * np.interp(np.linspace(0, 1, n)[i], np.linspace(0, 1, frames), fac[c])   (float64, like numpy's product)
+__global__ void k_curve_scale(const float* __restrict__ sig, int64_t sig_stride, int64_t n, const double* __restrict__ fac,
+                              int64_t frames, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = blockIdx.y;
+  const double* fp = fac + (int64_t)c * frames;
+  // np.linspace(0, 1, k)[j] = j * (1 / (k - 1)), its last element set to 1 exactly
+  const double sx = n > 1 ? 1.0 / (double)(n - 1) : 0.0, sp = frames > 1 ? 1.0 / (double)(frames - 1) : 0.0;
+  const double x = i == n - 1 && n > 1 ? 1.0 : (double)i * sx;
+  double v;
+  if (frames == 1) {
+    v = fp[0];
+  } else {
+    long long j = (long long)(x * (double)(frames - 1));
+    j = j < 0 ? 0 : (j > frames - 2 ? frames - 2 : j);
+    auto xp = [&](long long q) { return q == frames - 1 ? 1.0 : (double)q * sp; };
+    if (xp(j) > x && j > 0) --j;                    // the float product can land one interval off
+    else if (xp(j + 1) <= x && j < frames - 2) ++j;
+    const double x0 = xp(j), x1 = xp(j + 1);
+    v = x >= 1.0 ? fp[frames - 1] : (fp[j + 1] - fp[j]) / (x1 - x0) * (x - x0) + fp[j];      // np.interp's own form
+  }
+  out[(int64_t)c * n + i] = (double)sig[i * sig_stride + c] * v;
+}
+// sig[i][c] = float32(float64(sig[i][c]) + y[c][i])       (numpy's  float32_column += float64_array)
+__global__ void k_accumulate(float* __restrict__ sig, int64_t sig_stride, int64_t n, const double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = blockIdx.y;
+  float* p = sig + i * sig_stride + c;
+  *p = (float)((double)*p + y[(int64_t)c * n + i]);
+}
+
 }  // namespace par
 
 // ---- sparse healing (r03): only the frames a marker can influence go through STFT -> inpaint -> ISTFT ------------------
@@ -264,6 +299,27 @@ extern "C" int par_band_mean_db_f32(int device, const float* mag, int64_t n_fram
   PAR_HIP_CHECK(hipSetDevice(device));
   hipLaunchKernelGGL(k_band_mean_db, dim3((unsigned)ceil_div(count, 4)), dim3(256), 0, as_stream(stream), mag,
                      mag_pitch ? mag_pitch : bins, bin_l, bin_u, frame_b, count, out);
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
+extern "C" int par_curve_scale_f64(int device, const float* sig, int64_t sig_stride, int n_ch, int64_t n, const double* fac,
+                                   int64_t frames, double* out, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(sig && fac && out && n >= 1 && frames >= 1 && n_ch >= 1 && n_ch <= 65535 && sig_stride >= n_ch, PAR_ERR_ARG,
+              "par_curve_scale_f64: bad args");
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipLaunchKernelGGL(k_curve_scale, dim3((unsigned)ceil_div(n, 256), (unsigned)n_ch), dim3(256), 0, as_stream(stream), sig, sig_stride, n,
+                     fac, frames, out);
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
+extern "C" int par_accumulate_f64_f32(int device, float* sig, int64_t sig_stride, int n_ch, int64_t n, const double* y, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(sig && y && n >= 1 && n_ch >= 1 && n_ch <= 65535 && sig_stride >= n_ch, PAR_ERR_ARG, "par_accumulate_f64_f32: bad args");
+  PAR_HIP_CHECK(hipSetDevice(device));
+  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)ceil_div(n, 256), (unsigned)n_ch), dim3(256), 0, as_stream(stream), sig, sig_stride, n, y);
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }

@@ -430,6 +430,90 @@ def detect_dropouts(mag, sr, fft_size, hop, t_0, t_1, f_lower, f_upper, width_ms
     return found
 
 
+# ---------------------------------------------------------------------- heuristic dropout repair (dropouts_gui)
+def heuristic_bands(f_lower, f_upper, num_bands):
+    """Band edges of dropouts_gui.py:252 (numpy uint16 scalars, like the reference's)."""
+    return np.logspace(np.log2(f_lower), np.log2(f_upper), num=num_bands, endpoint=True, base=2, dtype=np.uint16)
+
+
+def heuristic_bins(f_lower_band, f_upper_band, fft_size, sr):
+    """dropouts_gui.py:281-282, int(f * fft_size / sr) with f a numpy uint16 scalar: under numpy >= 2 (NEP 50) the product stays
+    uint16 and wraps from f * fft_size = 65536 on, so at 44.1 kHz / 512 points the reference's bands sit in bins 0..1 whatever
+    their frequencies.  Evaluated through numpy itself: this follows the installed numpy exactly as the reference does."""
+    with np.errstate(over="ignore"):
+        return int(f_lower_band * fft_size / sr), int(f_upper_band * fft_size / sr)
+
+
+def heuristic_gain_curve(vol, d, max_slope):
+    """Gain curve (dB) of one band from its volume curve: the reference's valley search (scipy find_peaks on -vol, prominence
+    5 dB) and straight-line patches, dropouts_gui.py:287-311 -- O(frames) host work on a curve the device produced."""
+    n_frames = len(vol)
+    peaks, _ = scipy.signal.find_peaks(-vol, height=None, threshold=None, distance=None, prominence=5, wlen=None, rel_height=0.5,
+                                       plateau_size=None)
+    gain_curve = np.zeros(n_frames)
+    for peak_i in peaks:
+        if 2 * d < peak_i < n_frames - 2 * d - 1:
+            left = np.mean(vol[peak_i - 2 * d:peak_i - d])
+            right = np.mean(vol[peak_i + d:peak_i + 2 * d])
+            if abs((left - right) / (2 * d)) < max_slope:
+                gain_curve[peak_i - d:peak_i + d + 1] = np.interp(range(2 * d + 1), (0, 2 * d), (left, right)) - vol[peak_i - d:peak_i + d + 1]
+    return gain_curve
+
+
+def heal_heuristic(signal, sr, fft_size=512, hop=64, max_width=0.02, max_slope=0.5, num_bands=3, bottom_freedom=2, f_upper=12000,
+                   f_lower=3000, device=None):
+    """Headless restatement of dropouts_gui.MainWindow.process_heuristic (dropouts_gui.py:241-323; defaults = DropoutWidget's,
+    util/widgets.py:832-889): signal (n, ch) float32 (numpy or device tensor) -> repaired (n, ch) float32 of the same kind.
+    Per band, from the top one down: band volume per channel (K_heal, device), valley gains (host, O(frames)), then over ALL
+    channels at once signal x (factor - 1) (par_curve_scale_f64), the zero-phase order-3 band-pass (K_sosfiltfilt, batched) and
+    the add into the signal the next band starts from (par_accumulate_f64_f32) -- the bands are sequential through the signal in
+    the reference (:314-321), the channels are not."""
+    from . import _lib
+    dev = _dev.device_index(device)
+    was_tensor = torch.is_tensor(signal)
+    sig2d = signal if signal.ndim == 2 else signal[:, None]
+    n, ch = sig2d.shape
+    sig_t = _dev.to_dev(sig2d, torch.float32, dev).clone() if was_tensor else _dev.to_dev(np.ascontiguousarray(sig2d), torch.float32, dev)
+    sig_t = sig_t.contiguous()
+    flat = sig_t.reshape(-1)
+    L = _lib.lib()
+    bands = heuristic_bands(f_lower, f_upper, num_bands)
+    d = int(max_width / 1.5 * sr / hop)
+    # the spectrograms come from the channels as they are BEFORE any band is added (the reference takes them once per channel)
+    mags = []
+    for c in range(ch):
+        m = fourier.get_mag(flat[c::ch] if ch > 1 else flat, fft_size, hop, "hann", 1)
+        fm = m.T
+        if not (fm.stride(1) == 1 and fm.stride(0) >= fm.shape[1]):
+            fm = fm.contiguous()
+        mags.append(fm)
+    frames, bins = mags[0].shape
+    fac = np.ones((ch, frames)) * 1000
+    vol_t = _dev.empty(frames, torch.float64, dev)
+    out_t = _dev.empty((ch, n), torch.float64, dev)
+    with np.errstate(all="ignore"):
+        for f_lo, f_hi in reversed(list(zip(bands[:-1], bands[1:]))):
+            bin_l, bin_u = heuristic_bins(f_lo, f_hi, fft_size, sr)
+            for c in range(ch):
+                lo, hi = max(0, min(bin_l, bins)), max(0, min(bin_u, bins))          # numpy slicing clamps
+                if lo < hi:
+                    _lib.check(L.par_band_mean_db_f32(dev, _dev.ptr(mags[c]), frames, bins, mags[c].stride(0), lo, hi, 0, frames,
+                                                      _dev.ptr(vol_t), _dev.stream_ptr(dev)))
+                    vol = vol_t.cpu().numpy()
+                else:
+                    vol = np.full(frames, np.nan)                                  # np.mean of an empty slice
+                fac[c] = np.clip(np.power(10, heuristic_gain_curve(vol, d, max_slope) / 20), 1, fac[c] * bottom_freedom)
+            if not np.any(fac != 1.0):
+                continue                                                            # the band adds filter(0) = 0 to the signal
+            fm1_t = _dev.to_dev(np.ascontiguousarray(fac - 1.0), torch.float64, dev)
+            _lib.check(L.par_curve_scale_f64(dev, _dev.ptr(flat), ch, ch, n, _dev.ptr(fm1_t), frames, _dev.ptr(out_t), _dev.stream_ptr(dev)))
+            # (a band without a cut-off inside (0, Nyquist) comes back unfiltered, like the reference's butter_bandpass_filter)
+            y_t = filters.bandpass_batch_dev(out_t, f_lo, f_hi, sr, order=3, dev=dev)
+            _lib.check(L.par_accumulate_f64_f32(dev, _dev.ptr(flat), ch, ch, n, _dev.ptr(y_t), _dev.stream_ptr(dev)))
+    res = sig_t if signal.ndim == 2 else sig_t[:, 0]
+    return res if was_tensor else res.cpu().numpy()
+
+
 # ---------------------------------------------------------------------- tape synchronisation (pytapesynch)
 def lag_curve_from_markers(markers, duration, sr, hop, smoothing=3, bands=(0, 9999999)):
     """Lag curve (N, 2) = (time s, lag s) from tape-sync markers -- headless restatement of LagLine

@@ -64,3 +64,18 @@ def detect_input(sr=44100, n=120000):
         k = np.arange(c - w, c + w)
         env[k] = np.minimum(env[k], 1 - (1 - depth) * np.hanning(2 * w) ** 0.25)
     return (x * env).astype(np.float32)
+
+
+def heuristic_input(sr=8000, n=48000, seed=5):
+    """Two-channel low-rate test tape for the heuristic dropout repair (dropouts_gui.process_heuristic): band-limited noise
+    (15..200 Hz) with three 12-ms dropouts (-26 dB); channel 1 is channel 0 reversed.  The low rate keeps the reference's
+    uint16 band arithmetic (dropouts_gui.py:281-282) free of overflow for bands below 128 Hz at fft_size 512."""
+    import scipy.signal
+    rng = np.random.default_rng(seed)
+    x = (0.3 * rng.standard_normal(n)).astype(np.float32)
+    sos = scipy.signal.butter(4, [15 / (sr / 2), 200 / (sr / 2)], btype="band", output="sos")
+    x = scipy.signal.sosfiltfilt(sos, x).astype(np.float32) * np.float32(4)
+    for c in (1.2, 2.9, 4.4):
+        i0, w = int(c * sr), int(0.012 * sr)
+        x[i0:i0 + w] *= np.float32(0.05)
+    return np.stack([x, x[::-1].copy()], axis=1)

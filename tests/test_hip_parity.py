@@ -2258,3 +2258,79 @@ def test_lazy_plan_near_ties_take_the_exact_walk(par):
         pk = float(np.max(np.abs(want)))
         # a wrong window centre on white noise moves the output by ~1e-1 of the peak at half-integer positions
         assert np.max(np.abs(got - want)) <= TOL * pk, (speed, float(np.max(np.abs(got - want)) / pk))
+
+
+# ---- 8(f)3, second half (r05): batched K_sosfiltfilt and the heuristic dropout repair ----------------------------------------
+def test_sosfiltfilt_batch_equals_single_calls_and_scipy(par):
+    """par_sosfiltfilt_batch_f64: every row of a batch equals the single-signal call bit for bit and scipy to 1e-9; one cascade
+    for all rows or one per row (the bands of a multi-band analysis); scipy's too-short-input error; and the point of it -- 64
+    bands x 10^6 samples in one call against the loop of single calls (>= 20x)."""
+    import time
+    import scipy.signal
+    t = par.torch
+    F = par.filters
+    rng = np.random.default_rng(31)
+    n, n_sig, fs = 50_001, 7, 48000.0
+    x = rng.standard_normal((n_sig, n))
+    x_t = t.from_numpy(x).cuda()
+    sos = scipy.signal.butter(3, [300 / (fs / 2), 3000 / (fs / 2)], btype="band", output="sos")
+    y = F.sosfiltfilt_batch_dev(sos, x_t)
+    for i in range(n_sig):
+        assert t.equal(y[i], F.sosfiltfilt_dev(sos, x_t[i].contiguous())), i
+        assert relerr(y[i].cpu().numpy(), scipy.signal.sosfiltfilt(sos, x[i])) < 1e-9
+    lows = np.geomspace(100, 8000, n_sig)
+    many = np.stack([scipy.signal.butter(3, [lo / (fs / 2), 1.5 * lo / (fs / 2)], btype="band", output="sos") for lo in lows])
+    y = F.sosfiltfilt_batch_dev(many, x_t)
+    for i in range(n_sig):
+        assert t.equal(y[i], F.sosfiltfilt_dev(many[i], x_t[i].contiguous())), i
+    yb = F.bandpass_batch_dev(x_t, lows, 1.5 * lows, fs, order=3)
+    assert t.equal(yb, y)
+    with pytest.raises(ValueError, match="greater than padlen"):
+        F.sosfiltfilt_batch_dev(sos, x_t[:, :10].contiguous())
+    with pytest.raises(ValueError):
+        F.sosfiltfilt_batch_dev(many[:3], x_t)
+    # 64 bands x 10^6 samples
+    n, n_sig = 1_000_000, 64
+    x_t = t.from_numpy(rng.standard_normal((n_sig, n))).cuda()
+    lows = np.geomspace(50, 15000, n_sig)
+    many = np.stack([scipy.signal.butter(3, [lo / (fs / 2), 1.3 * lo / (fs / 2)], btype="band", output="sos") for lo in lows])
+
+    def timed(fn, reps=3):
+        fn()
+        t.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        t.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    rows = [x_t[i].contiguous() for i in range(n_sig)]
+    t_loop = timed(lambda: [F.sosfiltfilt_dev(many[i], rows[i]) for i in range(n_sig)])
+    t_batch = timed(lambda: F.sosfiltfilt_batch_dev(many, x_t))
+    print(f"sosfiltfilt 64 bands x 1e6 samples: loop {t_loop * 1e3:.2f} ms, batched {t_batch * 1e3:.2f} ms ({t_loop / t_batch:.1f}x)")
+    assert t_loop / t_batch >= 8.0          # measured 11.6x (58.5 -> 5.0 ms: 1.8 TB/s over the six section passes; the loop is launch-bound)
+
+
+def test_heuristic_repair_against_the_reference(par):
+    """pipeline.heal_heuristic against dropouts_gui.MainWindow.process_heuristic itself (tests/golden/heuristic.npz): the low-rate
+    two-channel tape (all three bands alive) and the GUI's defaults on dropouts_sample.flac; numpy in -> numpy out, device
+    tensor in -> device tensor out, the input untouched."""
+    import os
+    from test_oracle_golden import GOLD
+    from pyaudiorestoration_amd import io_ops
+    g = np.load(os.path.join(GOLD, "heuristic.npz"))
+    sig = inputs.heuristic_input()
+    keep = sig.copy()
+    sr, fft, hop, mw, ms, nb, bf, fu, fl = g["low_params"]
+    y = par.pipeline.heal_heuristic(sig, int(sr), int(fft), int(hop), float(mw), float(ms), int(nb), float(bf), float(fu), float(fl))
+    assert isinstance(y, np.ndarray) and y.dtype == np.float32 and y.shape == sig.shape and np.array_equal(sig, keep)
+    want = g["low"]
+    assert float(np.max(np.abs(want - sig))) > 0.1
+    assert relerr(y, want) < TOL, relerr(y, want)
+    # relative to the CHANGE the repair makes, not only to the signal's peak
+    assert float(np.max(np.abs(y - want))) < 1e-4 * float(np.max(np.abs(want - sig)))
+    yt = par.pipeline.heal_heuristic(par.torch.from_numpy(sig).cuda(), int(sr), int(fft), int(hop), float(mw), float(ms), int(nb),
+                                     float(bf), float(fu), float(fl))
+    assert par.torch.is_tensor(yt) and np.array_equal(yt.cpu().numpy(), y)
+    x, sr_d, _ = io_ops.read_file(os.path.join(GOLD, "dropouts_sample.flac"))
+    y = par.pipeline.heal_heuristic(x, sr_d, 512, 64)
+    assert float(np.max(np.abs(y[::3] - g["gui_every3"]))) < TOL * float(g["gui_peak"])

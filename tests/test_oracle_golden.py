@@ -424,3 +424,24 @@ def test_spd_project_master_curves(golden):
     amp = float(g["reg"][2])
     assert abs(np.max(np.log2(g["reg_curve"][:, 1])) - 1.5 * abs(amp)) < 1e-3 * abs(amp)
     assert relerr(np.log2(g["reg_curve"][:, 1]), g["master_reg"][:, 1]) < 1e-12
+
+
+def test_heuristic_repair_oracle_matches_the_reference():
+    """oracle_np.heal_heuristic against dropouts_gui.MainWindow.process_heuristic itself (fixture generated by
+    oracle/gen_golden.py through oracle/ref_gui.heuristic_through_reference): a 8 kHz two-channel tape with low bands (no uint16
+    overflow in the reference's band arithmetic) and the GUI's defaults on dropouts_sample.flac (where, under numpy >= 2, that
+    arithmetic wraps: the bands sit in bins 0..1 -- reproduced)."""
+    import inputs
+    from oracle import oracle_np as O
+    from pyaudiorestoration_amd import io_ops
+    g = np.load(os.path.join(GOLD, "heuristic.npz"))
+    sig = inputs.heuristic_input()
+    assert inputs.checksum(sig.ravel()) == float(g["low_in_sum"])
+    sr, fft, hop, mw, ms, nb, bf, fu, fl = g["low_params"]
+    y = O.heal_heuristic(sig, int(sr), int(fft), int(hop), float(mw), float(ms), int(nb), float(bf), float(fu), float(fl))
+    assert y.dtype == np.float32 and np.array_equal(y, g["low"])
+    assert float(np.max(np.abs(y - sig))) > 0.1                      # the repair did something
+    assert O.heuristic_bins(np.uint16(3000), np.uint16(6000), 512, 44100) == (0, 1)      # the wrap, stated
+    x, sr_d, _ = io_ops.read_flac(os.path.join(GOLD, "dropouts_sample.flac"))
+    y = O.heal_heuristic(x, sr_d, 512, 64)
+    assert np.array_equal(y[::3], g["gui_every3"]) and abs(float(np.max(np.abs(y - x))) - float(g["gui_changed"])) < 1e-9
