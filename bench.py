@@ -379,7 +379,7 @@ def config5_batch(a, ctx):
     world, rank, dev = ctx.world, ctx.rank, ctx.local
     L = _lib.lib()
     s = _dev.stream_ptr(dev)
-    sr, seconds, files = a.sr, 600.0, a.files
+    sr, seconds, files = a.sr, float(a.c5_seconds), a.files          # (--c5-seconds < 600: flow tests of many ranks on one device)
     n, m = int(sr * seconds), int(seconds * sr / 256)
     ring = []
     mono = torch.empty(n, dtype=torch.float32, device=f"cuda:{dev}")
@@ -434,6 +434,7 @@ def config5_batch(a, ctx):
     dt = ctx.timed(step, a.steps)
     total = ctx.reduce_sum(done["samples"])            # channel-samples of one step, all ranks
     files_max, files_min = ctx.reduce_max(done["files"]), -ctx.reduce_max(-done["files"])
+    files_sum = ctx.reduce_sum(done["files"])          # every file of the archive exactly once: must equal `files`
     e2e = None
     if not a.no_e2e:
         n1_e2e = solo(min(files, a.n1_e2e_files), True)
@@ -445,7 +446,7 @@ def config5_batch(a, ctx):
         res = {
             "metric": "Msamples/sec resampled (192 kHz varispeed)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 taps / f64 positions",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 taps / f64 positions (stereo files: the block kernel's vector tap loops)",
             "data": "synthetic",
             "n1_same_workload_value": round(n1, 3), "speedup_vs_n1": round(value / n1, 3),
             "efficiency": round(value / n1 / world, 4), "distinct_devices": ctx.distinct_devices,
@@ -453,6 +454,7 @@ def config5_batch(a, ctx):
                                    f"curve per file (0.55 Hz, hop 256, phase 0.7 + file index), {2 * a.nt}-tap Hann sinc; one step = the "
                                    "whole archive, files pulled by the ranks from a shared host-side queue (no collective, no RCCL)",
                        "files": files, "channel_samples_per_step": int(total), "files_per_rank_min_max": [int(files_min), int(files_max)],
+                       "files_processed": int(files_sum),
                        "value_per_gpu": round(value / world, 3),
                        "n1_same_workload": f"n1_same_workload_value = rank 0 alone over {min(files, a.n1_files)} files of this archive, "
                                            "same code path, measured in this run before the timed region (the other ranks idle); "
@@ -461,8 +463,9 @@ def config5_batch(a, ctx):
                                            "not build a curve from it",
                        "NT": a.nt, "resident": f"ring of {a.ring} synthetic stereo files per GPU + all {files} speed curves",
                        "queue": "one TCP-store fetch-add per 4 files",
-                       "step": "per file: plan (device scans, cumsum checkpoints, block records) + ONE stereo fused K_sinc launch; "
-                               "the next file's plan runs on a side stream under K_sinc"},
+                       "step": "per file: plan (device scans, block records; lazy: csrc/pos_plan.h) + ONE stereo fused K_sinc launch; "
+                               "the plans of the next files are made by planner threads on side streams under K_sinc "
+                               "(resampling.varispeed_batch_dev)"},
             "roofline": {"bound": "hbm", "achieved": round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / world, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / world / HBM_PEAK_GBS, 5),
                          "traffic": None, "kernel": "k_sinc_fused<2> (whole step, per GPU)", "limited_by": "valu",
@@ -502,6 +505,7 @@ def main():
     ap.add_argument("--block-kernel", action="store_true", help="A/B: the block kernel instead of the streaming kernel (par_debug_sinc_kernel(0))")
     ap.add_argument("--config5", action="store_true", help="time the 512-file stereo archive (default when --gpus > 1)")
     ap.add_argument("--files", type=int, default=512, help="files of the config-5 archive")
+    ap.add_argument("--c5-seconds", type=float, default=600.0, help="duration of the config-5 files (600 = the archive's; shorter: flow tests)")
     ap.add_argument("--ring", type=int, default=6, help="resident synthetic stereo files per GPU in the config-5 mode")
     ap.add_argument("--n1-files", type=int, default=64, help="files of the one-GPU same-workload base (config-5 mode)")
     ap.add_argument("--n1-e2e-files", type=int, default=24, help="files of the one-GPU base of the host-gather leg")

@@ -1987,6 +1987,31 @@ def test_two_rank_config5_bench_flow(par):
     assert r["value_e2e"] > 100.0 and r["e2e"]["n1_same_workload_value"] > 100.0 and r["value_e2e"] < r["value"]
 
 
+def test_eight_rank_config5_flow_on_one_device(par):
+    """Multi-GPU pre-flight (no 8-GPU node has run this code yet): the REAL 8-rank flow of `bench.py --gpus 8`
+    -- gloo rendezvous, the shared TCP-store work queue, eight batch drivers with their planner threads, the reductions -- on
+    this box's device(s), with short files so that eight processes fit.  Every file of the archive is processed exactly once
+    and no rank is starved."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["PAR_OVERSUBSCRIBE"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--files", "64",
+           "--c5-seconds", "20", "--ring", "2", "--n1-files", "8", "--no-e2e"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["n_gpus"] == 8 and r["scaling"] == "strong" and r["config"]["files"] == 64
+    assert r["config"]["files_processed"] == 64                      # every file once: nothing dropped, nothing done twice
+    lo, hi = r["config"]["files_per_rank_min_max"]
+    assert 0 <= lo <= hi <= 64 and hi >= 8                           # (the queue hands out four files per request)
+    assert r["config"]["channel_samples_per_step"] > 64 * 2 * 3_800_000 and r["value"] > 100.0
+    assert r["distinct_devices"] == min(8, par.torch.cuda.device_count())
+
+
 def test_batch_gather_equals_batch_dev(par):
     """resampling.varispeed_batch_gather (the host-gather leg): pinned host results equal the device-resident batch's,
     in order, across ring wrap-arounds, for mono and interleaved stereo items of different lengths."""
