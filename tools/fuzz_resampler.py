@@ -15,6 +15,8 @@ import torch
 from oracle import oracle_c as C
 from pyaudiorestoration_amd import _lib, resampling as R
 
+if os.environ.get("PAR_FUZZ_BLOCK"):
+    _lib.lib().par_debug_sinc_kernel(0)          # the block kernel for mono NT = 32 too
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 t_end = time.time() + budget
@@ -23,6 +25,7 @@ worst_f = 0.0
 why = {}
 paths = [0, 0, 0]            # plans that ran on the device / went to the serial host plan / took host-made lengths only
 worst_cfg = None
+n_lazy = n_cand = 0
 while time.time() < t_end:
     rng = np.random.default_rng(seed0 + case)
     n = int(rng.choice([3000, 20000, 150000, 700000]))
@@ -77,6 +80,15 @@ while time.time() < t_end:
     except _lib.ParError as e:
         raise SystemExit(f"case {case}: device plan failed where the oracle succeeded: {e}")
     paths[plan.path] += 1
+    if plan.lazy:
+        # a lazy plan (closed-form segment sums + exact sums for the offset chain's candidates, r05) against the eager one:
+        # segment starts and the offset chain bit for bit, the same length and trim
+        n_lazy += 1
+        eager = R.speed_plan_dev(st_t, sp_t, n, fused=True, eager=True)
+        assert eager.fused_ok and not eager.lazy and (eager.len_out, eager.trimmed, eager.path) == (plan.len_out, plan.trimmed, plan.path), (case, "lazy vs eager header")
+        mm = plan.m
+        assert torch.equal(plan.work[256:256 + 16 * mm], eager.work[256:256 + 16 * mm]), (case, "lazy vs eager: seg_start / seg_off differ", n, NT, seg, style)
+        n_cand += int(plan.work[:256].cpu().numpy().view(np.int32)[28])
     if plan.path:
         why[int(_lib.lib().par_last_plan_flags())] = why.get(int(_lib.lib().par_last_plan_flags()), 0) + 1
     pos = R.speed_to_pos_dev(st_t, sp_t, n).cpu().numpy()
@@ -119,4 +131,5 @@ while time.time() < t_end:
     case += 1
 print(f"fuzz ok: {case} cases ({refused} refused by both the oracle and the device), worst relative error {worst:.2e} at {worst_cfg}, "
       f"worst fused-vs-position-array difference {worst_f:.2e}; "
-      f"plan path device/serial-host/host-lengths = {paths[0]}/{paths[1]}/{paths[2]}, device flag words behind the host paths: {why}")
+      f"plan path device/serial-host/host-lengths = {paths[0]}/{paths[1]}/{paths[2]}, device flag words behind the host paths: {why}; "
+      f"lazy plans {n_lazy} (offset chain bit-identical to the eager plan's in every one; {n_cand} exact-sum candidates in all)")
