@@ -1000,8 +1000,9 @@ __device__ __forceinline__ SegFast seg_fast_record(const double* __restrict__ sp
   f.n = n < 0x7fffffffll ? (int)n : 0x7fffffff;
   f.step = n >= 2 ? (s1 - s0) / (double)(n - 1) : 0.0;
   const double smin = s0 < s1 ? s0 : s1, smax = s0 < s1 ? s1 : s0;
-  f.fast = off_ok && n >= 2 && n < 0x7fffffffll && smin >= 0.0625 && smax <= 64.0 &&
-           fabs(f.step) <= 6.0e-4 * smin * sqrt(sqrt(smin));
+  // |step| <= 6e-4 smin^(5/4), compared as fourth powers (two float64 square roots per segment were a third of this function)
+  const double st2 = f.step * f.step, sm2 = smin * smin;
+  f.fast = off_ok && n >= 2 && n < 0x7fffffffll && smin >= 0.0625 && smax <= 64.0 && st2 * st2 <= 1.296e-13 * sm2 * sm2 * smin;
   // level 2 (BlockRec with the cubic term): over the 32 centred steps of a block (|d| <= 16, up to 33 with the steps behind
   // the checkpoint) the quartic term of the reciprocal sum, z^3 d^4 / 4 with z = step / speed, stays < 1e-8 samples
   // level 3 (the block quadratic alone): the cubic term z^2 d^3 / 3 <= 1365 z^2 stays < 1e-8
@@ -1804,9 +1805,14 @@ __global__ __launch_bounds__(kScanThreads) void k_offs_elements(const double* __
         const int e = f64_exponent(xa);
         const double t = ldexp(v[k], 1075 - e);
         const double fr = t - floor(t);
-        const double s0 = sp[i], s1 = sp[i + 1];
-        const double bu = ldexp(lazy_bound((double)(seg_start[i + 1] - seg_start[i]), s0 < s1 ? s0 : s1), 1075 - e);
-        listed = !(fabs(fr - 0.5) > bu);
+        // the segment's own bound only where the largest one a lazy plan admits (K = kLazyMaxN, s_min = 1/16) does not settle it:
+        // 2 % of the segments at 7e8, all of them while ulp(x) is small
+        const double dist = fabs(fr - 0.5);
+        if (!(dist > ldexp(lazy_bound((double)kLazyMaxN, 0.0625), 1075 - e))) {
+          const double s0 = sp[i], s1 = sp[i + 1];
+          const double bu = ldexp(lazy_bound((double)(seg_start[i + 1] - seg_start[i]), s0 < s1 ? s0 : s1), 1075 - e);
+          listed = !(dist > bu);
+        }
       }
       if (listed) {
         const int slot = atomicAdd(&h->n_cand, 1);
