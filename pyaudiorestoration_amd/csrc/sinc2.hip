@@ -28,11 +28,13 @@
 #include "pos_plan.h"
 #include "sinc_taps_gen.h"
 #include "sinc_common.h"
+#include <algorithm>
 #include <limits.h>
 #include <type_traits>
 
+constexpr int kMaxTilesPerWave = 24;          // k_sinc_pipe's tiles per wave for long files (launch_sinc_stream picks 8 .. this)
 #ifndef PAR_S2_TILES
-#define PAR_S2_TILES 8          // tiles per wave
+#define PAR_S2_TILES 8          // tiles per wave of k_sinc_stream (experiment builds)
 #endif
 #ifndef PAR_S2_WAVES
 #define PAR_S2_WAVES 2          // waves per SIMD the kernel is built for (registers <= 512 / this)
@@ -96,6 +98,9 @@ struct S2Args {
   const BlockRec2* rec2;
   int* redo_count;
   int* redo_list;
+  int tiles;                                     // tiles per wave (k_sinc_pipe; <= 48: a lane per tile header)
+  int tiles_tail;                                // ... of the streams behind the first n_big (the launch's last round: short
+  int64_t n_big;                                 // streams, so that the GPU does not idle behind a few long ones)
   int64_t n_full;                                // full tiles of the file
   int64_t n_tiles;                               // tiles with a header
 };
@@ -992,9 +997,10 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
     __syncthreads();
   }
   const int64_t stream_id = (int64_t)blockIdx.x * NW + wv;
-  const int64_t Ta = stream_id * PAR_S2_TILES;
+  const int my_tiles = stream_id < a.n_big ? a.tiles : a.tiles_tail;
+  const int64_t Ta = stream_id < a.n_big ? stream_id * a.tiles : a.n_big * a.tiles + (stream_id - a.n_big) * a.tiles_tail;
   if (Ta >= a.n_full) return;
-  const int64_t Tb = Ta + PAR_S2_TILES < a.n_full ? Ta + PAR_S2_TILES : a.n_full;
+  const int64_t Tb = Ta + my_tiles < a.n_full ? Ta + my_tiles : a.n_full;
   const int64_t Ja = Ta * kSincTileOutputs, Jb = Tb * kSincTileOutputs;
   half8v fr[kBank2Frags];                        // (the MOM kernel reads its constants from the table instead)
   if constexpr (!MOM || kMomFrRegs > 0) {
@@ -1013,7 +1019,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
   int hd_dA, hd_fl;
   {
     const int64_t Ti = Ta + l < a.n_tiles ? Ta + l : a.n_tiles - 1;
-    const TileHdr h = a.hdr[l <= PAR_S2_TILES ? Ti : Ta];
+    const TileHdr h = a.hdr[l <= my_tiles ? Ti : Ta];
     A0 = __shfl(h.anchor, 0, kWave);
     const long long d = h.anchor - A0;
     hd_fl = h.flags | ((d > -0x40000000ll && d < 0x40000000ll) ? 0 : 1);
@@ -1427,7 +1433,23 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
   a.redo_list = fa.redo_list;
   a.n_full = len_out / kSincTileOutputs;
   a.n_tiles = ceil_div(len_out, kSincTileOutputs);
-  const int64_t grid = ceil_div(a.n_full, (int64_t)PAR_S2_TILES);
+  // Tiles per wave of the pipelined kernel: long streams amortise a wave's cold start and, beside a batch driver's plan kernels,
+  // leave fewer wave boundaries for them to slip into -- 60-min file, ms per pipelined step: 4 tiles 5.03, 8: 4.84, 12: 4.70,
+  // 16: 4.66, 24: 4.61, 32: 5.06 (10.3 rounds of the 2 048 wave slots: the last one nearly empty), 48: 4.67 (r05) -- while a
+  // short file still has to fill the GPU's wave slots a few times over.
+  static const int tiles_env = getenv("PAR_S2_TILES_RT") ? atoi(getenv("PAR_S2_TILES_RT")) : 0;       // experiment override, read once
+  const int64_t want = a.n_full / (4 * 2048);
+  a.tiles = tiles_env > 0 ? tiles_env : (int)(want < 8 ? 8 : (want > kMaxTilesPerWave ? kMaxTilesPerWave : want));
+  if (a.tiles > 48) a.tiles = 48;
+  // ... and the launch's last round (2 048 wave slots' worth of tiles) as four rounds of quarter-length streams: the tail in which
+  // the GPU empties behind the last long streams shrinks with them
+  // (24 tiles, K_sinc alone: no short tail 4.37 ms, quarter-length 4.22, 1/8 4.20, 1/12 4.23; two rounds of them 4.23 / 4.30)
+  static const int tail_env = getenv("PAR_S2_TAIL") ? atoi(getenv("PAR_S2_TAIL")) : 6;               // divisor (0: no short tail)
+  static const int tail_rounds = getenv("PAR_S2_TAIL_ROUNDS") ? atoi(getenv("PAR_S2_TAIL_ROUNDS")) : 1;
+  a.tiles_tail = a.tiles >= 8 && tail_env > 1 ? std::max(2, a.tiles / tail_env) : a.tiles;
+  a.n_big = (a.n_full - std::min<int64_t>(a.n_full, 2048ll * tail_rounds * a.tiles * (a.tiles_tail < a.tiles ? 1 : 0))) / a.tiles;
+  const int64_t grid = variant == 1 ? ceil_div(a.n_full, (int64_t)PAR_S2_TILES)
+                                    : a.n_big + ceil_div(a.n_full - a.n_big * a.tiles, (int64_t)a.tiles_tail);
 #if PAR_S2_VARIANTS
   if (grid > 0 && variant == 1) hipLaunchKernelGGL(k_sinc_stream, dim3((unsigned)grid), dim3(kWave), 0, s, a);
   else if (grid > 0 && variant == 2) hipLaunchKernelGGL((k_sinc_pipe<true, false>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
