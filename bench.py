@@ -553,8 +553,9 @@ def main():
     # Pipelined steps: K_sinc launches follow one another on the main stream; the plans of the next `depth` files are made by as
     # many planner threads, each on its own side stream (resampling.varispeed_batch_dev is the same driver for callers' items).
     # The streaming kernel leaves a plan no room beside it: plans advance in the gap behind a K_sinc -- `depth` of them together,
-    # being latency-bound -- so there is one such gap per `depth` files.  Depth 1 = the double-buffered pipeline of r02-r04.
-    depth = max(1, int(os.environ.get("PAR_BENCH_DEPTH", "4"))) if overlap else 0
+    # being latency-bound.  Depth 1 = the double-buffered pipeline of r02-r04; 3 measured best (ms per step at depth 1 / 2 / 3 / 4 / 8:
+    # 5.0 / 4.66 / 4.57 / 4.63 / 4.63) and is the batch driver's default too.
+    depth = max(1, int(os.environ.get("PAR_BENCH_DEPTH", "3"))) if overlap else 0
     n_slots = 2 * depth if overlap else 1
     work = [torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{dev}") for _ in range(n_slots)]
     if fused:       # cumsum checkpoints + tile map: positions are regenerated inside K_sinc, never stored

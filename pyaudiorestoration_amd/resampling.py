@@ -209,8 +209,9 @@ def varispeed_batch_dev(items, NT, dev=None, planners=None):
     of the next `planners` items -- each ~20 small latency-bound kernels and a header read-back, 0.6 ms on an idle
     GPU -- are made by as many planner threads, each on its own side stream.  Beside the block kernel a plan runs
     under the K_sinc in front of it; the streaming kernel (mono NT = 32) leaves it no room, so plans only advance
-    in the gap behind a K_sinc -- where `planners` of them then advance TOGETHER (they are latency-, not
-    throughput-bound): one gap per `planners` files instead of one per file (r05: 4.92 -> 4.6 ms per 60-min file).
+    in the gaps around a K_sinc -- where `planners` of them then advance TOGETHER (they are latency-, not
+    throughput-bound).  Measured on 60-min mono files (r05, ms per file): 1 planner 5.0, 2: 4.66, 3: 4.57, 4: 4.63, 8: 4.63
+    -- default 3 (PAR_PLANNERS).
     Plan buffers form a ring of 2 x planners slots; an event keeps a slot from being re-planned before the K_sinc
     that reads it has finished.  planners=1 is the double-buffered pipeline of r02-r04.
 
@@ -223,7 +224,7 @@ def varispeed_batch_dev(items, NT, dev=None, planners=None):
     import collections
     from concurrent.futures import ThreadPoolExecutor
     dev = _dev.device_index(dev)
-    P = max(1, int(planners if planners is not None else os.environ.get("PAR_PLANNERS", "4")))
+    P = max(1, int(planners if planners is not None else os.environ.get("PAR_PLANNERS", "3")))
     n_slots = 2 * P
     main = torch.cuda.current_stream(dev)
     sides = [torch.cuda.Stream(device=dev) for _ in range(P)]
