@@ -1298,6 +1298,13 @@ def test_host_batch_driver_equals_device_batch(par):
         host_items.append((st, sp, t.from_numpy(sig).pin_memory() if pin else sig))
         dev_items.append((t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), t.from_numpy(sig).cuda()))
     want = [out.clone() for _, out, _ in R.varispeed_batch_dev(dev_items, 16)]
+    # the number of planner threads changes the schedule, never a result (r05: 1 = the double-buffered pipeline of r02-r04)
+    for planners in (1, 2, 5):
+        got = [out.clone() for _, out, _ in R.varispeed_batch_dev(dev_items, 16, planners=planners)]
+        assert len(got) == len(want) and all(t.equal(a, b) for a, b in zip(got, want)), planners
+    gen = R.varispeed_batch_dev(dev_items, 16)                  # a consumer that stops early leaves no thread or plan behind
+    next(gen)
+    gen.close()
     got = []
     for k, out in R.varispeed_batch_host(iter(host_items), 16):
         assert out.is_pinned() and out.device.type == "cpu"
