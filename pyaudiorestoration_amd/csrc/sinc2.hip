@@ -201,6 +201,17 @@ __device__ __forceinline__ void dma_chunk128(const float* base, unsigned lane_by
                ::"v"(lane_bytes), "s"(bs), "s"(__builtin_amdgcn_readfirstlane(la)) : "memory", "m0");
 }
 
+// 128 stereo frames (256 consecutive floats): four direct loads
+__device__ __forceinline__ void dma_chunk256(const float* base, unsigned lane_bytes, const void* lds) {
+  const unsigned la = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds;
+  const unsigned long long b = (unsigned long long)(uintptr_t)base;
+  const unsigned long long bs = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1\n\tglobal_load_lds_dword %0, %1 offset:256\n\t"
+               "global_load_lds_dword %0, %1 offset:512\n\tglobal_load_lds_dword %0, %1 offset:768"
+               ::"v"(lane_bytes), "s"(bs), "s"(__builtin_amdgcn_readfirstlane(la)) : "memory", "m0");
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
   float res_p[2] = {0.0f, 0.0f};
   int nok_p[2] = {0, 0};
   unsigned j_p = 0u;
-  float* const outW = a.out + Ja;
+  float* const outW = a.out + NCH * Ja;
   const uint4* const recW = reinterpret_cast<const uint4*>(a.rec) + (Ja >> kRecShift);
   const uint4* const rec2W = reinterpret_cast<const uint4*>(a.rec2) + (Ja >> kRecShift);
   // The block records of a pass (<= 5 blocks, first and second pieces) come into LDS by one 16-byte direct load per lane of
@@ -638,12 +649,14 @@ constexpr int kRingH = 512;                       // samples per float16 image (
 
 // GENK: the kernel carries the fc < 1 path in its modulated-image form (two images, wider bank rows).  MOM: in its moment form
 // (one image; seven moment filters per centre beside the fc = 1 bank).
-template <bool GENK, bool MOM = false>
+// NCH = 2 (the moment form only): an interleaved stereo file -- the ring holds frames (left, right), each channel has its own
+// float16 images, and the two channels take turns in ONE set of bank rows (see the loop of k_sinc_pipe).
+template <bool GENK, bool MOM = false, int NCH = 1>
 struct S3LdsT {
-  float ring_head[4];                            // [2], [3] mirror ring[1022], ring[1023]
-  float ring[kRingF];
-  float ring_tail[4];                            // mirrors ring[0 .. 3]
-  _Float16 img[GENK ? 4 : 2][kRingH];            // x (or A) hi, lo x 4096; B hi, lo x 4096
+  float ring_head[4 * NCH];                      // frames -2, -1 mirror frames 1022, 1023
+  float ring[kRingF * NCH];
+  float ring_tail[4 * NCH];                      // mirrors frames 0 .. 3
+  _Float16 img[(GENK ? 4 : 2) * NCH][kRingH];    // x (or A) hi, lo x 4096; B hi, lo x 4096 (stereo: [2 ch], [2 ch + 1])
   float4v qa[kPass];                             // bank rows {e0, d0, e1, d1} of x / A, slot = ci ^ ((ci >> 3) & 7)
   float4v qb[GENK ? kPass : 1];                  // of B
   float4v qx[GENK ? kPass : 1];                  // .x = e2|d2 of x / A (halves), .y = e2|d2 of B, .z = H(A), .w = H(B)
@@ -665,7 +678,11 @@ template <class LDS> __device__ __forceinline__ float s3_e2d2(const LDS& L, int 
   else return L.qy[sl];
 }
 typedef S3LdsT<false, true> S3LdsMom;
+typedef S3LdsT<false, true, 2> S3LdsMom2;
 static_assert(offsetof(S3LdsMom, qm0) % 16 == 0 && offsetof(S3LdsMom, recs) % 16 == 0, "16-byte aligned");
+static_assert(offsetof(S3LdsMom2, ring) % 16 == 0 && offsetof(S3LdsMom2, img) % 16 == 0 && offsetof(S3LdsMom2, qa) % 16 == 0 &&
+              offsetof(S3LdsMom2, qm0) % 16 == 0 && offsetof(S3LdsMom2, recs) % 16 == 0, "16-byte aligned");
+static_assert(sizeof(S3LdsMom2) + 16 <= 20480, "eight stereo streams per compute unit (160 KB of LDS)");
 static_assert(offsetof(S3LdsT<true>, img) % 16 == 0 && offsetof(S3LdsT<true>, qa) % 16 == 0 && offsetof(S3LdsT<true>, recs) % 16 == 0, "16-byte aligned");
 static_assert(offsetof(S3LdsT<false>, img) % 16 == 0 && offsetof(S3LdsT<false>, qa) % 16 == 0 && offsetof(S3LdsT<false>, recs) % 16 == 0, "16-byte aligned");
 
@@ -750,15 +767,15 @@ constexpr int kMomHalf = (kMomFmRegs <= 12 && kMomTabFrags > 0) ? 3 : 0;        
 constexpr int kMomTabWords = (kMomTabFrags - kMomHalf) * kWave + kMomHalf * (kWave / 2);   // uint4 entries of the table
 template <bool MOMENTS, class LDS>
 __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Frags], const half8v (&fmr)[kBank3Frags],
-                                             const uint4* __restrict__ ctab, const int offs, const int l) {
+                                             const uint4* __restrict__ ctab, const int offs, const int l, const int ch = 0) {
   const int bb = l & 15, g = l >> 4;
   const int i0 = offs + 8 * bb + 8 * g;
   half8v xh[3], xl[3];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
     const int ix = (i0 + 32 * ks) & (kRingH - 1);
-    xh[ks] = *reinterpret_cast<const half8v*>(&L.img[0][ix]);
-    xl[ks] = *reinterpret_cast<const half8v*>(&L.img[1][ix]);
+    xh[ks] = *reinterpret_cast<const half8v*>(&L.img[2 * ch][ix]);
+    xl[ks] = *reinterpret_cast<const half8v*>(&L.img[2 * ch + 1][ix]);
   }
   const uint4* ct = ctab + l;
   auto frag = [&](int f) {
@@ -821,13 +838,14 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
 // the outputs of one row of a placed pass (bank and ring in LDS): MODE 1 fc = 1, MODE 2 modulated images, MODE 3 fc = 1 + the
 // moment correction  -g (cos(pi s) Re Q - sin(pi s) Im Q),  Q = sum_i M_i (i 32 G)^i (alpha_i + i beta_i),  G = pi g, w = G s,
 // alpha_i = 1/(i! (i+1)) - w^2 / (2 i! (i+3)),  beta_i = -w / (i! (i+2))   (tools/sinc3_model.py: 1e-7 for g <= 0.0101)
-template <int MODE, class LDS>
-__device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const float sr, const float epr, const int wsK, const float g0) {
+template <int MODE, int NCH = 1, class LDS>
+__device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const float sr, const float epr, const int wsK, const float g0,
+                                            const int ch = 0) {
   using T32 = TapTab<32>;
   const int sl = ci ^ ((ci >> 3) & 7);
   const int rc = (wsK + ci) & (kRingF - 1);
-  const float* xp = &L.ring[rc];
-  const float xm2 = xp[-2], xm1 = xp[-1], x0 = xp[0], xp1 = xp[1], xp2 = xp[2];
+  const float* xp = &L.ring[NCH * rc + ch];
+  const float xm2 = xp[-2 * NCH], xm1 = xp[-NCH], x0 = xp[0], xp1 = xp[NCH], xp2 = xp[2 * NCH];
   const float q = sr * sr, q64 = 64.0f * q;
   const float R1 = fast_rcp(fmaf(q, T32::B[1], T32::A[1])), R2 = fast_rcp(fmaf(q, T32::B[2], T32::A[2]));
   if (MODE == 1 || MODE == 3) {
@@ -949,6 +967,28 @@ __device__ __forceinline__ bool s3_convert(LDS& L, const int chunk, const int l,
   return ok;
 }
 
+// Stereo ring (frames left, right): channel `ch` of one chunk -> that channel's float16 images.  `mirrors`: the call also keeps the
+// ring's mirror frames (both channels': the caller converts channel 0 of a chunk first).
+template <class LDS>
+__device__ __forceinline__ bool s3_convert_ch(LDS& L, const int chunk, const int l, const int ch, const bool mirrors) {
+  const int wi = chunk * kPass + 2 * l;
+  const int ix = wi & (kRingF - 1), ih = wi & (kRingH - 1);
+  const float4v xx = *reinterpret_cast<const float4v*>(&L.ring[2 * ix]);
+  const float x0 = ch ? xx[1] : xx[0], x1 = ch ? xx[3] : xx[2];
+  const float am = fmaxf(fabsf(x0), fabsf(x1));
+  const bool ok = !(__ballot(!(fabsf(x0) < 32768.0f) || !(fabsf(x1) < 32768.0f)) != 0ull ||
+                    (__ballot(am >= kQuiet) == 0ull && __ballot(am > 0.0f) != 0ull));
+  if (mirrors) {
+    if ((chunk & 7) == 0 && l < 2) *reinterpret_cast<float4v*>(&L.ring_tail[2 * ix]) = xx;
+    if ((chunk & 7) == 7 && l == kWave - 1) *reinterpret_cast<float4v*>(&L.ring_head[4]) = xx;
+  }
+  const half2v h = {S2_HI(x0), S2_HI(x1)};
+  const half2v lo = {(_Float16)((x0 - (float)h[0]) * 4096.0f), (_Float16)((x1 - (float)h[1]) * 4096.0f)};
+  *reinterpret_cast<half2v*>(&L.img[2 * ch][ih]) = h;
+  *reinterpret_cast<half2v*>(&L.img[2 * ch + 1][ih]) = lo;
+  return ok;
+}
+
 // GENK = true: both tap regimes (two waves per SIMD: 15.5 KB of LDS and the fc < 1 path's registers).  GENK = false: fc = 1
 // passes only, tiles that hold an fc < 1 pass go to the block kernel's list (three waves per SIMD).
 // MOM = true (GENK = false): fc < 1 passes as fc = 1 + the moment correction (one image, no g0, no restarts; valid for
@@ -960,10 +1000,20 @@ constexpr float kEpMaxMom = 0.0125f / (1.0f - 0.0125f);      // period - 1 at 1 
 // VGPRs without spills.  Measured (fc < 1 / fc = 1 tapes): 96 / 137 Gsamples/s at 11 waves, 94 / 146 at 8, against 104.5 / 154
 // for one-wave workgroups with all 25 fragments in registers: a workgroup that owns the whole LDS of its compute unit starts
 // and ends as one (table load, cold start of every stream, the stragglers' tail: nothing else can start meanwhile).
-template <bool GENK, bool MOM>
+#ifndef PAR_S3_SB
+#define PAR_S3_SB 31
+#endif
+#ifndef PAR_S3_SHARE_OUT
+#define PAR_S3_SHARE_OUT 1
+#endif
+#ifndef PAR_S3_X
+#define PAR_S3_X 0
+#endif
+#define S3_SB(k) do { if ((PAR_S3_SB) & (k)) __builtin_amdgcn_sched_barrier(0); } while (0)
+template <bool GENK, bool MOM, int NCH = 1>
 struct S3Shared {
   uint4 fmtab[(MOM && kMomTabFrags > 0) ? kMomTabWords : 1];
-  S3LdsT<GENK, MOM> per[MOM ? PAR_S3_MOM_WAVES : 1];
+  S3LdsT<GENK, MOM, NCH> per[MOM ? PAR_S3_MOM_WAVES : 1];
 };
 #ifndef PAR_S3_NUM_VGPR
 #define PAR_S3_NUM_VGPR 0                           // experiment: cap the kernels' VGPRs below what the launch bounds allow
@@ -973,14 +1023,15 @@ struct S3Shared {
 #else
 #define S3_VGPR_CAP
 #endif
-template <bool GENK, bool MOM>
+template <bool GENK, bool MOM, int NCH = 1>
 __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S3_MOM_WAVES > 1) ? 1 : ((GENK || MOM) ? 2 : PAR_S3_UNITY_WAVES)) S3_VGPR_CAP void k_sinc_pipe(const S2Args a) {
   static_assert(!(GENK && MOM), "one form of the fc < 1 path per kernel");
+  static_assert(NCH == 1 || (NCH == 2 && MOM && PAR_S3_MOM_WAVES == 1), "stereo: the moment form, one stream per workgroup");
   constexpr int NW = MOM ? PAR_S3_MOM_WAVES : 1;
-  __shared__ S3Shared<GENK, MOM> SH;
+  __shared__ S3Shared<GENK, MOM, NCH> SH;
   const int l = threadIdx.x & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  S3LdsT<GENK, MOM>& L = SH.per[wv];
+  S3LdsT<GENK, MOM, NCH>& L = SH.per[wv];
   if constexpr (MOM && kMomTabFrags > 0) {
     const uint4* src2 = reinterpret_cast<const uint4*>(kBank2Frags32);
     const uint4* src3 = reinterpret_cast<const uint4*>(kBank3Frags32);
@@ -1033,7 +1084,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
   }
   const float tolf = (float)((fabs((double)A0) + 2.0e7) * 1.2e-16 + 2.0e-10) + 2.0e-7f;
   const int nJ = (int)(Jb - Ja);
-  float* const outW = a.out + Ja;
+  float* const outW = a.out + NCH * Ja;
   const uint4* const recW = reinterpret_cast<const uint4*>(a.rec) + (Ja >> kRecShift);
   const uint4* const rec2W = reinterpret_cast<const uint4*>(a.rec2) + (Ja >> kRecShift);
   const int blk_max = (int)(((a.len_out + kRec - 1) >> kRecShift) - (Ja >> kRecShift)) - 1;      // last block with a record, relative
@@ -1057,7 +1108,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
   const float* ring_src = a.sig;                 // &sig[A0 + wbase]
   auto ring_restart = [&]() {
     const long long o = A0 + wbase;
-    ring_src = a.sig + o;
+    ring_src = a.sig + NCH * o;
     const long long klo = o >= 0 ? 0 : (-o + kPass - 1) / kPass, khi = ((long long)a.len_in - o) / kPass - 1;
     dma_klo = (int)(klo > 0x3fffffff ? 0x3fffffff : klo);
     dma_khi = (int)(khi > 0x3fffffff ? 0x3fffffff : (khi < -1 ? -1 : khi));
@@ -1066,8 +1117,9 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
   auto chunk_dma = [&](int k) {
     const bool inside = k >= dma_klo && k <= dma_khi;
     if (!inside) dma_bad = k < dma_bad ? k : dma_bad;
-    const float* src = inside ? ring_src + (long long)kPass * k : a.sig;      // (a.sig: len_in >= 128 for every file this kernel is launched on)
-    dma_chunk128(src, lane_bytes, &L.ring[(k & 7) * kPass]);
+    const float* src = inside ? ring_src + (long long)(kPass * NCH) * k : a.sig;      // (a.sig: len_in >= 128 for every file this kernel is launched on)
+    if constexpr (NCH == 2) dma_chunk256(src, lane_bytes, &L.ring[(k & 7) * (kPass * 2)]);
+    else dma_chunk128(src, lane_bytes, &L.ring[(k & 7) * kPass]);
   };
   auto push_tile = [&](int64_t T) {
     if (l == 0) {
@@ -1128,20 +1180,45 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
   P.c[0] = P.c[1] = 0;
   P.s[0] = P.s[1] = P.ep[0] = P.ep[1] = 0.0f;
 
-  auto out_pass = [&](auto mode_tag, const S3Pass& Q, float (&res)[2]) {
+  auto out_pass = [&](auto mode_tag, const S3Pass& Q, float (&res)[2], const int ch = 0) {
     constexpr int MODE = decltype(mode_tag)::value;
     const int wsK = Q.ws - wbase;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       int ci = Q.c[r] - Q.ws;
       ci = ci < 0 ? 0 : (ci > kPass - 1 ? kPass - 1 : ci);
-      res[r] = s3_out_row<MODE>(L, ci, Q.s[r], Q.ep[r], wsK, g0);
+      float sr = Q.s[r], epr = Q.ep[r];
+#if !PAR_S3_SHARE_OUT
+      // Stereo, second channel: the ~25 channel-independent values of a row (reciprocals, sin(pi s)/s, the moment step's
+      // coefficients) are worked out again -- kept from channel 0's turn they would stay live through a bank, 50 registers the
+      // kernel does not have (the constant fragments would go to scratch: 8 reloads per iteration, measured 108 against 115 G)
+      if (NCH == 2 && ch == 1) asm volatile("" : "+v"(sr), "+v"(epr));
+#endif
+      res[r] = s3_out_row<MODE, NCH>(L, ci, sr, epr, wsK, g0, ch);
     }
   };
   auto store_pass = [&](const S3Pass& Q, const float (&res)[2]) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
       if (l < Q.nok[r] && !(PAR_S2_EXP & 4)) outW[(unsigned)Q.j + 64u * r + (unsigned)l] = res[r];
+  };
+  auto store_pass2 = [&](const S3Pass& Q, const float (&res0)[2], const float (&res1)[2]) {      // stereo: a frame per lane and row
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (l < Q.nok[r] && !(PAR_S2_EXP & 4))
+        reinterpret_cast<float2*>(outW)[(unsigned)Q.j + 64u * r + (unsigned)l] = make_float2(res0[r], res1[r]);
+  };
+  // one chunk of the ring -> float16 image(s); stereo: both channels of the chunk
+  auto convert_chunk = [&](int chunk) -> bool {
+    if constexpr (NCH == 2) {
+      const bool ok0 = s3_convert_ch(L, chunk, l, 0, true);
+      const bool ok1 = s3_convert_ch(L, chunk, l, 1, false);
+      return ok0 && ok1;
+    } else if constexpr (GENK) {
+      return mode == 1 ? s3_convert<1>(L, chunk, l, g0) : s3_convert<2>(L, chunk, l, g0);
+    } else {
+      return s3_convert<1>(L, chunk, l, g0);
+    }
   };
 
   // ---- the cold path: places, converts for, banks and -- unless it is a full pass the loop can take -- finishes the pass
@@ -1246,9 +1323,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
               skip = true;
               break;
             }
-            bool ok;
-            if constexpr (GENK) ok = mode == 1 ? s3_convert<1>(L, conv_next, l, g0) : s3_convert<2>(L, conv_next, l, g0);
-            else ok = s3_convert<1>(L, conv_next, l, g0);
+            const bool ok = convert_chunk(conv_next);
             if (!ok) {
               skip = true;
               break;
@@ -1289,7 +1364,18 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
         if constexpr (MOM) out_pass(std::integral_constant<int, 3>{}, N, res);
       } else if (!GENK || mode == 1) out_pass(std::integral_constant<int, 1>{}, N, res);
       else if constexpr (GENK) out_pass(std::integral_constant<int, 2>{}, N, res);
-      store_pass(N, res);
+      if constexpr (NCH == 2 && !(PAR_S3_X & 1)) {                   // the other channel through the same rows
+        float res1[2];
+        wave_lds_fence();
+        if (regime == 3) bank_image3m<true>(L, fr, fmr, fm, offs, l, 1);
+        else bank_image3m<false>(L, fr, fmr, fm, offs, l, 1);
+        wave_lds_fence();
+        if (regime == 3) out_pass(std::integral_constant<int, 3>{}, N, res1, 1);
+        else out_pass(std::integral_constant<int, 1>{}, N, res1, 1);
+        store_pass2(N, res, res1);
+      } else {
+        store_pass(N, res);
+      }
     }
   };
 
@@ -1315,7 +1401,8 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
 #if PAR_S2_EXP & 64
       const unsigned long long tA_ = __builtin_readcyclecounter();
 #endif
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      if constexpr (NCH == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");      // (seven memory operations per iteration)
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
 #if PAR_S2_EXP & 64
       const unsigned long long tB_ = __builtin_readcyclecounter();
       s3t_[0] += tB_ - tA_;
@@ -1325,12 +1412,15 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
 #endif
       wave_lds_fence();
       // PLACE(pk): the pass behind P
+      S3Pass N;
+      bool ok;
+      int wsK;
+      auto place_next = [&]() {
       const Placed Q = place(j0, pk & 3, rbA);
       const unsigned long long bad = __ballot(Q.R[0].bad || Q.R[1].bad);
       // some lane with fc < 1: 1 + ep != 1 in float32, i.e. ep > 2^-24 (ep >= 0)
       const unsigned long long gen = __ballot(fmaxf(Q.R[0].ep, Q.R[1].ep) > 5.9604645e-8f);
       const int ws = __builtin_amdgcn_readfirstlane(Q.R[0].c) & ~7;
-      S3Pass N;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         N.c[r] = Q.R[r].c;
@@ -1340,35 +1430,66 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
       }
       N.j = j0;
       N.ws = ws;
-      const int wsK = ws - wbase;
+      wsK = ws - wbase;
       const int d = kPass * conv_next - wsK;      // image converted up to d samples beyond the first bank centre
       // (bitwise: one chain of scalar operations, no branch per term; >= 120 finished outputs imply a full first row)
-      bool ok = (((Q.fl0 | Q.fl1) & 1) == 0) & (bad == 0ull) & (j0 + kPass <= nJ) & (N.nok[0] + N.nok[1] >= 120) &
-                (MODE == 1 ? gen == 0ull : gen != 0ull) & ((unsigned)(d - 161) <= 312u) & (conv_next + 1 < dma_bad) &
-                ((unsigned)((j0 >> kRecShift) - rbA) <= 1u);
+      ok = (((Q.fl0 | Q.fl1) & 1) == 0) & (bad == 0ull) & (j0 + kPass <= nJ) & (N.nok[0] + N.nok[1] >= 120) &
+           (MODE == 1 ? gen == 0ull : gen != 0ull) & ((unsigned)(d - 161) <= 312u) & (conv_next + 1 < dma_bad) &
+           ((unsigned)((j0 >> kRecShift) - rbA) <= 1u);
       if (MODE == 2) {
         const float g_0 = N.ep[0] * fast_rcp(1.0f + N.ep[0]), g_1 = N.ep[1] * fast_rcp(1.0f + N.ep[1]);
         ok = ok && __ballot(!(fabsf(g0 - g_0) <= kEpsTol) || !(fabsf(g0 - g_1) <= kEpsTol)) == 0ull;
       }
+      };
+      if constexpr (NCH == 1) place_next();       // (stereo: behind OUT(P, 1), fewer registers live through the banks)
       // BANK(pk) over [ws, ws + 128): image samples converted in earlier iterations
       // OUT(P) first in program order: its gathers must precede the bank's row writes
       float res[2];
       out_pass(mode_tag, P, res);
-      const int offs = wsK - 31;
-      if constexpr (MOM) {
-        s3_sched_fence();
-        bank_image3m<MODE == 3>(L, fr, fmr, fm, offs, l);
-        s3_sched_fence();
+      bool cok;
+      if constexpr (NCH == 2) {
+        // Stereo.  The bank rows in LDS hold ONE channel of one pass at a time: on entry channel 0 of P (banked by the previous
+        // iteration or by the cold path).  OUT(P, 0) above has gathered them; now BANK(P, 1) -> OUT(P, 1) -> BANK(N, 0), each after
+        // the reads of what it overwrites in program order.  Channel 1's image therefore runs one chunk behind channel 0's: its
+        // bank of a pass sees the image exactly as channel 0's bank of that pass did one iteration earlier.
+        float res1[2];
+        // (pinned here: left alone the compiler sinks a row's arithmetic into the store's lane mask at the END of the iteration,
+        // and the gathered rows and ring samples of both channels stay live through the banks: 33 registers in scratch)
+        asm volatile("" : "+v"(res[0]), "+v"(res[1]));
+        S3_SB(1);        // (the stages one after the other: interleaved they do not fit the registers)
+        bank_image3m<MODE == 3>(L, fr, fmr, fm, P.ws - wbase - 31, l, 1);
+        S3_SB(2);
+        out_pass(mode_tag, P, res1, 1);
+        asm volatile("" : "+v"(res1[0]), "+v"(res1[1]));
+        S3_SB(4);
+        place_next();
+        const int offs = wsK - 31;
+        S3_SB(8);
+        bank_image3m<MODE == 3>(L, fr, fmr, fm, offs, l, 0);
+        S3_SB(16);
+        const bool c0 = s3_convert_ch(L, conv_next, l, 0, true);
+        const bool c1 = s3_convert_ch(L, conv_next - 1, l, 1, false);
+        cok = c0 && c1;
+        fetch_records((pk + 2) & 3, rbC);
+        chunk_dma(dma_next);
+        store_pass2(P, res, res1);
       } else {
-        bank_image3<MODE == 2>(L, fr, offs, l, 0);
-        if constexpr (MODE == 2) bank_image3<true>(L, fr, offs, l, 1);
+        const int offs = wsK - 31;
+        if constexpr (MOM) {
+          s3_sched_fence();
+          bank_image3m<MODE == 3>(L, fr, fmr, fm, offs, l);
+          s3_sched_fence();
+        } else {
+          bank_image3<MODE == 2>(L, fr, offs, l, 0);
+          if constexpr (MODE == 2) bank_image3<true>(L, fr, offs, l, 1);
+        }
+        // CONV: one chunk per iteration
+        cok = s3_convert<MODE == 2 ? 2 : 1>(L, conv_next, l, g0);
+        // FETCH + stores: records of pass pk + 2, chunk conv_next + 2, then P's outputs (five memory operations, in this order)
+        fetch_records((pk + 2) & 3, rbC);
+        chunk_dma(dma_next);
+        store_pass(P, res);
       }
-      // CONV: one chunk per iteration
-      const bool cok = s3_convert<MODE == 2 ? 2 : 1>(L, conv_next, l, g0);
-      // FETCH + stores: records of pass pk + 2, chunk conv_next + 2, then P's outputs (five memory operations, in this order)
-      fetch_records((pk + 2) & 3, rbC);
-      chunk_dma(dma_next);
-      store_pass(P, res);
       wave_lds_fence();
       ++conv_next;
       ++dma_next;
@@ -1387,7 +1508,12 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
         else S3_COUNT(8);
       }
 #endif
-      if (!(ok && cok)) return;
+      if (!(ok && cok)) {
+        // stereo: channel 1's image catches up with channel 0's before the cold path takes over
+        if constexpr (NCH == 2 && !(PAR_S3_X & 2))
+          if (mode != 0 && !s3_convert_ch(L, conv_next - 1, l, 1, false)) mode = 0;
+        return;
+      }
       // N becomes P
       P = N;
       j0 += N.nok[0] + N.nok[1];
@@ -1419,7 +1545,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
 }
 
 int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
-                       hipStream_t s, int variant) {
+                       hipStream_t s, int variant, int nch) {
   (void)device;
   S2Args a;
   a.len_out = len_out;
@@ -1458,7 +1584,13 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
 #else
   (void)variant;
 #endif
-  if (grid > 0)
+  if (grid > 0 && nch == 2) {
+#if PAR_S3_MOM_WAVES == 1
+    hipLaunchKernelGGL((k_sinc_pipe<false, true, 2>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
+#else
+    return PAR_ERR_ARG;
+#endif
+  } else if (grid > 0)
     hipLaunchKernelGGL((k_sinc_pipe<false, true>), dim3((unsigned)ceil_div(grid, (int64_t)PAR_S3_MOM_WAVES)), dim3(kWave * PAR_S3_MOM_WAVES), 0, s, a);
   else if (a.n_tiles > 0) {
     // nothing but a partial tile: the caller's block kernel handles short files (launch_sinc_fused never comes here)

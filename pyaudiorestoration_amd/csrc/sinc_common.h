@@ -46,9 +46,9 @@ struct FusedArgs {
   int* redo_list;
 };
 
-// Streaming kernel (sinc2.hip): mono, NT = 32, unit strides.  Tiles it does not take are appended to fa.redo_list.
-// variant 1: k_sinc_stream (one pass after the other), 2: k_sinc_pipe (stages of different passes in one iteration)
+// Streaming kernel (sinc2.hip): NT = 32; nch = 1: a mono signal on unit strides, nch = 2: an interleaved stereo file (sig / out
+// point at the left channel's first sample; len_in / len_out count frames).  Tiles it does not take are appended to fa.redo_list.
 int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
-                       hipStream_t s, int variant);
+                       hipStream_t s, int variant, int nch);
 
 }  // namespace par

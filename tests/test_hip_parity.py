@@ -1770,7 +1770,15 @@ def test_full_size_config5_work_item(par):
     expect = (ind - 32 <= bad) & (bad < ind + 32)
     assert 60 <= int(expect.sum()) <= 68
     assert t.equal(t.isnan(out_n[:, 1]), expect) and not bool(t.isnan(out_n[:, 0]).any())
-    assert t.equal(out_n[:, 0], out[:, 0]) and t.equal(out_n[:, 1][~expect], out[:, 1][~expect])
+    # elsewhere the NaN changes nothing, bit for bit -- except in the tiles around it, which the streaming kernel hands to the
+    # block kernel (BOTH channels of them) when it meets input float16 cannot carry: same numbers to float32 rounding
+    jn = int(t.nonzero(expect)[0])
+    far = t.ones_like(expect)
+    far[max(0, jn - 16384):jn + 16384] = False
+    assert t.equal(out_n[:, 0][far], out[:, 0][far]) and t.equal(out_n[:, 1][far], out[:, 1][far])
+    near = ~far & ~expect
+    for c in range(2):
+        assert float((out_n[:, c][near] - out[:, c][near]).abs().max()) <= FUSED_TOL * float(out[:, c].abs().max()), c
 
 
 def test_config4_x256_tiles_one_launch(par):
