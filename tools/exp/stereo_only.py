@@ -7,7 +7,7 @@ from pyaudiorestoration_amd import _dev, _lib
 L = _lib.lib()
 if os.environ.get("PAR_BLOCK"):
     L.par_debug_sinc_kernel(0)      # the stereo block kernel instead of two strided streaming launches
-dev, sr, seconds, nt = 0, 192000, 300.0, int(os.environ.get("NT", "32"))
+dev, sr, seconds, nt = 0, 192000, float(os.environ.get("SECONDS_", "300")), int(os.environ.get("NT", "32"))
 s = _dev.stream_ptr(dev)
 n = int(sr * seconds); m = int(seconds * sr / 256)
 mono = torch.empty(n, dtype=torch.float32, device="cuda")
