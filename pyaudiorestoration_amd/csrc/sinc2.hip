@@ -28,6 +28,7 @@
 #include "pos_plan.h"
 #include "sinc_taps_gen.h"
 #include "sinc_common.h"
+#include "sinc_block.h"           // fused_wave: the file's end tiles are done the block kernel's way by the launch's first workgroups
 #include <algorithm>
 #include <limits.h>
 #include <type_traits>
@@ -103,7 +104,18 @@ struct S2Args {
   int64_t n_big;                                 // streams, so that the GPU does not idle behind a few long ones)
   int64_t n_full;                                // full tiles of the file
   int64_t n_tiles;                               // tiles with a header
+  // The file's END tiles -- the first (its ring would reach in front of the file), the last two full ones (... behind it) and the
+  // partial one -- are not streamed: the launch's first n_edge workgroups do them the block kernel's way (fused_wave, sinc_block.h),
+  // 128 outputs each, BESIDE the streams.  (Through the tile list they cost 50 us behind every launch: cold code -- the masked
+  // path of the last wave, the float64 slow path of the first outputs -- fetched by one wave while the GPU idles, r05.)
+  int n_edge;
+  FusedArgs fa;
+  const float4* tab;
+  TapModes tmd;
 };
+constexpr int kEdgeWaveOut = 128;                                   // outputs per end-tile workgroup (one wave)
+constexpr int kEdgeWavesPerTile = kSincTileOutputs / kEdgeWaveOut;
+constexpr int kTileEdge = 0x100;                                    // (kernel-local header flag: an end tile, nobody pushes it)
 
 __device__ __forceinline__ float sinpi_poly(float z) {       // sin(pi x) / x as a polynomial in z = x^2, |x| <= 0.52
   float p = -0.00737043094f;
@@ -276,6 +288,7 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
     A0 = __shfl(h.anchor, 0, kWave);
     const long long d = h.anchor - A0;
     hd_fl = h.flags | ((d > -0x40000000ll && d < 0x40000000ll) ? 0 : 1);
+    if (a.n_edge > 0 && (Ta + l == 0 || Ta + l >= a.n_full - 2)) hd_fl |= 1 | kTileEdge;      // end tiles: not streamed, not pushed
     hd_dA = (int)d;
   }
   // images start zeroed: the bank reads up to 88 samples beyond what a pass has converted (against zero coefficients)
@@ -1047,7 +1060,24 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
     }
     __syncthreads();
   }
-  const int64_t stream_id = (int64_t)blockIdx.x * NW + wv;
+  if constexpr (NW == 1 && MOM) {
+    if ((int)blockIdx.x < a.n_edge) {             // an end tile's wave: tile 0, then n_full - 2, n_full - 1 and the partial one
+      const int e = (int)blockIdx.x / kEdgeWavesPerTile, w = (int)blockIdx.x % kEdgeWavesPerTile;
+      const int64_t T = e == 0 ? 0 : a.n_full - 3 + e;
+      const int64_t jw = T * kSincTileOutputs + (int64_t)w * kEdgeWaveOut;
+      const int nrem = (int)(a.len_out - jw < (int64_t)kEdgeWaveOut ? (a.len_out - jw > 0 ? a.len_out - jw : 0) : kEdgeWaveOut);
+      float* const piece = reinterpret_cast<float*>(&SH);
+      static_assert(sizeof(SH) >= fused_capw(2 * NCH, NCH) * NCH * sizeof(float), "the wave's span fits the stream's LDS");
+      if (nrem == kEdgeWaveOut)
+        fused_wave<NCH, 32, 2 * NCH, true>(a.len_out, a.sig, a.sig + 1, NCH, a.len_in, 32, a.tab, a.tmd, a.out, a.out + 1, NCH, a.fa, piece, l,
+                                           jw, nrem, piece);
+      else if (nrem > 0)
+        fused_wave<NCH, 32, 2 * NCH, false>(a.len_out, a.sig, a.sig + 1, NCH, a.len_in, 32, a.tab, a.tmd, a.out, a.out + 1, NCH, a.fa, piece, l,
+                                            jw, nrem, piece);
+      return;
+    }
+  }
+  const int64_t stream_id = ((int64_t)blockIdx.x - (NW == 1 && MOM ? a.n_edge : 0)) * NW + wv;
   const int my_tiles = stream_id < a.n_big ? a.tiles : a.tiles_tail;
   const int64_t Ta = stream_id < a.n_big ? stream_id * a.tiles : a.n_big * a.tiles + (stream_id - a.n_big) * a.tiles_tail;
   if (Ta >= a.n_full) return;
@@ -1074,6 +1104,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
     A0 = __shfl(h.anchor, 0, kWave);
     const long long d = h.anchor - A0;
     hd_fl = h.flags | ((d > -0x40000000ll && d < 0x40000000ll) ? 0 : 1);
+    if (a.n_edge > 0 && (Ta + l == 0 || Ta + l >= a.n_full - 2)) hd_fl |= 1 | kTileEdge;      // end tiles: not streamed, not pushed
     hd_dA = (int)d;
   }
   {
@@ -1127,7 +1158,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
       a.redo_list[slot] = (int)T;
     }
   };
-  if (stream_id == 0 && a.n_full < a.n_tiles) push_tile(a.n_full);
+  if (stream_id == 0 && a.n_full < a.n_tiles && a.n_edge == 0) push_tile(a.n_full);
 
   // placement of the pass that starts at output j from record buffer `buf` (first block rb); the lanes' tile anchors
   struct Placed {
@@ -1334,7 +1365,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
         if (!skip && conv_next + 1 >= dma_bad) skip = true;      // the loop would convert a chunk that was never fetched
       }
       if (skip) {
-        push_tile(Ta + (j0 >> 10));
+        if (!(Q.fl0 & kTileEdge)) push_tile(Ta + (j0 >> 10));
         j0 = tend;
         mode = 0;
         continue;
@@ -1545,7 +1576,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
 }
 
 int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
-                       hipStream_t s, int variant, int nch) {
+                       const float4* tab, const TapModes& tmd, hipStream_t s, int variant, int nch) {
   (void)device;
   S2Args a;
   a.len_out = len_out;
@@ -1557,8 +1588,13 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
   a.rec2 = fa.rec2;
   a.redo_count = fa.redo_count;
   a.redo_list = fa.redo_list;
+  a.fa = fa;
+  a.tab = tab;
+  a.tmd = tmd;
   a.n_full = len_out / kSincTileOutputs;
   a.n_tiles = ceil_div(len_out, kSincTileOutputs);
+  // (launch_sinc_fused only comes here with >= 4 full tiles: the end tiles are distinct)
+  a.n_edge = (PAR_S3_MOM_WAVES == 1 && variant == 4 && a.n_full >= 4) ? (int)(3 + (a.n_tiles - a.n_full)) * kEdgeWavesPerTile : 0;
   // Tiles per wave of the pipelined kernel: long streams amortise a wave's cold start and, beside a batch driver's plan kernels,
   // leave fewer wave boundaries for them to slip into -- 60-min file, ms per pipelined step: 4 tiles 5.03, 8: 4.84, 12: 4.70,
   // 16: 4.66, 24: 4.61, 32: 5.06 (10.3 rounds of the 2 048 wave slots: the last one nearly empty), 48: 4.67 (r05) -- while a
@@ -1586,12 +1622,12 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
 #endif
   if (grid > 0 && nch == 2) {
 #if PAR_S3_MOM_WAVES == 1
-    hipLaunchKernelGGL((k_sinc_pipe<false, true, 2>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
+    hipLaunchKernelGGL((k_sinc_pipe<false, true, 2>), dim3((unsigned)(grid + a.n_edge)), dim3(kWave), 0, s, a);
 #else
     return PAR_ERR_ARG;
 #endif
   } else if (grid > 0)
-    hipLaunchKernelGGL((k_sinc_pipe<false, true>), dim3((unsigned)ceil_div(grid, (int64_t)PAR_S3_MOM_WAVES)), dim3(kWave * PAR_S3_MOM_WAVES), 0, s, a);
+    hipLaunchKernelGGL((k_sinc_pipe<false, true>), dim3((unsigned)(ceil_div(grid, (int64_t)PAR_S3_MOM_WAVES) + a.n_edge)), dim3(kWave * PAR_S3_MOM_WAVES), 0, s, a);
   else if (a.n_tiles > 0) {
     // nothing but a partial tile: the caller's block kernel handles short files (launch_sinc_fused never comes here)
   }

@@ -48,7 +48,8 @@ struct FusedArgs {
 
 // Streaming kernel (sinc2.hip): NT = 32; nch = 1: a mono signal on unit strides, nch = 2: an interleaved stereo file (sig / out
 // point at the left channel's first sample; len_in / len_out count frames).  Tiles it does not take are appended to fa.redo_list.
+struct TapModes;
 int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
-                       hipStream_t s, int variant, int nch);
+                       const float4* tab, const TapModes& tmd, hipStream_t s, int variant, int nch);
 
 }  // namespace par
