@@ -575,7 +575,7 @@ def main():
     if block_kernel:
         L.par_debug_sinc_kernel(0)                                 # A/B knob: the block kernel for the mono NT = 32 file too
     streaming = fused and a.nt == 32 and not block_kernel          # what par_varispeed_fused_f32 launches for this workload
-    kernel_symbols = (["k_sinc_pipe<false, true>", "k_sinc_fused_list"] if streaming else
+    kernel_symbols = (["k_sinc_pipe<false, true, 1>", "k_sinc_fused_list"] if streaming else
                       [f"k_sinc_fused<1, {a.nt if a.nt in (32, 50) else 0}, 4>"] if fused else
                       [f"k_sinc_pos<{a.nt if a.nt in (32, 50) else 0}>"])
     state_plan = {"lazy": False}

@@ -232,27 +232,30 @@ int par_varispeed_fused_f32(int device, const double* speeds, int64_t m, const v
                             int64_t max_out, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in,
                             int NT, float* out, int64_t out_stride, void* stream);
 
-/* Which kernel runs: mono NT = 32 files on unit strides of at least four 1024-output tiles and 4096 input samples take the
- * streaming kernel (csrc/sinc2.hip: one wave per eight tiles, the taps |n| >= 3 of both tap regimes as fixed filter banks on the
- * matrix cores, fc < 1 through seven moment filters) and hand the tiles it does not cover -- blocks outside the record model,
- * window-centre ties, input float16 does not suit, the file's ends -- to the block kernel (csrc/sinc.hip) through a tile list in
- * `aux`; everything else (stereo, other NT, strided views, short files) takes the block kernel.  Results agree within the
- * contract's tolerance and every window centre is the reference's either way.  K_sinc WRITES that list into `aux`: one
- * par_varispeed_fused_* launch per plan at a time (two launches of one plan on different streams would race on it). */
+/* Which kernel runs: NT = 32 files of at least four 1024-output tiles and 4096 input samples -- mono on unit strides, or
+ * (par_varispeed_fused_stereo_f32) the two channels of an INTERLEAVED file (sig1 = sig0 + 1, out1 = out0 + 1, strides 2, out0
+ * 8-byte aligned) -- take the streaming kernel (csrc/sinc2.hip: one wave per 8-24 tiles, the taps |n| >= 3 of both tap regimes
+ * as fixed filter banks on the matrix cores, fc < 1 through seven moment filters; stereo: one placement for both channels).  The
+ * file's end tiles (first, last two, the partial one) are done the block kernel's way by the first workgroups of the same
+ * launch; tiles the streams do not cover -- blocks outside the record model, window-centre ties, input float16 does not suit --
+ * go to the block kernel (csrc/sinc.hip, sinc_block.h) through a tile list in `aux`.  Everything else (other NT, strided or
+ * planar channel pairs, short files) takes the block kernel.  Results agree within the contract's tolerance and every window
+ * centre is the reference's either way.  K_sinc WRITES that list into `aux`: one par_varispeed_fused_* launch per plan at a time
+ * (two launches of one plan on different streams would race on it). */
 
 /* Process-wide choice of that kernel, for tests and A/B sessions: form -1 = the default above, 0 = the block kernel for
  * everything.  Returns the previous setting. */
 int par_debug_sinc_kernel(int form);
 
-/* Diagnostic: how many 1024-output tiles of the LAST par_varispeed_fused_f32 launch on this aux buffer the streaming kernel
- * (mono, NT = 32, unit strides) handed to the block kernel (blocks outside the record model, window-centre ties, input that
- * float16 does not suit, the file's ends).  Synchronises the stream.  0 when the streaming kernel did not run (the plan
- * zeroes the count). */
+/* Diagnostic: how many 1024-output tiles of the LAST par_varispeed_fused_* launch on this aux buffer the streaming kernel
+ * handed to the block kernel's tile list (blocks outside the record model, window-centre ties, input that float16 does not
+ * suit).  Synchronises the stream.  0 when the streaming kernel did not run (the plan zeroes the count). */
 int par_fused_redo_tiles(int device, const void* aux, int64_t max_out, int64_t m, int* tiles, void* stream);
 
 /* Stereo form: two channels of ONE file (same positions; sig0/sig1 and out0/out1 share the strides -- e.g. the two
  * columns of an interleaved (n, 2) array: sig1 = sig0 + 1, stride 2) in one launch.  Outputs equal two
- * par_varispeed_fused_f32 calls to float32 rounding (the lane/output map differs); position regeneration, prologue and tap weights are evaluated once for both. */
+ * par_varispeed_fused_f32 calls to float32 rounding (the lane/output map differs); position regeneration, prologue and tap
+ * weights are evaluated once for both.  Interleaved NT = 32 files take the streaming kernel's stereo form (see above). */
 int par_varispeed_fused_stereo_f32(int device, const double* speeds, int64_t m, const void* work, const void* aux,
                                    int64_t max_out, int64_t len_out, const float* sig0, const float* sig1,
                                    int64_t sig_stride, int64_t len_in, int NT, float* out0, float* out1,

@@ -1,4 +1,5 @@
-// K_sinc, streaming form (r04) -- the north-star kernel for mono NT = 32 files on unit strides.
+// K_sinc, streaming form (r04) -- the north-star kernel for mono NT = 32 files on unit strides and (r05, NCH = 2) for the two
+// channels of an interleaved NT = 32 stereo file.
 //
 // Semantics: resampling.sinc_core (reference util/resampling.py:51-90), fused with the speed curve like k_sinc_fused (sinc.hip).
 //
@@ -19,10 +20,15 @@
 //   * the input streams through a 512-sample ring per wave: 128-sample chunks are fetched two passes ahead into registers,
 //     converted ONCE (float32 ring for the near taps, float16 hi / lo images for the bank) -- no halo is ever re-read or
 //     re-converted; block records of the next pass are fetched while the current one computes.
-// What the record model or float16 do not cover goes to the block kernel through a tile list (k_sinc_fused_list, sinc.hip):
-// blocks flagged slow, outputs within the reference's own rounding of a half-integer position (window-centre ties), input
-// that is non-finite / >= 32768 / all but silent, chunks that reach over the file's ends.  Every window centre is the
-// reference's rint(p) either way.
+// What the record model or float16 do not cover goes to the block kernel through a tile list (k_sinc_fused_list / _list2,
+// sinc.hip): blocks flagged slow, outputs within the reference's own rounding of a half-integer position (window-centre ties),
+// input that is non-finite / >= 32768 / all but silent.  The file's END tiles (the ring would reach over the file's ends) are
+// not streamed at all: the launch's first workgroups do them the block kernel's way (fused_wave, sinc_block.h) beside the
+// streams.  Every window centre is the reference's rint(p) either way.
+// Stereo (k_sinc_pipe<false, true, 2>): the ring holds frames (left, right); a pass is placed ONCE and both channels are
+// converted, banked and gathered for it -- in ONE set of bank rows, which the channels take turns in (the order of the loop's
+// stages and the one-chunk lag of channel 1's image: see the loop) so that eight streams still fit a compute unit's LDS;
+// outputs leave as 8-byte frames.  177 -> ~140 vector instructions per channel-sample.
 #define PAR_WANT_BANK2 1
 #include "par_common.h"
 #include "pos_plan.h"
@@ -1022,6 +1028,9 @@ constexpr float kEpMaxMom = 0.0125f / (1.0f - 0.0125f);      // period - 1 at 1 
 #ifndef PAR_S3_X
 #define PAR_S3_X 0
 #endif
+#ifndef PAR_S3_PIN_MONO
+#define PAR_S3_PIN_MONO 0
+#endif
 #define S3_SB(k) do { if ((PAR_S3_SB) & (k)) __builtin_amdgcn_sched_barrier(0); } while (0)
 template <bool GENK, bool MOM, int NCH = 1>
 struct S3Shared {
@@ -1506,6 +1515,9 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
         store_pass2(P, res, res1);
       } else {
         const int offs = wsK - 31;
+#if PAR_S3_PIN_MONO
+        asm volatile("" : "+v"(res[0]), "+v"(res[1]));
+#endif
         if constexpr (MOM) {
           s3_sched_fence();
           bank_image3m<MODE == 3>(L, fr, fmr, fm, offs, l);
