@@ -446,7 +446,9 @@ def config5_batch(a, ctx):
         res = {
             "metric": "Msamples/sec resampled (192 kHz varispeed)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 taps / f64 positions (stereo files: the block kernel's vector tap loops)",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": ("f32 near taps, far taps (|n| >= 3) as float16 hi + lo x 2^-12 filter banks on v_mfma_f32_16x16x32_f16 with f32 accumulation / "
+                                                                                      "f64 positions (interleaved stereo files at NT = 32: the streaming kernel's stereo form)" if a.nt == 32 else
+                                                                                      "f32 taps / f64 positions (stereo files at this NT: the block kernel's vector tap loops)"),
             "data": "synthetic",
             "n1_same_workload_value": round(n1, 3), "speedup_vs_n1": round(value / n1, 3),
             "efficiency": round(value / n1 / world, 4), "distinct_devices": ctx.distinct_devices,
@@ -468,7 +470,7 @@ def config5_batch(a, ctx):
                                "(resampling.varispeed_batch_dev)"},
             "roofline": {"bound": "hbm", "achieved": round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / world, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / world / HBM_PEAK_GBS, 5),
-                         "traffic": None, "kernel": "k_sinc_fused<2> (whole step, per GPU)", "limited_by": "valu",
+                         "traffic": None, "kernel": "k_sinc stereo: k_sinc_pipe<false, true, 2> + k_sinc_fused_list2 at NT = 32 (whole step, per GPU)", "limited_by": "valu",
                          "note": "per-GPU whole-step rate x 8 algorithmic B per channel-sample against the HBM roof the contract "
                                  "names; what limits the kernel is VALU issue (the N = 1 line carries the per-kernel HIP-event "
                                  "timing, PMC traffic and the VALU roofline)"},
