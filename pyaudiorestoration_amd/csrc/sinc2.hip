@@ -1019,19 +1019,12 @@ constexpr float kEpMaxMom = 0.0125f / (1.0f - 0.0125f);      // period - 1 at 1 
 // VGPRs without spills.  Measured (fc < 1 / fc = 1 tapes): 96 / 137 Gsamples/s at 11 waves, 94 / 146 at 8, against 104.5 / 154
 // for one-wave workgroups with all 25 fragments in registers: a workgroup that owns the whole LDS of its compute unit starts
 // and ends as one (table load, cold start of every stream, the stragglers' tail: nothing else can start meanwhile).
-#ifndef PAR_S3_SB
-#define PAR_S3_SB 31
-#endif
 #ifndef PAR_S3_SHARE_OUT
-#define PAR_S3_SHARE_OUT 1
-#endif
-#ifndef PAR_S3_X
-#define PAR_S3_X 0
+#define PAR_S3_SHARE_OUT 1      // stereo: 0 = channel 1's row arithmetic worked out afresh (measured: 158 against 165 G on the benchmark's tape)
 #endif
 #ifndef PAR_S3_PIN_MONO
-#define PAR_S3_PIN_MONO 0
+#define PAR_S3_PIN_MONO 0       // 1: the mono loop's row results pinned like the stereo loop's (234 instead of 250 registers, 1 % slower)
 #endif
-#define S3_SB(k) do { if ((PAR_S3_SB) & (k)) __builtin_amdgcn_sched_barrier(0); } while (0)
 template <bool GENK, bool MOM, int NCH = 1>
 struct S3Shared {
   uint4 fmtab[(MOM && kMomTabFrags > 0) ? kMomTabWords : 1];
@@ -1229,9 +1222,8 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
       ci = ci < 0 ? 0 : (ci > kPass - 1 ? kPass - 1 : ci);
       float sr = Q.s[r], epr = Q.ep[r];
 #if !PAR_S3_SHARE_OUT
-      // Stereo, second channel: the ~25 channel-independent values of a row (reciprocals, sin(pi s)/s, the moment step's
-      // coefficients) are worked out again -- kept from channel 0's turn they would stay live through a bank, 50 registers the
-      // kernel does not have (the constant fragments would go to scratch: 8 reloads per iteration, measured 108 against 115 G)
+      // (experiment: channel 1's row arithmetic hidden from the common-subexpression pass.  By default the compiler keeps the
+      // channel-independent values of a row -- reciprocals, sin(pi s)/s, the moment step's coefficients -- from channel 0's turn)
       if (NCH == 2 && ch == 1) asm volatile("" : "+v"(sr), "+v"(epr));
 #endif
       res[r] = s3_out_row<MODE, NCH>(L, ci, sr, epr, wsK, g0, ch);
@@ -1404,7 +1396,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
         if constexpr (MOM) out_pass(std::integral_constant<int, 3>{}, N, res);
       } else if (!GENK || mode == 1) out_pass(std::integral_constant<int, 1>{}, N, res);
       else if constexpr (GENK) out_pass(std::integral_constant<int, 2>{}, N, res);
-      if constexpr (NCH == 2 && !(PAR_S3_X & 1)) {                   // the other channel through the same rows
+      if constexpr (NCH == 2) {                   // the other channel through the same rows
         float res1[2];
         wave_lds_fence();
         if (regime == 3) bank_image3m<true>(L, fr, fmr, fm, offs, l, 1);
@@ -1496,17 +1488,12 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
         // (pinned here: left alone the compiler sinks a row's arithmetic into the store's lane mask at the END of the iteration,
         // and the gathered rows and ring samples of both channels stay live through the banks: 33 registers in scratch)
         asm volatile("" : "+v"(res[0]), "+v"(res[1]));
-        S3_SB(1);        // (the stages one after the other: interleaved they do not fit the registers)
         bank_image3m<MODE == 3>(L, fr, fmr, fm, P.ws - wbase - 31, l, 1);
-        S3_SB(2);
         out_pass(mode_tag, P, res1, 1);
         asm volatile("" : "+v"(res1[0]), "+v"(res1[1]));
-        S3_SB(4);
         place_next();
         const int offs = wsK - 31;
-        S3_SB(8);
         bank_image3m<MODE == 3>(L, fr, fmr, fm, offs, l, 0);
-        S3_SB(16);
         const bool c0 = s3_convert_ch(L, conv_next, l, 0, true);
         const bool c1 = s3_convert_ch(L, conv_next - 1, l, 1, false);
         cok = c0 && c1;
@@ -1553,7 +1540,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
 #endif
       if (!(ok && cok)) {
         // stereo: channel 1's image catches up with channel 0's before the cold path takes over
-        if constexpr (NCH == 2 && !(PAR_S3_X & 2))
+        if constexpr (NCH == 2)
           if (mode != 0 && !s3_convert_ch(L, conv_next - 1, l, 1, false)) mode = 0;
         return;
       }
