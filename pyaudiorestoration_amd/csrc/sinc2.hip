@@ -1,34 +1,37 @@
-// K_sinc, streaming form (r04) -- the north-star kernel for mono NT = 32 files on unit strides and (r05, NCH = 2) for the two
-// channels of an interleaved NT = 32 stereo file.
+// K_sinc, streaming form -- the north-star kernel: NT = 32 files, mono on unit strides (k_sinc_pipe<1>) or the two channels of
+// an interleaved stereo file (k_sinc_pipe<2>, r05).
 //
 // Semantics: resampling.sinc_core (reference util/resampling.py:51-90), fused with the speed curve like k_sinc_fused (sinc.hip).
 //
-// Shape.  ONE WAVE = one worker that streams over kTilesPerWave consecutive 1024-output tiles of the file; waves never meet
-// (no workgroup, no barrier).  A pass takes the next 128 outputs (two per lane), places them from the plan's block records,
-// and evaluates their windows against ONE 128-centre stretch of the input grid [ws, ws + 128), ws = the first centre rounded
-// down to 8; outputs whose centre lies beyond it (a handful: periods differ from 1 by <= 3 %) simply open the next pass.
-//   * taps 3 <= |n| <= 31: a Farrow bank in q = shift^2 (minimax polynomials of (win_n/pi)/(n^2 - q), tools/sinc2_model.py) --
-//     six fixed FIR filters on the input grid, evaluated for the pass's 128 centres on the matrix cores
-//     (v_mfma_f32_16x16x32_f16, signal and dominant filter pair split float16 hi + lo 2^-12: 15 MFMAs), the 13 constant
-//     fragments RESIDENT IN REGISTERS for the life of the wave; the bank goes through the wave's own 6.5 KB of LDS and every
-//     output gathers its centre's row (one 16-byte + one 4-byte read);
-//   * fc < 1 (read head slower than the output clock): the cut-off sits in the numerators sin(pi fc (n - s)); with a
-//     pass-uniform g0 = 1 - fc0 it moves onto the SIGNAL -- two modulated images A_k = x_k sin(pi g0 k), B_k = x_k cos(pi g0 k)
-//     through the same bank, far = -cos(psi) U(A) - sin(psi) U(B) -- and a lane's own deviation eps = fc - fc0 enters through
-//     one more fixed filter pair (H, H1) to second order (derivation and error budget: tools/sinc2_model.py);
-//   * taps |n| <= 2 on the vector units with the lane's exact shift and fc (two reciprocals per output);
-//   * the input streams through a 512-sample ring per wave: 128-sample chunks are fetched two passes ahead into registers,
-//     converted ONCE (float32 ring for the near taps, float16 hi / lo images for the bank) -- no halo is ever re-read or
-//     re-converted; block records of the next pass are fetched while the current one computes.
+// Shape.  ONE WAVE = one worker that streams over 8-24 consecutive 1024-output tiles of the file; waves never meet (no
+// workgroup, no barrier).  A pass takes the next 128 outputs (two per lane), places them from the plan's block records, and
+// evaluates their windows against ONE 128-centre stretch of the input grid [ws, ws + 128), ws = the first centre rounded down
+// to 8; outputs whose centre lies beyond it (a handful: periods differ from 1 by <= 1.25 %) simply open the next pass.
+//   * taps 3 <= |n| <= 31 at fc = 1: a Farrow bank in q = shift^2 (minimax polynomials of (win_n/pi)/(n^2 - q),
+//     tools/sinc2_model.py) -- six fixed FIR filters on the input grid, evaluated for the pass's 128 centres on the matrix cores
+//     (v_mfma_f32_16x16x32_f16, signal and dominant filter pair split float16 hi + lo 2^-12: 15 MFMAs); the bank goes through
+//     the wave's own LDS and every output gathers its centre's row;
+//   * fc < 1 (read head slower than the output clock) = the fc = 1 result + a correction in g = 1 - fc whose taps are ENTIRE
+//     functions of g (n - s): all 63 taps enter through seven fixed MOMENT filters m_i = sum_n (-1)^n win_n (n/32)^i x[c + n]
+//     on the same image (18 more MFMAs) and a complex Horner in 32 pi g per output (tools/sinc3_model.py; 1e-7 of the peak for
+//     g <= 0.0101, 5e-7 to 0.0125; steeper tiles go to the block kernel).  One image, per-lane g exact, no restarts;
+//   * the 25 constant fragments of both filter sets RESIDENT IN REGISTERS for the life of the wave;
+//   * taps |n| <= 2 on the vector units with the lane's exact shift (two reciprocals per output);
+//   * the input streams through a ring per wave (8 chunks of 128 float32 samples, direct-to-LDS loads two passes ahead),
+//     converted ONCE to float16 hi / lo images for the banks -- no halo is ever re-read or re-converted; block records of the
+//     passes ahead are fetched while the current one computes.
 // What the record model or float16 do not cover goes to the block kernel through a tile list (k_sinc_fused_list / _list2,
 // sinc.hip): blocks flagged slow, outputs within the reference's own rounding of a half-integer position (window-centre ties),
 // input that is non-finite / >= 32768 / all but silent.  The file's END tiles (the ring would reach over the file's ends) are
 // not streamed at all: the launch's first workgroups do them the block kernel's way (fused_wave, sinc_block.h) beside the
 // streams.  Every window centre is the reference's rint(p) either way.
-// Stereo (k_sinc_pipe<false, true, 2>): the ring holds frames (left, right); a pass is placed ONCE and both channels are
-// converted, banked and gathered for it -- in ONE set of bank rows, which the channels take turns in (the order of the loop's
-// stages and the one-chunk lag of channel 1's image: see the loop) so that eight streams still fit a compute unit's LDS;
-// outputs leave as 8-byte frames.  177 -> ~140 vector instructions per channel-sample.
+// Stereo (k_sinc_pipe<2>): the ring holds frames (left, right); a pass is placed ONCE and both channels are converted, banked
+// and gathered for it -- in ONE set of bank rows, which the channels take turns in (the order of the loop's stages and the
+// one-chunk lag of channel 1's image: see the loop) so that eight streams still fit a compute unit's LDS; outputs leave as
+// 8-byte frames.  177 -> 133 vector instructions per channel-sample.
+// History: r04 built this kernel in four forms (a pass as a chain of stages; the pipelined loop with the fc < 1 taps as two
+// MODULATED images of the signal; an fc = 1-only kernel at three waves per SIMD; the moment form, also as workgroups of several
+// streams sharing the constants through LDS).  NOTES r04 has their numbers; the product carries the one that won.
 #define PAR_WANT_BANK2 1
 #include "par_common.h"
 #include "pos_plan.h"
@@ -40,16 +43,6 @@
 #include <type_traits>
 
 constexpr int kMaxTilesPerWave = 24;          // k_sinc_pipe's tiles per wave for long files (launch_sinc_stream picks 8 .. this)
-#ifndef PAR_S2_TILES
-#define PAR_S2_TILES 8          // tiles per wave of k_sinc_stream (experiment builds)
-#endif
-#ifndef PAR_S2_WAVES
-#define PAR_S2_WAVES 2          // waves per SIMD the kernel is built for (registers <= 512 / this)
-#endif
-#ifndef PAR_S2_VARIANTS
-#define PAR_S2_VARIANTS 0       // 1 (experiment builds, tools/exp/s2_variant.sh): also compile the r04 variants 1-3 (k_sinc_stream, k_sinc_pipe<true, false>,
-                                // k_sinc_pipe<false, false>; PAR_SINC_STREAM=1..3).  The product library holds ONE streaming kernel: the moment form.
-#endif
 #ifndef PAR_S2_EXP
 #define PAR_S2_EXP 0            // timing builds, never shipped: 1 no MFMAs, 2 no near taps, 4 no stores, 8 no conversion, 16 unity maths on every pass
 #endif
@@ -62,26 +55,8 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 
 constexpr int kRing = 512;                       // samples per ring (float32 and float16 images alike)
 constexpr int kPass = 128;                       // centres per pass = outputs tried per pass
-constexpr float kEpsTol = 1.5e-4f;               // |fc - fc0| a pass admits (second-order treatment: tools/sinc2_model.py)
 constexpr float kQuiet = 0.0001220703125f;       // 2^-13: a chunk whose loudest sample is below this (and not 0) leaves float16's range
 
-#if PAR_S2_VARIANTS
-struct S2Lds {
-  float ring_head[4];                            // [2], [3] mirror ring[510], ring[511]
-  float ring[kRing];
-  float ring_tail[8];                            // mirrors ring[0 .. 7]
-  _Float16 img[4][kRing];                        // x (or A) hi, lo x 4096; B hi, lo x 4096
-  float4v qa[kPass];                             // bank rows {e0, d0, e1, d1} of x / A, slot = ci ^ ((ci >> 3) & 7)
-  float4v qb[kPass];                             // of B
-  float4v qx[kPass];                             // .x = e2|d2 of x / A (halves), .y = e2|d2 of B, .z = H(A), .w = H(B) (float32 bits)
-  uint4 recs[16];                                // block records of the pass: [0..7] first pieces, [8..15] second pieces
-  float qy[kPass];                             // H1'(A) | H1'(B) (halves)
-#ifdef PAR_S2_LDS_PAD
-  char pad[PAR_S2_LDS_PAD];                      // (occupancy experiments)
-#endif
-};
-static_assert(offsetof(S2Lds, img) % 16 == 0 && offsetof(S2Lds, qa) % 16 == 0, "16-byte aligned fragments");
-#endif
 
 #if PAR_S2_EXP & 64
 __device__ unsigned long long* g_s2_phase;       // [waves][16] cycle sums per phase (timing builds only)
@@ -147,53 +122,6 @@ __device__ __forceinline__ unsigned pack_h2(float a, float b) {
 __device__ __forceinline__ float h_lo(unsigned w) { return (float)__builtin_bit_cast(half2v, w)[0]; }
 __device__ __forceinline__ float h_hi(unsigned w) { return (float)__builtin_bit_cast(half2v, w)[1]; }
 
-#if PAR_S2_VARIANTS
-// the bank of one image over the pass's 128 centres: element k = 32 ks + 8 g + j of block bb is image sample offs + 8 bb + k
-template <bool GEN>
-__device__ __forceinline__ void bank_image(S2Lds& L, const half8v (&fr)[kBank2Frags], const int offs, const int l, const int sel) {
-  const int bb = l & 15, g = l >> 4;
-  const int i0 = offs + 8 * bb + 8 * g;
-  half8v xh[3], xl[3];
-#pragma unroll
-  for (int ks = 0; ks < 3; ++ks) {
-    const int ix = (i0 + 32 * ks) & (kRing - 1);
-    xh[ks] = *reinterpret_cast<const half8v*>(&L.img[2 * sel][ix]);
-    xl[ks] = *reinterpret_cast<const half8v*>(&L.img[2 * sel + 1][ix]);
-  }
-  float4v e0 = {0.0f, 0.0f, 0.0f, 0.0f}, lo = e0, e1 = e0, x1 = e0, e2 = e0, hh = e0;
-  if (!(PAR_S2_EXP & 1)) {
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-      e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[ks], xh[ks], e0, 0, 0, 0);
-      lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[5 + ks], xh[ks], lo, 0, 0, 0);
-      if (ks < 2) e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[3 + ks], xh[ks], e1, 0, 0, 0);
-      if (GEN) hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[10 + ks], xh[ks], hh, 0, 0, 0);
-      lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[ks], xl[ks], lo, 0, 0, 0);
-      if (ks < 2) {
-        x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[3 + ks], xl[ks], x1, 0, 0, 0);
-        e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[8 + ks], xh[ks], e2, 0, 0, 0);
-      }
-    }
-  } else {
-    e0[0] = (float)xh[0][0] + (float)xl[1][1] + (float)xh[2][2];
-  }
-  const float4v v0 = e0 + lo * kBank2LoInv, v1 = e1 + x1 * kBank2LoInv;
-  // rows 4 g .. 4 g + 3 of column bb: (e, d) of the block's positions 2 g and 2 g + 1
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int sl = (8 * bb + 2 * g + p) ^ (bb & 7);
-    const float4v row = {v0[2 * p], v0[2 * p + 1], v1[2 * p], v1[2 * p + 1]};
-    (sel ? L.qb : L.qa)[sl] = row;
-    const unsigned e2d2 = pack_h2(e2[2 * p] * 0.015625f, e2[2 * p + 1] * 0.015625f);     // / 64: float16 range for input up to 32768
-    float* qx = reinterpret_cast<float*>(&L.qx[sl]);
-    qx[sel] = __uint_as_float(e2d2);
-    if (GEN) {
-      qx[2 + sel] = hh[2 * p];
-      reinterpret_cast<_Float16*>(&L.qy[sl])[sel] = (_Float16)(hh[2 * p + 1] * 0.0009765625f);    // / 1024
-    }
-  }
-}
-#endif
 
 // Direct-to-LDS loads as inline assembly: LDS address = M0 + 4 (or 16) x lane.  Through the compiler's builtin every later LDS
 // read that might alias the destination gets an s_waitcnt vmcnt(0) in front of it -- the very latency the stream is built to
@@ -269,385 +197,11 @@ __device__ __forceinline__ S2Row s2_place_row(const uint4 ra, const uint4 rb, co
   return o;
 }
 
-#if PAR_S2_VARIANTS     // r04 variant 1 (a pass as a chain of stages): experiment builds only, superseded by k_sinc_pipe
-__global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Args a) {
-  using T32 = TapTab<32>;
-  __shared__ S2Lds L;
-  const int l = threadIdx.x;
-  const int64_t Ta = (int64_t)blockIdx.x * PAR_S2_TILES;
-  if (Ta >= a.n_full) return;
-  const int64_t Tb = Ta + PAR_S2_TILES < a.n_full ? Ta + PAR_S2_TILES : a.n_full;
-  const int64_t Ja = Ta * kSincTileOutputs, Jb = Tb * kSincTileOutputs;
-  // constant fragments: resident for the life of the wave
-  half8v fr[kBank2Frags];
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(kBank2Frags32) + l;
-#pragma unroll
-    for (int f = 0; f < kBank2Frags; ++f) fr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
-  }
-  // tile headers of the range (+ the one behind it): lane i keeps tile Ta + i
-  long long A0;
-  int hd_dA, hd_fl;
-  {
-    const int64_t Ti = Ta + l < a.n_tiles ? Ta + l : a.n_tiles - 1;
-    const TileHdr h = a.hdr[l <= PAR_S2_TILES ? Ti : Ta];
-    A0 = __shfl(h.anchor, 0, kWave);
-    const long long d = h.anchor - A0;
-    hd_fl = h.flags | ((d > -0x40000000ll && d < 0x40000000ll) ? 0 : 1);
-    if (a.n_edge > 0 && (Ta + l == 0 || Ta + l >= a.n_full - 2)) hd_fl |= 1 | kTileEdge;      // end tiles: not streamed, not pushed
-    hd_dA = (int)d;
-  }
-  // images start zeroed: the bank reads up to 88 samples beyond what a pass has converted (against zero coefficients)
-  {
-    uint4* z = reinterpret_cast<uint4*>(&L.img[0][0]);
-    const uint4 zero = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(L.img) / 16 / kWave); ++i) z[i * kWave + l] = zero;
-  }
-  const float tolf = (float)((fabs((double)A0) + 2.0e7) * 1.2e-16 + 2.0e-10) + 2.0e-7f;
-  // ---- stream state (wave-uniform; indices of outputs are RELATIVE to Ja: 32-bit arithmetic throughout) ----
-  const int nJ = (int)(Jb - Ja);                 // outputs of the range
-  int j0 = 0;                                    // next output
-  int wbase = 0, conv_next = 0, dma_next = 0, dma_bad = INT_MAX, mode = 0;   // mode: 0 none, 1 plain image (fc = 1), 2 modulated images
-  float g0 = 0.0f;
-  int tend = 0, dA0 = 0, dA1 = 0, fl0 = 0, fl1 = 0;      // tile state: refreshed when j0 crosses a tile border
-  // results of the previous pass: stored one pass late, behind the wait for this pass's records -- gfx950 counts loads and
-  // stores in ONE counter, and a wave that waits for a load it issued behind a store waits for the store as well
-  float res_p[2] = {0.0f, 0.0f};
-  int nok_p[2] = {0, 0};
-  unsigned j_p = 0u;
-  float* const outW = a.out + NCH * Ja;
-  const uint4* const recW = reinterpret_cast<const uint4*>(a.rec) + (Ja >> kRecShift);
-  const uint4* const rec2W = reinterpret_cast<const uint4*>(a.rec2) + (Ja >> kRecShift);
-  // The block records of a pass (<= 5 blocks, first and second pieces) come into LDS by one 16-byte direct load per lane of
-  // lanes 0-15, issued as soon as the pass before knows where it ends -- no registers held across the pass.
-  auto load_records = [&](int jn) {
-    if (l < 16) dma_dwordx4((l < 8 ? recW : rec2W - 8) + (((unsigned)jn >> kRecShift) + (unsigned)l), &L.recs[0]);
-  };
-  load_records(0);
-  // chunk k = input samples [wbase + 128 k, + 128) (relative to A0) -> ring slot k & 3, straight from HBM/L2 into LDS; a
-  // chunk that reaches over the file's ends is not fetched
-  auto chunk_dma = [&](int k) {
-    const long long lo = A0 + wbase + (long long)kPass * k;
-    if (lo >= 0 && lo + kPass <= (long long)a.len_in) {
-      const float* gp = a.sig + lo + l;
-      float* dst = &L.ring[(k & 3) * kPass];
-      dma_dword(gp, dst);
-      dma_dword(gp + kWave, dst + kWave);
-    } else if (k < dma_bad) {
-      dma_bad = k;
-    }
-  };
-  auto push_tile = [&](int64_t T) {
-    if (l == 0) {
-      const int slot = atomicAdd(a.redo_count, 1);
-      a.redo_list[slot] = (int)T;
-    }
-  };
-  // the file's last, partial tile belongs to the block kernel
-  if (blockIdx.x == 0 && a.n_full < a.n_tiles) push_tile(a.n_full);
-  const int lbank = ((l & 15) * 8 + (l >> 4) * 8) * 2;            // this lane's byte offset inside a fragment row of the images
-
-#if PAR_S2_EXP & 64
-  unsigned long long ph_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_ = __builtin_readcyclecounter();
-#endif
-  // One pass.  EDGE = false: all 128 outputs lie inside one tile and inside the wave's range (7 passes of 8): no lane sets.
-  auto pass = [&](auto edge_tag) {
-    constexpr bool EDGE = decltype(edge_tag)::value;
-    // ---- 1. placement ----
-    const int t5 = (j0 & (kRec - 1)) + l;
-    const int u = t5 & (kRec - 1);               // the same for both rows (64 = 2 blocks)
-    uint4 ra[2], rb[2];
-    {
-      const uint4* rp = &L.recs[t5 >> kRecShift];                  // blocks 0 .. 2 of the pass (row 1: + 2)
-      ra[0] = rp[0];
-      rb[0] = rp[8];
-      ra[1] = rp[2];
-      rb[1] = rp[10];
-    }
-    int nv[2] = {64, 64}, nt[2] = {64, 64};      // valid lanes of row r: l < nv[r]; lanes of this tile: l < nt[r]
-    if (EDGE) {
-      const int jlim = ((fl1 & 1) && tend < nJ) ? tend : nJ;       // a tile out of range ends the pass at its border
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        nv[r] = clamp64(jlim - j0 - 64 * r);
-        nt[r] = clamp64(tend - j0 - 64 * r);
-      }
-    }
-    const int uc = u - kRec / 2;
-    const float uf = (float)uc, u2f = uf * uf, tw1 = fmaf(2.0f, uf, 1.0f), tw0 = tw1 - 2.0f;
-    S2Row R[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) R[r] = s2_place_row(ra[r], rb[r], u, (EDGE ? (l < nt[r] ? dA0 : dA1) : dA0) + uc, uf, u2f, tw1, tw0, tolf);
-    unsigned long long bad_here, gen;
-    if (EDGE) {
-      const unsigned long long b0 = __ballot(R[0].bad) & prefix(nv[0]), b1 = __ballot(R[1].bad) & prefix(nv[1]);
-      bad_here = (b0 & prefix(nt[0])) | (b1 & prefix(nt[1]));
-      if (((b0 & ~prefix(nt[0])) | (b1 & ~prefix(nt[1]))) != 0ull) {   // bad lanes of the next tile end the pass at the border
-        nv[0] = nv[0] < nt[0] ? nv[0] : nt[0];
-        nv[1] = nv[1] < nt[1] ? nv[1] : nt[1];
-      }
-      gen = (__ballot(1.0f + R[0].ep != 1.0f) & prefix(nv[0])) | (__ballot(1.0f + R[1].ep != 1.0f) & prefix(nv[1]));
-    } else {
-      bad_here = __ballot(R[0].bad || R[1].bad);
-      gen = __ballot(1.0f + R[0].ep != 1.0f || 1.0f + R[1].ep != 1.0f);
-    }
-    bool skip = (fl0 & 1) || bad_here != 0ull;
-    S2_MARK(0);
-    // the previous pass's outputs leave now: the records this pass waited for were issued before them
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-      if (l < nok_p[r] && !(PAR_S2_EXP & 4)) outW[j_p + 64u * r + (unsigned)l] = res_p[r];
-    asm volatile("" ::: "memory");
-    const int ws = __builtin_amdgcn_readfirstlane(R[0].c) & ~7;
-    // which outputs this pass finishes (centres inside [ws, ws + 128): a prefix of the valid lanes) -- and with that where the
-    // next pass starts: its records set out NOW, a whole pass ahead of their use
-    int ci[2], nok[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      ci[r] = R[r].c - ws;
-      const unsigned long long in = __ballot(ci[r] < kPass);
-      nok[r] = EDGE ? __popcll(in & prefix(nv[r])) : __popcll(in);
-      ci[r] = ci[r] < 0 ? 0 : (ci[r] > kPass - 1 ? kPass - 1 : ci[r]);         // lanes outside read a harmless slot
-    }
-    const int jn = j0 + nok[0] + nok[1];
-    wave_lds_fence();                            // every lane has read this pass's records
-    if (!skip) load_records(jn);
-    // ---- 2. the stream: mode, window, conversion ----
-    const int want = (gen == 0ull || (PAR_S2_EXP & 16)) ? 1 : 2;
-    float fc[2] = {1.0f, 1.0f}, gg[2] = {0.0f, 0.0f};
-    bool restart = mode != want || ws - wbase > (1 << 20);
-    if (want == 2) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        fc[r] = fast_rcp(1.0f + R[r].ep);
-        gg[r] = R[r].ep * fc[r];                 // 1 - fc
-      }
-      const unsigned long long far_off = EDGE ? (__ballot(!(fabsf(g0 - gg[0]) <= kEpsTol)) & prefix(nv[0])) | (__ballot(!(fabsf(g0 - gg[1]) <= kEpsTol)) & prefix(nv[1]))
-                                              : __ballot(!(fabsf(g0 - gg[0]) <= kEpsTol) || !(fabsf(g0 - gg[1]) <= kEpsTol));
-      restart = restart || far_off != 0ull;
-    }
-    if (!skip && restart) {
-      mode = want;
-      wbase = ws - 39;
-      conv_next = 0;
-      if (want == 2) {
-        g0 = __shfl(gg[0], nJ - j0 > 32 ? 32 : 0, kWave);
-        const unsigned long long far_off = (__ballot(!(fabsf(g0 - gg[0]) <= kEpsTol)) & prefix(nv[0])) | (__ballot(!(fabsf(g0 - gg[1]) <= kEpsTol)) & prefix(nv[1]));
-        if (far_off != 0ull) skip = true;        // a ramp too steep for one g0
-      }
-      dma_bad = INT_MAX;
-      dma_next = 0;                              // (the fetch below is the only exposed one of the stream: rare)
-    }
-    S2_MARK(1);
-    const int need_c = (ws + 160 - wbase) >> 7;  // the bank's non-zero coefficients reach window index ws + 160 - wbase: chunks <= need_c
-    // chunks up to need_c are converted below; the one behind them sets out now, a pass ahead.  (Its ring slot held the
-    // chunk four back, which ends before ws - 2: no near tap of this or a later pass reads it.)
-    if (!skip && dma_next <= need_c + 1) {
-      const bool late = dma_next <= need_c;      // only right behind a restart / a jump
-      while (dma_next <= need_c + 1) chunk_dma(dma_next++);
-      if (late) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        wave_lds_fence();
-      }
-    }
-    S2_MARK(8);
-    if (!skip) {
-#pragma unroll 1
-      while (conv_next <= need_c) {
-        if (conv_next >= dma_bad) {
-          skip = true;
-          break;
-        }
-        const int wi = conv_next * kPass + 2 * l;                    // window index of x0
-        const int ix = wi & (kRing - 1);
-        const float2 xx = *reinterpret_cast<const float2*>(&L.ring[ix]);
-        const float x0 = xx.x, x1 = xx.y;
-        const float am = fmaxf(fabsf(x0), fabsf(x1));                  // (maxnum: a NaN operand is dropped -- test both samples)
-        // float16 does not suit: non-finite or >= 32768 (NaN compares false), or all but silent
-        if (__ballot(!(fabsf(x0) < 32768.0f) || !(fabsf(x1) < 32768.0f)) != 0ull ||
-            (__ballot(am >= kQuiet) == 0ull && __ballot(am > 0.0f) != 0ull)) {
-          skip = true;
-          break;
-        }
-        S2_MARK(9);
-        // mirrors of the ring's two ends for the near taps (a chunk fills a quarter of the ring: wave-uniform tests)
-        if ((conv_next & 3) == 0 && l < 4) *reinterpret_cast<float2*>(&L.ring_tail[ix]) = xx;
-        if ((conv_next & 3) == 3 && l == kWave - 1) *reinterpret_cast<float2*>(&L.ring_head[2]) = xx;
-        if (!(PAR_S2_EXP & 8)) {
-          if (mode == 1) {
-            const half2v h = {S2_HI(x0), S2_HI(x1)};                   // (hi16: what the matrix cores will see)
-            const half2v lo = {(_Float16)((x0 - (float)h[0]) * 4096.0f), (_Float16)((x1 - (float)h[1]) * 4096.0f)};
-            *reinterpret_cast<half2v*>(&L.img[0][ix]) = h;
-            *reinterpret_cast<half2v*>(&L.img[1][ix]) = lo;
-          } else {
-            // modulated images x_k sin / cos(pi g0 k): g0 k / 2 in revolutions as hi + lo (fma), reduced to (-1/2, 1/2],
-            // then the hardware sine / cosine (v_sin_f32 / v_cos_f32: 1.2e-7 absolute, tools/exp/hw_sincos.hip)
-            const float gh = 0.5f * g0;
-            float ya[2], yb[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const float x = t ? x1 : x0;
-              const float kf = (float)(wi + t);
-              const float ph = gh * kf, pl = fmaf(gh, kf, -ph);
-              const float rv = (ph - rintf(ph)) + pl;
-              ya[t] = x * __builtin_amdgcn_sinf(rv);
-              yb[t] = x * __builtin_amdgcn_cosf(rv);
-              // (the products must be ROUNDED float32 values: left to contraction, the compiler derives lo from
-              // half(x sin) of the exact product but stores half(float(x sin)) -- a double rounding apart, 5e-5 of the peak)
-              asm volatile("" : "+v"(ya[t]), "+v"(yb[t]));
-            }
-            const half2v ha = {S2_HI(ya[0]), S2_HI(ya[1])}, hb = {S2_HI(yb[0]), S2_HI(yb[1])};
-            const half2v la = {(_Float16)((ya[0] - (float)ha[0]) * 4096.0f), (_Float16)((ya[1] - (float)ha[1]) * 4096.0f)};
-            const half2v lb = {(_Float16)((yb[0] - (float)hb[0]) * 4096.0f), (_Float16)((yb[1] - (float)hb[1]) * 4096.0f)};
-            *reinterpret_cast<half2v*>(&L.img[0][ix]) = ha;
-            *reinterpret_cast<half2v*>(&L.img[1][ix]) = la;
-            *reinterpret_cast<half2v*>(&L.img[2][ix]) = hb;
-            *reinterpret_cast<half2v*>(&L.img[3][ix]) = lb;
-          }
-        }
-        ++conv_next;
-        S2_MARK(10);
-      }
-    }
-    if (skip) {                                  // the tile of j0 goes to the block kernel; the stream restarts behind it
-      push_tile(Ta + (j0 >> 10));
-      nok_p[0] = nok_p[1] = 0;
-      j0 = tend;
-      mode = 0;
-      wave_lds_fence();
-      if (j0 < nJ) load_records(j0);
-      return;
-    }
-    S2_MARK(2);
-    // ---- 4. the bank over the centres ws .. ws + 127 ----
-    wave_lds_fence();
-    S2_MARK(3);
-    const int offs = ws - wbase - 31;            // = 8 (mod 8) by construction: 16-byte aligned fragments
-    if (mode == 1) {
-      bank_image<false>(L, fr, offs, l, 0);
-    } else {
-      bank_image<true>(L, fr, offs, l, 0);
-      bank_image<true>(L, fr, offs, l, 1);
-    }
-    wave_lds_fence();
-    S2_MARK(4);
-    // ---- 5. outputs ----
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int sl = ci[r] ^ ((ci[r] >> 3) & 7);
-      const int rc = (ws - wbase + ci[r]) & (kRing - 1);
-      const float* xp = &L.ring[rc];
-      const float xm2 = xp[-2], xm1 = xp[-1], x0 = xp[0], xp1 = xp[1], xp2 = xp[2];
-      const float sr = R[r].s, q = sr * sr, q64 = 64.0f * q;
-      const float E1 = xp1 + xm1, D1 = xp1 - xm1, E2 = xp2 + xm2, D2 = xp2 - xm2;
-      float res;
-      if (mode == 1) {
-        const float4v row = L.qa[sl];
-        const unsigned w2 = __float_as_uint(L.qx[sl][0]);
-        const float e = fmaf(q, fmaf(q64, h_lo(w2), row[2]), row[0]), d = fmaf(q, fmaf(q64, h_hi(w2), row[3]), row[1]);
-        float en = 0.0f, dn = 0.0f;
-        if (!(PAR_S2_EXP & 2)) {
-          const float R1 = fast_rcp(fmaf(q, T32::B[1], T32::A[1])), R2 = fast_rcp(fmaf(q, T32::B[2], T32::A[2]));
-          en = fmaf(E2, R2, -(E1 * R1));
-          dn = fmaf(D2 + D2, R2, -(D1 * R1));
-        }
-        const float et = fmaf(e, kBank2ScaleInv, en), dt = fmaf(d, kBank2ScaleInv, dn);
-        res = sinpi_poly(q) * fmaf(-sr, fmaf(sr, et, dt), x0 * 0.318309886f);
-      } else {
-        const float f = fc[r], g = gg[r];
-        // near taps with the lane's own cut-off: numerators sin(pi fc (n -+ s)) = -(-1)^n sin(pi g n +- phi), phi = pi fc s
-        const float h = f * sr, zh = h * h;
-        const float sph = sinpi_poly(zh);                            // sin(phi) / h: the centre tap needs the quotient
-        const float sinphi = h * sph, cosphi = __builtin_amdgcn_cosf(0.5f * h);
-        const float S1 = __builtin_amdgcn_sinf(0.5f * g), C1 = __builtin_amdgcn_cosf(0.5f * g);
-        const float S2 = 2.0f * S1 * C1, C2 = fmaf(-2.0f * S1, S1, 1.0f);
-        float accM = 0.0f, accP = 0.0f;
-        if (!(PAR_S2_EXP & 2)) {
-          const float R1 = fast_rcp(fmaf(q, T32::B[1], T32::A[1])), R2 = fast_rcp(fmaf(q, T32::B[2], T32::A[2]));
-          const float sc1 = S1 * cosphi, cs1 = C1 * sinphi, sc2 = S2 * cosphi, cs2 = C2 * sinphi;
-          const float G1 = xp1 * (sc1 + cs1), H1 = xm1 * (sc1 - cs1);
-          const float G2 = -xp2 * (sc2 + cs2), H2 = -xm2 * (sc2 - cs2);
-          accM = fmaf(G2 - H2, R2, (G1 - H1) * R1);
-          accP = fmaf(2.0f * (G2 + H2), R2, (G1 + H1) * R1);
-        }
-        const float near = fmaf(x0 * f, sph * 0.318309886f, fmaf(sr, accM, accP));
-        // far taps: psi / (2 pi) = (s (1 - g0) - g0 K) / 2, K = the centre's window index (the images' phase origin is the
-        // window's): g0 K / 2 as hi + lo, reduced, then the hardware cosine / sine
-        const float gh = 0.5f * g0;
-        const float Kf = (float)(ws - wbase + ci[r]);
-        const float ph = gh * Kf, pl = fmaf(gh, Kf, -ph);
-        const float tv = fmaf(sr, 0.5f - gh, -(ph - rintf(ph))) - pl;
-        const float cps = __builtin_amdgcn_cosf(tv), sps = __builtin_amdgcn_sinf(tv);
-        const float4v rowa = L.qa[sl], rowb = L.qb[sl];
-        const float4v Xf = L.qx[sl];
-        const unsigned Xa = __float_as_uint(Xf[0]), Xb = __float_as_uint(Xf[1]);
-        const unsigned Y = __float_as_uint(L.qy[sl]);
-        const float eA = fmaf(q, fmaf(q64, h_lo(Xa), rowa[2]), rowa[0]), dA = fmaf(q, fmaf(q64, h_hi(Xa), rowa[3]), rowa[1]);
-        const float eB = fmaf(q, fmaf(q64, h_lo(Xb), rowb[2]), rowb[0]), dB = fmaf(q, fmaf(q64, h_hi(Xb), rowb[3]), rowb[1]);
-        const float UA = fmaf(sr, eA, dA) * kBank2ScaleInv, UB = fmaf(sr, eB, dB) * kBank2ScaleInv;
-        const float HA = Xf[2], HB = Xf[3];
-        const float s1k = sr * 0.0009765625f;
-        const float H1A = fmaf(-s1k, HA, h_lo(Y)), H1B = fmaf(-s1k, HB, h_hi(Y));                 // H1 / 1024
-        const float eps = g0 - g;                                    // fc - fc0
-        float far = -fmaf(cps, UA, sps * UB);
-        far = fmaf(eps, fmaf(cps, HB, -(sps * HA)), far);
-        far = fmaf(1608.49544f * eps * eps, fmaf(cps, H1A, sps * H1B), far);                      // 1024 pi / 2
-        res = near + far;
-      }
-      res_p[r] = res;
-      nok_p[r] = nok[r];
-    }
-    j_p = (unsigned)j0;
-    j0 = jn;
-    S2_MARK(5);
-#if PAR_S2_EXP & 64
-    ph_[6] += 1;
-#endif
-  };
-
-  while (j0 < nJ) {
-    S2_MARK(7);
-    j0 = __builtin_amdgcn_readfirstlane(j0);     // (the compiler does not see that the loop's state is wave-uniform)
-    wbase = __builtin_amdgcn_readfirstlane(wbase);
-    conv_next = __builtin_amdgcn_readfirstlane(conv_next);
-    dma_next = __builtin_amdgcn_readfirstlane(dma_next);
-    dma_bad = __builtin_amdgcn_readfirstlane(dma_bad);
-    mode = __builtin_amdgcn_readfirstlane(mode);
-    tend = __builtin_amdgcn_readfirstlane(tend);
-    if (j0 >= tend) {                            // a new tile: its anchor and flags, and those of the tile behind it
-      const int Tt = j0 >> 10;
-      tend = (Tt + 1) << 10;
-      dA0 = __builtin_amdgcn_readlane(hd_dA, Tt);
-      dA1 = __builtin_amdgcn_readlane(hd_dA, Tt + 1);
-      fl0 = __builtin_amdgcn_readlane(hd_fl, Tt);
-      fl1 = __builtin_amdgcn_readlane(hd_fl, Tt + 1);
-    }
-    // everything this pass reads from LDS that came by direct load (its records, its newest chunk) set out a pass ago;
-    // nothing younger is in flight (the stores of the pass before leave BEHIND this wait)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    wave_lds_fence();
-    if (j0 + kPass <= tend && j0 + kPass <= nJ) pass(std::false_type{});
-    else pass(std::true_type{});
-  }
-#if PAR_S2_EXP & 64
-  if (l == 0)
-    for (int k = 0; k < 16; ++k) g_s2_phase[(size_t)blockIdx.x * 16 + k] = ph_[k];
-#endif
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-    if (l < nok_p[r] && !(PAR_S2_EXP & 4)) outW[j_p + 64u * r + (unsigned)l] = res_p[r];
-}
-
-#endif  // PAR_S2_VARIANTS
 
 // ------------------------------------------------------------------------------------------------------------------------
-// K_sinc, pipelined streaming form (r04, second shape).  Same mathematics and the same worker (one wave, kTilesPerWave
-// tiles, constants resident in registers) as k_sinc_stream above; what changes is the ORDER OF WORK.  k_sinc_stream runs a
-// pass as a chain -- records -> placement -> conversion -> bank -> gather -- with a wait for LDS or memory between every two
-// links: at the two waves per SIMD its registers allow, a wave issued one instruction every ~12 cycles (tools/exp/s2_phase.py:
-// 4 360 cycles per 128 outputs for ~350 instructions).  Here the links of one iteration belong to DIFFERENT passes:
+// The loop.  Run as a chain -- records -> placement -> conversion -> bank -> gather, a wait for LDS or memory between every two
+// links -- a pass took 4 360 cycles for ~350 instructions at the two waves per SIMD the registers allow (r04, first shape).
+// Here the links of one iteration belong to DIFFERENT passes:
 //     iteration k:   OUT(k)        gather + near taps + stores of the pass placed and banked in iteration k - 1
 //                    PLACE(k + 1)  from records that set out in iteration k - 2
 //                    BANK(k + 1)   over the centres PLACE(k + 1) just named, from image chunks converted in iterations <= k - 1
@@ -658,52 +212,31 @@ __global__ __launch_bounds__(kWave, PAR_S2_WAVES) void k_sinc_stream(const S2Arg
 // The ring holds 8 chunks of float32 samples (near taps) and 4 of the float16 images; the bank is single-buffered (an
 // iteration's gathers precede its bank writes in program order, LDS serves a wave's operations in order).
 // Whatever is not the plain case -- the first pass of a run, a pass that meets a flagged tile or block, the end of the
-// wave's range, a change of tap regime or of g0, a conversion window that has drifted out of its slack -- leaves the loop
+// wave's range, a change of tap regime, a conversion window that has drifted out of its slack -- leaves the loop
 // and is done by start_run(): the same stages, one after the other with full waits, which also primes the loop again.
-#ifndef PAR_S3_UNITY_WAVES
-#define PAR_S3_UNITY_WAVES 3
-#endif
 constexpr int kRingF = 1024;                      // float32 samples in the ring (8 chunks)
 constexpr int kRingH = 512;                       // samples per float16 image (4 chunks)
 
-// GENK: the kernel carries the fc < 1 path in its modulated-image form (two images, wider bank rows).  MOM: in its moment form
-// (one image; seven moment filters per centre beside the fc = 1 bank).
-// NCH = 2 (the moment form only): an interleaved stereo file -- the ring holds frames (left, right), each channel has its own
-// float16 images, and the two channels take turns in ONE set of bank rows (see the loop of k_sinc_pipe).
-template <bool GENK, bool MOM = false, int NCH = 1>
-struct S3LdsT {
+// A stream's LDS.  NCH = 2: an interleaved stereo file -- the ring holds frames (left, right), each channel has its own float16
+// images, and the two channels take turns in ONE set of bank rows (see the loop of k_sinc_pipe).
+template <int NCH>
+struct S3Lds {
   float ring_head[4 * NCH];                      // frames -2, -1 mirror frames 1022, 1023
   float ring[kRingF * NCH];
   float ring_tail[4 * NCH];                      // mirrors frames 0 .. 3
-  _Float16 img[(GENK ? 4 : 2) * NCH][kRingH];    // x (or A) hi, lo x 4096; B hi, lo x 4096 (stereo: [2 ch], [2 ch + 1])
-  float4v qa[kPass];                             // bank rows {e0, d0, e1, d1} of x / A, slot = ci ^ ((ci >> 3) & 7)
-  float4v qb[GENK ? kPass : 1];                  // of B
-  float4v qx[GENK ? kPass : 1];                  // .x = e2|d2 of x / A (halves), .y = e2|d2 of B, .z = H(A), .w = H(B)
-  float qy[MOM ? 1 : kPass];                     // GENK: H1'(A) | H1'(B) (halves); else: e2|d2 of x (halves); MOM: in qm0
-  float4v qm0[MOM ? kPass : 1];                  // moment rows {m0, m1, m2, e2|d2 of x (halves)} (same slots as qa)
-  float4v qm1[MOM ? kPass : 1];                  // {m3, m4, m5, m6}
+  _Float16 img[2 * NCH][kRingH];                 // x hi, lo x 4096 (stereo: [2 ch], [2 ch + 1])
+  float4v qa[kPass];                             // bank rows {e0, d0, e1, d1}, slot = ci ^ ((ci >> 3) & 7)
+  float4v qm0[kPass];                            // moment rows {m0, m1, m2, e2|d2 (halves)} (same slots)
+  float4v qm1[kPass];                            // {m3, m4, m5, m6}
 #ifdef PAR_S3_LDS_PAD
   uint4 pad[PAR_S3_LDS_PAD / 16];                // (occupancy experiments)
 #endif
   uint4 recs[4][16];                             // block records of four passes: [0..7] first pieces, [8..15] second pieces
 };
-// e2 | d2 of the fc = 1 bank: its own array, or word 3 of the moment row
-template <class LDS> __device__ __forceinline__ float& s3_e2d2(LDS& L, int sl) {
-  if constexpr (sizeof(L.qm0) > 16) return reinterpret_cast<float*>(&L.qm0[sl])[3];
-  else return L.qy[sl];
-}
-template <class LDS> __device__ __forceinline__ float s3_e2d2(const LDS& L, int sl) {
-  if constexpr (sizeof(L.qm0) > 16) return reinterpret_cast<const float*>(&L.qm0[sl])[3];
-  else return L.qy[sl];
-}
-typedef S3LdsT<false, true> S3LdsMom;
-typedef S3LdsT<false, true, 2> S3LdsMom2;
-static_assert(offsetof(S3LdsMom, qm0) % 16 == 0 && offsetof(S3LdsMom, recs) % 16 == 0, "16-byte aligned");
-static_assert(offsetof(S3LdsMom2, ring) % 16 == 0 && offsetof(S3LdsMom2, img) % 16 == 0 && offsetof(S3LdsMom2, qa) % 16 == 0 &&
-              offsetof(S3LdsMom2, qm0) % 16 == 0 && offsetof(S3LdsMom2, recs) % 16 == 0, "16-byte aligned");
-static_assert(sizeof(S3LdsMom2) + 16 <= 20480, "eight stereo streams per compute unit (160 KB of LDS)");
-static_assert(offsetof(S3LdsT<true>, img) % 16 == 0 && offsetof(S3LdsT<true>, qa) % 16 == 0 && offsetof(S3LdsT<true>, recs) % 16 == 0, "16-byte aligned");
-static_assert(offsetof(S3LdsT<false>, img) % 16 == 0 && offsetof(S3LdsT<false>, qa) % 16 == 0 && offsetof(S3LdsT<false>, recs) % 16 == 0, "16-byte aligned");
+static_assert(offsetof(S3Lds<1>, img) % 16 == 0 && offsetof(S3Lds<1>, qa) % 16 == 0 && offsetof(S3Lds<1>, recs) % 16 == 0, "16-byte aligned");
+static_assert(offsetof(S3Lds<2>, ring) % 16 == 0 && offsetof(S3Lds<2>, img) % 16 == 0 && offsetof(S3Lds<2>, qa) % 16 == 0 &&
+              offsetof(S3Lds<2>, recs) % 16 == 0, "16-byte aligned");
+static_assert(sizeof(S3Lds<2>) <= 20480, "eight stereo streams per compute unit (160 KB of LDS)");
 
 struct S3Pass {                                  // a placed pass: 128 candidate outputs j .. j + 127 (two per lane)
   int c[2];                                      // window centre relative to A0
@@ -712,81 +245,13 @@ struct S3Pass {                                  // a placed pass: 128 candidate
   int j, ws;                                     // first output (relative to Ja), first bank centre (wave-uniform)
 };
 
-template <bool GEN, class LDS>
-__device__ __forceinline__ void bank_image3(LDS& L, const half8v (&fr)[kBank2Frags], const int offs, const int l, const int sel) {
-  const int bb = l & 15, g = l >> 4;
-  const int i0 = offs + 8 * bb + 8 * g;
-  half8v xh[3], xl[3];
-#pragma unroll
-  for (int ks = 0; ks < 3; ++ks) {
-    const int ix = (i0 + 32 * ks) & (kRingH - 1);
-    xh[ks] = *reinterpret_cast<const half8v*>(&L.img[2 * sel][ix]);
-    xl[ks] = *reinterpret_cast<const half8v*>(&L.img[2 * sel + 1][ix]);
-  }
-  float4v e0 = {0.0f, 0.0f, 0.0f, 0.0f}, lo = e0, e1 = e0, x1 = e0, e2 = e0, hh = e0;
-#pragma unroll
-  for (int ks = 0; ks < 3; ++ks) {
-    e0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[ks], xh[ks], e0, 0, 0, 0);
-    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[5 + ks], xh[ks], lo, 0, 0, 0);
-    if (ks < 2) e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[3 + ks], xh[ks], e1, 0, 0, 0);
-    if (GEN) hh = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[10 + ks], xh[ks], hh, 0, 0, 0);
-    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[ks], xl[ks], lo, 0, 0, 0);
-    if (ks < 2) {
-      x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[3 + ks], xl[ks], x1, 0, 0, 0);
-      e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[8 + ks], xh[ks], e2, 0, 0, 0);
-    }
-  }
-  const float4v v0 = e0 + lo * kBank2LoInv, v1 = e1 + x1 * kBank2LoInv;
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int sl = (8 * bb + 2 * g + p) ^ (bb & 7);
-    const float4v row = {v0[2 * p], v0[2 * p + 1], v1[2 * p], v1[2 * p + 1]};
-    const unsigned e2d2 = pack_h2(e2[2 * p] * 0.015625f, e2[2 * p + 1] * 0.015625f);
-    if (GEN) {
-      (sel ? L.qb : L.qa)[sl] = row;
-      float* qx = reinterpret_cast<float*>(&L.qx[sl]);
-      qx[sel] = __uint_as_float(e2d2);
-      qx[2 + sel] = hh[2 * p];
-      reinterpret_cast<_Float16*>(&L.qy[sl])[sel] = (_Float16)(hh[2 * p + 1] * 0.0009765625f);
-    } else {
-      L.qa[sl] = row;
-      s3_e2d2(L, sl) = __uint_as_float(e2d2);
-    }
-  }
-}
-
-// fc = 1 bank AND the seven moment filters of the fc < 1 correction over the same 128 centres, from the same signal fragments
-// (fm: kBank3Frags32, sinc_taps_gen.h): 15 + 18 MFMAs.
-// ctab: the workgroup's table of constant fragments in LDS, fragment f of lane l at ctab[64 f + l]: 0-9 the fc = 1 bank's
-// (kBank2Frags32's first ten), 10-24 the moment filters' (kBank3Frags32).  MOMENTS = false: the fc = 1 bank alone.
+// fc = 1 bank AND the seven moment filters of the fc < 1 correction over the same 128 centres, from the same signal fragments:
+// 15 + 18 MFMAs.  fr: the fc = 1 bank's ten constant fragments (kBank2Frags32's first ten), fmr: the moment filters' fifteen
+// (kBank3Frags32, sinc_taps_gen.h); all resident in the wave's registers.  MOMENTS = false: the fc = 1 bank alone.
 constexpr int kCtabUnity = 10;
-#ifndef PAR_S3_MOM_FR_REGS
-#define PAR_S3_MOM_FR_REGS 5                       // how many of the fc = 1 bank's ten fragments stay in registers (the rest, and the moment filters', come from the table)
-#endif
-#ifndef PAR_S3_SCHED_BARRIERS
-#define PAR_S3_SCHED_BARRIERS 0                    // 1: the bank's two halves and the loop's stages are not interleaved by the compiler (fewer live registers)
-#endif
-__device__ __forceinline__ void s3_sched_fence() {
-#if PAR_S3_SCHED_BARRIERS
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-#ifndef PAR_S3_MOM_WAVES
-#define PAR_S3_MOM_WAVES 1                         // waves per workgroup of the moment kernel; 1: no table, all 25 fragments in registers
-#endif
-#ifndef PAR_S3_MOM_FM_REGS
-#define PAR_S3_MOM_FM_REGS 15                      // one-wave form: how many of the moment filters' 15 fragments stay in registers (the rest in the wave's LDS)
-#endif
-constexpr int kMomFrRegs = PAR_S3_MOM_WAVES == 1 ? kCtabUnity : PAR_S3_MOM_FR_REGS;
-constexpr int kMomFmRegs = PAR_S3_MOM_WAVES == 1 ? PAR_S3_MOM_FM_REGS : 0;
-constexpr int kMomTabFrags = (kCtabUnity - kMomFrRegs) + (kBank3Frags - kMomFmRegs);
-// The last three moment fragments hold (m6, -): their odd rows are zero filters whose results nobody reads, so the table keeps
-// the even lanes only (lane l reads entry l >> 1: an odd row then carries its neighbour's coefficients, harmlessly) -- half the bytes.
-constexpr int kMomHalf = (kMomFmRegs <= 12 && kMomTabFrags > 0) ? 3 : 0;            // fragments stored at half size
-constexpr int kMomTabWords = (kMomTabFrags - kMomHalf) * kWave + kMomHalf * (kWave / 2);   // uint4 entries of the table
 template <bool MOMENTS, class LDS>
 __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Frags], const half8v (&fmr)[kBank3Frags],
-                                             const uint4* __restrict__ ctab, const int offs, const int l, const int ch = 0) {
+                                             const int offs, const int l, const int ch = 0) {
   const int bb = l & 15, g = l >> 4;
   const int i0 = offs + 8 * bb + 8 * g;
   half8v xh[3], xl[3];
@@ -796,16 +261,7 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
     xh[ks] = *reinterpret_cast<const half8v*>(&L.img[2 * ch][ix]);
     xl[ks] = *reinterpret_cast<const half8v*>(&L.img[2 * ch + 1][ix]);
   }
-  const uint4* ct = ctab + l;
-  auto frag = [&](int f) {
-    if (f < kMomFrRegs) return fr[f];
-    if (f < kCtabUnity) return __builtin_bit_cast(half8v, ct[64 * (f - kMomFrRegs)]);
-    if (f - kCtabUnity < kMomFmRegs) return fmr[f - kCtabUnity];
-    const int tf = (kCtabUnity - kMomFrRegs) + (f - kCtabUnity - kMomFmRegs);      // fragment index inside the table
-    if (kMomHalf && f - kCtabUnity >= kBank3Frags - 3)
-      return __builtin_bit_cast(half8v, ctab[(kMomTabFrags - 3) * kWave + (f - kCtabUnity - (kBank3Frags - 3)) * (kWave / 2) + (l >> 1)]);
-    return __builtin_bit_cast(half8v, ct[64 * tf]);
-  };
+  auto frag = [&](int f) { return f < kCtabUnity ? fr[f] : fmr[f - kCtabUnity]; };
   const float4v z = {0.0f, 0.0f, 0.0f, 0.0f};
   float4v e0 = z, lo = z, e1 = z, x1 = z, e2 = z;
 #pragma unroll
@@ -823,7 +279,6 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
   }
   const float4v v0 = e0 + lo * kBank2LoInv, v1 = e1 + x1 * kBank2LoInv;
   float4v a01 = z, l01 = z, a23 = z, a45 = z, a6 = z;
-  s3_sched_fence();
   if (MOMENTS) {
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
@@ -849,17 +304,16 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
       const float4v r1 = {a23[2 * p + 1], a45[2 * p], a45[2 * p + 1], a6[2 * p]};
       L.qm1[sl] = r1;
     } else {
-      s3_e2d2(L, sl) = e2d2;
+      reinterpret_cast<float*>(&L.qm0[sl])[3] = e2d2;
     }
   }
 }
 
-// the outputs of one row of a placed pass (bank and ring in LDS): MODE 1 fc = 1, MODE 2 modulated images, MODE 3 fc = 1 + the
+// the outputs of one row of a placed pass (bank and ring in LDS): MODE 1 fc = 1, MODE 3 fc = 1 + the
 // moment correction  -g (cos(pi s) Re Q - sin(pi s) Im Q),  Q = sum_i M_i (i 32 G)^i (alpha_i + i beta_i),  G = pi g, w = G s,
 // alpha_i = 1/(i! (i+1)) - w^2 / (2 i! (i+3)),  beta_i = -w / (i! (i+2))   (tools/sinc3_model.py: 1e-7 for g <= 0.0101)
 template <int MODE, int NCH = 1, class LDS>
-__device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const float sr, const float epr, const int wsK, const float g0,
-                                            const int ch = 0) {
+__device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const float sr, const float epr, const int wsK, const int ch = 0) {
   using T32 = TapTab<32>;
   const int sl = ci ^ ((ci >> 3) & 7);
   const int rc = (wsK + ci) & (kRingF - 1);
@@ -867,7 +321,7 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
   const float xm2 = xp[-2 * NCH], xm1 = xp[-NCH], x0 = xp[0], xp1 = xp[NCH], xp2 = xp[2 * NCH];
   const float q = sr * sr, q64 = 64.0f * q;
   const float R1 = fast_rcp(fmaf(q, T32::B[1], T32::A[1])), R2 = fast_rcp(fmaf(q, T32::B[2], T32::A[2]));
-  if (MODE == 1 || MODE == 3) {
+  {
     const float E1 = xp1 + xm1, D1 = xp1 - xm1, E2 = xp2 + xm2, D2 = xp2 - xm2;
     const float4v row = L.qa[sl];
     float4v M0 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -876,7 +330,7 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
       M0 = L.qm0[sl];
       w2 = __float_as_uint(M0[3]);
     } else {
-      w2 = __float_as_uint(s3_e2d2(L, sl));
+      w2 = __float_as_uint(reinterpret_cast<const float*>(&L.qm0[sl])[3]);
     }
     const float e = fmaf(q, fmaf(q64, h_lo(w2), row[2]), row[0]), d = fmaf(q, fmaf(q64, h_hi(w2), row[3]), row[1]);
     const float en = fmaf(E2, R2, -(E1 * R1));
@@ -909,45 +363,12 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
 #undef S3_MOM_STEP
     const float S = sr * spq, C = __builtin_amdgcn_cosf(0.5f * sr);
     return fmaf(-g, fmaf(C, re, -(S * im)), unity);
-  } else {
-    const float f = fast_rcp(1.0f + epr), g = epr * f;               // fc, 1 - fc
-    const float h = f * sr, zh = h * h;
-    const float sph = sinpi_poly(zh);
-    const float sinphi = h * sph, cosphi = __builtin_amdgcn_cosf(0.5f * h);
-    const float S1 = __builtin_amdgcn_sinf(0.5f * g), C1 = __builtin_amdgcn_cosf(0.5f * g);
-    const float S2 = 2.0f * S1 * C1, C2 = fmaf(-2.0f * S1, S1, 1.0f);
-    const float sc1 = S1 * cosphi, cs1 = C1 * sinphi, sc2 = S2 * cosphi, cs2 = C2 * sinphi;
-    const float G1 = xp1 * (sc1 + cs1), H1 = xm1 * (sc1 - cs1);
-    const float G2 = -xp2 * (sc2 + cs2), H2 = -xm2 * (sc2 - cs2);
-    const float accM = fmaf(G2 - H2, R2, (G1 - H1) * R1);
-    const float accP = fmaf(2.0f * (G2 + H2), R2, (G1 + H1) * R1);
-    const float near = fmaf(x0 * f, sph * 0.318309886f, fmaf(sr, accM, accP));
-    const float gh = 0.5f * g0;
-    const float Kf = (float)(wsK + ci);
-    const float ph = gh * Kf, pl = fmaf(gh, Kf, -ph);
-    const float tv = fmaf(sr, 0.5f - gh, -(ph - rintf(ph))) - pl;
-    const float cps = __builtin_amdgcn_cosf(tv), sps = __builtin_amdgcn_sinf(tv);
-    const float4v rowa = L.qa[sl], rowb = L.qb[sl];
-    const float4v Xf = L.qx[sl];
-    const unsigned Xa = __float_as_uint(Xf[0]), Xb = __float_as_uint(Xf[1]);
-    const unsigned Y = __float_as_uint(L.qy[sl]);
-    const float eA = fmaf(q, fmaf(q64, h_lo(Xa), rowa[2]), rowa[0]), dA = fmaf(q, fmaf(q64, h_hi(Xa), rowa[3]), rowa[1]);
-    const float eB = fmaf(q, fmaf(q64, h_lo(Xb), rowb[2]), rowb[0]), dB = fmaf(q, fmaf(q64, h_hi(Xb), rowb[3]), rowb[1]);
-    const float UA = fmaf(sr, eA, dA) * kBank2ScaleInv, UB = fmaf(sr, eB, dB) * kBank2ScaleInv;
-    const float HA = Xf[2], HB = Xf[3];
-    const float s1k = sr * 0.0009765625f;
-    const float H1A = fmaf(-s1k, HA, h_lo(Y)), H1B = fmaf(-s1k, HB, h_hi(Y));
-    const float eps = g0 - g;
-    float far = -fmaf(cps, UA, sps * UB);
-    far = fmaf(eps, fmaf(cps, HB, -(sps * HA)), far);
-    far = fmaf(1608.49544f * eps * eps, fmaf(cps, H1A, sps * H1B), far);
-    return near + far;
   }
 }
 
 // one chunk of the ring -> float16 images (and the ring's mirrors); returns false when float16 does not suit the chunk
-template <int MODE, class LDS>
-__device__ __forceinline__ bool s3_convert(LDS& L, const int chunk, const int l, const float g0) {
+template <class LDS>
+__device__ __forceinline__ bool s3_convert(LDS& L, const int chunk, const int l) {
   const int wi = chunk * kPass + 2 * l;
   const int ix = wi & (kRingF - 1), ih = wi & (kRingH - 1);
   const float2 xx = *reinterpret_cast<const float2*>(&L.ring[ix]);
@@ -957,32 +378,10 @@ __device__ __forceinline__ bool s3_convert(LDS& L, const int chunk, const int l,
                     (__ballot(am >= kQuiet) == 0ull && __ballot(am > 0.0f) != 0ull));
   if ((chunk & 7) == 0 && l < 2) *reinterpret_cast<float2*>(&L.ring_tail[ix]) = xx;
   if ((chunk & 7) == 7 && l == kWave - 1) *reinterpret_cast<float2*>(&L.ring_head[2]) = xx;
-  if (MODE == 1) {
-    const half2v h = {S2_HI(x0), S2_HI(x1)};
-    const half2v lo = {(_Float16)((x0 - (float)h[0]) * 4096.0f), (_Float16)((x1 - (float)h[1]) * 4096.0f)};
-    *reinterpret_cast<half2v*>(&L.img[0][ih]) = h;
-    *reinterpret_cast<half2v*>(&L.img[1][ih]) = lo;
-  } else {
-    const float gh = 0.5f * g0;
-    float ya[2], yb[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float x = t ? x1 : x0;
-      const float kf = (float)(wi + t);
-      const float ph = gh * kf, pl = fmaf(gh, kf, -ph);
-      const float rv = (ph - rintf(ph)) + pl;
-      ya[t] = x * __builtin_amdgcn_sinf(rv);
-      yb[t] = x * __builtin_amdgcn_cosf(rv);
-      asm volatile("" : "+v"(ya[t]), "+v"(yb[t]));
-    }
-    const half2v ha = {S2_HI(ya[0]), S2_HI(ya[1])}, hb = {S2_HI(yb[0]), S2_HI(yb[1])};
-    const half2v la = {(_Float16)((ya[0] - (float)ha[0]) * 4096.0f), (_Float16)((ya[1] - (float)ha[1]) * 4096.0f)};
-    const half2v lb = {(_Float16)((yb[0] - (float)hb[0]) * 4096.0f), (_Float16)((yb[1] - (float)hb[1]) * 4096.0f)};
-    *reinterpret_cast<half2v*>(&L.img[0][ih]) = ha;
-    *reinterpret_cast<half2v*>(&L.img[1][ih]) = la;
-    *reinterpret_cast<half2v*>(&L.img[2][ih]) = hb;
-    *reinterpret_cast<half2v*>(&L.img[3][ih]) = lb;
-  }
+  const half2v h = {S2_HI(x0), S2_HI(x1)};
+  const half2v lo = {(_Float16)((x0 - (float)h[0]) * 4096.0f), (_Float16)((x1 - (float)h[1]) * 4096.0f)};
+  *reinterpret_cast<half2v*>(&L.img[0][ih]) = h;
+  *reinterpret_cast<half2v*>(&L.img[1][ih]) = lo;
   return ok;
 }
 
@@ -1008,96 +407,55 @@ __device__ __forceinline__ bool s3_convert_ch(LDS& L, const int chunk, const int
   return ok;
 }
 
-// GENK = true: both tap regimes (two waves per SIMD: 15.5 KB of LDS and the fc < 1 path's registers).  GENK = false: fc = 1
-// passes only, tiles that hold an fc < 1 pass go to the block kernel's list (three waves per SIMD).
-// MOM = true (GENK = false): fc < 1 passes as fc = 1 + the moment correction (one image, no g0, no restarts; valid for
-// 1 - fc <= kGMaxMom, steeper tiles go to the block kernel).
+// fc < 1 passes are fc = 1 + the moment correction (one image per channel, per-lane 1 - fc exact): valid for 1 - fc <= 0.0125,
+// steeper tiles go to the block kernel's list.  (r04's other forms -- a pass as a chain of stages, the modulated-image form of
+// the fc < 1 taps, an fc = 1-only kernel at three waves per SIMD, workgroups of several streams sharing the constants through
+// LDS -- are in the repository's history and in NOTES r04 with their numbers; the product carries this one.)
 constexpr float kEpMaxMom = 0.0125f / (1.0f - 0.0125f);      // period - 1 at 1 - fc = 0.0125
-// PAR_S3_MOM_WAVES > 1 (experiment): the MOM kernel as a workgroup of that many waves that never meet again after its head --
-// each streams over its own eight tiles with its own piece of LDS -- sharing a table of constant fragments in LDS (the moment
-// filters' 15 and 10 - PAR_S3_MOM_FR_REGS of the fc = 1 bank's), which frees up to 100 VGPRs: 11 waves = 2.75 per SIMD at 168
-// VGPRs without spills.  Measured (fc < 1 / fc = 1 tapes): 96 / 137 Gsamples/s at 11 waves, 94 / 146 at 8, against 104.5 / 154
-// for one-wave workgroups with all 25 fragments in registers: a workgroup that owns the whole LDS of its compute unit starts
-// and ends as one (table load, cold start of every stream, the stragglers' tail: nothing else can start meanwhile).
 #ifndef PAR_S3_SHARE_OUT
 #define PAR_S3_SHARE_OUT 1      // stereo: 0 = channel 1's row arithmetic worked out afresh (measured: 158 against 165 G on the benchmark's tape)
 #endif
 #ifndef PAR_S3_PIN_MONO
 #define PAR_S3_PIN_MONO 0       // 1: the mono loop's row results pinned like the stereo loop's (234 instead of 250 registers, 1 % slower)
 #endif
-template <bool GENK, bool MOM, int NCH = 1>
-struct S3Shared {
-  uint4 fmtab[(MOM && kMomTabFrags > 0) ? kMomTabWords : 1];
-  S3LdsT<GENK, MOM, NCH> per[MOM ? PAR_S3_MOM_WAVES : 1];
-};
-#ifndef PAR_S3_NUM_VGPR
-#define PAR_S3_NUM_VGPR 0                           // experiment: cap the kernels' VGPRs below what the launch bounds allow
-#endif
-#if PAR_S3_NUM_VGPR
-#define S3_VGPR_CAP __attribute__((amdgpu_num_vgpr(PAR_S3_NUM_VGPR)))
-#else
-#define S3_VGPR_CAP
-#endif
-template <bool GENK, bool MOM, int NCH = 1>
-__global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S3_MOM_WAVES > 1) ? 1 : ((GENK || MOM) ? 2 : PAR_S3_UNITY_WAVES)) S3_VGPR_CAP void k_sinc_pipe(const S2Args a) {
-  static_assert(!(GENK && MOM), "one form of the fc < 1 path per kernel");
-  static_assert(NCH == 1 || (NCH == 2 && MOM && PAR_S3_MOM_WAVES == 1), "stereo: the moment form, one stream per workgroup");
-  constexpr int NW = MOM ? PAR_S3_MOM_WAVES : 1;
-  __shared__ S3Shared<GENK, MOM, NCH> SH;
+template <int NCH>
+__global__ __launch_bounds__(kWave, 2) void k_sinc_pipe(const S2Args a) {
+  static_assert(NCH == 1 || NCH == 2, "mono, or an interleaved stereo file");
+  __shared__ S3Lds<NCH> L;
   const int l = threadIdx.x & (kWave - 1);
-  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  S3LdsT<GENK, MOM, NCH>& L = SH.per[wv];
-  if constexpr (MOM && kMomTabFrags > 0) {
-    const uint4* src2 = reinterpret_cast<const uint4*>(kBank2Frags32);
-    const uint4* src3 = reinterpret_cast<const uint4*>(kBank3Frags32);
-    constexpr int kU = (kCtabUnity - kMomFrRegs) * kWave;
-    constexpr int kFull = (kMomTabFrags - kMomHalf) * kWave;
-    for (int i = threadIdx.x; i < kMomTabWords; i += kWave * NW) {
-      if (i < kFull) {
-        SH.fmtab[i] = i < kU ? src2[i + kMomFrRegs * kWave] : src3[i - kU + kMomFmRegs * kWave];
-      } else {                                    // even lanes of the (m6, -) fragments
-        const int h = i - kFull, f = h / (kWave / 2), e = h % (kWave / 2);
-        SH.fmtab[i] = src3[(kBank3Frags - 3 + f) * kWave + 2 * e];
-      }
-    }
-    __syncthreads();
+  if ((int)blockIdx.x < a.n_edge) {               // an end tile's wave: tile 0, then n_full - 2, n_full - 1 and the partial one
+    const int e = (int)blockIdx.x / kEdgeWavesPerTile, w = (int)blockIdx.x % kEdgeWavesPerTile;
+    const int64_t T = e == 0 ? 0 : a.n_full - 3 + e;
+    const int64_t jw = T * kSincTileOutputs + (int64_t)w * kEdgeWaveOut;
+    const int nrem = (int)(a.len_out - jw < (int64_t)kEdgeWaveOut ? (a.len_out - jw > 0 ? a.len_out - jw : 0) : kEdgeWaveOut);
+    float* const piece = reinterpret_cast<float*>(&L);
+    static_assert(sizeof(L) >= fused_capw(2 * NCH, NCH) * NCH * sizeof(float), "the wave's span fits the stream's LDS");
+    if (nrem == kEdgeWaveOut)
+      fused_wave<NCH, 32, 2 * NCH, true>(a.len_out, a.sig, a.sig + 1, NCH, a.len_in, 32, a.tab, a.tmd, a.out, a.out + 1, NCH, a.fa, piece, l,
+                                         jw, nrem, piece);
+    else if (nrem > 0)
+      fused_wave<NCH, 32, 2 * NCH, false>(a.len_out, a.sig, a.sig + 1, NCH, a.len_in, 32, a.tab, a.tmd, a.out, a.out + 1, NCH, a.fa, piece, l,
+                                          jw, nrem, piece);
+    return;
   }
-  if constexpr (NW == 1 && MOM) {
-    if ((int)blockIdx.x < a.n_edge) {             // an end tile's wave: tile 0, then n_full - 2, n_full - 1 and the partial one
-      const int e = (int)blockIdx.x / kEdgeWavesPerTile, w = (int)blockIdx.x % kEdgeWavesPerTile;
-      const int64_t T = e == 0 ? 0 : a.n_full - 3 + e;
-      const int64_t jw = T * kSincTileOutputs + (int64_t)w * kEdgeWaveOut;
-      const int nrem = (int)(a.len_out - jw < (int64_t)kEdgeWaveOut ? (a.len_out - jw > 0 ? a.len_out - jw : 0) : kEdgeWaveOut);
-      float* const piece = reinterpret_cast<float*>(&SH);
-      static_assert(sizeof(SH) >= fused_capw(2 * NCH, NCH) * NCH * sizeof(float), "the wave's span fits the stream's LDS");
-      if (nrem == kEdgeWaveOut)
-        fused_wave<NCH, 32, 2 * NCH, true>(a.len_out, a.sig, a.sig + 1, NCH, a.len_in, 32, a.tab, a.tmd, a.out, a.out + 1, NCH, a.fa, piece, l,
-                                           jw, nrem, piece);
-      else if (nrem > 0)
-        fused_wave<NCH, 32, 2 * NCH, false>(a.len_out, a.sig, a.sig + 1, NCH, a.len_in, 32, a.tab, a.tmd, a.out, a.out + 1, NCH, a.fa, piece, l,
-                                            jw, nrem, piece);
-      return;
-    }
-  }
-  const int64_t stream_id = ((int64_t)blockIdx.x - (NW == 1 && MOM ? a.n_edge : 0)) * NW + wv;
+  const int64_t stream_id = (int64_t)blockIdx.x - a.n_edge;
   const int my_tiles = stream_id < a.n_big ? a.tiles : a.tiles_tail;
   const int64_t Ta = stream_id < a.n_big ? stream_id * a.tiles : a.n_big * a.tiles + (stream_id - a.n_big) * a.tiles_tail;
   if (Ta >= a.n_full) return;
   const int64_t Tb = Ta + my_tiles < a.n_full ? Ta + my_tiles : a.n_full;
   const int64_t Ja = Ta * kSincTileOutputs, Jb = Tb * kSincTileOutputs;
-  half8v fr[kBank2Frags];                        // (the MOM kernel reads its constants from the table instead)
-  if constexpr (!MOM || kMomFrRegs > 0) {
+  half8v fr[kBank2Frags];                        // the fc = 1 bank's constant fragments
+  {
     const uint4* src = reinterpret_cast<const uint4*>(kBank2Frags32) + l;
 #pragma unroll
     for (int f = 0; f < kBank2Frags; ++f) fr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
   }
-  half8v fmr[kBank3Frags];                       // the moment filters' fragments (one-wave form of the MOM kernel only)
-  if constexpr (MOM && kMomFmRegs > 0) {
+  half8v fmr[kBank3Frags];                       // the moment filters'
+  {
     const uint4* src = reinterpret_cast<const uint4*>(kBank3Frags32) + l;
 #pragma unroll
-    for (int f = 0; f < kMomFmRegs; ++f) fmr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
+    for (int f = 0; f < kBank3Frags; ++f) fmr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
   }
-  const uint4* const fm = SH.fmtab;
   long long A0;
   int hd_dA, hd_fl;
   {
@@ -1125,8 +483,8 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
   // ---- stream state (wave-uniform) ----
   int j0 = 0;                                    // first output not yet placed into a finished pass
   int wbase = 0, conv_next = 0, conv_lo = 0, dma_next = 0, dma_bad = INT_MAX, mode = 0, pk = 0;
-  int regime = 1;                                // the loop the current pass belongs to: 1 fc = 1, 2 modulated images, 3 moment correction
-  float g0 = 0.0f;                               // (mode: the form of the images in LDS -- 0 none, 1 the signal itself, 2 modulated)
+  int regime = 1;                                // the loop the current pass belongs to: 1 fc = 1, 3 fc = 1 + the moment correction
+                                                 // (mode: 1 = the float16 images in LDS follow the ring, 0 = to be rebuilt)
   int rbA = 0, rbB = 0, rbC = 0;                 // first block (relative) of the record buffers of passes pk + 1, pk + 2, pk + 3
 
   // records: lanes 0-7 fetch first pieces, 8-15 second pieces, one 16-byte direct load each.  (The plan's record arrays end four
@@ -1200,10 +558,8 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
       P.R[0] = s2_place_row(ra0, rb0, u, (l < P.nt[0] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
       P.R[1] = s2_place_row(ra1, rb1, u, (l < P.nt[1] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
     }
-    if (MOM) {                                   // the moment correction covers 1 - fc <= 0.0125
-      P.R[0].bad = P.R[0].bad || !(P.R[0].ep <= kEpMaxMom);
-      P.R[1].bad = P.R[1].bad || !(P.R[1].ep <= kEpMaxMom);
-    }
+    P.R[0].bad = P.R[0].bad || !(P.R[0].ep <= kEpMaxMom);      // the moment correction covers 1 - fc <= 0.0125
+    P.R[1].bad = P.R[1].bad || !(P.R[1].ep <= kEpMaxMom);
     return P;
   };
 
@@ -1226,7 +582,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
       // channel-independent values of a row -- reciprocals, sin(pi s)/s, the moment step's coefficients -- from channel 0's turn)
       if (NCH == 2 && ch == 1) asm volatile("" : "+v"(sr), "+v"(epr));
 #endif
-      res[r] = s3_out_row<MODE, NCH>(L, ci, sr, epr, wsK, g0, ch);
+      res[r] = s3_out_row<MODE, NCH>(L, ci, sr, epr, wsK, ch);
     }
   };
   auto store_pass = [&](const S3Pass& Q, const float (&res)[2]) {
@@ -1246,10 +602,8 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
       const bool ok0 = s3_convert_ch(L, chunk, l, 0, true);
       const bool ok1 = s3_convert_ch(L, chunk, l, 1, false);
       return ok0 && ok1;
-    } else if constexpr (GENK) {
-      return mode == 1 ? s3_convert<1>(L, chunk, l, g0) : s3_convert<2>(L, chunk, l, g0);
     } else {
-      return s3_convert<1>(L, chunk, l, g0);
+      return s3_convert(L, chunk, l);
     }
   };
 
@@ -1296,17 +650,9 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
       }
       N.j = j0;
       N.ws = ws;
-      const int want = gen == 0ull ? 1 : 2;
-      if (!GENK && !MOM && want == 2) skip = true;        // (this kernel leaves fc < 1 passes to the block kernel)
-      const int img_want = MOM ? 1 : want;        // the moment form works on the signal's own image
-      float gg[2];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) gg[r] = N.ep[r] * fast_rcp(1.0f + N.ep[r]);
-      auto far_off = [&](float gref) {
-        return ((__ballot(!(fabsf(gref - gg[0]) <= kEpsTol)) & prefix(nv[0])) | (__ballot(!(fabsf(gref - gg[1]) <= kEpsTol)) & prefix(nv[1]))) != 0ull;
-      };
+      const int want = gen == 0ull ? 1 : 3;       // the pass's regime
       if (!skip) {
-        bool rebuild = mode != img_want || (img_want == 2 && far_off(g0));
+        bool rebuild = mode != 1;
         // the ring: restarted at the first pass of the wave and after a jump the fetched chunks do not cover
         const int lo_need = ws - 39 - wbase;      // window index of the first image sample the bank reads
         if (mode == 0 || lo_need < kPass * (dma_next - 8) + kPass || lo_need < 0 || lo_need > kPass * dma_next || ws - wbase > (1 << 20)) {
@@ -1318,13 +664,9 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
           ring_restart();
         }
         const int wsK = ws - wbase;
-        regime = MOM ? (want == 1 ? 1 : 3) : want;
+        regime = want;
         if (rebuild) {
-          mode = img_want;
-          if (img_want == 2) {
-            g0 = __shfl(gg[0], nJ - j0 > 32 ? 32 : 0, kWave);
-            if (far_off(g0)) skip = true;         // a ramp too steep for one g0
-          }
+          mode = 1;
           conv_lo = conv_next = (wsK - 39) >> 7;
         }
         // slack of the conversion window.  The loop checks the pass BEHIND this one (its bank needs the image to reach
@@ -1373,15 +715,8 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
       }
       wave_lds_fence();
       const int offs = ws - wbase - 31;
-      if constexpr (MOM) {
-        if (regime == 3) bank_image3m<true>(L, fr, fmr, fm, offs, l);
-        else bank_image3m<false>(L, fr, fmr, fm, offs, l);
-      } else if (!GENK || mode == 1) {
-        bank_image3<false>(L, fr, offs, l, 0);
-      } else if constexpr (GENK) {
-        bank_image3<true>(L, fr, offs, l, 0);
-        bank_image3<true>(L, fr, offs, l, 1);
-      }
+      if (regime == 3) bank_image3m<true>(L, fr, fmr, offs, l);
+      else bank_image3m<false>(L, fr, fmr, offs, l);
       wave_lds_fence();
       j0 += N.nok[0] + N.nok[1];
       ++pk;
@@ -1392,15 +727,13 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
         return true;
       }
       float res[2];
-      if (MOM && regime == 3) {
-        if constexpr (MOM) out_pass(std::integral_constant<int, 3>{}, N, res);
-      } else if (!GENK || mode == 1) out_pass(std::integral_constant<int, 1>{}, N, res);
-      else if constexpr (GENK) out_pass(std::integral_constant<int, 2>{}, N, res);
+      if (regime == 3) out_pass(std::integral_constant<int, 3>{}, N, res);
+      else out_pass(std::integral_constant<int, 1>{}, N, res);
       if constexpr (NCH == 2) {                   // the other channel through the same rows
         float res1[2];
         wave_lds_fence();
-        if (regime == 3) bank_image3m<true>(L, fr, fmr, fm, offs, l, 1);
-        else bank_image3m<false>(L, fr, fmr, fm, offs, l, 1);
+        if (regime == 3) bank_image3m<true>(L, fr, fmr, offs, l, 1);
+        else bank_image3m<false>(L, fr, fmr, offs, l, 1);
         wave_lds_fence();
         if (regime == 3) out_pass(std::integral_constant<int, 3>{}, N, res1, 1);
         else out_pass(std::integral_constant<int, 1>{}, N, res1, 1);
@@ -1425,7 +758,6 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
     dma_next = __builtin_amdgcn_readfirstlane(dma_next);
     dma_bad = __builtin_amdgcn_readfirstlane(dma_bad);
     pk = __builtin_amdgcn_readfirstlane(pk);
-    g0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(g0)));
     rbA = __builtin_amdgcn_readfirstlane(rbA);
     rbB = __builtin_amdgcn_readfirstlane(rbB);
     rbC = __builtin_amdgcn_readfirstlane(rbC);
@@ -1468,10 +800,6 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
       ok = (((Q.fl0 | Q.fl1) & 1) == 0) & (bad == 0ull) & (j0 + kPass <= nJ) & (N.nok[0] + N.nok[1] >= 120) &
            (MODE == 1 ? gen == 0ull : gen != 0ull) & ((unsigned)(d - 161) <= 312u) & (conv_next + 1 < dma_bad) &
            ((unsigned)((j0 >> kRecShift) - rbA) <= 1u);
-      if (MODE == 2) {
-        const float g_0 = N.ep[0] * fast_rcp(1.0f + N.ep[0]), g_1 = N.ep[1] * fast_rcp(1.0f + N.ep[1]);
-        ok = ok && __ballot(!(fabsf(g0 - g_0) <= kEpsTol) || !(fabsf(g0 - g_1) <= kEpsTol)) == 0ull;
-      }
       };
       if constexpr (NCH == 1) place_next();       // (stereo: behind OUT(P, 1), fewer registers live through the banks)
       // BANK(pk) over [ws, ws + 128): image samples converted in earlier iterations
@@ -1488,12 +816,12 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
         // (pinned here: left alone the compiler sinks a row's arithmetic into the store's lane mask at the END of the iteration,
         // and the gathered rows and ring samples of both channels stay live through the banks: 33 registers in scratch)
         asm volatile("" : "+v"(res[0]), "+v"(res[1]));
-        bank_image3m<MODE == 3>(L, fr, fmr, fm, P.ws - wbase - 31, l, 1);
+        bank_image3m<MODE == 3>(L, fr, fmr, P.ws - wbase - 31, l, 1);
         out_pass(mode_tag, P, res1, 1);
         asm volatile("" : "+v"(res1[0]), "+v"(res1[1]));
         place_next();
         const int offs = wsK - 31;
-        bank_image3m<MODE == 3>(L, fr, fmr, fm, offs, l, 0);
+        bank_image3m<MODE == 3>(L, fr, fmr, offs, l, 0);
         const bool c0 = s3_convert_ch(L, conv_next, l, 0, true);
         const bool c1 = s3_convert_ch(L, conv_next - 1, l, 1, false);
         cok = c0 && c1;
@@ -1505,16 +833,9 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
 #if PAR_S3_PIN_MONO
         asm volatile("" : "+v"(res[0]), "+v"(res[1]));
 #endif
-        if constexpr (MOM) {
-          s3_sched_fence();
-          bank_image3m<MODE == 3>(L, fr, fmr, fm, offs, l);
-          s3_sched_fence();
-        } else {
-          bank_image3<MODE == 2>(L, fr, offs, l, 0);
-          if constexpr (MODE == 2) bank_image3<true>(L, fr, offs, l, 1);
-        }
+        bank_image3m<MODE == 3>(L, fr, fmr, offs, l);
         // CONV: one chunk per iteration
-        cok = s3_convert<MODE == 2 ? 2 : 1>(L, conv_next, l, g0);
+        cok = s3_convert(L, conv_next, l);
         // FETCH + stores: records of pass pk + 2, chunk conv_next + 2, then P's outputs (five memory operations, in this order)
         fetch_records((pk + 2) & 3, rbC);
         chunk_dma(dma_next);
@@ -1555,10 +876,8 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
   };
 
   while (start_run()) {
-    if (MOM && regime == 3) {
-      if constexpr (MOM) hot(std::integral_constant<int, 3>{});
-    } else if (!GENK || mode == 1) hot(std::integral_constant<int, 1>{});
-    else if constexpr (GENK) hot(std::integral_constant<int, 2>{});
+    if (regime == 3) hot(std::integral_constant<int, 3>{});
+    else hot(std::integral_constant<int, 1>{});
     // P has been finished by the loop; the pass at j0 needs the cold path
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1575,7 +894,7 @@ __global__ __launch_bounds__(kWave * (MOM ? PAR_S3_MOM_WAVES : 1), (MOM && PAR_S
 }
 
 int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
-                       const float4* tab, const TapModes& tmd, hipStream_t s, int variant, int nch) {
+                       const float4* tab, const TapModes& tmd, hipStream_t s, int nch) {
   (void)device;
   S2Args a;
   a.len_out = len_out;
@@ -1593,7 +912,7 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
   a.n_full = len_out / kSincTileOutputs;
   a.n_tiles = ceil_div(len_out, kSincTileOutputs);
   // (launch_sinc_fused only comes here with >= 4 full tiles: the end tiles are distinct)
-  a.n_edge = (PAR_S3_MOM_WAVES == 1 && variant == 4 && a.n_full >= 4) ? (int)(3 + (a.n_tiles - a.n_full)) * kEdgeWavesPerTile : 0;
+  a.n_edge = a.n_full >= 4 ? (int)(3 + (a.n_tiles - a.n_full)) * kEdgeWavesPerTile : 0;
   // Tiles per wave of the pipelined kernel: long streams amortise a wave's cold start and, beside a batch driver's plan kernels,
   // leave fewer wave boundaries for them to slip into -- 60-min file, ms per pipelined step: 4 tiles 5.03, 8: 4.84, 12: 4.70,
   // 16: 4.66, 24: 4.61, 32: 5.06 (10.3 rounds of the 2 048 wave slots: the last one nearly empty), 48: 4.67 (r05) -- while a
@@ -1609,27 +928,9 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
   static const int tail_rounds = getenv("PAR_S2_TAIL_ROUNDS") ? atoi(getenv("PAR_S2_TAIL_ROUNDS")) : 1;
   a.tiles_tail = a.tiles >= 8 && tail_env > 1 ? std::max(2, a.tiles / tail_env) : a.tiles;
   a.n_big = (a.n_full - std::min<int64_t>(a.n_full, 2048ll * tail_rounds * a.tiles * (a.tiles_tail < a.tiles ? 1 : 0))) / a.tiles;
-  const int64_t grid = variant == 1 ? ceil_div(a.n_full, (int64_t)PAR_S2_TILES)
-                                    : a.n_big + ceil_div(a.n_full - a.n_big * a.tiles, (int64_t)a.tiles_tail);
-#if PAR_S2_VARIANTS
-  if (grid > 0 && variant == 1) hipLaunchKernelGGL(k_sinc_stream, dim3((unsigned)grid), dim3(kWave), 0, s, a);
-  else if (grid > 0 && variant == 2) hipLaunchKernelGGL((k_sinc_pipe<true, false>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
-  else if (grid > 0 && variant == 3) hipLaunchKernelGGL((k_sinc_pipe<false, false>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
-  else
-#else
-  (void)variant;
-#endif
-  if (grid > 0 && nch == 2) {
-#if PAR_S3_MOM_WAVES == 1
-    hipLaunchKernelGGL((k_sinc_pipe<false, true, 2>), dim3((unsigned)(grid + a.n_edge)), dim3(kWave), 0, s, a);
-#else
-    return PAR_ERR_ARG;
-#endif
-  } else if (grid > 0)
-    hipLaunchKernelGGL((k_sinc_pipe<false, true>), dim3((unsigned)(ceil_div(grid, (int64_t)PAR_S3_MOM_WAVES) + a.n_edge)), dim3(kWave * PAR_S3_MOM_WAVES), 0, s, a);
-  else if (a.n_tiles > 0) {
-    // nothing but a partial tile: the caller's block kernel handles short files (launch_sinc_fused never comes here)
-  }
+  const int64_t grid = a.n_big + ceil_div(a.n_full - a.n_big * a.tiles, (int64_t)a.tiles_tail) + a.n_edge;
+  if (grid > 0 && nch == 2) hipLaunchKernelGGL(k_sinc_pipe<2>, dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  else if (grid > 0) hipLaunchKernelGGL(k_sinc_pipe<1>, dim3((unsigned)grid), dim3(kWave), 0, s, a);
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }

@@ -50,6 +50,6 @@ struct FusedArgs {
 // point at the left channel's first sample; len_in / len_out count frames).  Tiles it does not take are appended to fa.redo_list.
 struct TapModes;
 int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
-                       const float4* tab, const TapModes& tmd, hipStream_t s, int variant, int nch);
+                       const float4* tab, const TapModes& tmd, hipStream_t s, int nch);
 
 }  // namespace par

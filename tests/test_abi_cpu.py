@@ -303,13 +303,13 @@ def test_pmc_summary_picks_the_timed_kernel():
     rows = {("void par::k_sinc_fused<1, 32, 4>(long, float const*, float const*)", "FETCH_SIZE"): 1993364.0,
             ("void par::k_sinc_fused<1, 32, 4>(long, float const*, float const*)", "SQ_INSTS_VALU"): 3.281e9,
             ("void par::k_sinc_fused<2, 32, 4>(long, float const*, float const*)", "FETCH_SIZE"): 5.0e5,
-            ("void par::k_sinc_pipe<false, true, 1>(par::S2Args)", "FETCH_SIZE"): 1855254.0,
-            ("void par::k_sinc_pipe<false, true, 1>(par::S2Args)", "SQ_INSTS_VALU"): 1.944e9,
+            ("void par::k_sinc_pipe<1>(par::S2Args)", "FETCH_SIZE"): 1855254.0,
+            ("void par::k_sinc_pipe<1>(par::S2Args)", "SQ_INSTS_VALU"): 1.944e9,
             ("par::k_sinc_fused_list(long, float const*, long)", "FETCH_SIZE"): 1000.0,
             ("par::k_sinc_fused_list(long, float const*, long)", "SQ_INSTS_VALU"): 1.0e6}
     v, missing = S.pick_counters(rows, ["k_sinc_fused<1, 32, 4>"])
     assert not missing and v == {"FETCH_SIZE": 1993364.0, "SQ_INSTS_VALU": 3.281e9}
-    v, missing = S.pick_counters(rows, ["k_sinc_pipe<false, true, 1>", "k_sinc_fused_list"])
+    v, missing = S.pick_counters(rows, ["k_sinc_pipe<1>", "k_sinc_fused_list"])
     assert not missing and v["FETCH_SIZE"] == 1856254.0 and abs(v["SQ_INSTS_VALU"] - 1.945e9) < 1.0
     v, missing = S.pick_counters(rows, ["k_sinc_stream"])
     assert missing == ["k_sinc_stream"] and v == {}

@@ -1146,7 +1146,7 @@ def test_streaming_kernel_and_block_kernel(par, sinc_kernel, kernel):
 
 
 def test_stereo_streaming_kernel_against_the_oracle(par):
-    """The streaming kernel's stereo form (csrc/sinc2.hip, k_sinc_pipe<false, true, 2>: interleaved NT = 32 files, the default
+    """The streaming kernel's stereo form (csrc/sinc2.hip, k_sinc_pipe<2>: interleaved NT = 32 files, the default
     since r05; one placement for both channels, which take turns in one set of bank rows; the file's end tiles by the launch's
     first workgroups).  Each channel against the C oracle on a fast, a slow, a mixed and a unit tape, norm-wise and per
     4096-sample block, with DIFFERENT material in the two channels (a channel must not leak into the other: a full-scale Nyquist
@@ -1674,7 +1674,7 @@ def test_bench_contract_line():
     assert 1 <= cb["cores"] == cb["cores_usable"] <= cb["cores_reported"] and cb["per_core_Msamples/s"] > 0.1
     assert 0.2 < cb["sinc_only_parallel_efficiency"] < 1.6, cb
     # the line names the kernel(s) of a timed launch; PMC side files are only quoted when they describe exactly those
-    assert rl["kernel_symbols"] == ["k_sinc_pipe<false, true, 1>", "k_sinc_fused_list"] and rl["warm_launches_before_timed"] >= 30
+    assert rl["kernel_symbols"] == ["k_sinc_pipe<1>", "k_sinc_fused_list"] and rl["warm_launches_before_timed"] >= 30
     assert "float16" in r["dtype"] and "mfma" in r["dtype"].lower()
     assert r["config"]["plan"].startswith("lazy")
     if rl["traffic"] is not None:

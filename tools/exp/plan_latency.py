@@ -39,4 +39,4 @@ for _ in range(8):
     sinc(); sinc()                       # keep the GPU busy for ~10 ms
     t0 = time.perf_counter(); plan(1, sp_side); t.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
-print(f"plan under K_sinc (PAR_SINC_STREAM={os.environ.get('PAR_SINC_STREAM', '0')}): {np.median(t) * 1e3:.2f} ms  (all: {' '.join(f'{x * 1e3:.2f}' for x in t)})")
+print(f"plan under K_sinc: {np.median(t) * 1e3:.2f} ms  (all: {' '.join(f'{x * 1e3:.2f}' for x in t)})")

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from pyaudiorestoration_amd import _dev, _lib
 L = _lib.lib()
-dev, sr, seconds = 0, 192000, 3600.0
+dev, sr, seconds = 0, 192000, float(os.environ.get("SECONDS_", "3600"))
 s = _dev.stream_ptr(dev)
 n = int(sr * seconds); m = int(seconds * sr / 256)
 st = torch.empty(m, dtype=torch.float64, device="cuda"); sp = torch.empty(m, dtype=torch.float64, device="cuda")

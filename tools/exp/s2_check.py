@@ -1,5 +1,5 @@
 """Streaming K_sinc (sinc2.hip) against the C oracle: slow / fast / benchmark-mix tapes x noise / Nyquist / 0.45 fs, 2 M samples;
-prints the worst error and how many tiles went back to the block kernel.  PAR_SINC_STREAM=0: the block kernel alone."""
+prints the worst error and how many tiles went back to the block kernel.  par_debug_sinc_kernel(0): the block kernel alone."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -1,4 +1,4 @@
-"""Pipelined streaming K_sinc (k_sinc_pipe, PAR_SINC_STREAM=2): how many passes take the loop and why the others leave it.
+"""Pipelined streaming K_sinc (k_sinc_pipe): how many passes take the loop and why the others leave it.
 Needs a library whose sinc2.hip was built with -DPAR_S2_EXP=128 (tools/exp/s2_variant.sh cnt -DPAR_S2_EXP=128)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """k_sinc_pipe timing build (-DPAR_S2_EXP=64): per wave, cycles per loop iteration spent in the memory wait at its head, in the body,
-and outside the loop.  PAR_SINC_STREAM=2 / 3 selects the kernel."""
+and outside the loop."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

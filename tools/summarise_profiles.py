@@ -13,8 +13,8 @@ import sys
 
 def pick_counters(rows, symbols):
     """Counters of ONE timed K_sinc launch.  rows: {(kernel_name, counter_name): per-launch average} as rocprofv3 names kernels
-    (e.g. 'void par::k_sinc_pipe<false, true, 1>(par::S2Args)'); symbols: the template-qualified names the bench line says a timed
-    launch consists of (roofline.kernel_symbols, e.g. ['k_sinc_pipe<false, true, 1>', 'k_sinc_fused_list']).  A kernel belongs to a
+    (e.g. 'void par::k_sinc_pipe<1>(par::S2Args)'); symbols: the template-qualified names the bench line says a timed
+    launch consists of (roofline.kernel_symbols, e.g. ['k_sinc_pipe<1>', 'k_sinc_fused_list']).  A kernel belongs to a
     symbol when 'par::<symbol>(' occurs in its name -- 'k_sinc_fused<1, 32, 4>' does not pick up 'k_sinc_fused<2, 32, 4>' or
     'k_sinc_fused_list', and a second K_sinc kernel the same run happens to launch (r04: the opt-in moment kernel, whose rows
     overwrote the timed kernel's in profiles/pmc_*.json) is simply not asked for.  Returns ({counter: sum over the symbols},
