@@ -1218,6 +1218,35 @@ def test_stereo_streaming_kernel_against_the_oracle(par):
             assert relerr(got[:, c], C.sinc(pos, x, NT)) < TOL, (n2, speed, c)
 
 
+def test_streaming_kernel_files_of_whole_tiles(par):
+    """Files whose output is a whole number of 1024-output tiles (no partial tile: the streaming launch then has three end
+    tiles instead of four), down to the smallest file the streaming kernel takes (four tiles: only tile 1 is streamed), and
+    their neighbours in length -- mono and interleaved stereo against the C oracle."""
+    from oracle import oracle_c as C
+    t = par.torch
+    R = par.resampling
+    rng = np.random.default_rng(5)
+    whole = 0
+    for n in (4096, 4097, 5121, 8193, 8197, 20481, 20482):
+        for speed in (1.0, 0.9995):
+            st = np.linspace(0, n, 40)
+            sp = np.full(40, speed)
+            pos, _ = C.speed_to_pos(st, sp, n)
+            plan = R.speed_plan_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), n, fused=True)
+            assert plan.len_out == len(pos)
+            whole += plan.len_out % 1024 == 0
+            a, b = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+            want_a, want_b = C.sinc(pos, a, 32), C.sinc(pos, b, 32)
+            assert relerr(R.varispeed_fused_dev(plan, t.from_numpy(a).cuda(), 32).cpu().numpy(), want_a) < TOL, (n, speed)
+            inter = t.from_numpy(np.stack((a, b), axis=1)).cuda().reshape(-1)
+            out = t.empty((plan.len_out, 2), dtype=t.float32, device="cuda")
+            R.varispeed_fused_stereo_dev(plan, inter[0:], inter[1:], 32, out.reshape(-1)[0:], out.reshape(-1)[1:], sig_stride=2,
+                                         len_in=n, out_stride=2)
+            o = out.cpu().numpy()
+            assert relerr(o[:, 0], want_a) < TOL and relerr(o[:, 1], want_b) < TOL, (n, speed)
+    assert whole >= 4
+
+
 def test_kernel_choice_of_the_fused_entry_point(par, sinc_kernel):
     """par_varispeed_fused_f32 picks the streaming kernel for mono NT = 32 unit-stride files (the tile diagnostic says so) and the
     block kernel for everything else; forcing the block kernel changes the mono NT = 32 result by float32 rounding only and
