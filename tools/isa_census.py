@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Per-stage instruction census of the streaming kernel's two hot loops (fc = 1 and fc < 1), from the compiler's listing.
+    python tools/isa_census.py [NCH] [extra hipcc flags]   -> prints the table committed as profiles/r06_isa_census.txt
+Every instruction between a loop's `s_waitcnt vmcnt(N)` head and its back edge is attributed to the STAGE its .loc source
+line belongs to (source ranges of sinc2.hip named below; inlined header code is charged to the last csrc line seen)."""
+import os, re, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pyaudiorestoration_amd import build as B
+
+def stage_table(src):
+    """(first, last, stage) source ranges, found by marker comments / function names so that edits do not break them"""
+    lines = open(src).read().split("\n")
+    def find(pat, start=0):
+        for i in range(start, len(lines)):
+            if re.search(pat, lines[i]):
+                return i + 1
+        raise KeyError(pat)
+    def end_of(first):            # a column-0 function: closes at the first "^}" behind it
+        for i in range(first, len(lines)):
+            if lines[i].startswith("}"):
+                return i + 1
+    T = []
+    for name, pat in (("place_row", r"S2Row s2_place_row"), ("bank", r"void bank_image3m"), ("out_row", r"float s3_out_row"),
+                      ("convert", r"bool s3_convert\("), ("convert", r"bool s3_convert_ch\("), ("out_row", r"float sinpi_poly")):
+        a = find(r"__device__ __forceinline__ " + pat) if "S2Row" not in pat else find(pat)
+        T.append((a - 1, end_of(a), name))
+    a = find(r"auto place = \[&\]"); b = find(r"^\s*S3Pass P;", a)
+    T.append((a, b, "place"))
+    a = find(r"auto place_next = \[&\]"); b = find(r"^\s*};", a)
+    T.append((a, b, "place_next"))
+    a = find(r"auto out_pass = \[&\]"); b = find(r"auto store_pass = ", a)
+    T.append((a, b - 1, "out_pass"))
+    a = find(r"auto store_pass = \[&\]"); b = find(r"auto convert_chunk", a)
+    T.append((a, b - 1, "store"))
+    a = find(r"auto fetch_records = \[&\]"); b = find(r"auto push_tile", a)
+    T.append((a, b - 1, "fetch"))
+    for name, pat in (("dma", r"void dma_dword\("), ("dma", r"void dma_dwordx4"), ("dma", r"void dma_chunk128"), ("dma", r"void dma_chunk256"),
+                      ("fence", r"void wave_lds_fence")):
+        a = find(pat); T.append((a, end_of(a), name))
+    return T
+
+CLASS = (("mfma", r"v_mfma"), ("trans", r"v_(rcp|rsq|sqrt|sin|cos|exp|log)_"), ("valu", r"v_"), ("lds", r"ds_"),
+         ("vmem", r"(global|buffer|flat|scratch)_"), ("salu", r"s_"))
+
+def main():
+    nch = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].isdigit() else "1"
+    extra = [a for a in sys.argv[1:] if not a.isdigit()]
+    tmp = tempfile.mkdtemp()
+    src = os.path.join(B.CSRC, "sinc2.hip")
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + B.PER_FILE.get("sinc2.hip", []) + extra +
+                          ["-gline-tables-only", "-save-temps", "-c", src, "-o", os.path.join(tmp, "o.o")], cwd=tmp,
+                          stderr=subprocess.DEVNULL)
+    s = next(os.path.join(tmp, f) for f in os.listdir(tmp) if f.endswith("gfx950.s") and f.startswith("sinc2"))
+    L = open(s).read().split("\n")
+    files = {}
+    for l in L:
+        m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
+        if m: files[int(m.group(1))] = os.path.basename(m.group(3) or m.group(2))
+    start = next(i for i, l in enumerate(L) if re.match(r"^_ZN3par11k_sinc_pipeILi%sEEE" % nch, l))
+    end = next(i for i in range(start, len(L)) if L[i].startswith(".Lfunc_end"))
+    for i in range(end, min(end + 60, len(L))):
+        if re.search(r"; (NumVgprs|NumAgprs|ScratchSize|Occupancy|NumSgprs|LDSByteSize)", L[i]): print(L[i].strip())
+    stages = stage_table(src)
+    heads = [i for i in range(start, end) if re.search(r"s_waitcnt vmcnt\((5|7)\)", L[i])]
+    for hi, h in enumerate(heads):
+        # loop header: the nearest "Parent Loop" label above the head; body: every block that names it as its header
+        hl = next(i for i in range(h, start, -1) if re.match(r"^\.LBB\d+_\d+:.*Parent Loop", L[i]))
+        lab = L[hl].split(":")[0].lstrip(".L")
+        # the latch is the block in front of the header (it falls through into it); the body ends at the last branch to the latch
+        latch = next(L[i].split(":")[0] for i in range(hl - 1, start, -1) if re.match(r"^\.LBB\d+_\d+:", L[i]))
+        back = max(i for i in range(hl, end) if re.search(r"s_c?branch\w*\s+%s\b" % re.escape(latch), L[i]))
+        h = hl
+        cur, last_stage = ("?", 0), "loop"
+        tab = {}
+        for i in range(h, back + 1):
+            l = L[i].strip()
+            m = re.match(r"\.loc\s+(\d+)\s+(\d+)", l)
+            if m: cur = (files.get(int(m.group(1)), "?"), int(m.group(2))); continue
+            if not l or l.startswith((";", ".", "//")) or l.endswith(":"): continue
+            op = l.split()[0]
+            if cur[0] == "sinc2.hip":
+                st = next((n for a, b, n in stages if a <= cur[1] <= b), "loop")
+                last_stage = st
+            else:
+                st = last_stage
+            cls = next(c for c, p in CLASS if re.match(p, op))
+            tab.setdefault(st, {}).setdefault(cls, 0)
+            tab[st][cls] += 1
+        print(f"\nloop {hi} ({'fc = 1' if hi == 0 else 'fc < 1 (moment correction)'}): listing lines {h}..{back}  [static; the placement's "
+              "two variants (with / without second pieces) are both counted, one runs]")
+        cols = ["valu", "trans", "mfma", "lds", "vmem", "salu"]
+        print(f"{'stage':12s}" + "".join(f"{c:>7s}" for c in cols))
+        tot = dict.fromkeys(cols, 0)
+        for st in sorted(tab, key=lambda k: -sum(tab[k].values())):
+            print(f"{st:12s}" + "".join(f"{tab[st].get(c, 0):7d}" for c in cols))
+            for c in cols: tot[c] += tab[st].get(c, 0)
+        print(f"{'total':12s}" + "".join(f"{tot[c]:7d}" for c in cols))
+
+if __name__ == "__main__":
+    main()
