@@ -470,7 +470,7 @@ def config5_batch(a, ctx):
                                "(resampling.varispeed_batch_dev)"},
             "roofline": {"bound": "hbm", "achieved": round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / world, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / world / HBM_PEAK_GBS, 5),
-                         "traffic": None, "kernel": "k_sinc stereo: k_sinc_pipe<2> + k_sinc_fused_list2 at NT = 32 (whole step, per GPU)", "limited_by": "valu",
+                         "traffic": None, "kernel": "k_sinc stereo: k_sinc_pipe<2, 0> + k_sinc_fused_list2 at NT = 32 (whole step, per GPU)", "limited_by": "valu",
                          "note": "per-GPU whole-step rate x 8 algorithmic B per channel-sample against the HBM roof the contract "
                                  "names; what limits the kernel is VALU issue (the N = 1 line carries the per-kernel HIP-event "
                                  "timing, PMC traffic and the VALU roofline)"},
@@ -577,7 +577,7 @@ def main():
     if block_kernel:
         L.par_debug_sinc_kernel(0)                                 # A/B knob: the block kernel for the mono NT = 32 file too
     streaming = fused and a.nt == 32 and not block_kernel          # what par_varispeed_fused_f32 launches for this workload
-    kernel_symbols = (["k_sinc_pipe<1>", "k_sinc_fused_list"] if streaming else
+    kernel_symbols = (["k_sinc_pipe<1, 2>", "k_sinc_pipe<1, 1>", "k_sinc_fused_list"] if streaming else
                       [f"k_sinc_fused<1, {a.nt if a.nt in (32, 50) else 0}, 4>"] if fused else
                       [f"k_sinc_pos<{a.nt if a.nt in (32, 50) else 0}>"])
     state_plan = {"lazy": False}

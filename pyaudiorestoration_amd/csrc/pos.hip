@@ -1044,10 +1044,12 @@ __device__ __forceinline__ void tile_entry(const double* __restrict__ sp, const 
     // bit 1: some segment under the tile (or the one behind it: the last output's period reaches there) touches
     // speed >= 1, i.e. the tile may hold fc = 1 outputs.  A hint only: K_sinc's matrix-core path is taken by workgroups
     // whose tile carries it, everything else computes the same numbers on the vector path.
-    bool may_unity = false;
-    for (long long q = lo; q < nseg && seg_start[q] <= sample + kSincTileOutputs; ++q)
+    bool may_unity = false, may_slow = false;
+    for (long long q = lo; q < nseg && seg_start[q] <= sample + kSincTileOutputs; ++q) {
       may_unity = may_unity || !(sp[q] < kUnityHintBelow) || !(sp[q + 1] < kUnityHintBelow);
-    hd.flags = (ok ? 0 : 1) | (may_unity ? kTileMayUnity : 0) | (lazy ? kTileLazy : 0);
+      may_slow = may_slow || !(sp[q] >= kSlowHintBelow) || !(sp[q + 1] >= kSlowHintBelow);
+    }
+    hd.flags = (ok ? 0 : 1) | (may_unity ? kTileMayUnity : 0) | (may_slow ? kTileMaySlow : 0) | (lazy ? kTileLazy : 0);
     hdr[x] = hd;
   }
 }

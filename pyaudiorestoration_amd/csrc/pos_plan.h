@@ -257,6 +257,9 @@ struct TileHdr {
   int flags;                // 1: positions out of range (tile takes the float64 path); kTileMayUnity: see k_tile_seg
 };
 constexpr int kTileMayUnity = 2;
+constexpr int kTileMaySlow = 8;      // some segment under the tile (or the one behind it) touches speed < 1 + 2e-7 (or is not a number): the
+                                     // tile may hold fc < 1 outputs.  K_sinc's streaming launch sorts its streams by it (k_sinc_pipe's KIND)
+constexpr double kSlowHintBelow = 1.0000002;     // float32 period - 1 stays <= 0 at and above this speed
 constexpr double kUnityHintBelow = 0.9999998;    // float32 period - 1 rounds to 0 well above this speed
 static_assert(sizeof(TileHdr) == 32, "TileHdr is one s_load_dwordx8");
 constexpr int kBlocksPerTile = (int)(kSincTileOutputs / kRec);

@@ -219,15 +219,24 @@ constexpr int kRingH = 512;                       // samples per float16 image (
 
 // A stream's LDS.  NCH = 2: an interleaved stereo file -- the ring holds frames (left, right), each channel has its own float16
 // images, and the two channels take turns in ONE set of bank rows (see the loop of k_sinc_pipe).
-template <int NCH>
+// MOM = false: the stream of a kernel that only knows fc = 1 passes (k_sinc_pipe<1, 1>) -- no moment rows, the packed e2 | d2
+// halves in an array of their own: 9.8 KB, sixteen streams per compute unit.
+template <int NCH, bool MOM = true>
 struct S3Lds {
+  static constexpr bool kMoments = MOM;
   float ring_head[4 * NCH];                      // frames -2, -1 mirror frames 1022, 1023
   float ring[kRingF * NCH];
   float ring_tail[4 * NCH];                      // mirrors frames 0 .. 3
   _Float16 img[2 * NCH][kRingH];                 // x hi, lo x 4096 (stereo: [2 ch], [2 ch + 1])
   float4v qa[kPass];                             // bank rows {e0, d0, e1, d1}, slot = ci ^ ((ci >> 3) & 7)
-  float4v qm0[kPass];                            // moment rows {m0, m1, m2, e2|d2 (halves)} (same slots)
-  float4v qm1[kPass];                            // {m3, m4, m5, m6}
+  float4v qm0[MOM ? kPass : kPass / 4];          // moment rows {m0, m1, m2, e2|d2 (halves)} (same slots); !MOM: e2|d2 alone, a float per slot
+  float4v qm1[MOM ? kPass : 1];                  // {m3, m4, m5, m6}
+  __device__ __forceinline__ float& e2d2(int sl) {
+    return MOM ? reinterpret_cast<float*>(&qm0[sl])[3] : reinterpret_cast<float*>(&qm0[0])[sl];
+  }
+  __device__ __forceinline__ const float& e2d2(int sl) const {
+    return MOM ? reinterpret_cast<const float*>(&qm0[sl])[3] : reinterpret_cast<const float*>(&qm0[0])[sl];
+  }
 #ifdef PAR_S3_LDS_PAD
   uint4 pad[PAR_S3_LDS_PAD / 16];                // (occupancy experiments)
 #endif
@@ -237,6 +246,9 @@ static_assert(offsetof(S3Lds<1>, img) % 16 == 0 && offsetof(S3Lds<1>, qa) % 16 =
 static_assert(offsetof(S3Lds<2>, ring) % 16 == 0 && offsetof(S3Lds<2>, img) % 16 == 0 && offsetof(S3Lds<2>, qa) % 16 == 0 &&
               offsetof(S3Lds<2>, recs) % 16 == 0, "16-byte aligned");
 static_assert(sizeof(S3Lds<2>) <= 20480, "eight stereo streams per compute unit (160 KB of LDS)");
+using S3LdsUnity = S3Lds<1, false>;
+static_assert(sizeof(S3LdsUnity) <= 10240 && offsetof(S3LdsUnity, recs) % 16 == 0 && offsetof(S3LdsUnity, qa) % 16 == 0,
+              "sixteen fc = 1 streams per compute unit");
 
 struct S3Pass {                                  // a placed pass: 128 candidate outputs j .. j + 127 (two per lane)
   int c[2];                                      // window centre relative to A0
@@ -298,13 +310,13 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
     const float4v row = {v0[2 * p], v0[2 * p + 1], v1[2 * p], v1[2 * p + 1]};
     L.qa[sl] = row;
     const float e2d2 = __uint_as_float(pack_h2(e2[2 * p] * 0.015625f, e2[2 * p + 1] * 0.015625f));
-    if (MOMENTS) {
+    if constexpr (MOMENTS) {
       const float4v r0 = {m01[2 * p], m01[2 * p + 1], a23[2 * p], e2d2};
       L.qm0[sl] = r0;
       const float4v r1 = {a23[2 * p + 1], a45[2 * p], a45[2 * p + 1], a6[2 * p]};
       L.qm1[sl] = r1;
     } else {
-      reinterpret_cast<float*>(&L.qm0[sl])[3] = e2d2;
+      L.e2d2(sl) = e2d2;
     }
   }
 }
@@ -326,11 +338,11 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
     const float4v row = L.qa[sl];
     float4v M0 = {0.0f, 0.0f, 0.0f, 0.0f};
     unsigned w2;
-    if (MODE == 3) {
+    if constexpr (MODE == 3) {
       M0 = L.qm0[sl];
       w2 = __float_as_uint(M0[3]);
     } else {
-      w2 = __float_as_uint(reinterpret_cast<const float*>(&L.qm0[sl])[3]);
+      w2 = __float_as_uint(L.e2d2(sl));
     }
     const float e = fmaf(q, fmaf(q64, h_lo(w2), row[2]), row[0]), d = fmaf(q, fmaf(q64, h_hi(w2), row[3]), row[1]);
     const float en = fmaf(E2, R2, -(E1 * R1));
@@ -338,7 +350,8 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
     const float et = fmaf(e, kBank2ScaleInv, en), dt = fmaf(d, kBank2ScaleInv, dn);
     const float spq = sinpi_poly(q);                                  // sin(pi s) / s
     const float unity = spq * fmaf(-sr, fmaf(sr, et, dt), x0 * 0.318309886f);
-    if (MODE == 1) return unity;
+    if constexpr (MODE == 1) return unity;
+    else {
     const float4v Mh = L.qm1[sl];
     const float m3 = Mh[0], m4 = Mh[1], m5 = Mh[2], m6 = Mh[3];
     const float g = epr * fast_rcp(1.0f + epr);                        // 1 - fc
@@ -363,6 +376,7 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
 #undef S3_MOM_STEP
     const float S = sr * spq, C = __builtin_amdgcn_cosf(0.5f * sr);
     return fmaf(-g, fmaf(C, re, -(S * im)), unity);
+    }
   }
 }
 
@@ -418,12 +432,25 @@ constexpr float kEpMaxMom = 0.0125f / (1.0f - 0.0125f);      // period - 1 at 1 
 #ifndef PAR_S3_PIN_MONO
 #define PAR_S3_PIN_MONO 0       // 1: the mono loop's row results pinned like the stereo loop's (234 instead of 250 registers, 1 % slower)
 #endif
-template <int NCH>
-__global__ __launch_bounds__(kWave, 2) void k_sinc_pipe(const S2Args a) {
+// KIND: which streams of the launch the kernel takes, and what it has to know for them (r06).  A wave issues an instruction
+// every ~5 cycles whatever its kind, so two waves per SIMD -- what the 25 constant fragments of both filter sets leave room
+// for -- cannot fill the SIMD's issue slots; a stream whose tiles hold fc = 1 outputs only needs the fc = 1 bank's ten:
+//   0  every stream, both tap regimes (stereo: its LDS allows two streams per SIMD either way)
+//   1  the streams WITHOUT a tile the plan marks kTileMaySlow: fc = 1 passes only, 10 fragments, no moment rows in LDS:
+//      three waves per SIMD.  (A pass with an fc < 1 lane after all -- the hint is conservative, this does not happen -- sends
+//      its tile to the block kernel's list.)
+//   2  the streams with such a tile: both regimes, as KIND 0
+// A mono file is launched as KIND 2 and KIND 1 back to back over the same grid; a wave of the wrong kind leaves at once.
+template <int NCH, int KIND>
+__global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2Args a) {
   static_assert(NCH == 1 || NCH == 2, "mono, or an interleaved stereo file");
-  __shared__ S3Lds<NCH> L;
+  static_assert(KIND == 0 || NCH == 1, "the stereo form takes every stream");
+  constexpr bool kMom = KIND != 1;
+  __shared__ S3Lds<NCH, kMom> L;
   const int l = threadIdx.x & (kWave - 1);
   if ((int)blockIdx.x < a.n_edge) {               // an end tile's wave: tile 0, then n_full - 2, n_full - 1 and the partial one
+    if constexpr (KIND == 1) return;              // (done by the launch of the other kind)
+    else {
     const int e = (int)blockIdx.x / kEdgeWavesPerTile, w = (int)blockIdx.x % kEdgeWavesPerTile;
     const int64_t T = e == 0 ? 0 : a.n_full - 3 + e;
     const int64_t jw = T * kSincTileOutputs + (int64_t)w * kEdgeWaveOut;
@@ -437,6 +464,7 @@ __global__ __launch_bounds__(kWave, 2) void k_sinc_pipe(const S2Args a) {
       fused_wave<NCH, 32, 2 * NCH, false>(a.len_out, a.sig, a.sig + 1, NCH, a.len_in, 32, a.tab, a.tmd, a.out, a.out + 1, NCH, a.fa, piece, l,
                                           jw, nrem, piece);
     return;
+    }
   }
   const int64_t stream_id = (int64_t)blockIdx.x - a.n_edge;
   const int my_tiles = stream_id < a.n_big ? a.tiles : a.tiles_tail;
@@ -444,28 +472,36 @@ __global__ __launch_bounds__(kWave, 2) void k_sinc_pipe(const S2Args a) {
   if (Ta >= a.n_full) return;
   const int64_t Tb = Ta + my_tiles < a.n_full ? Ta + my_tiles : a.n_full;
   const int64_t Ja = Ta * kSincTileOutputs, Jb = Tb * kSincTileOutputs;
+  long long A0;
+  int hd_dA, hd_fl;
+  {
+    const int64_t Ti = Ta + l < a.n_tiles ? Ta + l : a.n_tiles - 1;
+    const TileHdr h = a.hdr[l <= my_tiles ? Ti : Ta];
+    // (lane 0's anchor through readfirstlane, not a shuffle: the compiler takes a shuffle's result for lane-variant, and with A0
+    // everything derived from it -- the ring's source, the chunks inside the file, dma_bad, hence the loop's exit test and every
+    // piece of state the loop carries -- sat in vector registers behind exec-masked branches, r06)
+    A0 = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)h.anchor >> 32)) << 32) |
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)h.anchor));
+    const long long d = h.anchor - A0;
+    hd_fl = h.flags | ((d > -0x40000000ll && d < 0x40000000ll) ? 0 : 1);
+    if (a.n_edge > 0 && (Ta + l == 0 || Ta + l >= a.n_full - 2)) hd_fl |= 1 | kTileEdge;      // end tiles: not streamed, not pushed
+    hd_dA = (int)d;
+    if constexpr (KIND != 0) {                    // is this stream the kernel's kind?
+      const bool any_slow = __ballot(l < my_tiles && Ta + l < Tb && (h.flags & kTileMaySlow) != 0) != 0ull;
+      if (any_slow != (KIND == 2)) return;
+    }
+  }
   half8v fr[kBank2Frags];                        // the fc = 1 bank's constant fragments
   {
     const uint4* src = reinterpret_cast<const uint4*>(kBank2Frags32) + l;
 #pragma unroll
     for (int f = 0; f < kBank2Frags; ++f) fr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
   }
-  half8v fmr[kBank3Frags];                       // the moment filters'
-  {
+  half8v fmr[kBank3Frags];                       // the moment filters' (kinds 0 and 2)
+  if constexpr (kMom) {
     const uint4* src = reinterpret_cast<const uint4*>(kBank3Frags32) + l;
 #pragma unroll
     for (int f = 0; f < kBank3Frags; ++f) fmr[f] = __builtin_bit_cast(half8v, src[f * kWave]);
-  }
-  long long A0;
-  int hd_dA, hd_fl;
-  {
-    const int64_t Ti = Ta + l < a.n_tiles ? Ta + l : a.n_tiles - 1;
-    const TileHdr h = a.hdr[l <= my_tiles ? Ti : Ta];
-    A0 = __shfl(h.anchor, 0, kWave);
-    const long long d = h.anchor - A0;
-    hd_fl = h.flags | ((d > -0x40000000ll && d < 0x40000000ll) ? 0 : 1);
-    if (a.n_edge > 0 && (Ta + l == 0 || Ta + l >= a.n_full - 2)) hd_fl |= 1 | kTileEdge;      // end tiles: not streamed, not pushed
-    hd_dA = (int)d;
   }
   {
     uint4* z = reinterpret_cast<uint4*>(&L.img[0][0]);
@@ -651,6 +687,7 @@ __global__ __launch_bounds__(kWave, 2) void k_sinc_pipe(const S2Args a) {
       N.j = j0;
       N.ws = ws;
       const int want = gen == 0ull ? 1 : 3;       // the pass's regime
+      if (!kMom && want == 3) skip = true;        // (a kernel of fc = 1 streams met an fc < 1 lane: the block kernel's tile)
       if (!skip) {
         bool rebuild = mode != 1;
         // the ring: restarted at the first pass of the wave and after a jump the fetched chunks do not cover
@@ -715,7 +752,7 @@ __global__ __launch_bounds__(kWave, 2) void k_sinc_pipe(const S2Args a) {
       }
       wave_lds_fence();
       const int offs = ws - wbase - 31;
-      if (regime == 3) bank_image3m<true>(L, fr, fmr, offs, l);
+      if (kMom && regime == 3) bank_image3m<kMom>(L, fr, fmr, offs, l);
       else bank_image3m<false>(L, fr, fmr, offs, l);
       wave_lds_fence();
       j0 += N.nok[0] + N.nok[1];
@@ -727,7 +764,7 @@ __global__ __launch_bounds__(kWave, 2) void k_sinc_pipe(const S2Args a) {
         return true;
       }
       float res[2];
-      if (regime == 3) out_pass(std::integral_constant<int, 3>{}, N, res);
+      if (kMom && regime == 3) out_pass(std::integral_constant<int, kMom ? 3 : 1>{}, N, res);
       else out_pass(std::integral_constant<int, 1>{}, N, res);
       if constexpr (NCH == 2) {                   // the other channel through the same rows
         float res1[2];
@@ -876,7 +913,7 @@ __global__ __launch_bounds__(kWave, 2) void k_sinc_pipe(const S2Args a) {
   };
 
   while (start_run()) {
-    if (regime == 3) hot(std::integral_constant<int, 3>{});
+    if (kMom && regime == 3) hot(std::integral_constant<int, kMom ? 3 : 1>{});
     else hot(std::integral_constant<int, 1>{});
     // P has been finished by the loop; the pass at j0 needs the cold path
   }
@@ -929,8 +966,14 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
   a.tiles_tail = a.tiles >= 8 && tail_env > 1 ? std::max(2, a.tiles / tail_env) : a.tiles;
   a.n_big = (a.n_full - std::min<int64_t>(a.n_full, 2048ll * tail_rounds * a.tiles * (a.tiles_tail < a.tiles ? 1 : 0))) / a.tiles;
   const int64_t grid = a.n_big + ceil_div(a.n_full - a.n_big * a.tiles, (int64_t)a.tiles_tail) + a.n_edge;
-  if (grid > 0 && nch == 2) hipLaunchKernelGGL(k_sinc_pipe<2>, dim3((unsigned)grid), dim3(kWave), 0, s, a);
-  else if (grid > 0) hipLaunchKernelGGL(k_sinc_pipe<1>, dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  if (grid > 0 && nch == 2) {
+    hipLaunchKernelGGL((k_sinc_pipe<2, 0>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  } else if (grid > 0) {
+    // mono: the streams with an fc < 1 tile (two waves per SIMD: all 25 constant fragments) and the end tiles, then the fc = 1
+    // streams (three per SIMD), over the same grid -- a wave of the other kind leaves behind its tile headers
+    hipLaunchKernelGGL((k_sinc_pipe<1, 2>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
+    hipLaunchKernelGGL((k_sinc_pipe<1, 1>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  }
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }

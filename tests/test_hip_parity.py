@@ -1703,7 +1703,7 @@ def test_bench_contract_line():
     assert 1 <= cb["cores"] == cb["cores_usable"] <= cb["cores_reported"] and cb["per_core_Msamples/s"] > 0.1
     assert 0.2 < cb["sinc_only_parallel_efficiency"] < 1.6, cb
     # the line names the kernel(s) of a timed launch; PMC side files are only quoted when they describe exactly those
-    assert rl["kernel_symbols"] == ["k_sinc_pipe<1>", "k_sinc_fused_list"] and rl["warm_launches_before_timed"] >= 30
+    assert rl["kernel_symbols"] == ["k_sinc_pipe<1, 2>", "k_sinc_pipe<1, 1>", "k_sinc_fused_list"] and rl["warm_launches_before_timed"] >= 30
     assert "float16" in r["dtype"] and "mfma" in r["dtype"].lower()
     assert r["config"]["plan"].startswith("lazy")
     if rl["traffic"] is not None:
