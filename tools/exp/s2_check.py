@@ -34,7 +34,7 @@ for cname, sp in (("fast 1.000..1.010", 1.005 + 0.005 * np.sin(2 * np.pi * 0.55 
     lo, tr, ok = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int(0)
     _lib.check(L.par_speed_to_pos_plan_fused(dev, _dev.ptr(st_t), _dev.ptr(sp_t), m, n, _dev.ptr(work), nb, _dev.ptr(aux), ab, cap,
                                              ctypes.byref(lo), ctypes.byref(tr), 0, None, ctypes.byref(ok), s))
-    assert ok.value == 1 and lo.value == len(pos), (ok.value, lo.value, len(pos))
+    assert ok.value in (1, 2) and lo.value == len(pos), (ok.value, lo.value, len(pos))
     for name, sig in signals.items():
         want = C.sinc(pos, sig, 32, threads=32)
         sg = torch.from_numpy(sig).cuda()

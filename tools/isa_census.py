@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-stage instruction census of the streaming kernel's two hot loops (fc = 1 and fc < 1), from the compiler's listing.
-    python tools/isa_census.py [NCH] [extra hipcc flags]   -> prints the table committed as profiles/r06_isa_census.txt
+    python tools/isa_census.py [NCH [KIND]] [extra hipcc flags]   -> prints the table committed as profiles/r06_isa_census.txt
 Every instruction between a loop's `s_waitcnt vmcnt(N)` head and its back edge is attributed to the STAGE its .loc source
 line belongs to (source ranges of sinc2.hip named below; inlined header code is charged to the last csrc line seen)."""
 import os, re, subprocess, sys, tempfile
@@ -43,8 +43,25 @@ def stage_table(src):
 CLASS = (("mfma", r"v_mfma"), ("trans", r"v_(rcp|rsq|sqrt|sin|cos|exp|log)_"), ("valu", r"v_"), ("lds", r"ds_"),
          ("vmem", r"(global|buffer|flat|scratch)_"), ("salu", r"s_"))
 
+SLOW = r"v_(cvt|rndne|trunc|floor|fract|med3|bfe|lshl_or|lshl_add|add3|and_or|or3|xad|bitop3|perm|cmp|cndmask|readlane|readfirstlane|writelane|permlane|alignbit|mad_|mul_lo|mul_hi|sad|min3|max3|bfi|lshrrev_b64|lshlrev_b64)"
+def port_cycles(l):
+    """vector-port price of one instruction (nominal-clock cycles per wave64 instruction and SIMD, tools/exp/valu_forms.hip, r06): plain
+    float / integer VOP2-style forms 2.4 (a literal or inline constant costs nothing), anything with an SGPR operand and the
+    conversions, selects, compares, three-operand integer forms 4.3, transcendentals 8.2, packed float 4.8, MFMA 16x16x32 16"""
+    op = l.split()[0]
+    args = l[len(op):]
+    src = args.split(",", 1)[1] if "," in args else ""
+    if op.startswith("v_mfma"): return 16.0
+    if re.match(r"v_(rcp|rsq|sqrt|sin|cos|exp|log)_", op): return 8.2
+    if op.startswith("v_pk_"): return 4.8
+    if not op.startswith("v_"): return 0.0
+    if re.match(SLOW, op) or "_f64" in op or "_u64" in op or "_b64" in op: return 4.3
+    if re.search(r"(?<![\w\[])s\d+|s\[\d+:\d+\]|\bvcc\b|\bexec\b|\bm0\b", src): return 4.3
+    return 2.4
+
 def main():
     nch = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].isdigit() else "1"
+    kind = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2].isdigit() else ("2" if nch == "1" else "0")
     extra = [a for a in sys.argv[1:] if not a.isdigit()]
     tmp = tempfile.mkdtemp()
     src = os.path.join(B.CSRC, "sinc2.hip")
@@ -57,7 +74,7 @@ def main():
     for l in L:
         m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
         if m: files[int(m.group(1))] = os.path.basename(m.group(3) or m.group(2))
-    start = next(i for i, l in enumerate(L) if re.match(r"^_ZN3par11k_sinc_pipeILi%sEEE" % nch, l))
+    start = next(i for i, l in enumerate(L) if re.match(r"^_ZN3par11k_sinc_pipeILi%sELi%sEEE" % (nch, kind), l))
     end = next(i for i in range(start, len(L)) if L[i].startswith(".Lfunc_end"))
     for i in range(end, min(end + 60, len(L))):
         if re.search(r"; (NumVgprs|NumAgprs|ScratchSize|Occupancy|NumSgprs|LDSByteSize)", L[i]): print(L[i].strip())
@@ -87,15 +104,16 @@ def main():
             cls = next(c for c, p in CLASS if re.match(p, op))
             tab.setdefault(st, {}).setdefault(cls, 0)
             tab[st][cls] += 1
+            tab[st]["port"] = tab[st].get("port", 0.0) + port_cycles(l)
         print(f"\nloop {hi} ({'fc = 1' if hi == 0 else 'fc < 1 (moment correction)'}): listing lines {h}..{back}  [static; the placement's "
               "two variants (with / without second pieces) are both counted, one runs]")
         cols = ["valu", "trans", "mfma", "lds", "vmem", "salu"]
-        print(f"{'stage':12s}" + "".join(f"{c:>7s}" for c in cols))
-        tot = dict.fromkeys(cols, 0)
-        for st in sorted(tab, key=lambda k: -sum(tab[k].values())):
-            print(f"{st:12s}" + "".join(f"{tab[st].get(c, 0):7d}" for c in cols))
-            for c in cols: tot[c] += tab[st].get(c, 0)
-        print(f"{'total':12s}" + "".join(f"{tot[c]:7d}" for c in cols))
+        print(f"{'stage':12s}" + "".join(f"{c:>7s}" for c in cols) + "  port cycles")
+        tot = dict.fromkeys(cols + ["port"], 0)
+        for st in sorted(tab, key=lambda k: -tab[k].get("port", 0.0)):
+            print(f"{st:12s}" + "".join(f"{tab[st].get(c, 0):7d}" for c in cols) + f"  {tab[st].get('port', 0.0):8.0f}")
+            for c in cols + ["port"]: tot[c] += tab[st].get(c, 0)
+        print(f"{'total':12s}" + "".join(f"{tot[c]:7d}" for c in cols) + f"  {tot['port']:8.0f}   = {tot['port'] / 128:.2f} SIMD cycles per output")
 
 if __name__ == "__main__":
     main()
