@@ -251,6 +251,9 @@ int par_debug_sinc_kernel(int form);
  * handed to the block kernel's tile list (blocks outside the record model, window-centre ties, input that float16 does not
  * suit).  Synchronises the stream.  0 when the streaming kernel did not run (the plan zeroes the count). */
 int par_fused_redo_tiles(int device, const void* aux, int64_t max_out, int64_t m, int* tiles, void* stream);
+/* ... and which tiles: *count = the length of that list, tiles[0 .. min(*count, cap)) = its entries (host buffer; the order is
+ * the order in which the streams pushed them).  Tests aim their oracle windows at them.  Synchronises the stream. (ABI 105) */
+int par_fused_redo_list(int device, const void* aux, int64_t max_out, int64_t m, int* tiles, int cap, int* count, void* stream);
 
 /* Stereo form: two channels of ONE file (same positions; sig0/sig1 and out0/out1 share the strides -- e.g. the two
  * columns of an interleaved (n, 2) array: sig1 = sig0 + 1, stride 2) in one launch.  Outputs equal two

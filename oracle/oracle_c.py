@@ -26,6 +26,8 @@ def lib():
         L = ctypes.CDLL(_SO)
         L.oracle_speed_to_pos.restype = ci
         L.oracle_speed_to_pos.argtypes = [vp, vp, i64, i64, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(ci)]
+        L.oracle_speed_to_pos_windows.restype = ci
+        L.oracle_speed_to_pos_windows.argtypes = [vp, vp, i64, i64, vp, ci, i64, vp, ctypes.POINTER(i64), ctypes.POINTER(ci), ci]
         L.oracle_end_guess.restype = i64
         L.oracle_end_guess.argtypes = [vp, vp, i64]
         L.oracle_sinc.restype = ci
@@ -60,6 +62,22 @@ def speed_to_pos(sampletimes, speeds, n_in):
     if rc != 0:
         raise ValueError(f"oracle_speed_to_pos status {rc}")
     return out[:n.value].copy(), bool(tr.value)
+
+
+def speed_to_pos_windows(sampletimes, speeds, n_in, starts, width, threads=1):
+    """(positions [len(starts)][width] of the outputs starts[w] .. starts[w] + width - 1, len_out, trimmed): the same values as
+    speed_to_pos(...)[0][s:s + width] (NaN at and beyond len_out) without the whole array; see par_oracle.c"""
+    st = np.ascontiguousarray(sampletimes, dtype=np.float64)
+    sp = np.ascontiguousarray(speeds, dtype=np.float64)
+    ss = np.ascontiguousarray(starts, dtype=np.int64)
+    out = np.empty((len(ss), int(width)), dtype=np.float64)
+    n = i64(0)
+    tr = ci(0)
+    rc = lib().oracle_speed_to_pos_windows(_p(st), _p(sp), len(st), int(n_in), _p(ss), len(ss), int(width), _p(out),
+                                           ctypes.byref(n), ctypes.byref(tr), int(threads))
+    if rc != 0:
+        raise ValueError(f"oracle_speed_to_pos_windows status {rc}")
+    return out, n.value, bool(tr.value)
 
 
 def sinc(pos, sig, NT, threads=1):

@@ -101,6 +101,137 @@ int64_t oracle_end_guess(const double* st, const double* sp, int64_t m) {
   return (int64_t)((np_pairwise_sum(sp, m) / (double)m) * (st[m - 1] - st[0]) * 1.01);
 }
 
+/* ------------------------------------------------------------------ speed_to_pos, windows of it
+ * The same positions as oracle_speed_to_pos (util/resampling.py:93-137) for the outputs [starts[w], starts[w] + width), w < count,
+ * without the whole array (5.5 GB for the benchmark's file) and with the one parallel piece run on threads -- the SAME floating-point
+ * operations in the SAME order per value:
+ *   pass 1  the rounding chain of the segment lengths n_i (serial, O(m)): inerr = period * mean + err, n = round(inerr), err = inerr - n;
+ *   pass 2  every segment's last cumsum value: c runs from 0.0 inside a segment, independent of every other segment (threads);
+ *   pass 3  the offset chain  offset_{i+1} = c_last_i + offset_i  and the end trim (serial, O(m); the trim segment is walked);
+ *   pass 4  the windows: a segment's cumsum from its first step, + offset.
+ * out: [count][width] doubles; outputs at or beyond *len_out are NaN.  Test infrastructure like the rest of this file; pinned to
+ * oracle_speed_to_pos bit for bit by tests/test_oracle_golden.py. */
+typedef struct {
+  const double* sp;
+  const int64_t* n;
+  double* clast;
+  double* cfirst;
+  int64_t a, b;
+} SegSumJob;
+
+static void* seg_sum_worker(void* v) {
+  SegSumJob* j = (SegSumJob*)v;
+  for (int64_t i = j->a; i < j->b; ++i) {
+    const int64_t n = j->n[i];
+    const double ds = j->sp[i + 1] - j->sp[i], nm1 = (double)(n - 1);
+    double c = 0.0;
+    for (int64_t k = 0; k < n; ++k) {
+      const double bs = ((double)k / nm1) * ds + j->sp[i];
+      c += 1.0 / bs;
+      if (k == 0) j->cfirst[i] = c;
+    }
+    j->clast[i] = c;
+  }
+  return NULL;
+}
+
+int oracle_speed_to_pos_windows(const double* st, const double* sp, int64_t m, int64_t n_in, const int64_t* starts, int count,
+                                int64_t width, double* out, int64_t* len_out, int* trimmed, int threads) {
+  const int64_t nseg = m - 1, cap = oracle_end_guess(st, sp, m);
+  int64_t* n = (int64_t*)malloc((size_t)(nseg + 1) * sizeof(int64_t));
+  int64_t* w0 = (int64_t*)malloc((size_t)(nseg + 1) * sizeof(int64_t));
+  double* clast = (double*)malloc((size_t)(nseg + 1) * sizeof(double));
+  double* cfirst = (double*)malloc((size_t)(nseg + 1) * sizeof(double));
+  double* off = (double*)malloc((size_t)(nseg + 1) * sizeof(double));
+  if (!n || !w0 || !clast || !cfirst || !off) return -3;
+  int rc = 0;
+  double err = 0.0;
+  int64_t used = nseg;                                   /* segments the reference visits (it stops where the cap is hit) */
+  for (int64_t i = 0; i < nseg; ++i) {                   /* pass 1 */
+    const double period = st[i + 1] - st[i];
+    const double mean = (sp[i] + sp[i + 1]) / 2.0;
+    const double inerr = period * mean + err;
+    const double r = nearbyint(inerr);
+    if (r < 2.0) { rc = -1; used = i; break; }
+    n[i] = (int64_t)r;
+    err = inerr - r;
+  }
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  {                                                      /* pass 2 */
+    pthread_t th[256];
+    SegSumJob jobs[256];
+    const int64_t per = (used + threads - 1) / threads;
+    int started = 0;
+    for (int t = 0; t < threads; ++t) {
+      const int64_t a = t * per, b = a + per < used ? a + per : used;
+      if (a >= b) break;
+      jobs[t] = (SegSumJob){sp, n, clast, cfirst, a, b};
+      if (pthread_create(&th[t], NULL, seg_sum_worker, &jobs[t]) != 0) { seg_sum_worker(&jobs[t]); th[t] = 0; }
+      ++started;
+    }
+    for (int t = 0; t < started; ++t) if (th[t]) pthread_join(th[t], NULL);
+  }
+  double offset = st[0];                                 /* pass 3 */
+  int64_t w = 0;
+  *trimmed = 0;
+  *len_out = -1;
+  int64_t visited = 0;
+  for (int64_t i = 0; i < used; ++i) {
+    if (w + n[i] > cap) { rc = -2; break; }
+    w0[i] = w;
+    off[i] = offset;
+    visited = i + 1;
+    const double first = cfirst[i] + offset, last = clast[i] + offset;
+    if (first <= (double)n_in && (double)n_in <= last) {
+      const double ds = sp[i + 1] - sp[i], nm1 = (double)(n[i] - 1);
+      double c = 0.0, best = INFINITY;
+      int64_t arg = 0;
+      for (int64_t k = 0; k < n[i]; ++k) {
+        const double bs = ((double)k / nm1) * ds + sp[i];
+        c += 1.0 / bs;
+        const double d = fabs((c + offset) - (double)n_in);
+        if (d < best) { best = d; arg = k; }
+      }
+      *len_out = w + arg;
+      *trimmed = 1;
+      break;
+    }
+    offset = last;
+    w += n[i];
+  }
+  if (*len_out < 0 && rc == 0) *len_out = w;
+  if (rc == 0 || *len_out >= 0) {                        /* pass 4 */
+    const int64_t total = *len_out;
+    for (int c_ = 0; c_ < count; ++c_) {
+      for (int64_t q = 0; q < width; ++q) out[(int64_t)c_ * width + q] = NAN;
+      int64_t j = starts[c_];
+      const int64_t j_end = j + width < total ? j + width : total;
+      if (j < 0 || j >= j_end) continue;
+      int64_t lo = 0, hi = visited - 1;                  /* segment of output j: the last one with w0 <= j */
+      while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (w0[mid] <= j) lo = mid; else hi = mid - 1;
+      }
+      for (int64_t i = lo; i < visited && j < j_end; ++i) {
+        const double ds = sp[i + 1] - sp[i], nm1 = (double)(n[i] - 1);
+        double c = 0.0;
+        for (int64_t k = 0; k < n[i] && w0[i] + k < j_end; ++k) {
+          const double bs = ((double)k / nm1) * ds + sp[i];
+          c += 1.0 / bs;
+          if (w0[i] + k >= j) {
+            out[(int64_t)c_ * width + (w0[i] + k - starts[c_])] = c + off[i];
+            j = w0[i] + k + 1;
+          }
+        }
+      }
+    }
+    if (*len_out >= 0) rc = 0;
+  }
+  free(n); free(w0); free(clast); free(cfirst); free(off);
+  return rc;
+}
+
 /* ------------------------------------------------------------------ sinc_core */
 static float hann32(int k, int NT) { return (float)(0.5 + 0.5 * cos(M_PI * (double)(k - NT) / (double)NT)); }
 

@@ -64,6 +64,7 @@ SIGNATURES = {
                                             ctypes.POINTER(c_int), c_vp]),
     "par_debug_sinc_kernel": (c_int, [c_int]),
     "par_fused_redo_tiles": (c_int, [c_int, c_vp, c_i64, c_i64, ctypes.POINTER(c_int), c_vp]),
+    "par_fused_redo_list": (c_int, [c_int, c_vp, c_i64, c_i64, ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int), c_vp]),
     "par_varispeed_fused_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64,
                                         c_vp]),
     "par_varispeed_fused_stereo_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_int,

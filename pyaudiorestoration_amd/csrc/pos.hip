@@ -2260,9 +2260,13 @@ static int host_plan(const PlanView& pv, const double* d_st, const double* d_sp,
 __global__ __launch_bounds__(256) void k_pos_fill_ck(const double* __restrict__ sp, const int64_t* __restrict__ seg_start,
                                                      const double* __restrict__ seg_off, int64_t nseg,
                                                      const double* __restrict__ ck, int64_t n_slots, int64_t len_out,
-                                                     double* __restrict__ pos) {
+                                                     double* __restrict__ pos, const PlanHeader* __restrict__ h) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_slots) return;
+  // A LAZY plan (ck_valid 2, ABI 103+) or one whose checkpoints did not fit (0) left `ck` unwritten: a caller on the older
+  // contract ("fused_ok != 0, so the fused fill is allowed") gets NaN positions, not garbage that looks like positions
+  // (no host synchronisation needed: the header is read here)
+  const bool have_ck = h->ck_valid == 1;
   long long lo = 0, hi = nseg - 1;                        // largest segment whose first slot is <= g
   while (lo < hi) {
     const long long mid = (lo + hi + 1) >> 1;
@@ -2282,7 +2286,7 @@ __global__ __launch_bounds__(256) void k_pos_fill_ck(const double* __restrict__ 
   for (int u = 0; u < kCk; ++u) {
     c = c + rr[u];
     const long long jj = start + k0 + u;
-    if (k0 + u < n && jj < (long long)len_out) pos[jj] = c + off;
+    if (k0 + u < n && jj < (long long)len_out) pos[jj] = have_ck ? c + off : __longlong_as_double(0x7ff8000000000000ll);
   }
 }
 
@@ -2582,7 +2586,7 @@ int par_speed_to_pos_fill_fused(int device, const double* speeds, int64_t m, con
   PlanView pv = plan_view(const_cast<void*>(work), m);
   const int64_t n_slots = (int64_t)fused_ck_len(max_out, m);
   hipLaunchKernelGGL(k_pos_fill_ck, dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, as_stream(stream), speeds,
-                     pv.seg_start, pv.seg_off, m - 1, static_cast<const double*>(aux), n_slots, len_out, pos);
+                     pv.seg_start, pv.seg_off, m - 1, static_cast<const double*>(aux), n_slots, len_out, pos, pv.hdr);
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;
 }

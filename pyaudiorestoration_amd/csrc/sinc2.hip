@@ -39,6 +39,7 @@
 #include "sinc_common.h"
 #include "sinc_block.h"           // fused_wave: the file's end tiles are done the block kernel's way by the launch's first workgroups
 #include <algorithm>
+#include <atomic>
 #include <limits.h>
 #include <type_traits>
 
@@ -289,7 +290,10 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
       e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag(8 + ks), xh[ks], e2, 0, 0, 0);
     }
   }
-  const float4v v0 = e0 + lo * kBank2LoInv, v1 = e1 + x1 * kBank2LoInv;
+  // (the factor in a vector register: a VALU instruction with an SGPR operand issues at 4.3 cycles instead of 2.4, tools/exp/valu_forms.hip)
+  float lo_inv = kBank2LoInv;
+  asm volatile("" : "+v"(lo_inv));
+  const float4v v0 = e0 + lo * lo_inv, v1 = e1 + x1 * lo_inv;
   float4v a01 = z, l01 = z, a23 = z, a45 = z, a6 = z;
   if (MOMENTS) {
 #pragma unroll
@@ -303,7 +307,7 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
       a6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag(kCtabUnity + 12 + ks), xh[ks], a6, 0, 0, 0);
     }
   }
-  const float4v m01 = a01 + l01 * kBank2LoInv;
+  const float4v m01 = a01 + l01 * lo_inv;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int sl = (8 * bb + 2 * g + p) ^ (bb & 7);
@@ -362,7 +366,7 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
     im = 0.0f;
 #define S3_MOM_STEP(Mi, A0, A1, B0)                                   \
     {                                                                 \
-      const float al_ = fmaf(w2m, -(A1), (A0)), be_ = w * -(B0);      \
+      const float al_ = (A1) != 0.0f ? fmaf(w2m, -(A1), (A0)) : (A0), be_ = w * -(B0);      /* (A1 = 0: no fma with -0.0) */ \
       const float nre_ = fmaf(-G32, im, (Mi) * al_), nim_ = fmaf(G32, re, (Mi) * be_); \
       re = nre_;                                                      \
       im = nim_;                                                      \
@@ -561,6 +565,7 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
     S2Row R[2];
     int nt[2];
     int fl0, fl1, tend;
+    int epm;                                     // the larger period - 1 of the lane's two outputs, as its bit pattern (ep >= 0: ordered like the floats)
   };
   int tc_T = -1, tc_dA0 = 0, tc_dA1 = 0, tc_fl0 = 0, tc_fl1 = 0;      // anchors and flags of the tile of j and of the one behind it (refreshed once per tile)
   auto place = [&](int j, int buf, int rb) {
@@ -594,8 +599,9 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
       P.R[0] = s2_place_row(ra0, rb0, u, (l < P.nt[0] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
       P.R[1] = s2_place_row(ra1, rb1, u, (l < P.nt[1] ? dA0 : dA1) + uc, uf, u2f, tw1, tw0, tolf);
     }
-    P.R[0].bad = P.R[0].bad || !(P.R[0].ep <= kEpMaxMom);      // the moment correction covers 1 - fc <= 0.0125
-    P.R[1].bad = P.R[1].bad || !(P.R[1].ep <= kEpMaxMom);
+    // (one integer maximum serves the regime test and the moment correction's limit: two compares where there were a float
+    // maximum with its quieting moves and three; ep is fmed3(e, 0, 3e38): never NaN, -0 sorts below everything)
+    P.epm = max(__float_as_int(P.R[0].ep), __float_as_int(P.R[1].ep));
     return P;
   };
 
@@ -665,7 +671,9 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
       const int tend = Q.tend;
       // lane sets: valid lanes (inside the range), lanes of this tile
       int nv[2] = {clamp64(nJ - j0), clamp64(nJ - j0 - 64)};
-      const unsigned long long b0 = __ballot(Q.R[0].bad) & prefix(nv[0]), b1 = __ballot(Q.R[1].bad) & prefix(nv[1]);
+      // the moment correction covers 1 - fc <= 0.0125
+      const unsigned long long b0 = __ballot(Q.R[0].bad || !(Q.R[0].ep <= kEpMaxMom)) & prefix(nv[0]),
+                               b1 = __ballot(Q.R[1].bad || !(Q.R[1].ep <= kEpMaxMom)) & prefix(nv[1]);
       const unsigned long long bad_here = (b0 & prefix(Q.nt[0])) | (b1 & prefix(Q.nt[1]));
       const bool bad_next = ((b0 & ~prefix(Q.nt[0])) | (b1 & ~prefix(Q.nt[1])) | (unsigned long long)((Q.fl1 & 1) && tend < nJ)) != 0ull;
       if (bad_next) {                             // the pass ends at the tile border
@@ -818,9 +826,9 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
       int wsK;
       auto place_next = [&]() {
       const Placed Q = place(j0, pk & 3, rbA);
-      const unsigned long long bad = __ballot(Q.R[0].bad || Q.R[1].bad);
+      const unsigned long long bad = __ballot(Q.R[0].bad || Q.R[1].bad || Q.epm > __float_as_int(kEpMaxMom));
       // some lane with fc < 1: 1 + ep != 1 in float32, i.e. ep > 2^-24 (ep >= 0)
-      const unsigned long long gen = __ballot(fmaxf(Q.R[0].ep, Q.R[1].ep) > 5.9604645e-8f);
+      const unsigned long long gen = __ballot(Q.epm > 0x33800000);          // 2^-24
       const int ws = __builtin_amdgcn_readfirstlane(Q.R[0].c) & ~7;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
@@ -930,9 +938,24 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
 #endif
 }
 
+// wave slots of the device for the two-waves-per-SIMD kernels (compute units x 4 SIMDs x 2; 2 048 on an MI355X): from the device's
+// properties, so that a partitioned or CU-masked device cuts its streams for what it has
+static int64_t stream_wave_slots(int device) {
+  static std::atomic<int> cached[64];
+  const int d = device >= 0 && device < 64 ? device : 0;
+  int v = cached[d].load(std::memory_order_relaxed);
+  if (v == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    v = cus * 8;
+    cached[d].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
 int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
                        const float4* tab, const TapModes& tmd, hipStream_t s, int nch) {
-  (void)device;
+  const int64_t slots = stream_wave_slots(device);
   S2Args a;
   a.len_out = len_out;
   a.sig = sig;
@@ -954,17 +977,21 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
   // leave fewer wave boundaries for them to slip into -- 60-min file, ms per pipelined step: 4 tiles 5.03, 8: 4.84, 12: 4.70,
   // 16: 4.66, 24: 4.61, 32: 5.06 (10.3 rounds of the 2 048 wave slots: the last one nearly empty), 48: 4.67 (r05) -- while a
   // short file still has to fill the GPU's wave slots a few times over.
-  static const int tiles_env = getenv("PAR_S2_TILES_RT") ? atoi(getenv("PAR_S2_TILES_RT")) : 0;       // experiment override, read once
-  const int64_t want = a.n_full / (4 * 2048);
+#ifdef PAR_EXPERIMENT            // (experiment builds only: the product reads no knob from the environment)
+  static const int tiles_env = getenv("PAR_S2_TILES_RT") ? std::min(48, std::max(0, atoi(getenv("PAR_S2_TILES_RT")))) : 0;
+  static const int tail_env = getenv("PAR_S2_TAIL") ? std::max(0, atoi(getenv("PAR_S2_TAIL"))) : 6;
+  static const int tail_rounds = getenv("PAR_S2_TAIL_ROUNDS") ? std::max(0, atoi(getenv("PAR_S2_TAIL_ROUNDS"))) : 1;
+#else
+  constexpr int tiles_env = 0, tail_env = 6, tail_rounds = 1;      // tail_env: divisor of the last round's stream length
+#endif
+  const int64_t want = a.n_full / (4 * slots);
   a.tiles = tiles_env > 0 ? tiles_env : (int)(want < 8 ? 8 : (want > kMaxTilesPerWave ? kMaxTilesPerWave : want));
   if (a.tiles > 48) a.tiles = 48;
   // ... and the launch's last round (2 048 wave slots' worth of tiles) as four rounds of quarter-length streams: the tail in which
   // the GPU empties behind the last long streams shrinks with them
   // (24 tiles, K_sinc alone: no short tail 4.37 ms, quarter-length 4.22, 1/8 4.20, 1/12 4.23; two rounds of them 4.23 / 4.30)
-  static const int tail_env = getenv("PAR_S2_TAIL") ? atoi(getenv("PAR_S2_TAIL")) : 6;               // divisor (0: no short tail)
-  static const int tail_rounds = getenv("PAR_S2_TAIL_ROUNDS") ? atoi(getenv("PAR_S2_TAIL_ROUNDS")) : 1;
   a.tiles_tail = a.tiles >= 8 && tail_env > 1 ? std::max(2, a.tiles / tail_env) : a.tiles;
-  a.n_big = (a.n_full - std::min<int64_t>(a.n_full, 2048ll * tail_rounds * a.tiles * (a.tiles_tail < a.tiles ? 1 : 0))) / a.tiles;
+  a.n_big = (a.n_full - std::min<int64_t>(a.n_full, slots * tail_rounds * a.tiles * (a.tiles_tail < a.tiles ? 1 : 0))) / a.tiles;
   const int64_t grid = a.n_big + ceil_div(a.n_full - a.n_big * a.tiles, (int64_t)a.tiles_tail) + a.n_edge;
   if (grid > 0 && nch == 2) {
     hipLaunchKernelGGL((k_sinc_pipe<2, 0>), dim3((unsigned)grid), dim3(kWave), 0, s, a);

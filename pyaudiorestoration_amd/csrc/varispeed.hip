@@ -140,14 +140,19 @@ int par_fused_redo_tiles(int device, const void* aux, int64_t max_out, int64_t m
   return PAR_OK;
 }
 
-// experiment builds of the streaming kernel (-DPAR_S2_EXP=128) count passes by kind in the 16 words behind the redo count
-int par_debug_fused_counters(int device, const void* aux, int64_t max_out, int64_t m, int* words16, void* stream) {
+// ... and which: the first min(count, cap) entries of that list (tile indices, in the order the streams pushed them)
+int par_fused_redo_list(int device, const void* aux, int64_t max_out, int64_t m, int* tiles, int cap, int* count, void* stream) {
   using namespace par;
-  PAR_REQUIRE(aux && words16 && m >= 2 && max_out >= 2, PAR_ERR_ARG, "par_debug_fused_counters: bad argument");
+  PAR_REQUIRE(aux && count && (tiles || cap == 0) && cap >= 0 && m >= 2 && max_out >= 2, PAR_ERR_ARG, "par_fused_redo_list: bad argument");
   PAR_HIP_CHECK(hipSetDevice(device));
   const FusedAux av = fused_aux_view(const_cast<void*>(aux), max_out, m);
-  PAR_HIP_CHECK(hipMemcpyAsync(words16, av.redo_count, 16 * sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)));
+  PAR_HIP_CHECK(hipMemcpyAsync(count, av.redo_count, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)));
   PAR_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  const int n = *count < cap ? *count : cap;
+  if (n > 0) {
+    PAR_HIP_CHECK(hipMemcpyAsync(tiles, av.redo_list, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)));
+    PAR_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  }
   return PAR_OK;
 }
 

@@ -25,7 +25,30 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/par_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms, "ctypes signature table and header disagree"
-    assert L.par_version() >= 100
+    assert L.par_version() >= 105
+    # ... and nothing else: the product build exports no entry point the header does not declare (an experiment
+    # hook was exported undeclared)
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if re.search(r" [TW] par_[a-z0-9_]+$", ln)})
+    assert exported == syms, sorted(set(exported) ^ set(syms))
+
+
+def test_product_sources_read_no_environment_knobs():
+    """experiment knobs (getenv, timing #ifs) are compiled only into -DPAR_EXPERIMENT builds"""
+    csrc = os.path.join(ROOT, "pyaudiorestoration_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".h")):
+            continue
+        depth_exp = 0
+        for ln in open(os.path.join(csrc, name)):
+            t = ln.strip()
+            if t.startswith("#ifdef PAR_EXPERIMENT"):
+                depth_exp += 1
+            elif depth_exp and t.startswith(("#else", "#endif")):
+                depth_exp -= 1
+            elif "getenv(" in t and not t.startswith("//"):
+                assert depth_exp, f"{name}: getenv outside PAR_EXPERIMENT: {t}"
 
 
 def test_pure_host_entry_points_and_argument_errors():

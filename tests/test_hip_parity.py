@@ -3,6 +3,7 @@
  (3) size-independent properties at larger sizes.
 Tolerances: float outputs within 1e-5 relative (norm-wise, BASELINE.md) -- most are ~1e-6;
 positions, lengths and frame counts exact."""
+import ctypes
 import numpy as np
 import pytest
 import scipy.signal
@@ -681,6 +682,100 @@ def test_large_properties(par):
         assert relerr(out[i:i + 2000], ref) < TOL
     part = par.resampling.sinc_resample_dev(pos_t[123457:323457], sig_t, 32).cpu().numpy()
     assert relerr(part[:-1], out[123457:323456]) < 2e-6     # chunk invariance (tile phase changes which waves take the fc==1 path)
+
+
+def test_fill_fused_from_a_lazy_plan_fails_loudly(par):
+    """a caller on the ABI-102 contract ('fused_ok != 0, so par_speed_to_pos_fill_fused is allowed') used to read
+    the never-written checkpoints of a LAZY plan and got garbage positions with PAR_OK.  The fill now reads the plan header on the
+    device: without checkpoints every position it writes is NaN; an eager plan fills the reference's positions as before."""
+    from oracle import oracle_c as C
+    from pyaudiorestoration_amd import _lib, _dev
+    t = par.torch
+    L = _lib.lib()
+    sr, n = 48000, 400_000
+    curve = inputs.bench_speed_curve(n / sr, sr)
+    st_t = t.from_numpy(curve[:, 0] * sr).cuda()
+    sp_t = t.from_numpy(curve[:, 1].copy()).cuda()
+    ref, _ = C.speed_to_pos(curve[:, 0] * sr, curve[:, 1], n)
+    for eager in (False, True):
+        plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True, eager=eager)
+        assert plan.fused_ok and plan.lazy == (not eager) and plan.len_out == len(ref)
+        pos = t.full((plan.len_out,), 7.0, dtype=t.float64, device="cuda")
+        _lib.check(L.par_speed_to_pos_fill_fused(0, _dev.ptr(sp_t), plan.m, _dev.ptr(plan.work), _dev.ptr(plan.aux), plan.max_out,
+                                                 _dev.ptr(pos), plan.len_out, _dev.stream_ptr(0)))
+        if eager:
+            assert t.equal(pos.cpu(), t.from_numpy(ref))
+        else:
+            assert bool(t.isnan(pos).all())
+
+
+def redo_list(plan, cap=4096):
+    """tiles the streaming kernel handed to the block kernel's list in the last fused launch on this plan (par_fused_redo_list)"""
+    from pyaudiorestoration_amd import _lib, _dev
+    L = _lib.lib()
+    buf = (ctypes.c_int * cap)()
+    cnt = ctypes.c_int(-1)
+    _lib.check(L.par_fused_redo_list(0, _dev.ptr(plan.aux), plan.max_out, plan.m, buf, cap, ctypes.byref(cnt), _dev.stream_ptr(0)))
+    return cnt.value, sorted(buf[i] for i in range(min(cnt.value, cap)))
+
+
+def test_full_size_benchmark_workload(par):
+    """The file bench.py times, at ITS size (the timed workload was never checked at its own size): 3600 s @ 192 kHz
+    mono = 691.2 M samples, +-1 % / 0.55 Hz curve sampled every 256 samples, NT = 32, through the default path (lazy plan + the
+    streaming kernels).  Positions to 6.9e8 (ulp 1.2e-7), 675 k tiles, 24-tile streams and the sixth-length tail streams.
+      1. whole-file positions (the float64 position array from the same curve) bit-equal to the C oracle's;
+      2. the fused output against the C oracle's sinc on >= 24 windows: spread over the hour, the first tile, the tiles of the
+         streaming kernel's list (window-centre ties: the block kernel's), the sixth-length tail streams, the last two full
+         tiles and the partial one."""
+    from oracle import oracle_c as C
+    from pyaudiorestoration_amd import _lib, _dev
+    t = par.torch
+    sr, dur = 192000, 3600.0
+    n = int(sr * dur)
+    L = _lib.lib()
+    sig_t = t.empty(n, dtype=t.float32, device="cuda")
+    _lib.check(L.par_synth_signal_f32(0, _dev.ptr(sig_t), 0, n, float(sr), 0x5EED, _dev.stream_ptr(0)))
+    m = int(dur * sr / 256)
+    st_t = t.empty(m, dtype=t.float64, device="cuda")
+    sp_t = t.empty(m, dtype=t.float64, device="cuda")
+    _lib.check(L.par_synth_speed_curve_f64(0, _dev.ptr(st_t), _dev.ptr(sp_t), m, dur, float(sr), 0.01, 0.55, 0.7,
+                                           _dev.stream_ptr(0)))
+    plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
+    assert plan.fused_ok and plan.lazy and plan.path == 0              # what bench.py's step gets
+    ref_pos, _ = C.speed_to_pos(st_t.cpu().numpy(), sp_t.cpu().numpy(), n)
+    assert plan.len_out == len(ref_pos) == 691199999
+    pos_t = par.resampling.speed_to_pos_dev(st_t, sp_t, n)
+    assert pos_t.numel() == len(ref_pos)
+    for a in range(0, len(ref_pos), 1 << 27):                          # (compared in pieces: no second 5.5 GB host copy)
+        assert t.equal(pos_t[a:a + (1 << 27)].cpu(), t.from_numpy(ref_pos[a:a + (1 << 27)])), a
+    del pos_t
+    out = par.resampling.varispeed_fused_dev(plan, sig_t, 32)
+    assert out.numel() == plan.len_out
+    n_redo, tiles = redo_list(plan)
+    n_tiles = plan.len_out // 1024
+    assert 0 <= n_redo <= 1024, n_redo     # window-centre ties only (324 measured: |p| to 6.9e8, tie band ~3e-7 of a sample), < 0.2 % of the 675 k tiles
+    assert not t.isnan(out).any()
+    W = 2000
+    last = len(ref_pos) - W - 1
+    starts = [int(i) for i in np.linspace(0, last, 24)]
+    starts += [0, 1024 - W // 2, last, (n_tiles - 2) * 1024 - W // 2, (n_tiles - 1) * 1024 - W // 2]      # first tile and its border, the last tiles
+    # the launch's last round: sixth-length (4-tile) streams over the last 2048 x 24 tiles; windows over several stream borders
+    tail0 = n_tiles - 2048 * 24
+    starts += [(tail0 + k) * 1024 - W // 2 for k in (0, 4, 8, 1000 * 4, 6000 * 4 + 3)]
+    starts += [(tail0 - 24) * 1024 - W // 2, (tail0 - 24 * 1000) * 1024 + 37]                             # ... and the long streams in front
+    starts += [max(0, T * 1024 - 200) for T in tiles[:8]]                                                 # tiles of the list
+    assert len(starts) >= 36 or not tiles
+    worst = 0.0
+    for i in starts:
+        i = min(max(int(i), 0), last)
+        lo = max(0, int(ref_pos[i]) - 200)
+        hi = min(n, int(ref_pos[i + W]) + 200)
+        sig_win = sig_t[lo:hi].cpu().numpy()
+        ref = C.sinc(ref_pos[i:i + W + 1] - lo, sig_win, 32)[:W] if lo else C.sinc(ref_pos[i:i + W + 1], sig_win, 32)[:W]
+        e = relerr(out[i:i + W].cpu().numpy(), ref)
+        worst = max(worst, e)
+        assert e < TOL, (i, e)
+    print(f"benchmark workload at full size: {len(starts)} oracle windows, worst {worst:.2e}; {n_redo} tiles through the list")
 
 
 def test_full_size_config2_properties(par):

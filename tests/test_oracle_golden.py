@@ -255,6 +255,31 @@ def test_c_oracle_speed_to_pos(golden):
     assert not trimmed and np.array_equal(pos, g["untrimmed_pos"])
 
 
+def test_c_oracle_speed_to_pos_windows(golden):
+    """oracle_speed_to_pos_windows (the windowed, threaded form bench.py's parity check and the full-size tests use) against the
+    reference's own positions (golden fixtures) and against oracle_speed_to_pos, bit for bit -- including windows over segment
+    borders, over the trim, beyond the end, and curves that end untrimmed"""
+    from oracle import oracle_c as C
+    g = golden["speed_to_pos"]
+    n = 8192
+    st = np.linspace(0, n, 33)
+    sp = 1 + 0.01 * np.sin(2 * np.pi * np.arange(33) / 16 + 0.7)
+    sc = inputs.bench_speed_curve(2.0, 48000)
+    cases = ((st, sp, n, g["kat3_pos"], True), (np.array((0.0, 20000.0)), np.array((0.5, 2.0)), 20000, g["ramp_pos"], None),
+             (sc[:, 0] * 48000, sc[:, 1], 96000, g["bench_pos"], None), (g["wobble_st"], g["wobble_sp"], 30000, g["wobble_pos"], None),
+             (g["untrimmed_st"], g["untrimmed_sp"], 10000, g["untrimmed_pos"], False))
+    for st_, sp_, n_, want, trimmed in cases:
+        for width, threads in ((1, 1), (300, 3), (len(want) + 7, 16)):
+            starts = sorted({0, 1, 255, 256, 257, len(want) // 3, max(0, len(want) - width), len(want) - 1, len(want), len(want) + 11})
+            win, len_out, tr = C.speed_to_pos_windows(st_, sp_, n_, starts, width, threads=threads)
+            assert len_out == len(want) and (trimmed is None or tr == trimmed)
+            for w, s0 in enumerate(starts):
+                ref = np.full(width, np.nan)
+                k = max(0, min(width, len(want) - s0))
+                ref[:k] = want[s0:s0 + k]
+                assert np.array_equal(win[w], ref, equal_nan=True), (len(want), width, s0)
+
+
 def test_c_oracle_sinc(golden):
     from oracle import oracle_c as C
     g = golden["sinc"]
