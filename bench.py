@@ -394,7 +394,12 @@ def config5_dry_run(a, ctx):
                           "n1_same_workload_value": round(n1, 3), "speedup_vs_n1": round(value / n1, 3),
                           "speedup_base": "n1_same_workload_value (the archive on one GPU, this run) -- the N = 1 line carries the "
                                           "same quantity as archive_value",
-                          "efficiency": round(value / n1 / ctx.world, 4)}), flush=True)
+                          "efficiency": round(value / n1 / ctx.world, 4),
+                          "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                                       "kernel_ms_per_file_alone_min_max": None},
+                          "cpu_baseline": None,
+                          "cpu_baseline_note": "timed on the N = 1 lines only (python bench.py, python bench.py --config5): the contract's rule"}),
+              flush=True)
     ctx.close()
 
 
@@ -429,10 +434,12 @@ def config5_batch(a, ctx):
             sig[:, c] = mono
         ring.append(sig)
     del mono
-    curves = torch.empty((files, 2, m), dtype=torch.float64, device=f"cuda:{dev}")
-    for f in range(files):
-        _lib.check(L.par_synth_speed_curve_f64(dev, _dev.ptr(curves[f, 0]), _dev.ptr(curves[f, 1]), m, seconds, float(sr), 0.01,
-                                               0.55, 0.7 + f, s))
+    # Speed curves: made per PULLED file (7.2 MB, a closed form on the device, ~2 us) into a small ring -- not all 512 of them
+    # resident on every rank (3.7 GB each, r05).  The ring outlives the batch driver's prefetch (planners + 1 items, see
+    # resampling.varispeed_batch_dev's PREFETCH CONTRACT): the kernel that fills slot k % 8 is enqueued on the main stream behind
+    # the K_sinc of the file that last used it.
+    n_curves = 8
+    curves = torch.empty((n_curves, 2, m), dtype=torch.float64, device=f"cuda:{dev}")
     torch.cuda.synchronize()
     done = {"samples": 0, "files": 0}
     step_no = [0]
@@ -441,7 +448,10 @@ def config5_batch(a, ctx):
         """One GPU's loop over the files it is handed -> (channel-samples, files)."""
         def produce():
             for k, f in enumerate(file_iter):
-                yield curves[f, 0], curves[f, 1], ring[k % a.ring]
+                c = curves[k % n_curves]
+                _lib.check(L.par_synth_speed_curve_f64(dev, _dev.ptr(c[0]), _dev.ptr(c[1]), m, seconds, float(sr), 0.01, 0.55,
+                                                       0.7 + f, _dev.stream_ptr(dev)))
+                yield c[0], c[1], ring[k % a.ring]
         n_s = n_f = 0
         driver = resampling.varispeed_batch_gather if gather else resampling.varispeed_batch_dev
         for _, out, plan in driver(produce(), a.nt, dev):
@@ -480,6 +490,24 @@ def config5_batch(a, ctx):
         dt_e = ctx.timed(lambda: step(True), 1)
         total_e = ctx.reduce_sum(done["samples"])
         e2e = (total_e / dt_e / 1e6, n1_e2e, dt_e)
+    # K_sinc of one file with this rank's GPU to itself (HIP events on the launch stream, 6 launches back to back behind 2 warm
+    # ones): every rank measures its own device; the line carries the spread
+    c0 = curves[0]
+    _lib.check(L.par_synth_speed_curve_f64(dev, _dev.ptr(c0[0]), _dev.ptr(c0[1]), m, seconds, float(sr), 0.01, 0.55, 0.7 + rank, s))
+    plan_k = resampling.speed_plan_dev(c0[0], c0[1], n, dev, fused=True)
+    k_ms = 0.0
+    if plan_k.fused_ok:
+        item_k = (c0[0], c0[1], ring[0])
+        for _ in range(2):
+            resampling._resample_item(plan_k, item_k, a.nt, dev)      # (the batch driver's own launch: one stereo K_sinc)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(dev))
+        for _ in range(6):
+            resampling._resample_item(plan_k, item_k, a.nt, dev)
+        ev1.record(torch.cuda.current_stream(dev))
+        ev1.synchronize()
+        k_ms = ev0.elapsed_time(ev1) / 6
+    k_ms_max, k_ms_min = ctx.reduce_max(k_ms), -ctx.reduce_max(-k_ms)
     if rank == 0:
         value = total * a.steps / dt / 1e6
         res = {
@@ -502,7 +530,7 @@ def config5_batch(a, ctx):
                                            "speedup_vs_n1 = value / that, efficiency = speedup / n_gpus.  The `--gpus 1` line without "
                                            "--config5 times a different workload (the mono 60-min file of BASELINE configs[1]): do "
                                            "not build a curve from it",
-                       "NT": a.nt, "resident": f"ring of {a.ring} synthetic stereo files per GPU + all {files} speed curves",
+                       "NT": a.nt, "resident": f"ring of {a.ring} synthetic stereo files per GPU; each file's speed curve is made when the file is pulled (ring of {n_curves})",
                        "queue": "one TCP-store fetch-add per 4 files",
                        "step": "per file: plan (device scans, block records; lazy: csrc/pos_plan.h) + ONE stereo fused K_sinc launch; "
                                "the plans of the next files are made by planner threads on side streams under K_sinc "
@@ -510,10 +538,18 @@ def config5_batch(a, ctx):
             "roofline": {"bound": "hbm", "achieved": round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / world, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ALGO_BYTES_PER_SAMPLE * value * 1e6 / 1e9 / world / HBM_PEAK_GBS, 5),
                          "traffic": None, "kernel": "k_sinc stereo: k_sinc_pipe<2, 0> + k_sinc_fused_list2 at NT = 32 (whole step, per GPU)", "limited_by": "valu",
+                         "kernel_ms_per_file_alone_min_max": [round(k_ms_min, 4), round(k_ms_max, 4)],
+                         "kernel_frac_alone_min_max": ([round(ALGO_BYTES_PER_SAMPLE * 2 * plan_k.len_out / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                                        for k in (k_ms_max, k_ms_min)] if k_ms_min > 0 else None),
                          "note": "per-GPU whole-step rate x 8 algorithmic B per channel-sample against the HBM roof the contract "
                                  "names; what limits the kernel is VALU issue (the N = 1 line carries the per-kernel HIP-event "
                                  "timing, PMC traffic and the VALU roofline)"},
         }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.sr, a.nt)          # (rank 0 at N = 1 only: the contract)
+        else:
+            res["cpu_baseline"] = None
+            res["cpu_baseline_note"] = "timed on the N = 1 lines only (python bench.py, python bench.py --config5): the contract's rule"
         if e2e is not None:
             v_e, n1_e, dt_e = e2e
             res["value_e2e"] = round(v_e, 3)

@@ -232,14 +232,15 @@ int par_varispeed_fused_f32(int device, const double* speeds, int64_t m, const v
                             int64_t max_out, int64_t len_out, const float* sig, int64_t sig_stride, int64_t len_in,
                             int NT, float* out, int64_t out_stride, void* stream);
 
-/* Which kernel runs: NT = 32 files of at least four 1024-output tiles and 4096 input samples -- mono on unit strides, or
- * (par_varispeed_fused_stereo_f32) the two channels of an INTERLEAVED file (sig1 = sig0 + 1, out1 = out0 + 1, strides 2, out0
- * 8-byte aligned) -- take the streaming kernel (csrc/sinc2.hip: one wave per 8-24 tiles, the taps |n| >= 3 of both tap regimes
+/* Which kernel runs: NT = 32 files of at least four 1024-output tiles and 4096 input samples -- mono on unit strides, ONE
+ * channel of a two-channel interleaved file (sig_stride == 2, any out_stride: the reference's use_channels column views,
+ * util/resampling.py:211-227; r06), or (par_varispeed_fused_stereo_f32) the two channels of an INTERLEAVED file (sig1 = sig0 + 1,
+ * out1 = out0 + 1, strides 2, out0 8-byte aligned) -- take the streaming kernel (csrc/sinc2.hip: one wave per 8-24 tiles, the taps |n| >= 3 of both tap regimes
  * as fixed filter banks on the matrix cores, fc < 1 through seven moment filters; stereo: one placement for both channels).  The
  * file's end tiles (first, last two, the partial one) are done the block kernel's way by the first workgroups of the same
  * launch; tiles the streams do not cover -- blocks outside the record model, window-centre ties, input float16 does not suit --
- * go to the block kernel (csrc/sinc.hip, sinc_block.h) through a tile list in `aux`.  Everything else (other NT, strided or
- * planar channel pairs, short files) takes the block kernel.  Results agree within the contract's tolerance and every window
+ * go to the block kernel (csrc/sinc.hip, sinc_block.h) through a tile list in `aux`.  Everything else (other NT, channels of
+ * files with three or more channels, planar channel pairs, short files) takes the block kernel.  Results agree within the contract's tolerance and every window
  * centre is the reference's either way.  K_sinc WRITES that list into `aux`: one par_varispeed_fused_* launch per plan at a time
  * (two launches of one plan on different streams would race on it). */
 

@@ -91,6 +91,7 @@ struct S2Args {
   // 128 outputs each, BESIDE the streams.  (Through the tile list they cost 50 us behind every launch: cold code -- the masked
   // path of the last wave, the float64 slow path of the first outputs -- fetched by one wave while the GPU idles, r05.)
   int n_edge;
+  int64_t out_stride;                            // k_sinc_pipe<2, 3> only (one channel of frames): elements between two outputs
   FusedArgs fa;
   const float4* tab;
   TapModes tmd;
@@ -444,11 +445,18 @@ constexpr float kEpMaxMom = 0.0125f / (1.0f - 0.0125f);      // period - 1 at 1 
 //      three waves per SIMD.  (A pass with an fc < 1 lane after all -- the hint is conservative, this does not happen -- sends
 //      its tile to the block kernel's list.)
 //   2  the streams with such a tile: both regimes, as KIND 0
+//   3  (NCH = 2) ONE channel of an interleaved two-channel file -- the reference's use_channels, a strided column view
+//      (util/resampling.py:211-227): the ring holds the frames as they lie in memory (a.sig = the wanted channel's first sample:
+//      it is channel 0 of the frames that start there), conversion, bank and gather take that channel only, the loop is the
+//      mono one; outputs a.out_stride elements apart.  Every stream, both regimes.
 // A mono file is launched as KIND 2 and KIND 1 back to back over the same grid; a wave of the wrong kind leaves at once.
 template <int NCH, int KIND>
 __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2Args a) {
   static_assert(NCH == 1 || NCH == 2, "mono, or an interleaved stereo file");
-  static_assert(KIND == 0 || NCH == 1, "the stereo form takes every stream");
+  static_assert(KIND == 0 || KIND == 3 || NCH == 1, "the stereo form takes every stream");
+  static_assert(KIND != 3 || NCH == 2, "one channel of FRAMES");
+  constexpr bool kPick = KIND == 3;               // one channel of two-channel frames: stereo ring, mono loop
+  constexpr bool kTwo = NCH == 2 && !kPick;       // both channels of a pass: the stereo loop
   constexpr bool kMom = KIND != 1;
   __shared__ S3Lds<NCH, kMom> L;
   const int l = threadIdx.x & (kWave - 1);
@@ -461,6 +469,13 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
     const int nrem = (int)(a.len_out - jw < (int64_t)kEdgeWaveOut ? (a.len_out - jw > 0 ? a.len_out - jw : 0) : kEdgeWaveOut);
     float* const piece = reinterpret_cast<float*>(&L);
     static_assert(sizeof(L) >= fused_capw(2 * NCH, NCH) * NCH * sizeof(float), "the wave's span fits the stream's LDS");
+    if constexpr (kPick) {                        // a strided view: the block kernel's general path, 128 outputs per wave too
+      static_assert(sizeof(L) >= fused_capw(2, 1) * sizeof(float), "the wave's span fits the stream's LDS");
+      if (nrem > 0)
+        fused_wave<1, 32, 2, false>(a.len_out, a.sig, nullptr, 2, a.len_in, 32, a.tab, a.tmd, a.out, nullptr, a.out_stride, a.fa, piece, l,
+                                    jw, nrem, piece);
+      return;
+    }
     if (nrem == kEdgeWaveOut)
       fused_wave<NCH, 32, 2 * NCH, true>(a.len_out, a.sig, a.sig + 1, NCH, a.len_in, 32, a.tab, a.tmd, a.out, a.out + 1, NCH, a.fa, piece, l,
                                          jw, nrem, piece);
@@ -490,7 +505,7 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
     hd_fl = h.flags | ((d > -0x40000000ll && d < 0x40000000ll) ? 0 : 1);
     if (a.n_edge > 0 && (Ta + l == 0 || Ta + l >= a.n_full - 2)) hd_fl |= 1 | kTileEdge;      // end tiles: not streamed, not pushed
     hd_dA = (int)d;
-    if constexpr (KIND != 0) {                    // is this stream the kernel's kind?
+    if constexpr (KIND == 1 || KIND == 2) {       // is this stream the kernel's kind?
       const bool any_slow = __ballot(l < my_tiles && Ta + l < Tb && (h.flags & kTileMaySlow) != 0) != 0ull;
       if (any_slow != (KIND == 2)) return;
     }
@@ -515,7 +530,7 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
   }
   const float tolf = (float)((fabs((double)A0) + 2.0e7) * 1.2e-16 + 2.0e-10) + 2.0e-7f;
   const int nJ = (int)(Jb - Ja);
-  float* const outW = a.out + NCH * Ja;
+  float* const outW = a.out + (kPick ? a.out_stride : (int64_t)NCH) * Ja;
   const uint4* const recW = reinterpret_cast<const uint4*>(a.rec) + (Ja >> kRecShift);
   const uint4* const rec2W = reinterpret_cast<const uint4*>(a.rec2) + (Ja >> kRecShift);
   const int blk_max = (int)(((a.len_out + kRec - 1) >> kRecShift) - (Ja >> kRecShift)) - 1;      // last block with a record, relative
@@ -540,7 +555,8 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
   auto ring_restart = [&]() {
     const long long o = A0 + wbase;
     ring_src = a.sig + NCH * o;
-    const long long klo = o >= 0 ? 0 : (-o + kPass - 1) / kPass, khi = ((long long)a.len_in - o) / kPass - 1;
+    // (one channel of frames: the last frame's second word may lie one float behind the caller's view -- never fetched)
+    const long long klo = o >= 0 ? 0 : (-o + kPass - 1) / kPass, khi = ((long long)a.len_in - (kPick ? 1 : 0) - o) / kPass - 1;
     dma_klo = (int)(klo > 0x3fffffff ? 0x3fffffff : klo);
     dma_khi = (int)(khi > 0x3fffffff ? 0x3fffffff : (khi < -1 ? -1 : khi));
   };
@@ -630,7 +646,10 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
   auto store_pass = [&](const S3Pass& Q, const float (&res)[2]) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
-      if (l < Q.nok[r] && !(PAR_S2_EXP & 4)) outW[(unsigned)Q.j + 64u * r + (unsigned)l] = res[r];
+      if (l < Q.nok[r] && !(PAR_S2_EXP & 4)) {
+        if constexpr (kPick) outW[(int64_t)((unsigned)Q.j + 64u * r + (unsigned)l) * a.out_stride] = res[r];
+        else outW[(unsigned)Q.j + 64u * r + (unsigned)l] = res[r];
+      }
   };
   auto store_pass2 = [&](const S3Pass& Q, const float (&res0)[2], const float (&res1)[2]) {      // stereo: a frame per lane and row
 #pragma unroll
@@ -640,7 +659,9 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
   };
   // one chunk of the ring -> float16 image(s); stereo: both channels of the chunk
   auto convert_chunk = [&](int chunk) -> bool {
-    if constexpr (NCH == 2) {
+    if constexpr (kPick) {
+      return s3_convert_ch(L, chunk, l, 0, true);
+    } else if constexpr (NCH == 2) {
       const bool ok0 = s3_convert_ch(L, chunk, l, 0, true);
       const bool ok1 = s3_convert_ch(L, chunk, l, 1, false);
       return ok0 && ok1;
@@ -774,7 +795,7 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
       float res[2];
       if (kMom && regime == 3) out_pass(std::integral_constant<int, kMom ? 3 : 1>{}, N, res);
       else out_pass(std::integral_constant<int, 1>{}, N, res);
-      if constexpr (NCH == 2) {                   // the other channel through the same rows
+      if constexpr (kTwo) {                       // the other channel through the same rows
         float res1[2];
         wave_lds_fence();
         if (regime == 3) bank_image3m<true>(L, fr, fmr, offs, l, 1);
@@ -846,13 +867,13 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
            (MODE == 1 ? gen == 0ull : gen != 0ull) & ((unsigned)(d - 161) <= 312u) & (conv_next + 1 < dma_bad) &
            ((unsigned)((j0 >> kRecShift) - rbA) <= 1u);
       };
-      if constexpr (NCH == 1) place_next();       // (stereo: behind OUT(P, 1), fewer registers live through the banks)
+      if constexpr (!kTwo) place_next();          // (stereo: behind OUT(P, 1), fewer registers live through the banks)
       // BANK(pk) over [ws, ws + 128): image samples converted in earlier iterations
       // OUT(P) first in program order: its gathers must precede the bank's row writes
       float res[2];
       out_pass(mode_tag, P, res);
       bool cok;
-      if constexpr (NCH == 2) {
+      if constexpr (kTwo) {
         // Stereo.  The bank rows in LDS hold ONE channel of one pass at a time: on entry channel 0 of P (banked by the previous
         // iteration or by the cold path).  OUT(P, 0) above has gathered them; now BANK(P, 1) -> OUT(P, 1) -> BANK(N, 0), each after
         // the reads of what it overwrites in program order.  Channel 1's image therefore runs one chunk behind channel 0's: its
@@ -880,7 +901,7 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
 #endif
         bank_image3m<MODE == 3>(L, fr, fmr, offs, l);
         // CONV: one chunk per iteration
-        cok = s3_convert(L, conv_next, l);
+        cok = convert_chunk(conv_next);
         // FETCH + stores: records of pass pk + 2, chunk conv_next + 2, then P's outputs (five memory operations, in this order)
         fetch_records((pk + 2) & 3, rbC);
         chunk_dma(dma_next);
@@ -906,7 +927,7 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
 #endif
       if (!(ok && cok)) {
         // stereo: channel 1's image catches up with channel 0's before the cold path takes over
-        if constexpr (NCH == 2)
+        if constexpr (kTwo)
           if (mode != 0 && !s3_convert_ch(L, conv_next - 1, l, 1, false)) mode = 0;
         return;
       }
@@ -954,9 +975,10 @@ static int64_t stream_wave_slots(int device) {
 }
 
 int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
-                       const float4* tab, const TapModes& tmd, hipStream_t s, int nch) {
+                       const float4* tab, const TapModes& tmd, hipStream_t s, int nch, int64_t pick_out_stride) {
   const int64_t slots = stream_wave_slots(device);
   S2Args a;
+  a.out_stride = pick_out_stride;
   a.len_out = len_out;
   a.sig = sig;
   a.len_in = len_in;
@@ -993,7 +1015,9 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
   a.tiles_tail = a.tiles >= 8 && tail_env > 1 ? std::max(2, a.tiles / tail_env) : a.tiles;
   a.n_big = (a.n_full - std::min<int64_t>(a.n_full, slots * tail_rounds * a.tiles * (a.tiles_tail < a.tiles ? 1 : 0))) / a.tiles;
   const int64_t grid = a.n_big + ceil_div(a.n_full - a.n_big * a.tiles, (int64_t)a.tiles_tail) + a.n_edge;
-  if (grid > 0 && nch == 2) {
+  if (grid > 0 && nch == 2 && pick_out_stride > 0) {
+    hipLaunchKernelGGL((k_sinc_pipe<2, 3>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  } else if (grid > 0 && nch == 2) {
     hipLaunchKernelGGL((k_sinc_pipe<2, 0>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
   } else if (grid > 0) {
     // mono: the streams with an fc < 1 tile (two waves per SIMD: all 25 constant fragments) and the end tiles, then the fc = 1

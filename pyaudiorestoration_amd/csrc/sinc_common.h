@@ -47,9 +47,11 @@ struct FusedArgs {
 };
 
 // Streaming kernel (sinc2.hip): NT = 32; nch = 1: a mono signal on unit strides, nch = 2: an interleaved stereo file (sig / out
-// point at the left channel's first sample; len_in / len_out count frames).  Tiles it does not take are appended to fa.redo_list.
+// point at the left channel's first sample; len_in / len_out count frames); nch = 2 with pick_out_stride > 0: ONE channel of a
+// two-channel interleaved file (sig = that channel's first sample, input stride 2; outputs pick_out_stride elements apart).
+// Tiles it does not take are appended to fa.redo_list.
 struct TapModes;
 int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
-                       const float4* tab, const TapModes& tmd, hipStream_t s, int nch);
+                       const float4* tab, const TapModes& tmd, hipStream_t s, int nch, int64_t pick_out_stride = 0);
 
 }  // namespace par

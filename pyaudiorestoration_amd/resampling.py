@@ -139,8 +139,8 @@ def speed_to_pos_dev(sampletimes_t, speeds_t, num_imput_samples, dev=None, force
 def varispeed_fused_dev(plan, sig_t, NT, out_t=None, sig_stride=1, len_in=None, out_stride=1):
     """Sinc interpolation of one channel straight from a fused SpeedPlan: K_sinc places every output itself from the plan's
     block records (no position array in HBM).  Same output as the two-step path within the contract's tolerance, every window
-    centre the reference's.  Mono NT = 32 on unit strides takes the streaming kernel, everything else the block kernel
-    (include/par_hip.h)."""
+    centre the reference's.  NT = 32 on unit strides, or one channel of a two-channel interleaved file (sig_stride=2: the
+    reference's use_channels views), takes the streaming kernel, everything else the block kernel (include/par_hip.h)."""
     if not plan.fused_ok:
         raise ValueError("plan cannot feed the fused resampler: build it with speed_plan_dev(..., fused=True)")
     dev = plan.dev
@@ -215,6 +215,11 @@ def varispeed_batch_dev(items, NT, dev=None, planners=None):
     Plan buffers form a ring of 2 x planners slots; an event keeps a slot from being re-planned before the K_sinc
     that reads it has finished.  planners=1 is the double-buffered pipeline of r02-r04.
 
+    PREFETCH CONTRACT: `planners` items (default 3) are taken from the iterable AHEAD of the one being resampled, and their
+    tensors are read until that item's output has been yielded -- a producer that recycles its input tensors needs a ring of
+    at least planners + 1 of them (planners=1 is the one-ahead contract of r02-r04).  Memory: 2 x planners plan / aux buffer
+    pairs stay allocated, each sized for the eager plan's checkpoints (~1.3 B per output sample: 0.9 GB for a 60-min file).
+
     items: iterable of (sampletimes_t, speeds_t, sig_t) or (sampletimes_t, speeds_t, sig_t, sig_stride, len_in)
     with float64 / float32 device tensors; a 2-D sig_t is an interleaved (n, ch) file whose channels share the plan
     (channel pairs go through the stereo launch) and yields an (len_out, ch) output.  Up to `planners` items are
@@ -224,7 +229,13 @@ def varispeed_batch_dev(items, NT, dev=None, planners=None):
     import collections
     from concurrent.futures import ThreadPoolExecutor
     dev = _dev.device_index(dev)
-    P = max(1, int(planners if planners is not None else os.environ.get("PAR_PLANNERS", "3")))
+    P = planners if planners is not None else os.environ.get("PAR_PLANNERS", "3")
+    try:
+        P = int(P)
+    except (TypeError, ValueError):
+        raise ValueError(f"planners / PAR_PLANNERS must be an integer 1..8, got {P!r}")
+    if not 1 <= P <= 8:
+        raise ValueError(f"planners / PAR_PLANNERS must be an integer 1..8, got {P}")
     n_slots = 2 * P
     main = torch.cuda.current_stream(dev)
     sides = [torch.cuda.Stream(device=dev) for _ in range(P)]

@@ -1313,6 +1313,56 @@ def test_stereo_streaming_kernel_against_the_oracle(par):
             assert relerr(got[:, c], C.sinc(pos, x, NT)) < TOL, (n2, speed, c)
 
 
+def test_one_channel_of_an_interleaved_file_through_the_streaming_kernel(par):
+    """The reference's use_channels (util/resampling.py:211-227: sinc_wrapper_mt(output[:, out_channel], sample_at, signal[:, in_channel]))
+    on a two-channel file: a strided column view in, a column of the (length, n_used) output array out.  k_sinc_pipe<2, 3> (r06)
+    rings the frames as they lie in memory and banks one channel.  Each channel against the C oracle on fast / slow / mixed tapes
+    with different material per channel, output strides 1 (one channel used) and 2 (both used, one at a time), the OTHER channel
+    holding a NaN (must not leak), an odd length; the tile diagnostic shows that the streams took the file."""
+    from oracle import oracle_c as C
+    from pyaudiorestoration_amd import _lib, _dev
+    t = par.torch
+    L = _lib.lib()
+    n, sr = 777_777, 192000
+    m = n // 256
+    st = np.linspace(0, n, m)
+    tt = st / sr
+    rng = np.random.default_rng(123)
+    k = np.arange(n)
+    left = (rng.standard_normal(n) * np.where((k > n // 3) & (k < n // 2), 1e-3, 1.0)).astype(np.float32)
+    right = np.cos(np.pi * k).astype(np.float32)                         # a full-scale Nyquist tone beside noise
+    frames = np.stack([left, right], axis=1).copy()
+    x = t.from_numpy(frames).cuda().reshape(-1)
+    redo = ctypes.c_int(-1)
+    for cname, sp in (("mixed", 1.0 + 0.01 * np.sin(2 * np.pi * 4.4 * tt + 0.7)), ("fast", 1.005 + 0.005 * np.sin(2 * np.pi * 3.0 * tt)),
+                      ("slow", 0.995 + 0.0049 * np.sin(2 * np.pi * 3.0 * tt + 1.0))):
+        plan = par.resampling.speed_plan_dev(t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), n, fused=True)
+        pos, _ = C.speed_to_pos(st, sp, n)
+        assert plan.len_out == len(pos)
+        for ch, src in ((0, left), (1, right)):
+            want = C.sinc(pos, src, 32, threads=8)
+            for out_stride in (1, 2):
+                out = t.full((plan.len_out * out_stride,), 7.0, dtype=t.float32, device="cuda")
+                par.resampling.varispeed_fused_dev(plan, x[ch:], 32, out[(ch if out_stride == 2 else 0):], sig_stride=2, len_in=n,
+                                                   out_stride=out_stride)
+                _lib.check(L.par_fused_redo_tiles(0, _dev.ptr(plan.aux), plan.max_out, plan.m, ctypes.byref(redo), _dev.stream_ptr(0)))
+                assert 0 <= redo.value <= 8, (cname, ch, redo.value)     # the streams took the file (ties only in the list)
+                got = out.cpu().numpy()
+                if out_stride == 2:
+                    assert np.all(got[(1 - ch)::2] == 7.0)               # the other column untouched
+                    got = got[ch::2]
+                assert relerr(got, want) < TOL and block_relerr(got, want) < 2 * TOL, (cname, ch, out_stride, relerr(got, want))
+    # a NaN in the OTHER channel stays there
+    bad = frames.copy()
+    bad[400_000, 1] = np.nan
+    xb = t.from_numpy(bad).cuda().reshape(-1)
+    out = par.resampling.varispeed_fused_dev(plan, xb[0:], 32, sig_stride=2, len_in=n).cpu().numpy()
+    assert not np.isnan(out).any() and relerr(out, C.sinc(pos, left, 32, threads=8)) < TOL
+    out = par.resampling.varispeed_fused_dev(plan, xb[1:], 32, sig_stride=2, len_in=n).cpu().numpy()
+    ind = np.rint(pos).astype(np.int64)
+    assert np.array_equal(np.isnan(out), (ind - 32 <= 400_000) & (400_000 < ind + 32))
+
+
 def test_streaming_kernel_files_of_whole_tiles(par):
     """Files whose output is a whole number of 1024-output tiles (no partial tile: the streaming launch then has three end
     tiles instead of four), down to the smallest file the streaming kernel takes (four tiles: only tile 1 is streamed), and
@@ -1371,8 +1421,13 @@ def test_kernel_choice_of_the_fused_entry_point(par, sinc_kernel):
                 assert 0 <= redo.value <= 8                  # rounding ties (the file's end tiles are done inside the streaming launch)
             elif NT == 32:
                 assert redo.value == 0 or form == 0          # (the list keeps the streaming launch's count until the next plan)
-        # a strided channel of an interleaved file: never the streaming kernel
+        # one channel of the two-channel interleaved file (the reference's use_channels view): since r06 the streaming kernel's
+        # one-channel-of-frames form at NT = 32 (the tile diagnostic says so); a channel of a THREE-channel file: the block kernel
         res[form, "strided"] = par.resampling.varispeed_fused_dev(plan, x[1:], 32, sig_stride=2, len_in=n).cpu().numpy()
+        _lib.check(L.par_fused_redo_tiles(0, _dev.ptr(plan.aux), plan.max_out, plan.m, ctypes.byref(redo), _dev.stream_ptr(0)))
+        assert (0 <= redo.value <= 8) if form == -1 else True
+        x3 = t.from_numpy(np.stack([sig[::-1], sig, sig], axis=1).copy()).cuda().reshape(-1)
+        res[form, "strided3"] = par.resampling.varispeed_fused_dev(plan, x3[1:], 32, sig_stride=3, len_in=n).cpu().numpy()
         # both channels of the interleaved file in one launch: the streaming kernel's stereo form at NT = 32, else the block kernel
         for NT in (32, 50):
             o2 = t.empty((plan.len_out, 2), dtype=t.float32, device="cuda")
@@ -1385,14 +1440,18 @@ def test_kernel_choice_of_the_fused_entry_point(par, sinc_kernel):
             assert relerr(res[form, NT], want) < TOL and block_relerr(res[form, NT], want) < 2 * TOL, (form, NT)
     assert relerr(res[-1, 32], res[0, 32]) < 5e-6 and not np.array_equal(res[-1, 32], res[0, 32])
     assert np.array_equal(res[-1, 50], res[0, 50]) and np.array_equal(res[-1, 16], res[0, 16])
-    assert np.array_equal(res[-1, "strided"], res[0, "strided"])
+    assert relerr(res[-1, "strided"], res[0, "strided"]) < 5e-6 and not np.array_equal(res[-1, "strided"], res[0, "strided"])
+    assert np.array_equal(res[-1, "strided3"], res[0, "strided3"])
     assert relerr(res[-1, "stereo", 32], res[0, "stereo", 32]) < 5e-6 and not np.array_equal(res[-1, "stereo", 32], res[0, "stereo", 32])
     assert np.array_equal(res[-1, "stereo", 50], res[0, "stereo", 50])
     for form in (-1, 0):
         for c in (0, 1):
             want = C.sinc(pos, st2[:, c].copy(), 32, threads=8)
             assert relerr(res[form, "stereo", 32][:, c], want) < TOL and block_relerr(res[form, "stereo", 32][:, c], want) < 2 * TOL, (form, c)
-    assert relerr(res[0, "strided"], C.sinc(pos, st2[:, 1].copy(), 32, threads=8)) < TOL
+    for form in (-1, 0):
+        want = C.sinc(pos, st2[:, 1].copy(), 32, threads=8)
+        assert relerr(res[form, "strided"], want) < TOL and block_relerr(res[form, "strided"], want) < 2 * TOL, form
+    assert relerr(res[0, "strided3"], C.sinc(pos, sig, 32, threads=8)) < TOL
 
 
 def test_fused_extreme_curves_and_channels(par):
@@ -2557,7 +2616,16 @@ def test_sosfiltfilt_batch_equals_single_calls_and_scipy(par):
     t_loop = timed(lambda: [F.sosfiltfilt_dev(many[i], rows[i]) for i in range(n_sig)])
     t_batch = timed(lambda: F.sosfiltfilt_batch_dev(many, x_t))
     print(f"sosfiltfilt 64 bands x 1e6 samples: loop {t_loop * 1e3:.2f} ms, batched {t_batch * 1e3:.2f} ms ({t_loop / t_batch:.1f}x)")
-    assert t_loop / t_batch >= 8.0          # measured 11.6x (58.5 -> 5.0 ms: 1.8 TB/s over the six section passes; the loop is launch-bound)
+    # (measured 11.6x: 58.5 -> 5.0 ms, 1.8 TB/s over the six section passes; the loop is launch-bound.  A wall-clock ratio is not a
+    # unit test's business on a shared GPU: reported above and in NOTES, asserted only loosely)
+    assert t_loop / t_batch >= 2.0
+    # the VALUES of this size: n_sig x L >= 20 M takes the LDS-tiled batched kernels (k_sos_block_zero_bt / _run_bt), which the
+    # 7 x 50 001 case above never reaches
+    yb = F.sosfiltfilt_batch_dev(many, x_t)
+    for i in (0, 1, 17, 40, 63):
+        assert t.equal(yb[i], F.sosfiltfilt_dev(many[i], rows[i])), i
+    for i in (0, 31, 63):
+        assert relerr(yb[i].cpu().numpy(), scipy.signal.sosfiltfilt(many[i], x_t[i].cpu().numpy())) < 1e-9, i
 
 
 def test_heuristic_repair_against_the_reference(par):

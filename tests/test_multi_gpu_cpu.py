@@ -76,6 +76,10 @@ def test_bench_gpus2_starts_its_own_ranks():
     assert r["n_gpus"] == 2 and r["dry_run"] is True and r["steps"] == 2 and r["warmup"] == 1
     assert r["config"]["channel_samples_per_step"] == 42 * 2 * 115_200_000      # every file exactly once per step
     assert {"n1_same_workload_value", "speedup_vs_n1", "efficiency", "speedup_base"} <= set(r)
+    # the N > 1 lines' shape: a roofline object with the per-GPU K_sinc time, and the CPU baseline's key --
+    # null with a note, because the contract times the CPU port on the N = 1 lines only
+    assert {"roofline", "cpu_baseline", "cpu_baseline_note"} <= set(r) and "kernel_ms_per_file_alone_min_max" in r["roofline"]
+    assert r["cpu_baseline"] is None and "N = 1" in r["cpu_baseline_note"]
     assert 1.2 < r["speedup_vs_n1"] < 3.5                      # (sleep-per-file dry run: ~2; a busy host stretches the one-rank base)
     # the curve's base is the ARCHIVE on one GPU (the N = 1 line's archive_value), never the mono file of that line's `value`
     assert abs(r["speedup_vs_n1"] - r["value"] / r["n1_same_workload_value"]) < 2e-3 and "archive" in r["speedup_base"]
