@@ -43,7 +43,7 @@
 #include <limits.h>
 #include <type_traits>
 
-constexpr int kMaxTilesPerWave = 24;          // k_sinc_pipe's tiles per wave for long files (launch_sinc_stream picks 8 .. this)
+constexpr int kMaxTilesPerWave = 23;          // k_sinc_pipe's tiles per wave for long files (launch_sinc_stream picks 8 .. this)
 #ifndef PAR_S2_EXP
 #define PAR_S2_EXP 0            // timing builds, never shipped: 1 no MFMAs, 2 no near taps, 4 no stores, 8 no conversion, 16 unity maths on every pass
 #endif
@@ -1007,12 +1007,15 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
   constexpr int tiles_env = 0, tail_env = 6, tail_rounds = 1;      // tail_env: divisor of the last round's stream length
 #endif
   const int64_t want = a.n_full / (4 * slots);
-  a.tiles = tiles_env > 0 ? tiles_env : (int)(want < 8 ? 8 : (want > kMaxTilesPerWave ? kMaxTilesPerWave : want));
-  if (a.tiles > 48) a.tiles = 48;
+  // ... and an ODD number of them (r06): the concurrent streams start tiles x 4 KB (8 KB stereo) apart, and when that is a multiple
+  // of 64 KB they camp on the same memory channels -- 60-min file, ms per step: 32 tiles 5.71, 16: 4.20, 48: 4.19 against
+  // 4.09-4.18 for every odd count from 17 to 37 and 4.02-4.19 for 24 (what looked like rounds of the wave slots in r05 was this)
+  a.tiles = tiles_env > 0 ? tiles_env : (int)(want < 8 ? 8 : (want > kMaxTilesPerWave ? kMaxTilesPerWave : want)) | 1;
+  if (a.tiles > 48) a.tiles = 47;
   // ... and the launch's last round (2 048 wave slots' worth of tiles) as four rounds of quarter-length streams: the tail in which
   // the GPU empties behind the last long streams shrinks with them
   // (24 tiles, K_sinc alone: no short tail 4.37 ms, quarter-length 4.22, 1/8 4.20, 1/12 4.23; two rounds of them 4.23 / 4.30)
-  a.tiles_tail = a.tiles >= 8 && tail_env > 1 ? std::max(2, a.tiles / tail_env) : a.tiles;
+  a.tiles_tail = a.tiles >= 8 && tail_env > 1 ? std::max(2, a.tiles / tail_env) | 1 : a.tiles;
   a.n_big = (a.n_full - std::min<int64_t>(a.n_full, slots * tail_rounds * a.tiles * (a.tiles_tail < a.tiles ? 1 : 0))) / a.tiles;
   const int64_t grid = a.n_big + ceil_div(a.n_full - a.n_big * a.tiles, (int64_t)a.tiles_tail) + a.n_edge;
   if (grid > 0 && nch == 2 && pick_out_stride > 0) {
