@@ -423,6 +423,7 @@ def config5_batch(a, ctx):
     world, rank, dev = ctx.world, ctx.rank, ctx.local
     L = _lib.lib()
     s = _dev.stream_ptr(dev)
+    numa = multi_gpu.bind_to_device_node(dev) if world > 1 else None      # pinned gather buffers on the GPU's own socket
     sr, seconds, files = a.sr, float(a.c5_seconds), a.files          # (--c5-seconds < 600: flow tests of many ranks on one device)
     n, m = int(sr * seconds), int(seconds * sr / 256)
     ring = []
@@ -557,6 +558,7 @@ def config5_batch(a, ctx):
                           "n1_same_workload_value": round(n1_e, 3), "speedup_vs_n1": round(v_e / n1_e, 3),
                           "efficiency": round(v_e / n1_e / world, 4),
                           "GB_per_s_to_host_per_gpu": round(v_e * 1e6 * 4 / 1e9 / world, 2),
+                          "rank0_numa_node": numa,
                           "what": "the same archive, every output copied to a ring of 3 pinned host buffers per rank on a "
                                   "separate stream under the next files' kernels (inputs stay resident in HBM); the bus (one "
                                   "0.92 GB D2H per file), not the kernels, sets this rate; one-GPU base = rank 0 alone over "

@@ -96,3 +96,12 @@ def test_work_queue_grabs_four_items_per_request():
     ctx = multi_gpu.RankContext()
     q = multi_gpu.WorkQueue(ctx, list(range(10, 21)), "solo4")
     assert q.grab == 4 and list(q) == list(range(10, 21)) and q._next == 16    # 3 requests served items, the 4th came back empty
+
+
+def test_numa_binding_helpers(tmp_path):
+    """bind_to_device_node's parsing and its refusal to do anything it cannot justify (no GPU here: the topology is unreadable)"""
+    assert multi_gpu.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert multi_gpu.parse_cpulist("") == set() and multi_gpu.parse_cpulist("5") == {5}
+    before = os.sched_getaffinity(0)
+    assert multi_gpu.bind_to_device_node(0, sysfs=str(tmp_path)) is None
+    assert os.sched_getaffinity(0) == before
