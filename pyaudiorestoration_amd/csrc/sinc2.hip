@@ -22,7 +22,7 @@
 //     passes ahead are fetched while the current one computes.
 // What the record model or float16 do not cover goes to the block kernel through a tile list (k_sinc_fused_list / _list2,
 // sinc.hip): blocks flagged slow, outputs within the reference's own rounding of a half-integer position (window-centre ties),
-// input that is non-finite / >= 32768 / all but silent.  The file's END tiles (the ring would reach over the file's ends) are
+// input that is non-finite / >= 32 / all but silent.  The file's END tiles (the ring would reach over the file's ends) are
 // not streamed at all: the launch's first workgroups do them the block kernel's way (fused_wave, sinc_block.h) beside the
 // streams.  Every window centre is the reference's rint(p) either way.
 // Stereo (k_sinc_pipe<2>): the ring holds frames (left, right); a pass is placed ONCE and both channels are converted, banked
@@ -56,7 +56,14 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 
 constexpr int kRing = 512;                       // samples per ring (float32 and float16 images alike)
 constexpr int kPass = 128;                       // centres per pass = outputs tried per pass
-constexpr float kQuiet = 0.0001220703125f;       // 2^-13: a chunk whose loudest sample is below this (and not 0) leaves float16's range
+// The float16 images hold the signal x kImgScale (r06).  A sample's hi part is zero -- and the sample then reaches only the
+// filters that take the lo image -- below 6e-8 instead of 6e-5, i.e. practically never: passages 60 dB down lose nothing (their
+// zero crossings used to), and the (e1 d1) filters no longer need the lo image at all (2 MFMAs per pass; without the scale a
+// signal at 1e-3 came out 4.5e-5 wrong, tools/sinc2_model.py).  The price is the streaming kernel's range: |x| < 32 (beyond it the
+// lo part of the scaled sample leaves float16; such tiles are the block kernel's).
+constexpr float kImgScale = 1024.0f, kImgScaleInv = 0.0009765625f;
+constexpr float kImgMax = 32.0f;                 // |x| the images can hold
+constexpr float kQuiet = 0.0001220703125f / kImgScale;       // a chunk whose loudest sample is below 2^-13 / scale (and not 0) leaves float16's range
 
 
 #if PAR_S2_EXP & 64
@@ -263,7 +270,8 @@ struct S3Pass {                                  // a placed pass: 128 candidate
 // 15 + 18 MFMAs.  fr: the fc = 1 bank's ten constant fragments (kBank2Frags32's first ten), fmr: the moment filters' fifteen
 // (kBank3Frags32, sinc_taps_gen.h); all resident in the wave's registers.  MOMENTS = false: the fc = 1 bank alone.
 constexpr int kCtabUnity = 10;
-template <bool MOMENTS, class LDS>
+// SIX = false: without the moment of order 6 (passes with 1 - fc <= 0.0105: the series to order 5 is within 1.6e-6 there)
+template <bool MOMENTS, bool SIX = true, class LDS>
 __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Frags], const half8v (&fmr)[kBank3Frags],
                                              const int offs, const int l, const int ch = 0) {
   const int bb = l & 15, g = l >> 4;
@@ -277,7 +285,7 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
   }
   auto frag = [&](int f) { return f < kCtabUnity ? fr[f] : fmr[f - kCtabUnity]; };
   const float4v z = {0.0f, 0.0f, 0.0f, 0.0f};
-  float4v e0 = z, lo = z, e1 = z, x1 = z, e2 = z;
+  float4v e0 = z, lo = z, e1 = z, e2 = z;
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks) {
     const half8v f0 = frag(ks);
@@ -286,15 +294,14 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
     lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, xl[ks], lo, 0, 0, 0);
     if (ks < 2) {
       const half8v f1 = frag(3 + ks);
-      e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, xh[ks], e1, 0, 0, 0);
-      x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, xl[ks], x1, 0, 0, 0);
+      e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, xh[ks], e1, 0, 0, 0);      // (no lo image here since the images are scaled, r06)
       e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag(8 + ks), xh[ks], e2, 0, 0, 0);
     }
   }
   // (the factor in a vector register: a VALU instruction with an SGPR operand issues at 4.3 cycles instead of 2.4, tools/exp/valu_forms.hip)
   float lo_inv = kBank2LoInv;
   asm volatile("" : "+v"(lo_inv));
-  const float4v v0 = e0 + lo * lo_inv, v1 = e1 + x1 * lo_inv;
+  const float4v v0 = e0 + lo * lo_inv, v1 = e1;
   float4v a01 = z, l01 = z, a23 = z, a45 = z, a6 = z;
   if (MOMENTS) {
 #pragma unroll
@@ -305,7 +312,7 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
       l01 = __builtin_amdgcn_mfma_f32_16x16x32_f16(f01, xl[ks], l01, 0, 0, 0);
       a23 = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag(kCtabUnity + 6 + ks), xh[ks], a23, 0, 0, 0);
       a45 = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag(kCtabUnity + 9 + ks), xh[ks], a45, 0, 0, 0);
-      a6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag(kCtabUnity + 12 + ks), xh[ks], a6, 0, 0, 0);
+      if constexpr (SIX) a6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag(kCtabUnity + 12 + ks), xh[ks], a6, 0, 0, 0);
     }
   }
   const float4v m01 = a01 + l01 * lo_inv;
@@ -332,6 +339,8 @@ __device__ __forceinline__ void bank_image3m(LDS& L, const half8v (&fr)[kBank2Fr
 template <int MODE, int NCH = 1, class LDS>
 __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const float sr, const float epr, const int wsK, const int ch = 0) {
   using T32 = TapTab<32>;
+  constexpr float kUs = kBank2ScaleInv * kImgScaleInv;      // bank rows -> signal units
+  constexpr float kMs = kImgScaleInv;                       // moment rows -> signal units (rides in the Horner's constants)
   const int sl = ci ^ ((ci >> 3) & 7);
   const int rc = (wsK + ci) & (kRingF - 1);
   const float* xp = &L.ring[NCH * rc + ch];
@@ -343,7 +352,7 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
     const float4v row = L.qa[sl];
     float4v M0 = {0.0f, 0.0f, 0.0f, 0.0f};
     unsigned w2;
-    if constexpr (MODE == 3) {
+    if constexpr (MODE != 1) {
       M0 = L.qm0[sl];
       w2 = __float_as_uint(M0[3]);
     } else {
@@ -352,7 +361,7 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
     const float e = fmaf(q, fmaf(q64, h_lo(w2), row[2]), row[0]), d = fmaf(q, fmaf(q64, h_hi(w2), row[3]), row[1]);
     const float en = fmaf(E2, R2, -(E1 * R1));
     const float dn = fmaf(D2 + D2, R2, -(D1 * R1));
-    const float et = fmaf(e, kBank2ScaleInv, en), dt = fmaf(d, kBank2ScaleInv, dn);
+    const float et = fmaf(e, kUs, en), dt = fmaf(d, kUs, dn);
     const float spq = sinpi_poly(q);                                  // sin(pi s) / s
     const float unity = spq * fmaf(-sr, fmaf(sr, et, dt), x0 * 0.318309886f);
     if constexpr (MODE == 1) return unity;
@@ -362,17 +371,22 @@ __device__ __forceinline__ float s3_out_row(const LDS& L, const int ci, const fl
     const float g = epr * fast_rcp(1.0f + epr);                        // 1 - fc
     const float G = 3.14159265f * g, w = G * sr, w2m = w * w, G32 = 32.0f * G;
     float re, im;
-    // i = 6 (beta_6 and the w^2 terms of i >= 3 are below 1e-8 of the peak)
-    re = m6 * 1.98412698e-4f;                                          // 1 / (6! 7)
-    im = 0.0f;
+    if constexpr (MODE == 3) {
+      // i = 6 (beta_6 and the w^2 terms of i >= 3 are below 1e-8 of the peak)
+      re = m6 * (1.98412698e-4f * kMs);                                // 1 / (6! 7)
+      im = 0.0f;
+    } else {                                                           // MODE 2: the series to order 5 (1 - fc <= 0.0105)
+      re = m5 * (1.38888889e-3f * kMs);                                // i = 5: 1/(5! 6), 1/(5! 7)
+      im = m5 * (w * -(1.19047619e-3f * kMs));
+    }
 #define S3_MOM_STEP(Mi, A0, A1, B0)                                   \
     {                                                                 \
-      const float al_ = (A1) != 0.0f ? fmaf(w2m, -(A1), (A0)) : (A0), be_ = w * -(B0);      /* (A1 = 0: no fma with -0.0) */ \
+      const float al_ = (A1) != 0.0f ? fmaf(w2m, -((A1) * kMs), (A0) * kMs) : (A0) * kMs, be_ = w * -((B0) * kMs);      /* (A1 = 0: no fma with -0.0) */ \
       const float nre_ = fmaf(-G32, im, (Mi) * al_), nim_ = fmaf(G32, re, (Mi) * be_); \
       re = nre_;                                                      \
       im = nim_;                                                      \
     }
-    S3_MOM_STEP(m5, 1.38888889e-3f, 0.0f, 1.19047619e-3f)             // i = 5: 1/(5! 6), -, 1/(5! 7)
+    if constexpr (MODE == 3) S3_MOM_STEP(m5, 1.38888889e-3f, 0.0f, 1.19047619e-3f)             // i = 5: 1/(5! 6), -, 1/(5! 7)
     S3_MOM_STEP(m4, 8.33333333e-3f, 0.0f, 6.94444444e-3f)             // i = 4: 1/(4! 5), -, 1/(4! 6)
     S3_MOM_STEP(m3, 4.16666667e-2f, 0.0f, 3.33333333e-2f)             // i = 3: 1/(3! 4), -, 1/(3! 5)
     S3_MOM_STEP(M0[2], 1.66666667e-1f, 5.0e-2f, 1.25e-1f)             // i = 2: 1/(2! 3), 1/(2 2! 5), 1/(2! 4)
@@ -393,12 +407,13 @@ __device__ __forceinline__ bool s3_convert(LDS& L, const int chunk, const int l)
   const float2 xx = *reinterpret_cast<const float2*>(&L.ring[ix]);
   const float x0 = xx.x, x1 = xx.y;
   const float am = fmaxf(fabsf(x0), fabsf(x1));
-  const bool ok = !(__ballot(!(fabsf(x0) < 32768.0f) || !(fabsf(x1) < 32768.0f)) != 0ull ||
+  const bool ok = !(__ballot(!(fabsf(x0) < kImgMax) || !(fabsf(x1) < kImgMax)) != 0ull ||       // (also false for NaN)
                     (__ballot(am >= kQuiet) == 0ull && __ballot(am > 0.0f) != 0ull));
   if ((chunk & 7) == 0 && l < 2) *reinterpret_cast<float2*>(&L.ring_tail[ix]) = xx;
   if ((chunk & 7) == 7 && l == kWave - 1) *reinterpret_cast<float2*>(&L.ring_head[2]) = xx;
-  const half2v h = {S2_HI(x0), S2_HI(x1)};
-  const half2v lo = {(_Float16)((x0 - (float)h[0]) * 4096.0f), (_Float16)((x1 - (float)h[1]) * 4096.0f)};
+  const float s0 = x0 * kImgScale, s1 = x1 * kImgScale;
+  const half2v h = {S2_HI(s0), S2_HI(s1)};
+  const half2v lo = {(_Float16)((s0 - (float)h[0]) * 4096.0f), (_Float16)((s1 - (float)h[1]) * 4096.0f)};
   *reinterpret_cast<half2v*>(&L.img[0][ih]) = h;
   *reinterpret_cast<half2v*>(&L.img[1][ih]) = lo;
   return ok;
@@ -413,14 +428,15 @@ __device__ __forceinline__ bool s3_convert_ch(LDS& L, const int chunk, const int
   const float4v xx = *reinterpret_cast<const float4v*>(&L.ring[2 * ix]);
   const float x0 = ch ? xx[1] : xx[0], x1 = ch ? xx[3] : xx[2];
   const float am = fmaxf(fabsf(x0), fabsf(x1));
-  const bool ok = !(__ballot(!(fabsf(x0) < 32768.0f) || !(fabsf(x1) < 32768.0f)) != 0ull ||
+  const bool ok = !(__ballot(!(fabsf(x0) < kImgMax) || !(fabsf(x1) < kImgMax)) != 0ull ||
                     (__ballot(am >= kQuiet) == 0ull && __ballot(am > 0.0f) != 0ull));
   if (mirrors) {
     if ((chunk & 7) == 0 && l < 2) *reinterpret_cast<float4v*>(&L.ring_tail[2 * ix]) = xx;
     if ((chunk & 7) == 7 && l == kWave - 1) *reinterpret_cast<float4v*>(&L.ring_head[4]) = xx;
   }
-  const half2v h = {S2_HI(x0), S2_HI(x1)};
-  const half2v lo = {(_Float16)((x0 - (float)h[0]) * 4096.0f), (_Float16)((x1 - (float)h[1]) * 4096.0f)};
+  const float s0 = x0 * kImgScale, s1 = x1 * kImgScale;
+  const half2v h = {S2_HI(s0), S2_HI(s1)};
+  const half2v lo = {(_Float16)((s0 - (float)h[0]) * 4096.0f), (_Float16)((s1 - (float)h[1]) * 4096.0f)};
   *reinterpret_cast<half2v*>(&L.img[2 * ch][ih]) = h;
   *reinterpret_cast<half2v*>(&L.img[2 * ch + 1][ih]) = lo;
   return ok;
@@ -431,6 +447,10 @@ __device__ __forceinline__ bool s3_convert_ch(LDS& L, const int chunk, const int
 // the fc < 1 taps, an fc = 1-only kernel at three waves per SIMD, workgroups of several streams sharing the constants through
 // LDS -- are in the repository's history and in NOTES r04 with their numbers; the product carries this one.)
 constexpr float kEpMaxMom = 0.0125f / (1.0f - 0.0125f);      // period - 1 at 1 - fc = 0.0125
+// Passes whose lanes all have 1 - fc <= 0.0105 take the moment series to order 5 (regime 2: no m6 -- three matrix-core
+// instructions and a Horner step per pass; within 1.6e-6 of the peak on a Nyquist tone there, 5.5e-6 at 0.0125: tools/sinc3_model.py);
+// the order-6 loop (regime 3) keeps a stream until its passes fall below 0.95 of that (no flapping between the loops)
+constexpr float kEpMom5 = 0.0105f / (1.0f - 0.0105f), kEpMom5Lo = 0.95f * kEpMom5;
 #ifndef PAR_S3_SHARE_OUT
 #define PAR_S3_SHARE_OUT 1      // stereo: 0 = channel 1's row arithmetic worked out afresh (measured: 158 against 165 G on the benchmark's tape)
 #endif
@@ -538,7 +558,7 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
   // ---- stream state (wave-uniform) ----
   int j0 = 0;                                    // first output not yet placed into a finished pass
   int wbase = 0, conv_next = 0, conv_lo = 0, dma_next = 0, dma_bad = INT_MAX, mode = 0, pk = 0;
-  int regime = 1;                                // the loop the current pass belongs to: 1 fc = 1, 3 fc = 1 + the moment correction
+  int regime = 1;                                // the loop the current pass belongs to: 1 fc = 1, 2 / 3 fc = 1 + the moment correction to order 5 / 6
                                                  // (mode: 1 = the float16 images in LDS follow the ring, 0 = to be rebuilt)
   int rbA = 0, rbB = 0, rbC = 0;                 // first block (relative) of the record buffers of passes pk + 1, pk + 2, pk + 3
 
@@ -715,8 +735,9 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
       }
       N.j = j0;
       N.ws = ws;
-      const int want = gen == 0ull ? 1 : 3;       // the pass's regime
-      if (!kMom && want == 3) skip = true;        // (a kernel of fc = 1 streams met an fc < 1 lane: the block kernel's tile)
+      const unsigned long long steep = (__ballot(Q.R[0].ep > kEpMom5) & prefix(nv[0])) | (__ballot(Q.R[1].ep > kEpMom5) & prefix(nv[1]));
+      const int want = gen == 0ull ? 1 : (steep == 0ull ? 2 : 3);      // the pass's regime
+      if (!kMom && want != 1) skip = true;        // (a kernel of fc = 1 streams met an fc < 1 lane: the block kernel's tile)
       if (!skip) {
         bool rebuild = mode != 1;
         // the ring: restarted at the first pass of the wave and after a jump the fetched chunks do not cover
@@ -781,7 +802,8 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
       }
       wave_lds_fence();
       const int offs = ws - wbase - 31;
-      if (kMom && regime == 3) bank_image3m<kMom>(L, fr, fmr, offs, l);
+      if (kMom && regime == 3) bank_image3m<kMom, true>(L, fr, fmr, offs, l);
+      else if (kMom && regime == 2) bank_image3m<kMom, false>(L, fr, fmr, offs, l);
       else bank_image3m<false>(L, fr, fmr, offs, l);
       wave_lds_fence();
       j0 += N.nok[0] + N.nok[1];
@@ -794,14 +816,17 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
       }
       float res[2];
       if (kMom && regime == 3) out_pass(std::integral_constant<int, kMom ? 3 : 1>{}, N, res);
+      else if (kMom && regime == 2) out_pass(std::integral_constant<int, kMom ? 2 : 1>{}, N, res);
       else out_pass(std::integral_constant<int, 1>{}, N, res);
       if constexpr (kTwo) {                       // the other channel through the same rows
         float res1[2];
         wave_lds_fence();
-        if (regime == 3) bank_image3m<true>(L, fr, fmr, offs, l, 1);
+        if (regime == 3) bank_image3m<true, true>(L, fr, fmr, offs, l, 1);
+        else if (regime == 2) bank_image3m<true, false>(L, fr, fmr, offs, l, 1);
         else bank_image3m<false>(L, fr, fmr, offs, l, 1);
         wave_lds_fence();
         if (regime == 3) out_pass(std::integral_constant<int, 3>{}, N, res1, 1);
+        else if (regime == 2) out_pass(std::integral_constant<int, 2>{}, N, res1, 1);
         else out_pass(std::integral_constant<int, 1>{}, N, res1, 1);
         store_pass2(N, res, res1);
       } else {
@@ -850,6 +875,10 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
       const unsigned long long bad = __ballot(Q.R[0].bad || Q.R[1].bad || Q.epm > __float_as_int(kEpMaxMom));
       // some lane with fc < 1: 1 + ep != 1 in float32, i.e. ep > 2^-24 (ep >= 0)
       const unsigned long long gen = __ballot(Q.epm > 0x33800000);          // 2^-24
+      // order 5 while no lane is steeper than 1 - fc = 0.0105; order 6 while some lane is above 0.95 of that
+      bool tier = true;
+      if constexpr (MODE == 2) tier = __ballot(Q.epm > __float_as_int(kEpMom5)) == 0ull;
+      if constexpr (MODE == 3) tier = __ballot(Q.epm > __float_as_int(kEpMom5Lo)) != 0ull;
       const int ws = __builtin_amdgcn_readfirstlane(Q.R[0].c) & ~7;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
@@ -864,7 +893,7 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
       const int d = kPass * conv_next - wsK;      // image converted up to d samples beyond the first bank centre
       // (bitwise: one chain of scalar operations, no branch per term; >= 120 finished outputs imply a full first row)
       ok = (((Q.fl0 | Q.fl1) & 1) == 0) & (bad == 0ull) & (j0 + kPass <= nJ) & (N.nok[0] + N.nok[1] >= 120) &
-           (MODE == 1 ? gen == 0ull : gen != 0ull) & ((unsigned)(d - 161) <= 312u) & (conv_next + 1 < dma_bad) &
+           (MODE == 1 ? gen == 0ull : gen != 0ull) & tier & ((unsigned)(d - 161) <= 312u) & (conv_next + 1 < dma_bad) &
            ((unsigned)((j0 >> kRecShift) - rbA) <= 1u);
       };
       if constexpr (!kTwo) place_next();          // (stereo: behind OUT(P, 1), fewer registers live through the banks)
@@ -882,12 +911,12 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
         // (pinned here: left alone the compiler sinks a row's arithmetic into the store's lane mask at the END of the iteration,
         // and the gathered rows and ring samples of both channels stay live through the banks: 33 registers in scratch)
         asm volatile("" : "+v"(res[0]), "+v"(res[1]));
-        bank_image3m<MODE == 3>(L, fr, fmr, P.ws - wbase - 31, l, 1);
+        bank_image3m<MODE != 1, MODE == 3>(L, fr, fmr, P.ws - wbase - 31, l, 1);
         out_pass(mode_tag, P, res1, 1);
         asm volatile("" : "+v"(res1[0]), "+v"(res1[1]));
         place_next();
         const int offs = wsK - 31;
-        bank_image3m<MODE == 3>(L, fr, fmr, offs, l, 0);
+        bank_image3m<MODE != 1, MODE == 3>(L, fr, fmr, offs, l, 0);
         const bool c0 = s3_convert_ch(L, conv_next, l, 0, true);
         const bool c1 = s3_convert_ch(L, conv_next - 1, l, 1, false);
         cok = c0 && c1;
@@ -899,7 +928,7 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
 #if PAR_S3_PIN_MONO
         asm volatile("" : "+v"(res[0]), "+v"(res[1]));
 #endif
-        bank_image3m<MODE == 3>(L, fr, fmr, offs, l);
+        bank_image3m<MODE != 1, MODE == 3>(L, fr, fmr, offs, l);
         // CONV: one chunk per iteration
         cok = convert_chunk(conv_next);
         // FETCH + stores: records of pass pk + 2, chunk conv_next + 2, then P's outputs (five memory operations, in this order)
@@ -943,6 +972,7 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
 
   while (start_run()) {
     if (kMom && regime == 3) hot(std::integral_constant<int, kMom ? 3 : 1>{});
+    else if (kMom && regime == 2) hot(std::integral_constant<int, kMom ? 2 : 1>{});
     else hot(std::integral_constant<int, 1>{});
     // P has been finished by the loop; the pass at j0 needs the cold path
   }

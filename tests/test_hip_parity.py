@@ -62,7 +62,10 @@ def block_relerr(a, b, block=4096, floor_db=-80.0):
     return float(np.max(be[keep] / bw[keep])) if keep.any() else 0.0
 
 
-FUSED_TOL = 2e-6
+# (r06: 2e-6 -> 4e-6.  The streaming kernel's (e1 d1) filters no longer take the signal's lo image -- two matrix-core
+# instructions per pass -- which moves its error on noise from 7e-7 to 1.5e-6 of the peak, 2.5e-6 on the worst tones; against the
+# ORACLE every streaming test holds the contract's 1e-5, this bound only says how far two HIP paths may sit apart)
+FUSED_TOL = 4e-6
 
 
 def same_resample(fused, via_pos):

@@ -105,7 +105,9 @@ def main():
             tab.setdefault(st, {}).setdefault(cls, 0)
             tab[st][cls] += 1
             tab[st]["port"] = tab[st].get("port", 0.0) + port_cycles(l)
-        print(f"\nloop {hi} ({'fc = 1' if hi == 0 else 'fc < 1 (moment correction)'}): listing lines {h}..{back}  [static; the placement's "
+        n_mfma = sum(v.get("mfma", 0) for v in tab.values())
+        what = "fc = 1" if n_mfma <= 16 else ("fc < 1, moment correction to order 5 (1 - fc <= 0.0105)" if n_mfma <= 29 else "fc < 1, moment correction to order 6")
+        print(f"\nloop {hi} ({what}): listing lines {h}..{back}  [static; the placement's "
               "two variants (with / without second pieces) are both counted, one runs]")
         cols = ["valu", "trans", "mfma", "lds", "vmem", "salu"]
         print(f"{'stage':12s}" + "".join(f"{c:>7s}" for c in cols) + "  port cycles")
