@@ -63,7 +63,10 @@ constexpr int kPass = 128;                       // centres per pass = outputs t
 // lo part of the scaled sample leaves float16; such tiles are the block kernel's).
 constexpr float kImgScale = 1024.0f, kImgScaleInv = 0.0009765625f;
 constexpr float kImgMax = 32.0f;                 // |x| the images can hold
-constexpr float kQuiet = 0.0001220703125f / kImgScale;       // a chunk whose loudest sample is below 2^-13 / scale (and not 0) leaves float16's range
+// A chunk whose loudest sample is below 2^-13 (and not 0) is the block kernel's, as before the scale: a sample with a zero hi part
+// (below 6e-8) loses its (e1 d1) and m2.. contributions, ~2e-3 of what it adds to an output -- 1.2e-10, which must stay below
+// 1e-6 of the passage's own level (a file at 1e-6 came out 1.9e-4 wrong with the threshold scaled down, test_unity_path_matrix_core_bank)
+constexpr float kQuiet = 0.0001220703125f;
 
 
 #if PAR_S2_EXP & 64
