@@ -43,7 +43,9 @@ def relerr(a, b):
     a = np.asarray(a)
     b = np.asarray(b)
     assert a.shape == b.shape, (a.shape, b.shape)
-    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+    # (float64 scalars: under numpy 2 a float32 numerator turns the python float 1e-300 into float32 0 -- an all-zero float32
+    # reference, e.g. a window beyond the signal's end, then read 0 / 0 = nan instead of 0)
+    return float(np.float64(np.max(np.abs(a - b))) / max(float(np.max(np.abs(b))), 1e-300))
 
 
 def block_relerr(a, b, block=4096, floor_db=-80.0):
@@ -78,6 +80,35 @@ def same_resample(fused, via_pos):
         return False
     return bool(((a - b).abs().max() <= FUSED_TOL * b.abs().max()).item()) and bool((a.isnan() == b.isnan()).all().item())
 
+
+
+def oracle_spot(out_t, pos, sig_t, NT, windows=5, width=1200, sig_stride=1, tol=TOL):
+    """A few windows of a device output against the C oracle's sinc at the given float64 positions (numpy, or a device tensor
+    that another assertion holds bit-equal to the oracle's) -- VERDICT r05 1b: tests that compared two HIP paths with each other
+    (same_resample) now also say what the numbers ARE.  Windows: spread, first and last."""
+    from oracle import oracle_c as C
+    pos = pos.cpu().numpy() if hasattr(pos, "cpu") else np.asarray(pos)
+    n_out = len(pos)
+    sig = (sig_t.cpu().numpy() if hasattr(sig_t, "cpu") else np.asarray(sig_t)).reshape(-1)[::sig_stride]
+    out = out_t.reshape(-1) if hasattr(out_t, "reshape") else out_t
+    width = min(width, n_out - 1)
+    worst = 0.0
+    for i in sorted({int(v) for v in np.linspace(0, n_out - width - 1, windows)}):
+        p = pos[i:i + width + 1]
+        finite = np.isfinite(p)
+        lo = int(max(0, np.floor(np.min(p[finite])) - 200)) if finite.any() else 0
+        hi = int(min(len(sig), np.ceil(np.max(p[finite])) + 200)) if finite.any() else len(sig)
+        if lo == 0 or hi - lo > 4_000_000 or lo > len(sig) - 4096:      # (window-local coordinates only where they are safe and pay:
+            # the leading edge and windows at or beyond the signal's end -- an empty or clipped slice -- keep absolute ones)
+            ref = C.sinc(p, sig, NT)[:width]
+        else:
+            ref = C.sinc(p - lo, sig[lo:hi], NT)[:width]
+        got = out[i:i + width]
+        got = got.cpu().numpy() if hasattr(got, "cpu") else np.asarray(got)
+        e = relerr(got, ref)
+        worst = max(worst, e)
+        assert e < tol, (i, e)
+    return worst
 
 
 @pytest.fixture(scope="module")
@@ -961,7 +992,9 @@ def test_dropout_detector_matches_golden(par, golden):
 def test_fused_varispeed_equals_position_array_path(par):
     """Fused K_sinc (positions regenerated per tile in LDS from cumsum checkpoints) must give exactly the
     output of speed_to_pos + sinc on the materialised float64 positions, for smooth, jittery, coarse and
-    short-segment curves, with and without the end trim, and on the serial-host plan path."""
+    short-segment curves, with and without the end trim, and on the serial-host plan path; windows of every fused output
+    against the C oracle (positions by the oracle's own speed_to_pos)."""
+    from oracle import oracle_c as C
     t = par.torch
     rng = np.random.default_rng(3)
     cases = []
@@ -986,13 +1019,17 @@ def test_fused_varispeed_equals_position_array_path(par):
             out = par.resampling.varispeed_fused_dev(plan, sig_t, 32)
             t.cuda.synchronize()
             assert same_resample(out, out_ref), (name, force_host, float((out - out_ref).abs().max()))
+            oracle_spot(out, C.speed_to_pos(st, sp, n_in)[0], sig_t, 32)
     # other qualities through the same fused path
     sig_t = t.from_numpy(inputs.noise(n, 6)).cuda()
     st_t, sp_t = t.from_numpy(sc[:, 0] * sr).cuda(), t.from_numpy(np.ascontiguousarray(sc[:, 1])).cuda()
     pos_ref = par.resampling.speed_to_pos_dev(st_t, sp_t, n)
+    pos_np, _ = C.speed_to_pos(sc[:, 0] * sr, np.ascontiguousarray(sc[:, 1]), n)
     for NT in (5, 50):
         plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
-        assert same_resample(par.resampling.varispeed_fused_dev(plan, sig_t, NT), par.resampling.sinc_resample_dev(pos_ref, sig_t, NT))
+        out = par.resampling.varispeed_fused_dev(plan, sig_t, NT)
+        assert same_resample(out, par.resampling.sinc_resample_dev(pos_ref, sig_t, NT))
+        oracle_spot(out, pos_np, sig_t, NT)
 
 
 def test_config1_and_config3_on_reference_samples(par, golden):
@@ -1097,6 +1134,7 @@ def test_block_records_cover_benchmark_and_flutter_curves(par):
         pos_t = par.resampling.speed_to_pos_dev(st_t, sp_t, n_in)
         via_pos = par.resampling.sinc_resample_dev(pos_t, sig_t, NT)
         assert same_resample(fused, via_pos), (name, float((fused - via_pos).abs().max() / via_pos.abs().max()))
+        oracle_spot(fused, pos_t, sig_t, NT)           # (pos_t: bit-equal to the oracle's, test_speed_to_pos_* / the full-size tests)
 
 
 def test_unity_path_matrix_core_bank(par):
@@ -1544,7 +1582,9 @@ def test_degenerate_segment_behind_the_trim_is_harmless(par):
             plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
             assert plan.path == want_path and plan.fused_ok and plan.len_out == len(ref)
             sig_t = t.from_numpy(inputs.noise(n, 3)).cuda()
-            assert same_resample(par.resampling.varispeed_fused_dev(plan, sig_t, 16), par.resampling.sinc_resample_dev(pos, sig_t, 16))
+            out16 = par.resampling.varispeed_fused_dev(plan, sig_t, 16)
+            assert same_resample(out16, par.resampling.sinc_resample_dev(pos, sig_t, 16))
+            oracle_spot(out16, ref, sig_t, 16)
         else:
             with pytest.raises(ValueError):
                 C.speed_to_pos(st, sp, n)
@@ -1709,7 +1749,9 @@ def test_sparse_speed_curves_take_the_chunked_exact_cumsum(par):
                                                          plan.len_out, _dev.stream_ptr(0)))
             assert t.equal(old, pos_t)
         for NT in (3, 32):
-            assert same_resample(R.varispeed_fused_dev(plan, sig_t, NT), R.sinc_resample_dev(pos_t, sig_t, NT)), (n, speeds[:3], NT)
+            out = R.varispeed_fused_dev(plan, sig_t, NT)
+            assert same_resample(out, R.sinc_resample_dev(pos_t, sig_t, NT)), (n, speeds[:3], NT)
+            oracle_spot(out, ref_pos, sig_t, NT, windows=4)
 
 
 def test_sparse_curves_random_window_layouts(par):
@@ -1755,8 +1797,10 @@ def test_full_size_two_point_curve(par):
     sig_t = t.empty(n, dtype=t.float32, device="cuda").normal_()
     plan = par.resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
     assert plan.fused_ok and plan.len_out == pos_t.numel()
-    assert same_resample(par.resampling.varispeed_fused_dev(plan, sig_t, 32), par.resampling.sinc_resample_dev(pos_t, sig_t, 32))
-    del pos_t, plan
+    out = par.resampling.varispeed_fused_dev(plan, sig_t, 32)
+    assert same_resample(out, par.resampling.sinc_resample_dev(pos_t, sig_t, 32))
+    oracle_spot(out, pos_t, sig_t, 32, windows=8)      # (pos_t equals the oracle's bit for bit: asserted above)
+    del pos_t, plan, out
     # segments of 2.7e8 (258 windows of 4096 chunks: two steps of the window-level scan), 5e7, 2e7 and 5.6e6 samples in
     # one curve, positions against the C oracle
     st = np.array([0.0, 2.7e8, 3.2e8, 3.4e8, float(n)])
