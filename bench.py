@@ -266,6 +266,33 @@ def heal_secondary(dev, tiles=256):
     return res
 
 
+def nt50_secondary(dev, sig, st, spd, n_in, work, aux, cap, n_out):
+    """Secondary line: the timed file at the reference's DEFAULT quality (sinc_quality = 50, util/resampling.py:162): 100 taps.  The
+    block kernel: fc = 1 taps as a Farrow bank on the matrix cores (four K slices, r06), fc < 1 taps on the vector units (no
+    moment form for this tap count).  K_sinc alone, 6 launches back to back behind 2 warm ones, from the timed file's plan."""
+    import torch
+    from pyaudiorestoration_amd import _dev, _lib
+    L = _lib.lib()
+    s = _dev.stream_ptr(dev)
+    m = st.numel()
+    out = torch.empty(cap, dtype=torch.float32, device=f"cuda:{dev}")
+    def launch():
+        _lib.check(L.par_varispeed_fused_f32(dev, _dev.ptr(spd), m, _dev.ptr(work), _dev.ptr(aux), cap, n_out, _dev.ptr(sig), 1, n_in, 50,
+                                             _dev.ptr(out), 1, s))
+    for _ in range(2):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream(dev))
+    for _ in range(6):
+        launch()
+    e1.record(torch.cuda.current_stream(dev))
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / 6
+    return {"workload": "the timed file at NT = 50 (the reference's default sinc_quality): 100-tap Hann sinc", "ms": round(ms, 3),
+            "Msamples/s": round(n_out / ms / 1e3, 1), "frac_of_hbm_peak": round(ALGO_BYTES_PER_SAMPLE * n_out / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernel": "k_sinc_fused<1, 50, 4> (block kernel): fc = 1 far taps as a Farrow bank on v_mfma_f32_16x16x32_f16, fc < 1 taps on the vector units"}
+
+
 def stereo_secondary(dev, sr=192000, seconds=600.0, nt=32):
     """Secondary line: one work item of BASELINE config 5 -- a 10-min 192 kHz STEREO file, interleaved (n, 2) like the
     reference holds it: one plan per file and ONE stereo K_sinc launch (positions, prologue and tap weights shared by the
@@ -873,6 +900,10 @@ def main():
             res["secondary_config4"] = heal_secondary(dev)
             if hasattr(L, "par_varispeed_fused_stereo_f32"):        # absent only in an older build under PAR_HIP_LIB
                 res["secondary_config5"] = stereo_secondary(dev)
+            if fused and a.nt == 32:
+                # (a fresh plan of the timed curve on the main stream: the pipelined steps' plan slots have moved on)
+                n50 = plan_fused(0, sp_)
+                res["secondary_nt50"] = nt50_secondary(dev, sig, st, spd, n_in, work[0], aux[0], cap, n50)
                 # the 1-GPU point of the --gpus N > 1 curve under a stable key: N > 1 lines time the config-5 archive (stereo
                 # files through the batch driver), not this line's mono file -- a scaling reader divides value(N) by THIS
                 res["archive_value"] = res["secondary_config5"]["batched_Msamples/s"]

@@ -708,12 +708,32 @@ typedef _Float16 half8v __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
-constexpr int kFarImage = 224;                         // halves per float16 image: 128 centres + 63 taps, padded to 3 K slices
+// Geometry of the bank by NT (r06: NT = 50, the reference's default quality, mono): K slices of 32 taps, where the fragments of
+// (e1 d1), the lo parts of (e0 d0) and (e2 d2) start in the table and which slices they cover (tools/gen_sinc_taps.py).
+template <int NT>
+struct FarGeom;
+template <>
+struct FarGeom<32> {
+  static constexpr int kFrags = kFarrowFrags, kSlices = 3, kImage = 224;       // image: 128 centres + 63 taps, padded to the slices
+  static constexpr int kE1Frag = 3, kE1First = 0, kE1Count = 2, kLoFrag = 5, kE2Frag = 8, kE2First = 0, kE2Count = 2;
+  static constexpr float kScaleInv = kFarrowScaleInv;
+  __device__ static const unsigned int* table() { return kFarrowFrags32; }
+};
+template <>
+struct FarGeom<50> {
+  static constexpr int kFrags = kFarrowFrags50, kSlices = 4, kImage = 256;     // 128 centres + 99 taps
+  static constexpr int kE1Frag = 4, kE1First = 0, kE1Count = 3, kLoFrag = 7, kE2Frag = 11, kE2First = 1, kE2Count = 2;
+  static constexpr float kScaleInv = kFarrowScaleInv50;
+  __device__ static const unsigned int* table() { return kFarrowFrags50_32; }
+};
+__host__ __device__ constexpr int far_const_bytes(int NTC) { return (NTC == 50 ? kFarrowFrags50 : kFarrowFrags) * 1024; }
 constexpr int kFarSpanMax = 384;                       // floats of a wave's LDS piece the span may use on this path (the rest: image / bank)
 constexpr int kFarSpanMax2 = 448;                      // ... of the stereo kernel's piece (1280 floats): 128 outputs x 2 interleaved channels + halo
-constexpr int kFarConstBytes = kFarrowFrags * 1024;
+constexpr int kFarConstBytes = far_const_bytes(32);
 static_assert(kFarSpanMax * 4 + 4 * 128 * 4 + 2 * 128 * 2 <= 1024 * 4, "span + bank fit the wave's LDS piece");
-static_assert(2 * kFarImage * 2 <= 4 * 128 * 4, "the bank overwrites the image");
+static_assert(2 * FarGeom<32>::kImage * 2 <= 4 * 128 * 4 && 2 * FarGeom<50>::kImage * 2 <= 4 * 128 * 4, "the bank overwrites the image");
+static_assert(8 * 15 + 32 * FarGeom<50>::kSlices <= FarGeom<50>::kImage + 8 && 8 * 15 + 32 * FarGeom<32>::kSlices <= FarGeom<32>::kImage + 8,
+              "the last lane's last fragment ends inside the image (+ its 8 trailing halves of slack)");
 static_assert(kFarSpanMax2 * 4 + 4 * 128 * 4 + 2 * 128 * 2 <= 1280 * 4, "span + bank fit the stereo wave's LDS piece");
 
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
@@ -723,11 +743,13 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 // LS = 1: mono, slots (0, 1) and (2, 3) are the two row pairs (256 consecutive outputs).  LS = 2: an interleaved stereo span
 // (sample i of channel ch at word 2 i + ch), slots (0, 2) are the row pair of channel 0, (1, 3) of channel 1; c[] are WORD
 // indices, the image of a pair takes every LS-th word from its first centre's.
-template <int kOut, int LS>
+template <int NT, int kOut, int LS>
 __device__ __forceinline__ void unity_far_mfma(const float* __restrict__ tile, const int nlim, float* __restrict__ scratch,
                                                const unsigned consts_addr, const int l, const int (&c)[kOut],
                                                const float (&s)[kOut], const float (&q)[kOut], float (&far)[kOut]) {
   static_assert(kOut == 4 && (LS == 1 || LS == 2), "two row pairs per wave");
+  using G = FarGeom<NT>;
+  constexpr int kFarImage = G::kImage;
   _Float16* rb = reinterpret_cast<_Float16*>(scratch);             // [2][kFarImage]: hi, lo x 4096
   float* bank = scratch;                                            // [4][128] float32: e0 d0 e1 d1
   _Float16* bankh = reinterpret_cast<_Float16*>(scratch + 4 * 128); // [2][128] float16: e2 d2 (1e-4 of the sum: 11 bits are plenty)
@@ -738,9 +760,9 @@ __device__ __forceinline__ void unity_far_mfma(const float* __restrict__ tile, c
   for (int rp = 0; rp < 2; ++rp) {
     const int r0 = LS == 1 ? 2 * rp : rp, rstep = LS == 1 ? 1 : 2;   // the pair's slots: r0, r0 + rstep
     const int p0 = __builtin_amdgcn_readlane(c[r0], 0);             // first centre of the pair (LDS index); centres p0 .. p0 + 127 (samples)
-    // float16 image of the samples p0 - 31 .. p0 + 192 (zero behind the staged span: only zero coefficients meet those)
+    // float16 image of the samples p0 - (NT - 1) .. (zero behind the staged span: only zero coefficients meet those)
     for (int i2 = l; i2 < ((PAR_MFMA_EXP & 4) ? 0 : kFarImage / 2); i2 += kWave) {
-      const int ti = p0 + (2 * i2 - 31) * LS;
+      const int ti = p0 + (2 * i2 - (NT - 1)) * LS;
       const float x0 = ti < nlim ? tile[ti] : 0.0f, x1 = ti + LS < nlim ? tile[ti + LS] : 0.0f;
       const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
       const half2v hv = {h0, h1};
@@ -754,9 +776,10 @@ __device__ __forceinline__ void unity_far_mfma(const float* __restrict__ tile, c
     // fragment element k = 32 ks + 8 g + j  ->  x16[8 bb + k]
     const unsigned off = rb_addr + (unsigned)(8 * bb + 8 * g) * 2u;
     float4v a_e0 = {0.0f, 0.0f, 0.0f, 0.0f}, a_lo = a_e0, a_e1 = a_e0, a_x1 = a_e0, a_e2 = a_e0;
-    // constants: fragments 0-2 (e0 d0)h slices 0-2; 3-4 (e1 d1)h slices 0-1; 5-7 (e0 d0)lo slices 0-2; 8-9 (e2 d2)h slices 0-1
+    // constants (NT = 32): fragments 0-2 (e0 d0)h slices 0-2; 3-4 (e1 d1)h slices 0-1; 5-7 (e0 d0)lo slices 0-2; 8-9 (e2 d2)h slices 0-1
+    // (NT = 50: FarGeom<50>)
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
+    for (int ks = 0; ks < G::kSlices; ++ks) {
       // four fragments in flight at a time (16 VGPRs): the kernel lives in 80 registers
       half8v xh, xl, ca_, cb_;
       if (PAR_MFMA_EXP & 2) {
@@ -765,7 +788,7 @@ __device__ __forceinline__ void unity_far_mfma(const float* __restrict__ tile, c
       asm volatile("ds_read_b128 %0, %1" : "=v"(xh) : "v"(off + (unsigned)(64 * ks)));
       asm volatile("ds_read_b128 %0, %1" : "=v"(xl) : "v"(off + (unsigned)(64 * ks + 2 * kFarImage)));
       asm volatile("ds_read_b128 %0, %1" : "=v"(ca_) : "v"(ca + (unsigned)(ks * 1024)));
-      asm volatile("ds_read_b128 %0, %1" : "=v"(cb_) : "v"(ca + (unsigned)((5 + ks) * 1024)));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(cb_) : "v"(ca + (unsigned)((G::kLoFrag + ks) * 1024)));
       // the fragments are the asm's outputs: the wait has to name them or the MFMAs may be scheduled above it
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xh), "+v"(xl), "+v"(ca_), "+v"(cb_)::"memory");
       }
@@ -777,16 +800,20 @@ __device__ __forceinline__ void unity_far_mfma(const float* __restrict__ tile, c
         a_e0[0] += (float)xh[0] + (float)cb_[1];
         a_lo[0] += (float)xl[0] + (float)ca_[1];
       }
-      if (ks < 2) {
+      const bool has_e1 = ks >= G::kE1First && ks < G::kE1First + G::kE1Count;       // (compile-time: the loop is unrolled)
+      const bool has_e2 = ks >= G::kE2First && ks < G::kE2First + G::kE2Count;
+      if (has_e1 || has_e2) {
         if (!(PAR_MFMA_EXP & 2)) {
-        asm volatile("ds_read_b128 %0, %1" : "=v"(ca_) : "v"(ca + (unsigned)((3 + ks) * 1024)));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(cb_) : "v"(ca + (unsigned)((8 + ks) * 1024)));
+        if (has_e1) asm volatile("ds_read_b128 %0, %1" : "=v"(ca_) : "v"(ca + (unsigned)((G::kE1Frag + ks - G::kE1First) * 1024)));
+        if (has_e2) asm volatile("ds_read_b128 %0, %1" : "=v"(cb_) : "v"(ca + (unsigned)((G::kE2Frag + ks - G::kE2First) * 1024)));
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca_), "+v"(cb_)::"memory");
         }
         if (!(PAR_MFMA_EXP & 1)) {
-        a_e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca_, xh, a_e1, 0, 0, 0);
-        a_x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca_, xl, a_x1, 0, 0, 0);
-        a_e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(cb_, xh, a_e2, 0, 0, 0);
+        if (has_e1) {
+          a_e1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca_, xh, a_e1, 0, 0, 0);
+          a_x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca_, xl, a_x1, 0, 0, 0);
+        }
+        if (has_e2) a_e2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(cb_, xh, a_e2, 0, 0, 0);
         } else {
           a_e1[0] += (float)ca_[0];
           a_x1[0] += (float)cb_[0];
@@ -870,7 +897,7 @@ __device__ __forceinline__ void taps_unity_near(const float* __restrict__ tile, 
       }
     });
     const float centre = tile[c[r]] * fast_rcp(s[r] * b0);
-    res[r] = -sinpi_half(s[r]) * (centre + fmaf(far[r], kFarrowScaleInv, fmaf(s[r], e0, d0)));
+    res[r] = -sinpi_half(s[r]) * (centre + fmaf(far[r], FarGeom<NT == 50 ? 50 : 32>::kScaleInv, fmaf(s[r], e0, d0)));
   }
 }
 
@@ -1239,7 +1266,7 @@ __global__ __launch_bounds__(kSincBlock, 6) void k_sinc_pos(const double* __rest
 #define PAR_SINC_MFMA_STEREO 0
 #endif
 __host__ __device__ constexpr bool fused_is_farrow(int NCH, int NTC, int NS) {
-  return (NCH == 1 || (NCH == 2 && PAR_SINC_MFMA_STEREO)) && NTC == 32 && NS == 4 && PAR_SINC_MFMA;
+  return ((NCH == 1 && (NTC == 32 || NTC == 50)) || (NCH == 2 && NTC == 32 && PAR_SINC_MFMA_STEREO)) && NS == 4 && PAR_SINC_MFMA;
 }
 __host__ __device__ constexpr int fused_waves(int NCH, int NTC, int NS) {
   return fused_is_farrow(NCH, NTC, NS) ? (NCH == 1 ? PAR_FARROW_WAVES : kSincTile / (kWave * NS / NCH)) : kSincBlock / kWave;
@@ -1296,11 +1323,12 @@ __device__ __forceinline__ void fused_wave(const int64_t len_out, const float* _
     if (farrow_wg && !(PAR_MFMA_EXP & 32)) {
       constexpr int kWaves = fused_waves(NCH, NTC, NS);
       const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-      const char* src = reinterpret_cast<const char*>(kFarrowFrags32) + l * 16;
+      using FG = FarGeom<NTC == 50 ? 50 : 32>;
+      const char* src = reinterpret_cast<const char*>(FG::table()) + l * 16;
 #pragma unroll
-      for (int k = 0; k < (kFarrowFrags + kWaves - 1) / kWaves; ++k) {
+      for (int k = 0; k < (FG::kFrags + kWaves - 1) / kWaves; ++k) {
         const int f = wv + k * kWaves;
-        if (f < kFarrowFrags)
+        if (f < FG::kFrags)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024),
                                            (__attribute__((address_space(3))) void*)(lds_front + f * 256), 16, 0, 0);
       }
@@ -1533,8 +1561,8 @@ __device__ __forceinline__ void fused_wave(const int64_t len_out, const float* _
       float qs[NS], far[NS];
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) qs[sl] = ss[sl] * ss[sl];
-      unity_far_mfma<NS, LS>(tile, nlim, tile + kSpanMax, far_consts, l, cs, ss, qs, far);
-      taps_unity_near<32, NS, LS, true>(tile, cs, ss, qs, far, res);
+      unity_far_mfma<NTC == 50 ? 50 : 32, NS, LS>(tile, nlim, tile + kSpanMax, far_consts, l, cs, ss, qs, far);
+      taps_unity_near<NTC == 50 ? 50 : 32, NS, LS, true>(tile, cs, ss, qs, far, res);
       taps_done = true;
     }
   }
@@ -1652,7 +1680,7 @@ __global__ __launch_bounds__(fused_waves(NCH, NTC, NS) * kWave, PAR_SINC_WAVES) 
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   // the mono NT = 32 kernel keeps the constant fragments of the unity path's Farrow bank at the front of its LDS
   constexpr bool kFarrow = fused_is_farrow(NCH, NTC, NS);
-  constexpr int kConstFloats = kFarrow ? kFarConstBytes / 4 : 0;
+  constexpr int kConstFloats = kFarrow ? far_const_bytes(NTC) / 4 : 0;
   // ... in workgroups whose tile may hold fc = 1 outputs (fused_wave fetches them behind its record loads)
   float* tile = lds_all + kConstFloats + wv * (capw * NCH);        // this wave's span: channel 0, then channel 1 `capw` floats on
   const int64_t jw = ((int64_t)blockIdx.x * kWaves + wv) * kWaveOut;   // the wave's outputs: jw + l + 64 r, r < kOut

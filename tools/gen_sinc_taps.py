@@ -100,10 +100,21 @@ FARROW_FRAGS = ((0, 3, 0, 0), (0, 3, 1, 0), (0, 3, 2, 0), (1, 4, 0, 0), (1, 4, 1
                 (0, 3, 0, 1), (0, 3, 1, 1), (0, 3, 2, 1), (2, 5, 0, 0), (2, 5, 1, 0))
 
 
+# r06: the same bank for NT = 50 (the reference's default quality; block kernel only).  99 taps + 8 positions need FOUR 32-tap
+# slices; (e1 d1) -- nonzero for |n| < 37 -- occupies slices 0-2, (e2 d2) -- |n| < 9 -- slices 1-2: 13 fragments,
+# 0-3 (e0 d0)h, 4-6 (e1 d1)h slices 0-2, 7-10 (e0 d0)lo, 11-12 (e2 d2)h slices 1-2.  Scale 1024, not 32: the matrix cores flush
+# float16 subnormals (found in r04), and at 32 the e0 coefficients of taps 47-49 (1e-7 .. 1.3e-6) would be lost.
+FARROW50_SCALE = 1024.0
+FARROW50_FRAGS = ((0, 3, 0, 0), (0, 3, 1, 0), (0, 3, 2, 0), (0, 3, 3, 0), (1, 4, 0, 0), (1, 4, 1, 0), (1, 4, 2, 0),
+                  (0, 3, 0, 1), (0, 3, 1, 1), (0, 3, 2, 1), (0, 3, 3, 1), (2, 5, 1, 0), (2, 5, 2, 0))
+
+
 def farrow_fragments(NT):
-    """uint16 [10][64][8]: the float16 bit patterns of the constant A fragments (NT = 32 only: 63 taps + 8 positions fit
-    three 32-tap slices)."""
-    assert NT == 32
+    """uint16 [frags][64][8]: the float16 bit patterns of the constant A fragments (NT = 32: 63 taps + 8 positions fit three
+    32-tap slices, 10 fragments; NT = 50: four slices, 13 fragments)."""
+    assert NT in (32, 50)
+    if NT == 50:
+        return farrow_fragments_general(50, FARROW50_FRAGS, FARROW50_SCALE)
     _, _, rows = tables(NT)
 
     def coef(f, n):
@@ -137,6 +148,55 @@ def farrow_fragments(NT):
     return out.view(np.uint16)
 
 
+def farrow_fragments_general(NT, frags, scale):
+    _, _, rows = tables(NT)
+    n_slices = (2 * NT - 1 + 8 + 31) // 32
+
+    def coef(f, n):
+        a = abs(n)
+        if a < 5 or a >= NT:
+            return 0.0
+        mode, A, B, C = rows[a]
+        A, B, C = float(np.float32(A)), float(np.float32(B)), float(np.float32(C))
+        sg = -1.0 if n < 0 else 1.0
+        fa = float(np.float32(np.float32(a) * np.float32(A)))
+        fb = float(np.float32(np.float32(a) * np.float32(B)))
+        fc = float(np.float32(np.float32(a) * np.float32(C)))
+        v = (A, B if mode <= 2 else 0.0, C if mode == 1 else 0.0, sg * fa, sg * fb if mode <= 2 else 0.0,
+             sg * fc if mode == 1 else 0.0)[f]
+        return scale * v
+    # every nonzero coefficient of a filter pair must sit in a slice the pair has a fragment for, and be a NORMAL float16
+    have, flushed = {}, {}
+    for fe, fd, ks, lo in frags:
+        have.setdefault((fe, fd), set()).add(ks)
+    for (fe, fd), sl in have.items():
+        for f in (fe, fd):
+            for i in range(8):
+                for k in range(32 * n_slices):
+                    c = coef(f, k - (NT - 1) - i)
+                    assert c == 0.0 or (k // 32) in sl, (NT, f, i, k)
+                    if f in (0, 3):                      # the constant terms: every coefficient a normal float16
+                        assert c == 0.0 or abs(c) >= 2.0 ** -14, (NT, f, k, c)
+                    elif c != 0.0 and abs(c) < 2.0 ** -14 and i == 0:
+                        flushed[f] = flushed.get(f, 0.0) + abs(c) / scale * (0.25 if f in (1, 4) else 0.0625)
+    # (higher-order coefficients of far taps that are float16 subnormals are zero to the matrix cores: what they would have added,
+    # at the largest q, for a unit-peak signal)
+    assert sum(flushed.values()) < 2.0e-7, flushed
+    for f in (0, 3):
+        for i in range(8):
+            assert coef(f, 32 * n_slices - (NT - 1) - i) == 0.0 and coef(f, -NT - i) == 0.0
+    out = np.zeros((len(frags), 64, 8), dtype=np.float16)
+    for fr, (fe, fd, ks, lo) in enumerate(frags):
+        for lane in range(64):
+            m, g = lane & 15, lane >> 4
+            for j in range(8):
+                cf = coef(fd if (m >> 3) else fe, 32 * ks + 8 * g + j - (NT - 1) - (m & 7))
+                hi = np.float16(cf)
+                out[fr, lane, j] = np.float16((cf - float(hi)) * FARROW_LO) if lo else hi
+    # (lo parts below float16's normal range are flushed by the matrix cores: they carry < 2^-26 of a coefficient)
+    return out.view(np.uint16)
+
+
 def render():
     out = ["// GENERATED by tools/gen_sinc_taps.py -- do not edit.  Compile-time tap tables of the NT-specialised K_sinc loops.",
            "#pragma once", "", "namespace par {", "",
@@ -160,6 +220,19 @@ def render():
     out.append("__device__ const unsigned int kFarrowFrags32[%d] = {" % len(words))
     for i in range(0, len(words), 12):
         out.append("  " + ", ".join("0x%08xu" % w for w in words[i:i + 12]) + ",")
+    out.append("};")
+    out.append("#endif")
+    out.append("")
+    fr50 = farrow_fragments(50).reshape(-1, 2)
+    words50 = (fr50[:, 0].astype(np.uint32) | (fr50[:, 1].astype(np.uint32) << 16))
+    out.append("// ... and for NT = 50 (r06): [13 fragments][64 lanes][8 halves], four 32-tap slices; 0-3 (e0 d0)h, 4-6 (e1 d1)h slices 0-2,")
+    out.append("// 7-10 (e0 d0)lo, 11-12 (e2 d2)h slices 1-2; scale %g, lo parts x %g." % (FARROW50_SCALE, FARROW_LO))
+    out.append("constexpr int kFarrowFrags50 = %d;" % len(FARROW50_FRAGS))
+    out.append("constexpr float kFarrowScaleInv50 = %sf;" % repr(1.0 / FARROW50_SCALE))
+    out.append("#ifdef __HIPCC__")
+    out.append("__device__ const unsigned int kFarrowFrags50_32[%d] = {" % len(words50))
+    for i in range(0, len(words50), 12):
+        out.append("  " + ", ".join("0x%08xu" % w for w in words50[i:i + 12]) + ",")
     out.append("};")
     out.append("#endif")
     out.append("")
