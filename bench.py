@@ -463,10 +463,10 @@ def config5_batch(a, ctx):
         ring.append(sig)
     del mono
     # Speed curves: made per PULLED file (7.2 MB, a closed form on the device, ~2 us) into a small ring -- not all 512 of them
-    # resident on every rank (3.7 GB each, r05).  The ring outlives the batch driver's prefetch (planners + 1 items, see
-    # resampling.varispeed_batch_dev's PREFETCH CONTRACT): the kernel that fills slot k % 8 is enqueued on the main stream behind
-    # the K_sinc of the file that last used it.
-    n_curves = 8
+    # resident on every rank (3.7 GB each, r05).  The ring outlives the batch driver's prefetch (at most 16 items taken ahead
+    # + a group of 8 in flight, see resampling.varispeed_batch_dev's PREFETCH CONTRACT): the kernel that fills slot k % 32 is
+    # enqueued on the main stream behind the K_sinc of the file that last used it.
+    n_curves = 32
     curves = torch.empty((n_curves, 2, m), dtype=torch.float64, device=f"cuda:{dev}")
     torch.cuda.synchronize()
     done = {"samples": 0, "files": 0}

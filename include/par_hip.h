@@ -256,6 +256,27 @@ int par_fused_redo_tiles(int device, const void* aux, int64_t max_out, int64_t m
  * the order in which the streams pushed them).  Tests aim their oracle windows at them.  Synchronises the stream. (ABI 105) */
 int par_fused_redo_list(int device, const void* aux, int64_t max_out, int64_t m, int* tiles, int cap, int* count, void* stream);
 
+/* Several planned files in ONE call (ABI 106; the reference loops over files, util/resampling.py:168, and an archive of short files
+ * pays per file for the tails and gaps of the two or three kernels a file's K_sinc is): items that ALL take the streaming kernel in
+ * one form -- NT = 32 and every item mono on unit strides, or every item an interleaved stereo file (sig1 = sig0 + 1, out1 = out0 + 1,
+ * strides 2, out0 8-byte aligned) -- are launched merged, up to eight files per launch; any other mix is done item by item.
+ * Outputs are bit-identical to par_varispeed_fused_f32 / par_varispeed_fused_stereo_f32 called per item (each file's streams are cut
+ * as in its own launch).  sig1 == out1 == NULL: one channel.  Every item needs its own plan buffers (work, aux). */
+typedef struct par_fused_item {
+  const double* speeds;
+  int64_t m;
+  const void* work;
+  const void* aux;
+  int64_t max_out, len_out;
+  const float* sig0;
+  const float* sig1;
+  int64_t sig_stride, len_in;
+  float* out0;
+  float* out1;
+  int64_t out_stride;
+} par_fused_item;
+int par_varispeed_fused_batch_f32(int device, int n_items, const par_fused_item* items, int NT, void* stream);
+
 /* Stereo form: two channels of ONE file (same positions; sig0/sig1 and out0/out1 share the strides -- e.g. the two
  * columns of an interleaved (n, 2) array: sig1 = sig0 + 1, stride 2) in one launch.  Outputs equal two
  * par_varispeed_fused_f32 calls to float32 rounding (the lane/output map differs); position regeneration, prologue and tap

@@ -19,6 +19,13 @@ c_sz = ctypes.c_size_t
 c_float = ctypes.c_float
 c_u64 = ctypes.c_uint64
 
+class FusedItem(ctypes.Structure):
+    """par_fused_item of include/par_hip.h (one planned file of par_varispeed_fused_batch_f32)"""
+    _fields_ = [("speeds", c_vp), ("m", c_i64), ("work", c_vp), ("aux", c_vp), ("max_out", c_i64), ("len_out", c_i64),
+                ("sig0", c_vp), ("sig1", c_vp), ("sig_stride", c_i64), ("len_in", c_i64), ("out0", c_vp), ("out1", c_vp),
+                ("out_stride", c_i64)]
+
+
 # name -> (restype, argtypes); mirrors include/par_hip.h one to one
 SIGNATURES = {
     "par_version": (c_int, []),
@@ -67,6 +74,7 @@ SIGNATURES = {
     "par_fused_redo_list": (c_int, [c_int, c_vp, c_i64, c_i64, ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int), c_vp]),
     "par_varispeed_fused_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_i64,
                                         c_vp]),
+    "par_varispeed_fused_batch_f32": (c_int, [c_int, c_int, ctypes.POINTER(FusedItem), c_int, c_vp]),
     "par_varispeed_fused_stereo_f32": (c_int, [c_int, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_int,
                                                c_vp, c_vp, c_i64, c_vp]),
     "par_profile_enable": (c_int, [c_int, c_int]),

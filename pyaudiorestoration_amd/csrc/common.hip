@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int par_version(void) { return 105; }     // 105 (r06): par_fused_redo_list; par_speed_to_pos_fill_fused NaN-fills from a plan without checkpoints (lazy / not fused_ok); the mono streaming launch is two kernels by stream kind (k_sinc_pipe<1, 2>, <1, 1>); 104 (r05): stereo form of the streaming kernel (interleaved NT = 32 files), end tiles inside the streaming launch; 103 (r05): lazy plans (fused_ok 2, force_host | 8), the streaming kernel is par_varispeed_fused_f32's default for mono NT = 32 (par_varispeed_fused_alone_f32 is gone), par_sosfiltfilt_batch_f64
+int par_version(void) { return 106; }     // 106 (r06): par_varispeed_fused_batch_f32 (several files per launch); 105 (r06): par_fused_redo_list; par_speed_to_pos_fill_fused NaN-fills from a plan without checkpoints (lazy / not fused_ok); the mono streaming launch is two kernels by stream kind (k_sinc_pipe<1, 2>, <1, 1>); 104 (r05): stereo form of the streaming kernel (interleaved NT = 32 files), end tiles inside the streaming launch; 103 (r05): lazy plans (fused_ok 2, force_host | 8), the streaming kernel is par_varispeed_fused_f32's default for mono NT = 32 (par_varispeed_fused_alone_f32 is gone), par_sosfiltfilt_batch_f64
 
 int par_device_count(void) {
   int n = 0;

@@ -61,6 +61,22 @@ int launch_sinc(int device, const double* pos, int64_t len_out, int64_t j_begin,
 int launch_sinc_fused(int device, const double* speeds, int64_t m, const void* work, const void* aux, int64_t max_out,
                       int64_t len_out, const float* sig, const float* sig1, int64_t sig_stride, int64_t len_in, int NT,
                       float* out, float* out1, int64_t out_stride, hipStream_t s, int form = 0);
+// several files in one call (include/par_hip.h par_fused_item: the same fields): merged launches where they all take the streaming
+// kernel in one form, file by file otherwise
+struct FusedBatchItem {
+  const double* speeds;
+  int64_t m;
+  const void* work;
+  const void* aux;
+  int64_t max_out, len_out;
+  const float* sig;
+  const float* sig1;
+  int64_t sig_stride, len_in;
+  float* out;
+  float* out1;
+  int64_t out_stride;
+};
+int launch_sinc_fused_batch(int device, int n, const FusedBatchItem* items, int NT, hipStream_t s);
 constexpr int64_t kSincTileOutputs = 1024;   // outputs per K_sinc workgroup (chunk boundaries align to it)
 
 }  // namespace par

@@ -473,20 +473,20 @@ constexpr float kEpMom5 = 0.0105f / (1.0f - 0.0105f), kEpMom5Lo = 0.95f * kEpMom
 //      it is channel 0 of the frames that start there), conversion, bank and gather take that channel only, the loop is the
 //      mono one; outputs a.out_stride elements apart.  Every stream, both regimes.
 // A mono file is launched as KIND 2 and KIND 1 back to back over the same grid; a wave of the wrong kind leaves at once.
+// (the body of the kernel: workgroup `bx` of one file's launch -- k_sinc_pipe has one file, k_sinc_pipe_n up to eight)
 template <int NCH, int KIND>
-__global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2Args a) {
+__device__ __forceinline__ void sinc_pipe_body(const S2Args& a, const int bx, S3Lds<NCH, KIND != 1>& L) {
   static_assert(NCH == 1 || NCH == 2, "mono, or an interleaved stereo file");
   static_assert(KIND == 0 || KIND == 3 || NCH == 1, "the stereo form takes every stream");
   static_assert(KIND != 3 || NCH == 2, "one channel of FRAMES");
   constexpr bool kPick = KIND == 3;               // one channel of two-channel frames: stereo ring, mono loop
   constexpr bool kTwo = NCH == 2 && !kPick;       // both channels of a pass: the stereo loop
   constexpr bool kMom = KIND != 1;
-  __shared__ S3Lds<NCH, kMom> L;
   const int l = threadIdx.x & (kWave - 1);
-  if ((int)blockIdx.x < a.n_edge) {               // an end tile's wave: tile 0, then n_full - 2, n_full - 1 and the partial one
+  if (bx < a.n_edge) {                            // an end tile's wave: tile 0, then n_full - 2, n_full - 1 and the partial one
     if constexpr (KIND == 1) return;              // (done by the launch of the other kind)
     else {
-    const int e = (int)blockIdx.x / kEdgeWavesPerTile, w = (int)blockIdx.x % kEdgeWavesPerTile;
+    const int e = bx / kEdgeWavesPerTile, w = bx % kEdgeWavesPerTile;
     const int64_t T = e == 0 ? 0 : a.n_full - 3 + e;
     const int64_t jw = T * kSincTileOutputs + (int64_t)w * kEdgeWaveOut;
     const int nrem = (int)(a.len_out - jw < (int64_t)kEdgeWaveOut ? (a.len_out - jw > 0 ? a.len_out - jw : 0) : kEdgeWaveOut);
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
     return;
     }
   }
-  const int64_t stream_id = (int64_t)blockIdx.x - a.n_edge;
+  const int64_t stream_id = (int64_t)bx - a.n_edge;
   const int my_tiles = stream_id < a.n_big ? a.tiles : a.tiles_tail;
   const int64_t Ta = stream_id < a.n_big ? stream_id * a.tiles : a.n_big * a.tiles + (stream_id - a.n_big) * a.tiles_tail;
   if (Ta >= a.n_full) return;
@@ -992,6 +992,34 @@ __global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2
 #endif
 }
 
+template <int NCH, int KIND>
+__global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe(const S2Args a) {
+  __shared__ S3Lds<NCH, KIND != 1> L;
+  sinc_pipe_body<NCH, KIND>(a, (int)blockIdx.x, L);
+}
+
+// Several files in ONE launch (r06; the archive's 10-min files): a file's K_sinc is two or three kernels, each with a tail in
+// which the GPU empties, plus the gaps between them -- ~0.13 ms per file, a sixth of a 10-min mono file's time.  Here the
+// workgroups of file k + 1 follow those of file k inside the same grid: the tails and gaps are paid once per launch.
+constexpr int kBatchFiles = kFusedBatchMax;
+struct S2Batch {
+  int n;
+  int first[kBatchFiles + 1];                    // first workgroup of file k; first[n] = the grid
+  S2Args f[kBatchFiles];
+};
+static_assert(sizeof(S2Batch) <= 3584, "kernel arguments fit the 4 KB segment");
+template <int NCH, int KIND>
+__global__ __launch_bounds__(kWave, KIND == 1 ? 3 : 2) void k_sinc_pipe_n(const S2Batch b) {
+  __shared__ S3Lds<NCH, KIND != 1> L;
+  const int bx = (int)blockIdx.x;
+  int fi = 0;
+#pragma unroll
+  for (int k = 1; k < kBatchFiles; ++k) fi += (k < b.n && bx >= b.first[k]) ? 1 : 0;
+  const S2Args* pa = &b.f[fi];                    // (kernel-argument memory: scalar loads at a wave-uniform offset)
+  const S2Args a = *pa;
+  sinc_pipe_body<NCH, KIND>(a, bx - b.first[fi], L);
+}
+
 // wave slots of the device for the two-waves-per-SIMD kernels (compute units x 4 SIMDs x 2; 2 048 on an MI355X): from the device's
 // properties, so that a partitioned or CU-masked device cuts its streams for what it has
 static int64_t stream_wave_slots(int device) {
@@ -1007,10 +1035,10 @@ static int64_t stream_wave_slots(int device) {
   return v;
 }
 
-int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
-                       const float4* tab, const TapModes& tmd, hipStream_t s, int nch, int64_t pick_out_stride) {
+// the launch's arguments and its grid for one file
+static int64_t make_stream_args(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
+                                const float4* tab, const TapModes& tmd, int64_t pick_out_stride, S2Args& a) {
   const int64_t slots = stream_wave_slots(device);
-  S2Args a;
   a.out_stride = pick_out_stride;
   a.len_out = len_out;
   a.sig = sig;
@@ -1050,7 +1078,13 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
   // (24 tiles, K_sinc alone: no short tail 4.37 ms, quarter-length 4.22, 1/8 4.20, 1/12 4.23; two rounds of them 4.23 / 4.30)
   a.tiles_tail = a.tiles >= 8 && tail_env > 1 ? std::max(2, a.tiles / tail_env) | 1 : a.tiles;
   a.n_big = (a.n_full - std::min<int64_t>(a.n_full, slots * tail_rounds * a.tiles * (a.tiles_tail < a.tiles ? 1 : 0))) / a.tiles;
-  const int64_t grid = a.n_big + ceil_div(a.n_full - a.n_big * a.tiles, (int64_t)a.tiles_tail) + a.n_edge;
+  return a.n_big + ceil_div(a.n_full - a.n_big * a.tiles, (int64_t)a.tiles_tail) + a.n_edge;
+}
+
+int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
+                       const float4* tab, const TapModes& tmd, hipStream_t s, int nch, int64_t pick_out_stride) {
+  S2Args a;
+  const int64_t grid = make_stream_args(device, len_out, sig, len_in, out, fa, tab, tmd, pick_out_stride, a);
   if (grid > 0 && nch == 2 && pick_out_stride > 0) {
     hipLaunchKernelGGL((k_sinc_pipe<2, 3>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
   } else if (grid > 0 && nch == 2) {
@@ -1060,6 +1094,29 @@ int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t le
     // streams (three per SIMD), over the same grid -- a wave of the other kind leaves behind its tile headers
     hipLaunchKernelGGL((k_sinc_pipe<1, 2>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
     hipLaunchKernelGGL((k_sinc_pipe<1, 1>), dim3((unsigned)grid), dim3(kWave), 0, s, a);
+  }
+  PAR_HIP_CHECK(hipGetLastError());
+  return PAR_OK;
+}
+
+// n <= kBatchFiles files of ONE form (nch 1: mono on unit strides; nch 2: interleaved stereo) in one launch per kernel kind
+int launch_sinc_stream_batch(int device, int n, const StreamItem* items, const float4* tab, const TapModes& tmd, hipStream_t s, int nch) {
+  if (n < 1 || n > kBatchFiles) return PAR_ERR_ARG;
+  S2Batch b;
+  b.n = n;
+  int64_t at = 0;
+  for (int k = 0; k < n; ++k) {
+    b.first[k] = (int)at;
+    at += make_stream_args(device, items[k].len_out, items[k].sig, items[k].len_in, items[k].out, items[k].fa, tab, tmd, 0, b.f[k]);
+    if (at > INT_MAX) return PAR_ERR_ARG;
+  }
+  for (int k = n; k <= kBatchFiles; ++k) b.first[k] = (int)at;
+  if (at <= 0) return PAR_OK;
+  if (nch == 2) {
+    hipLaunchKernelGGL((k_sinc_pipe_n<2, 0>), dim3((unsigned)at), dim3(kWave), 0, s, b);
+  } else {
+    hipLaunchKernelGGL((k_sinc_pipe_n<1, 2>), dim3((unsigned)at), dim3(kWave), 0, s, b);
+    hipLaunchKernelGGL((k_sinc_pipe_n<1, 1>), dim3((unsigned)at), dim3(kWave), 0, s, b);
   }
   PAR_HIP_CHECK(hipGetLastError());
   return PAR_OK;

@@ -54,4 +54,15 @@ struct TapModes;
 int launch_sinc_stream(int device, int64_t len_out, const float* sig, int64_t len_in, float* out, const FusedArgs& fa,
                        const float4* tab, const TapModes& tmd, hipStream_t s, int nch, int64_t pick_out_stride = 0);
 
+// ... and several files of one form in one launch per kernel kind (k_sinc_pipe_n; at most kFusedBatchMax)
+constexpr int kFusedBatchMax = 8;
+struct StreamItem {
+  int64_t len_out;
+  const float* sig;
+  int64_t len_in;
+  float* out;
+  FusedArgs fa;
+};
+int launch_sinc_stream_batch(int device, int n, const StreamItem* items, const float4* tab, const TapModes& tmd, hipStream_t s, int nch);
+
 }  // namespace par

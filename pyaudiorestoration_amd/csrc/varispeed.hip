@@ -167,6 +167,28 @@ int par_varispeed_fused_stereo_f32(int device, const double* speeds, int64_t m, 
                               sig_stride, len_in, NT, out0, out1, out_stride, stream);
 }
 
+// Several planned files in one call (r06): the K_sinc launches of files that all take the streaming kernel in one form (NT = 32;
+// mono on unit strides, or interleaved stereo) are merged -- their tails and launch gaps are paid once per batch of up to eight;
+// any other mix is done file by file.  Results are bit-identical to par_varispeed_fused_f32 / _stereo_f32 per file.
+int par_varispeed_fused_batch_f32(int device, int n_items, const par_fused_item* items, int NT, void* stream) {
+  using namespace par;
+  PAR_REQUIRE(n_items >= 0 && (items || n_items == 0), PAR_ERR_ARG, "par_varispeed_fused_batch_f32: null items");
+  PAR_REQUIRE(NT >= 1 && NT <= 512, PAR_ERR_ARG, "par_varispeed_fused_batch_f32: NT=%d outside [1,512]", NT);
+  if (n_items == 0) return PAR_OK;
+  std::vector<FusedBatchItem> v((size_t)n_items);
+  for (int k = 0; k < n_items; ++k) {
+    const par_fused_item& f = items[k];
+    PAR_REQUIRE(f.speeds && f.work && f.aux && f.sig0 && f.out0 && f.m >= 2, PAR_ERR_ARG, "par_varispeed_fused_batch_f32: item %d: null pointer", k);
+    PAR_REQUIRE((f.sig1 == nullptr) == (f.out1 == nullptr), PAR_ERR_ARG, "par_varispeed_fused_batch_f32: item %d: sig1 / out1 come together", k);
+    PAR_REQUIRE(f.len_out >= 2 && f.len_out <= f.max_out, PAR_ERR_ARG, "par_varispeed_fused_batch_f32: item %d: len_out=%lld outside [2, max_out=%lld]", k,
+                (long long)f.len_out, (long long)f.max_out);
+    PAR_REQUIRE(f.len_in >= 1 && f.sig_stride >= 1 && f.out_stride >= 1, PAR_ERR_ARG, "par_varispeed_fused_batch_f32: item %d: bad sizes", k);
+    v[k] = FusedBatchItem{f.speeds, f.m, f.work, f.aux, f.max_out, f.len_out, f.sig0, f.sig1, f.sig_stride, f.len_in, f.out0, f.out1, f.out_stride};
+  }
+  PAR_HIP_CHECK(hipSetDevice(device));
+  return launch_sinc_fused_batch(device, n_items, v.data(), NT, as_stream(stream));
+}
+
 // profiling hook for bench.py: HIP-event timing of the K_sinc launches issued by the last pipelined call
 int par_profile_enable(int device, int on) {
   using namespace par;

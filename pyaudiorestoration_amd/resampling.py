@@ -7,6 +7,7 @@ only own the buffers); the numpy-signature functions wrap them with H2D/D2H copi
 import ctypes
 import logging
 import os
+import threading
 from time import time
 
 import numpy as np
@@ -203,7 +204,86 @@ def _resample_item(plan, item, NT, dev):
     return varispeed_resample_dev(plan, sig_t, NT, sig_stride=stride, len_in=len_in)[0]
 
 
-def varispeed_batch_dev(items, NT, dev=None, planners=None):
+def _group_class(item):
+    """Items whose K_sinc launches par_varispeed_fused_batch_f32 can merge: 'mono' (1-D, unit stride), 'stereo' (an interleaved
+    (n, 2) file); None: launched on its own."""
+    sig_t = item[2]
+    if sig_t.ndim == 2:
+        return "stereo" if sig_t.shape[1] == 2 and sig_t.is_contiguous() else None
+    return "mono" if len(item) <= 3 or item[3] == 1 else None
+
+
+def _group_size(item):
+    """How many files of this class and size go into one launch.  Measured (r06, tools/exp/group_speed.py; G samples/s):
+    K_sinc alone on ready plans gains from merging -- 10-s mono files 22 -> 85, 60-s 80 -> 152, 10-min mono 167 -> 183, 10-min
+    stereo 205 -> 208 -- because a file's K_sinc is two or three kernels with a tail of idle wave slots each.  Through the batch
+    driver (plans included) what is left of that: 10-min mono 132 -> 141 in groups of four, 60-s mono 50 -> 58 (the host side
+    of a plan, ~0.2 ms per file, bounds short files); stereo files LOSE (archive 182 -> 178 in pairs, 170 in fours: the plans
+    of a group start together and then compete with one long launch instead of slipping into the gaps between short ones); so
+    do 60-min files.  Hence: stereo and long mono files one by one, other mono files four at a time."""
+    sig_t = item[2]
+    if sig_t.ndim == 2 or sig_t.numel() >= 400_000_000:
+        return 1
+    return 4
+
+
+def _resample_group(plans, group, NT, dev):
+    """ONE merged K_sinc launch (par_varispeed_fused_batch_f32) for the planned items of a group -> their output tensors."""
+    L = _lib.lib()
+    arr = (_lib.FusedItem * len(group))()
+    outs = []
+    for k, (plan, item) in enumerate(zip(plans, group)):
+        sig_t = item[2]
+        f = arr[k]
+        f.speeds, f.m, f.work, f.aux = _dev.ptr(plan.speeds_t).value, plan.m, _dev.ptr(plan.work).value, _dev.ptr(plan.aux).value
+        f.max_out, f.len_out = plan.max_out, plan.len_out
+        if sig_t.ndim == 2:
+            out_t = _dev.empty((plan.len_out, 2), torch.float32, dev)
+            base, obase = _dev.ptr(sig_t).value, _dev.ptr(out_t).value
+            f.sig0, f.sig1, f.sig_stride, f.len_in = base, base + 4, 2, sig_t.shape[0]
+            f.out0, f.out1, f.out_stride = obase, obase + 4, 2
+        else:
+            out_t = _dev.empty(plan.len_out, torch.float32, dev)
+            f.sig0, f.sig1, f.sig_stride, f.len_in = _dev.ptr(sig_t).value, None, 1, (item[4] if len(item) > 4 else sig_t.numel())
+            f.out0, f.out1, f.out_stride = _dev.ptr(out_t).value, None, 1
+        outs.append(out_t)
+    _lib.check(L.par_varispeed_fused_batch_f32(dev, len(group), arr, int(NT), _dev.stream_ptr(dev)))
+    return outs
+
+
+# plan / aux buffers, slot events and planner streams of varispeed_batch_dev, kept per device between calls: a call that had to
+# allocate them afresh (hipMalloc of 6-32 buffers of 0.15-0.9 GB, on new streams whose allocator pools are empty) paid for it
+# inside its first files -- 48-file runs measured 4 % below 512-file ones (r06)
+_plan_rings = {}
+_plan_rings_lock = threading.Lock()
+
+
+def _borrow_plan_ring(dev, n_slots, P):
+    """The device's cached ring, grown to n_slots slots and P planner streams; a private one when the cached ring is in use
+    (two batch drivers at once on one device).  The slot events carry over: a plan of the next call still waits for the
+    K_sinc of the previous call that read its slot."""
+    with _plan_rings_lock:
+        ring = _plan_rings.get(dev)
+        if ring is None or ring["busy"]:
+            ring = {"busy": False, "sides": [], "work": [], "aux": [], "free": []}
+            if dev not in _plan_rings:
+                _plan_rings[dev] = ring
+        ring["busy"] = True
+    while len(ring["sides"]) < P:
+        ring["sides"].append(torch.cuda.Stream(device=dev))
+    for key in ("work", "aux", "free"):
+        ring[key].extend([None] * (n_slots - len(ring[key])))
+    return ring
+
+
+def release_plan_rings():
+    """Free the plan buffers varispeed_batch_dev keeps between calls (2 x lookahead slots of ~1.3 B per output sample each)."""
+    with _plan_rings_lock:
+        for dev in [d for d, r in _plan_rings.items() if not r["busy"]]:
+            del _plan_rings[dev]
+
+
+def varispeed_batch_dev(items, NT, dev=None, planners=None, group=None):
     """Software-pipelined fused resampling of a batch of device-resident work items on one GPU (the per-GPU
     inner loop of a file batch).  K_sinc launches follow one another on the current stream; the plans
     of the next `planners` items -- each ~20 small latency-bound kernels and a header read-back, 0.6 ms on an idle
@@ -218,7 +298,15 @@ def varispeed_batch_dev(items, NT, dev=None, planners=None):
     PREFETCH CONTRACT: `planners` items (default 3) are taken from the iterable AHEAD of the one being resampled, and their
     tensors are read until that item's output has been yielded -- a producer that recycles its input tensors needs a ring of
     at least planners + 1 of them (planners=1 is the one-ahead contract of r02-r04).  Memory: 2 x planners plan / aux buffer
-    pairs stay allocated, each sized for the eager plan's checkpoints (~1.3 B per output sample: 0.9 GB for a 60-min file).
+    pairs, each sized for the eager plan's checkpoints (~1.3 B per output sample: 0.9 GB for a 60-min file), stay allocated
+    BETWEEN calls as well (release_plan_rings() frees them).
+
+    GROUPS (r06): consecutive items of one class -- mono on unit strides, or interleaved stereo files -- are resampled by ONE merged
+    K_sinc launch per group (par_varispeed_fused_batch_f32; default: mono files below 400 M samples four at a time, everything
+    else one by one -- _group_size has the measurements; `group` = 1..8 overrides): a file's K_sinc is two or three kernels,
+    each ending in a tail of idle wave slots.  Outputs are bit-identical to the ungrouped launches; a group's
+    items are yielded together once its launch has been queued.  The prefetch contract grows to max(planners + group - 1, 2 x group)
+    items taken ahead (the next group is planned under the launch of this one): a recycling producer needs that many + group tensors.
 
     items: iterable of (sampletimes_t, speeds_t, sig_t) or (sampletimes_t, speeds_t, sig_t, sig_stride, len_in)
     with float64 / float32 device tensors; a 2-D sig_t is an interleaved (n, ch) file whose channels share the plan
@@ -236,10 +324,24 @@ def varispeed_batch_dev(items, NT, dev=None, planners=None):
         raise ValueError(f"planners / PAR_PLANNERS must be an integer 1..8, got {P!r}")
     if not 1 <= P <= 8:
         raise ValueError(f"planners / PAR_PLANNERS must be an integer 1..8, got {P}")
-    n_slots = 2 * P
+    if group is None and os.environ.get("PAR_GROUP"):        # (A/B sessions: 1 = the ungrouped launches of r05)
+        group = os.environ["PAR_GROUP"]
+    try:
+        group = None if group is None else int(group)
+    except (TypeError, ValueError):
+        raise ValueError(f"group / PAR_GROUP must be an integer 1..8, got {group!r}")
+    if group is not None and not 1 <= group <= 8:
+        raise ValueError(f"group / PAR_GROUP must be an integer 1..8, got {group!r}")
+    G_max = int(group) if group is not None else 8
+    def lookahead(g):
+        # a group's K_sinc is queued only once the NEXT group's items have been taken as well: whatever their producer queues on
+        # the main stream then precedes the long launch and their plans run under it (with g - 1 extra items only, half of the
+        # next group's plans started after the launch they should have hidden under: archive 165 -> 158 G, r06)
+        return P if g <= 1 else max(P + g - 1, 2 * g)
+    n_slots = 2 * lookahead(G_max)
     main = torch.cuda.current_stream(dev)
-    sides = [torch.cuda.Stream(device=dev) for _ in range(P)]
-    work, aux, free = [None] * n_slots, [None] * n_slots, [None] * n_slots
+    ring = _borrow_plan_ring(dev, n_slots, P)
+    sides, work, aux, free = ring["sides"], ring["work"], ring["aux"], ring["free"]
 
     def plan_item(item, j, ready):
         slot, stream = j % n_slots, sides[j % P]
@@ -266,11 +368,11 @@ def varispeed_batch_dev(items, NT, dev=None, planners=None):
     ahead = collections.deque()                          # (index, item, future of its plan), oldest first
     pool = ThreadPoolExecutor(max_workers=P)
     try:
-        j, k, done = 0, 0, False
+        j, k, done, g_now = 0, 0, False, 1
         while True:
             # take items BEFORE launching the next K_sinc: whatever their producer enqueues on the main stream (uploads,
             # generators) then precedes the long kernel instead of queueing behind it
-            while not done and len(ahead) < P:
+            while not done and len(ahead) < lookahead(g_now):
                 try:
                     item = next(it)
                 except StopIteration:
@@ -282,17 +384,29 @@ def varispeed_batch_dev(items, NT, dev=None, planners=None):
                 j += 1
             if not ahead:
                 return
-            k, item, fut = ahead.popleft()
-            plan = fut.result()
-            out_t = _resample_item(plan, item, NT, dev)
+            head = ahead[0][1]
+            cls = _group_class(head)
+            g_now = 1 if cls is None else (int(group) if group is not None else _group_size(head))
+            if g_now > 1 and not done and len(ahead) < g_now:
+                continue                                   # (take the rest of the group first)
+            grp = [ahead.popleft()]
+            while len(grp) < g_now and ahead and _group_class(ahead[0][1]) == cls:
+                grp.append(ahead.popleft())
+            plans = [fut.result() for _, _, fut in grp]
+            if len(grp) > 1 and all(p.fused_ok for p in plans) and int(NT) == 32:
+                outs = _resample_group(plans, [g_item for _, g_item, _ in grp], NT, dev)
+            else:
+                outs = [_resample_item(p, g_item, NT, dev) for p, (_, g_item, _) in zip(plans, grp)]
             ev = torch.cuda.Event()
             ev.record(main)
-            free[k % n_slots] = ev
-            yield k, out_t, plan
+            for (k, _, _), out_t, plan in zip(grp, outs, plans):
+                free[k % n_slots] = ev
+                yield k, out_t, plan
     finally:
         for _, _, fut in ahead:
             fut.cancel()
         pool.shutdown(wait=True)
+        ring["busy"] = False
 
 
 # pinned staging / output slots of varispeed_batch_host, kept between calls (page-locking 0.5 GB costs ~0.1 s)

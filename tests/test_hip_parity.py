@@ -1408,6 +1408,44 @@ def test_one_channel_of_an_interleaved_file_through_the_streaming_kernel(par):
     assert np.array_equal(np.isnan(out), (ind - 32 <= 400_000) & (400_000 < ind + 32))
 
 
+def test_grouped_launches_equal_file_by_file(par):
+    """par_varispeed_fused_batch_f32 / the batch driver's groups (r06): several planned files in one merged K_sinc launch -- mono
+    files of different lengths and curves, interleaved stereo files, a mixed sequence (classes change: groups end there), a file
+    too short for the streaming kernel inside a group -- give BIT-identical outputs to the ungrouped launches (each file's streams
+    are cut as in its own launch), and one of them is checked against the C oracle."""
+    from oracle import oracle_c as C
+    t = par.torch
+    R = par.resampling
+    rng = np.random.default_rng(77)
+    sr = 192000
+
+    def curve(n, k):
+        m = n // 256
+        st = np.linspace(0, n, m)
+        sp = 1.0 + 0.01 * np.sin(2 * np.pi * (2.0 + k) * st / sr + 0.7 + k)
+        return t.from_numpy(st).cuda(), t.from_numpy(sp).cuda(), st, sp
+    mono, stereo = [], []
+    for k, n in enumerate((300_000, 777_777, 4_000, 1_234_567, 650_001, 300_000, 411_111, 902_000, 333_333)):
+        st_t, sp_t, st, sp = curve(n, k)
+        mono.append((st_t, sp_t, t.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()))
+        if k == 1:
+            keep = (st, sp, n, mono[-1][2].cpu().numpy())
+    for k, n in enumerate((500_000, 250_001, 800_000, 612_345, 377_000)):
+        st_t, sp_t, _, _ = curve(n, 10 + k)
+        stereo.append((st_t, sp_t, t.from_numpy(rng.standard_normal((n, 2)).astype(np.float32)).cuda()))
+    for items in (mono, stereo, mono[:3] + stereo[:2] + mono[3:5] + stereo[2:]):
+        ref = [o.clone() for _, o, _ in R.varispeed_batch_dev(items, 32, group=1)]
+        for g in (None, 2, 8):
+            got = list(R.varispeed_batch_dev(items, 32, group=g))
+            assert [k for k, _, _ in got] == list(range(len(items)))
+            for (k, o, plan), want in zip(got, ref):
+                assert o.shape == want.shape and t.equal(o, want), (g, k)
+    st, sp, n, sig = keep
+    pos, _ = C.speed_to_pos(st, sp, n)
+    out1 = [o for _, o, _ in R.varispeed_batch_dev(mono, 32, group=8)][1].cpu().numpy()
+    assert relerr(out1, C.sinc(pos, sig, 32, threads=8)) < TOL
+
+
 def test_streaming_kernel_files_of_whole_tiles(par):
     """Files whose output is a whole number of 1024-output tiles (no partial tile: the streaming launch then has three end
     tiles instead of four), down to the smallest file the streaming kernel takes (four tiles: only tile 1 is streamed), and
