@@ -62,7 +62,8 @@ def port_cycles(l):
 def main():
     nch = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].isdigit() else "1"
     kind = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2].isdigit() else ("2" if nch == "1" else "0")
-    extra = [a for a in sys.argv[1:] if not a.isdigit()]
+    dump = next((a[7:] for a in sys.argv[1:] if a.startswith("--dump=")), None)     # --dump=STAGE: list that stage's instructions
+    extra = [a for a in sys.argv[1:] if not a.isdigit() and not a.startswith("--dump=")]
     tmp = tempfile.mkdtemp()
     src = os.path.join(B.CSRC, "sinc2.hip")
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + B.FLAGS + B.PER_FILE.get("sinc2.hip", []) + extra +
@@ -105,6 +106,8 @@ def main():
             tab.setdefault(st, {}).setdefault(cls, 0)
             tab[st][cls] += 1
             tab[st]["port"] = tab[st].get("port", 0.0) + port_cycles(l)
+            if dump == st and cls in ("valu", "trans", "mfma"):
+                print(f"   [{hi}] {cur[1]:5d} {port_cycles(l):4.1f}  {l}")
         n_mfma = sum(v.get("mfma", 0) for v in tab.values())
         what = "fc = 1" if n_mfma <= 16 else ("fc < 1, moment correction to order 5 (1 - fc <= 0.0105)" if n_mfma <= 29 else "fc < 1, moment correction to order 6")
         print(f"\nloop {hi} ({what}): listing lines {h}..{back}  [static; the placement's "
