@@ -66,6 +66,17 @@ def test_pure_host_entry_points_and_argument_errors():
     assert rc == 3 and "power of two" in _lib.last_error()      # PAR_ERR_UNSUPPORTED -> caller falls through
     with pytest.raises(_lib.ParUnsupported):
         _lib.check(rc)
+    # the multi-file launch (ABI 106): an empty batch is a no-op, a bad item is named before any HIP call
+    assert L.par_varispeed_fused_batch_f32(0, 0, None, 32, None) == 0
+    assert L.par_varispeed_fused_batch_f32(0, 2, None, 32, None) == 1 and "null items" in _lib.last_error()
+    arr = (_lib.FusedItem * 2)()
+    for f in arr:
+        f.speeds, f.work, f.aux, f.sig0, f.out0 = 8, 8, 8, 8, 8
+        f.m, f.max_out, f.len_out, f.sig_stride, f.len_in, f.out_stride = 4, 100, 50, 1, 60, 1
+    arr[1].len_out = 101
+    assert L.par_varispeed_fused_batch_f32(0, 2, arr, 32, None) == 1 and "item 1" in _lib.last_error() and "len_out" in _lib.last_error()
+    arr[1].len_out, arr[1].sig1 = 50, 8                            # a second input channel without a second output
+    assert L.par_varispeed_fused_batch_f32(0, 2, arr, 32, None) == 1 and "sig1 / out1" in _lib.last_error()
     # scratch sizing (host arithmetic): the fused ISTFT needs no frame array up to 2048 points when its overlap-add span fits
     # LDS; 4096 and 8192 points and over-long hops go through [n_frames][n_fft]
     assert L.par_istft_scratch_floats(100, 512, 32) == 0 and L.par_istft_scratch_floats(100, 2048, 512) == 0
