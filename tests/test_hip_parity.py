@@ -1599,6 +1599,19 @@ def test_batch_pipeline_equals_item_by_item(par):
     for (k, out, n_out), w in zip(got, want):
         assert n_out == w.numel() and t.equal(out, w), k
     assert list(R.varispeed_batch_dev([], 16)) == []
+    # the driver's plan buffers, slot events and planner streams live on between calls (r06): other planner counts, an abandoned
+    # generator (its ring stays busy: the next call makes a private one) and a release in between change nothing
+    for planners in (1, 5, 2):
+        got = [out.clone() for _, out, _ in R.varispeed_batch_dev(items, 16, planners=planners)]
+        assert all(t.equal(o, w) for o, w in zip(got, want)), planners
+    gen = R.varispeed_batch_dev(items, 16)
+    first = next(gen)[1].clone()
+    got = [out.clone() for _, out, _ in R.varispeed_batch_dev(items, 16)]          # while `gen` still holds the cached ring
+    assert t.equal(first, want[0]) and all(t.equal(o, w) for o, w in zip(got, want))
+    gen.close()
+    R.release_plan_rings()
+    got = [out.clone() for _, out, _ in R.varispeed_batch_dev(items, 16)]
+    assert all(t.equal(o, w) for o, w in zip(got, want))
 
 
 def test_degenerate_segment_behind_the_trim_is_harmless(par):
