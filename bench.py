@@ -344,8 +344,10 @@ def stereo_secondary(dev, sr=192000, seconds=600.0, nt=32):
     from pyaudiorestoration_amd import resampling
     del out, work, aux
     items = [(st, sp, sig)] * 48
-    # (warm-up over more items than the driver has plan slots -- 2 x planners = 6 -- so that every slot's buffers exist)
-    for _ in resampling.varispeed_batch_dev(items[:8], nt, dev=dev):
+    # warm-up: the whole batch once, untimed -- every plan slot's buffers exist afterwards, and the GPU is back at its working
+    # clocks (this leg follows seconds of host-only work, the CPU legs of the other secondaries: timed cold, the 65 ms of
+    # the batch read 5-8 % low -- tools/exp/archive_gap.py has the same call at 1.26-1.27 ms per file after 10 s of GPU work)
+    for _ in resampling.varispeed_batch_dev(items, nt, dev=dev):
         pass
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -49,3 +49,13 @@ for name, v in (("list, same item", v_list), ("generator, same item", v_gen_same
         for _, out, plan in resampling.varispeed_batch_dev(v(), 32, 0): tot += 2 * plan.len_out
         torch.cuda.synchronize(); reps.append(time.perf_counter() - t0); best = min(best, reps[-1])
     print(f"{name:50s} {best * 1e3 / F:.3f} ms per file = {tot / best / 1e9:.1f} G   reps: " + " ".join(f"{r * 1e3 / F:.3f}" for r in reps))
+import bench
+for rep in range(2):
+    r = bench.stereo_secondary(0)
+    print(f"bench.stereo_secondary: serial {r['ms_per_file']} ms, batched {r['batched_ms_per_file']} ms = {r['batched_Msamples/s']} M/s", flush=True)
+best, reps = 1e9, []
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _, out, plan in resampling.varispeed_batch_dev(v_list(), 32, 0): pass
+    torch.cuda.synchronize(); reps.append(time.perf_counter() - t0)
+print("list, same item, after stereo_secondary: " + " ".join(f"{r * 1e3 / F:.3f}" for r in reps))
