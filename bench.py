@@ -875,7 +875,10 @@ def main():
                          "warm_launches_before_timed": (30 if overlap else 0) + a.warmup,
                          "kernel_ms": round(k_ms, 4), "launches_per_step": n_launch // len(sinc_ms),
                          "samples_per_launch": int(samples_per_launch),
-                         "note": "achieved = 8 algorithmic B/output sample (4 B in + 4 B out) / HIP-event K_sinc time; "
+                         "note": "achieved = 8 algorithmic B/output sample (4 B in + 4 B out) / HIP-event K_sinc time (events on the launch stream "
+                                 "around the whole launch: for the streaming path its two or three kernels AND the dispatch gaps between them, "
+                                 "~0.1-0.2 ms beside the planners' kernels -- the per-kernel durations of profiles/r06_kernel_stats.txt sum to "
+                                 "that much less); "
                                  "traffic = PMC HBM bytes/sample (FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json: a separate "
                                  "rocprofv3 --pmc pass, stamped with the digest of the kernel sources it ran; `source.stale` says "
                                  "whether that is the code running now) at this run's rate" + (": signal + output + 1 B/sample cumsum checkpoints + tile halos"
