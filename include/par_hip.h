@@ -235,7 +235,7 @@ int par_varispeed_fused_f32(int device, const double* speeds, int64_t m, const v
 /* Which kernel runs: NT = 32 files of at least four 1024-output tiles and 4096 input samples -- mono on unit strides, ONE
  * channel of a two-channel interleaved file (sig_stride == 2, any out_stride: the reference's use_channels column views,
  * util/resampling.py:211-227; r06), or (par_varispeed_fused_stereo_f32) the two channels of an INTERLEAVED file (sig1 = sig0 + 1,
- * out1 = out0 + 1, strides 2, out0 8-byte aligned) -- take the streaming kernel (csrc/sinc2.hip: one wave per 8-24 tiles, the taps |n| >= 3 of both tap regimes
+ * out1 = out0 + 1, strides 2, out0 8-byte aligned) -- take the streaming kernel (csrc/sinc2.hip: one wave per 9-23 tiles, the taps |n| >= 3 of both tap regimes
  * as fixed filter banks on the matrix cores, fc < 1 through seven moment filters; stereo: one placement for both channels).  The
  * file's end tiles (first, last two, the partial one) are done the block kernel's way by the first workgroups of the same
  * launch; tiles the streams do not cover -- blocks outside the record model, window-centre ties, input float16 does not suit --

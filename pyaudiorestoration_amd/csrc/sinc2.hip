@@ -1,21 +1,22 @@
-// K_sinc, streaming form -- the north-star kernel: NT = 32 files, mono on unit strides (k_sinc_pipe<1>) or the two channels of
-// an interleaved stereo file (k_sinc_pipe<2>, r05).
+// K_sinc, streaming form -- the north-star kernel: NT = 32 files, mono on unit strides (k_sinc_pipe<1, 2> + <1, 1>: two kernels by
+// stream kind, r06), the two channels of an interleaved stereo file (k_sinc_pipe<2, 0>, r05), one channel of such a file (<2, 3>,
+// r06); k_sinc_pipe_n<...>: the same bodies over the streams of up to eight files in one launch (r06).
 //
 // Semantics: resampling.sinc_core (reference util/resampling.py:51-90), fused with the speed curve like k_sinc_fused (sinc.hip).
 //
-// Shape.  ONE WAVE = one worker that streams over 8-24 consecutive 1024-output tiles of the file; waves never meet (no
+// Shape.  ONE WAVE = one worker that streams over 9-23 (an odd number of) consecutive 1024-output tiles of the file; waves never meet (no
 // workgroup, no barrier).  A pass takes the next 128 outputs (two per lane), places them from the plan's block records, and
 // evaluates their windows against ONE 128-centre stretch of the input grid [ws, ws + 128), ws = the first centre rounded down
 // to 8; outputs whose centre lies beyond it (a handful: periods differ from 1 by <= 1.25 %) simply open the next pass.
 //   * taps 3 <= |n| <= 31 at fc = 1: a Farrow bank in q = shift^2 (minimax polynomials of (win_n/pi)/(n^2 - q),
 //     tools/sinc2_model.py) -- six fixed FIR filters on the input grid, evaluated for the pass's 128 centres on the matrix cores
-//     (v_mfma_f32_16x16x32_f16, signal and dominant filter pair split float16 hi + lo 2^-12: 15 MFMAs); the bank goes through
+//     (v_mfma_f32_16x16x32_f16, signal and dominant filter pair split float16 hi + lo 2^-12: 13 MFMAs since r06); the bank goes through
 //     the wave's own LDS and every output gathers its centre's row;
 //   * fc < 1 (read head slower than the output clock) = the fc = 1 result + a correction in g = 1 - fc whose taps are ENTIRE
 //     functions of g (n - s): all 63 taps enter through seven fixed MOMENT filters m_i = sum_n (-1)^n win_n (n/32)^i x[c + n]
-//     on the same image (18 more MFMAs) and a complex Horner in 32 pi g per output (tools/sinc3_model.py; 1e-7 of the peak for
+//     on the same image (18 more MFMAs; 15 to order 5 where every lane of the pass has g <= 0.0105, r06) and a complex Horner in 32 pi g per output (tools/sinc3_model.py; 1e-7 of the peak for
 //     g <= 0.0101, 5e-7 to 0.0125; steeper tiles go to the block kernel).  One image, per-lane g exact, no restarts;
-//   * the 25 constant fragments of both filter sets RESIDENT IN REGISTERS for the life of the wave;
+//   * the 25 constant fragments of both filter sets RESIDENT IN REGISTERS for the life of the wave (the fc = 1 kernel <1, 1>: its 10);
 //   * taps |n| <= 2 on the vector units with the lane's exact shift (two reciprocals per output);
 //   * the input streams through a ring per wave (8 chunks of 128 float32 samples, direct-to-LDS loads two passes ahead),
 //     converted ONCE to float16 hi / lo images for the banks -- no halo is ever re-read or re-converted; block records of the
