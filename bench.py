@@ -443,7 +443,7 @@ def config5_dry_run(a, ctx):
 
 def config5_batch(a, ctx):
     """BASELINE config 5 as the timed workload (N > 1, or --config5): 512 stereo 10-min files at 192 kHz, one step =
-    the whole archive.  Every rank pulls files (four per request) from the shared longest-first queue
+    the whole archive.  Every rank pulls files (four per request, the last 4 x ranks of them one by one) from the shared longest-first queue
     (multi_gpu.WorkQueue: a host-side fetch-add, no collective) and runs them through resampling.varispeed_batch_dev: one
     plan per file (each file has its own speed curve: phase 0.7 + file index) and ONE stereo K_sinc launch,
     the next file's plan on a side stream under it.  Inputs resident in HBM before the timed region: a ring of `--ring`
@@ -573,7 +573,7 @@ def config5_batch(a, ctx):
                                            "--config5 times a different workload (the mono 60-min file of BASELINE configs[1]): do "
                                            "not build a curve from it",
                        "NT": a.nt, "resident": f"ring of {a.ring} synthetic stereo files per GPU; each file's speed curve is made when the file is pulled (ring of {n_curves})",
-                       "queue": "one TCP-store fetch-add per 4 files",
+                       "queue": "one TCP-store fetch-add per 4 files; the last 4 x n_gpus files one per request (tail balance)",
                        "step": "per file: plan (device scans, block records; lazy: csrc/pos_plan.h) + ONE stereo fused K_sinc launch; "
                                "the plans of the next files are made by planner threads on side streams under K_sinc "
                                "(resampling.varispeed_batch_dev)"},

@@ -145,12 +145,16 @@ class WorkQueue:
     `grab` items with ONE fetch-add on a key of a c10d TCP store -- host-side, no collective, no GPU traffic.  `order`
     is the item list, longest first (equal-sized items: any order); `tag` separates queues (one per benchmark step).
     grab = 4: a rank asks rank 0's store thread once per four files (8 ranks x 1.8 ms per file would otherwise be
-    ~4400 requests/s); the tail imbalance is at most grab - 1 items per rank."""
+    ~4400 requests/s) -- except for the LAST grab x world items, which go out one by one (r06): the requests are tickets (one
+    fetch-add of 1 each) that every rank maps to the same ranges, so the tail imbalance is one item per rank, not grab - 1 (at 8 GPUs
+    a rank's share of the archive is 64 files: three files of imbalance were 5 % of the step)."""
     _store = None
 
     def __init__(self, ctx, order, tag, grab=4):
         self.ctx, self.order, self.key, self._next = ctx, list(order), f"par_queue_{tag}", 0
         self.grab, self._have = max(1, int(grab)), []
+        # tickets 0 .. n_big - 1 are chunks of `grab` items, every later ticket one item of the tail
+        self._n_big = max(0, (len(self.order) - self.grab * max(1, int(ctx.world))) // self.grab)
         if ctx.dist and WorkQueue._store is None:
             # rank 0 binds the first free port above the rendezvous port and tells the others through the gloo group
             addr, base = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29533"))
@@ -174,10 +178,15 @@ class WorkQueue:
         """Next item, or None when the queue is empty."""
         if not self._have:
             if self.ctx.dist:
-                k = WorkQueue._store.add(self.key, self.grab) - self.grab
+                t = WorkQueue._store.add(self.key, 1) - 1
             else:
-                k, self._next = self._next, self._next + self.grab
-            self._have = list(range(k, min(k + self.grab, len(self.order))))
+                t, self._next = self._next, self._next + 1
+            if t < self._n_big:
+                lo, hi = t * self.grab, (t + 1) * self.grab
+            else:
+                lo = self._n_big * self.grab + (t - self._n_big)
+                hi = lo + 1
+            self._have = list(range(lo, min(hi, len(self.order))))
             if not self._have:
                 return None
         return self.order[self._have.pop(0)]

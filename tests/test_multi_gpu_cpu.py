@@ -92,10 +92,24 @@ def test_bench_refuses_a_world_that_differs_from_gpus():
     assert out.returncode != 0 and "WORLD_SIZE=4" in out.stderr
 
 
-def test_work_queue_grabs_four_items_per_request():
+def test_work_queue_grabs_four_items_per_request_and_single_items_at_the_tail():
     ctx = multi_gpu.RankContext()
     q = multi_gpu.WorkQueue(ctx, list(range(10, 21)), "solo4")
-    assert q.grab == 4 and list(q) == list(range(10, 21)) and q._next == 16    # 3 requests served items, the 4th came back empty
+    # 11 items, one rank: one chunk of four, then the last grab x world = 4 (+ the 3 that fill no chunk) one by one, then an empty ticket
+    assert q.grab == 4 and q._n_big == 1 and list(q) == list(range(10, 21)) and q._next == 1 + 7 + 1
+
+    class Eight:                                       # the archive on eight ranks: 120 chunks of four, then 32 single files
+        dist, world, rank = None, 8, 0
+    q = multi_gpu.WorkQueue(Eight(), list(range(512)), "eight")
+    seen, sizes = [], []
+    while True:
+        first = q.pull()
+        if first is None:
+            break
+        got = [first] + [q.pull() for _ in range(len(q._have))]
+        seen += got
+        sizes.append(len(got))
+    assert seen == list(range(512)) and sizes == [4] * 120 + [1] * 32
 
 
 def test_numa_binding_helpers(tmp_path):
