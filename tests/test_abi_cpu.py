@@ -34,6 +34,14 @@ def test_library_exports_every_declared_symbol():
     assert exported == syms, sorted(set(exported) ^ set(syms))
 
 
+def test_documents_name_the_abi_version_the_library_reports():
+    """DESIGN / INTEGRATION / the header speak of the ABI version par_version() returns (a bump must reach the documents)"""
+    from pyaudiorestoration_amd import _lib
+    v = str(_lib.lib().par_version())
+    for name in ("DESIGN.md", "INTEGRATION.md", os.path.join("include", "par_hip.h")):
+        assert ("ABI " + v in open(os.path.join(ROOT, name)).read() or "version " + v in open(os.path.join(ROOT, name)).read()), name
+
+
 def test_product_sources_read_no_environment_knobs():
     """experiment knobs (getenv, timing #ifs) are compiled only into -DPAR_EXPERIMENT builds"""
     csrc = os.path.join(ROOT, "pyaudiorestoration_amd", "csrc")
