@@ -27,7 +27,7 @@ def _worker(dev, jobs, args, results):
     release the GIL) on a helper thread while the current one is on the GPU."""
     from concurrent.futures import ThreadPoolExecutor
     import torch
-    from . import io_ops, pipeline, resampling
+    from . import _dev, io_ops, pipeline, resampling
     torch.cuda.set_device(dev)
 
     def take():
@@ -60,7 +60,7 @@ def _worker(dev, jobs, args, results):
                     t0, f0, t1, f1 = args.trail
                     r = pipeline.respeed(signal, sr, [(t0, f0), (t1, f1)], args.fft_size, args.hop, 1, args.mode,
                                          args.tolerance, (0, args.lowpass), quality, device=dev)
-                    out = r["output"].cpu().numpy()
+                    out = _dev.to_host(r["output"])
                     io_ops.write_wav_float(f"{os.path.splitext(path)[0]}_res{suffix}.wav", out, sr)
                     np.save(f"{os.path.splitext(path)[0]}_speed{suffix}.npy", r["speed_curve"])
                 else:

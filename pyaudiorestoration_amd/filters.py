@@ -113,7 +113,7 @@ def butter_bandpass_filter(data, lowcut, highcut, fs, order=5):
     if _design(lowcut, highcut, fs, order) is None:
         return data
     y = bandpass_dev(data, lowcut, highcut, fs, order)
-    return y if isinstance(data, torch.Tensor) else y.cpu().numpy()
+    return y if isinstance(data, torch.Tensor) else _dev.to_host(y)
 
 
 def moving_average(a, n=3):

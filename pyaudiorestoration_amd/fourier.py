@@ -98,7 +98,7 @@ def hip_rfft2(n_fft, step, window, x, zeropad, _mode=0):
         x_t = _dev.to_dev(x, torch.float32, dev)
         w_t = _dev.to_dev(window, torch.float32, dev)
         res = stft_dev(x_t, n_fft, step, w_t, zeropad, _mode, dev=dev)
-        return res.cpu().numpy()
+        return _dev.to_host(res)
 
 
 def stft(x, n_fft=1024, step=512, window_name='blackmanharris', zeropad=1, _mode=0):
@@ -168,7 +168,8 @@ def istft(stft_matrix, hop_length=None, win_length=None, window_name='blackmanha
     dev = _dev.device_index(None)
     S = np.asarray(stft_matrix)
     spec_t = _dev.to_dev(S.T, torch.complex64, dev).T
-    y = istft_dev(spec_t, hop_length, _dev.to_dev(window, torch.float32, dev), length, dev).cpu().numpy()
+    y = istft_dev(spec_t, hop_length, _dev.to_dev(window, torch.float32, dev), length, dev)
+    y = _dev.to_host(y)
     if dtype is not None:
         y = y.astype(dtype)
     return y

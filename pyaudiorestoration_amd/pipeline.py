@@ -366,7 +366,7 @@ def heal_dropouts(signal, sr, markers, fft_size=512, hop=32, channels=None, devi
     for c in channels:
         gain, plan = heal_dropouts_dev(sig_t, n, ch, c, geometry, fft_size, hop, out_t, dev, sparse, gain, plan)
     out = np.empty(sig2d.shape, dtype=sig2d.dtype)                          # channels not selected stay uninitialised, like the reference's np.empty
-    got = out_t.cpu().numpy()
+    got = _dev.to_host(out_t)
     for c in channels:
         out[:, c] = got[:, c]
     return out
@@ -511,7 +511,7 @@ def heal_heuristic(signal, sr, fft_size=512, hop=64, max_width=0.02, max_slope=0
             y_t = filters.bandpass_batch_dev(out_t, f_lo, f_hi, sr, order=3, dev=dev)
             _lib.check(L.par_accumulate_f64_f32(dev, _dev.ptr(flat), ch, ch, n, _dev.ptr(y_t), _dev.stream_ptr(dev)))
     res = sig_t if signal.ndim == 2 else sig_t[:, 0]
-    return res if was_tensor else res.cpu().numpy()
+    return res if was_tensor else _dev.to_host(res)
 
 
 # ---------------------------------------------------------------------- tape synchronisation (pytapesynch)

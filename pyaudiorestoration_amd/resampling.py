@@ -454,7 +454,7 @@ def varispeed_batch_host(items, NT, dev=None):
                 in_done[slot].synchronize()              # the upload that last read this staging slot is through
             pin_in[slot] = pinned(pin_in[slot], src.numel())
             stage = pin_in[slot][:src.numel()].view(src.shape)
-            stage.copy_(src)
+            _dev.host_copy(stage, src)                   # (on the staging threads: one core's memcpy was this loop's pace, r06)
             src = stage
         with torch.cuda.stream(up):
             st_t = torch.from_numpy(st).to(device, non_blocking=False)
@@ -557,7 +557,7 @@ def speed_to_pos(sampletimes, speeds, num_imput_samples):
     dev = _dev.device_index(None)
     st = _dev.to_dev(np.asarray(sampletimes, dtype=np.float64), torch.float64, dev)
     sp = _dev.to_dev(np.asarray(speeds, dtype=np.float64), torch.float64, dev)
-    return speed_to_pos_dev(st, sp, num_imput_samples, dev).cpu().numpy()
+    return _dev.to_host(speed_to_pos_dev(st, sp, num_imput_samples, dev))
 
 
 # ----------------------------------------------------------------------------- interpolation
@@ -621,14 +621,15 @@ def sinc_wrapper(sample_at, signal, lowpass, NT):
         return np.empty(0, np.float32)
     if len(sample_at) == 1:
         raise UnboundLocalError("local variable 'period_to' referenced before assignment")   # reference behaviour
-    sample_at = np.asarray(sample_at, dtype=np.float64)
-    if not np.isfinite(sample_at).all():            # the reference's int(round(p)) raises on these
-        if np.isnan(sample_at).any():
+    pos_t = _dev.to_dev(np.asarray(sample_at, dtype=np.float64), torch.float64, dev)
+    # the reference's int(round(p)) raises on non-finite positions -- looked for in HBM (a host pass over 115 M positions was
+    # 40 % of this call, r06)
+    if not bool(torch.isfinite(pos_t).all()):
+        if bool(torch.isnan(pos_t).any()):
             raise ValueError("cannot convert float NaN to integer")
         raise OverflowError("cannot convert float infinity to integer")
-    pos_t = _dev.to_dev(np.asarray(sample_at, dtype=np.float64), torch.float64, dev)
     sig_t = _dev.to_dev(signal, torch.float32, dev)
-    return sinc_resample_dev(pos_t, sig_t, NT, dev=dev).cpu().numpy()
+    return _dev.to_host(sinc_resample_dev(pos_t, sig_t, NT, dev=dev))
 
 
 def sinc_wrapper_mt(output, sample_at, signal, lowpass, NT):

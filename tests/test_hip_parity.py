@@ -2754,3 +2754,38 @@ def test_heuristic_repair_against_the_reference(par):
     x, sr_d, _ = io_ops.read_file(os.path.join(GOLD, "dropouts_sample.flac"))
     y = par.pipeline.heal_heuristic(x, sr_d, 512, 64)
     assert float(np.max(np.abs(y[::3] - g["gui_every3"]))) < TOL * float(g["gui_peak"])
+
+
+def test_staged_host_transfers_are_exact(par):
+    """_dev.to_dev / _dev.to_host move large pageable numpy arrays through a ring of pinned chunks filled / drained by threads (r06):
+    byte-exact for sizes around the chunk and ring boundaries, for the widening upload, into a caller's array, and when two
+    threads ask at once (the second one takes the plain copy)."""
+    import threading
+    t = par.torch
+    from pyaudiorestoration_amd import _dev
+    rng = np.random.default_rng(12)
+    C, R = _dev._STAGE_CHUNK, _dev._STAGE_RING
+    for nbytes in (_dev._STAGE_MIN, _dev._STAGE_MIN + 4, C * R + 8, C * (R + 1) - 4, C * (2 * R + 3) + 12):
+        a = rng.integers(0, 2 ** 31, nbytes // 4, dtype=np.int32).view(np.float32)
+        d = _dev.to_dev(a, t.float32, 0)
+        assert d.dtype == t.float32 and np.array_equal(d.view(t.int32).cpu().numpy(), a.view(np.int32)), nbytes
+        back = _dev.to_host(d)
+        assert back.dtype == np.float32 and np.array_equal(back.view(np.int32), a.view(np.int32)), nbytes
+        into = np.empty_like(a)
+        assert _dev.to_host(d, into) is into and np.array_equal(into.view(np.int32), a.view(np.int32))
+    a16 = rng.integers(-30000, 30000, 40_000_001, dtype=np.int16)            # widening: the narrow form travels
+    assert np.array_equal(_dev.to_dev(a16, t.float32, 0).cpu().numpy(), a16.astype(np.float32))
+    a64 = rng.standard_normal(9_000_001)
+    assert np.array_equal(_dev.to_host(_dev.to_dev(a64, t.float64, 0)), a64)
+    a2 = rng.standard_normal((5_000_001, 4)).astype(np.float32)
+    assert np.array_equal(_dev.to_host(_dev.to_dev(a2[:, ::2], t.float32, 0)), a2[:, ::2])     # strided source, 2-D
+    res = [None, None]
+
+    def up(k):
+        res[k] = _dev.to_dev(a64 + k, t.float64, 0).cpu().numpy()
+    th = [threading.Thread(target=up, args=(k,)) for k in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert np.array_equal(res[0], a64) and np.array_equal(res[1], a64 + 1)

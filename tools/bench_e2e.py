@@ -30,16 +30,20 @@ def wall(fn, reps=3):
     return (time.perf_counter() - t0) / reps, out
 
 
-def flow_pageable():
-    sig_t = _dev.to_dev(sig, torch.float32, 0)
+def flow_pageable(staged=True):
+    sig_t = _dev.to_dev(sig, torch.float32, 0) if staged else torch.from_numpy(sig).to("cuda:0")
     st_t = _dev.to_dev(curve[:, 0] * sr, torch.float64, 0)
     sp_t = _dev.to_dev(np.ascontiguousarray(curve[:, 1]), torch.float64, 0)
     plan = resampling.speed_plan_dev(st_t, sp_t, n, fused=True)
-    return resampling.varispeed_fused_dev(plan, sig_t, 32).cpu().numpy()
+    out = resampling.varispeed_fused_dev(plan, sig_t, 32)
+    return _dev.to_host(out) if staged else out.cpu().numpy()
 
 
 dt, y = wall(flow_pageable)
-res["run()-style flow, pageable numpy in/out"] = {"s": round(dt, 4), "Msamples/s": round(len(y) / dt / 1e6, 1)}
+res["run()-style flow, pageable numpy in/out (r06: through the pinned chunk ring, _dev.to_dev / to_host)"] = {"s": round(dt, 4), "Msamples/s": round(len(y) / dt / 1e6, 1)}
+dt, y0 = wall(lambda: flow_pageable(False))
+res["the same with the runtime's own pageable copies (r05)"] = {"s": round(dt, 4), "Msamples/s": round(len(y0) / dt / 1e6, 1)}
+assert np.array_equal(y, y0)
 
 pin_in = torch.from_numpy(sig).pin_memory()
 pin_out = torch.empty(int(n * 1.02) + 1024, dtype=torch.float32).pin_memory()
