@@ -139,10 +139,11 @@ def to_host(t, out=None):
     """Device tensor -> numpy array (`out`: a contiguous array of the same shape and dtype to fill).  Large tensors leave through
     the pinned ring."""
     t = t.contiguous()
+    np_dtype = torch.empty(0, dtype=t.dtype).numpy().dtype
     if out is None:
-        out = np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=t.dtype).numpy().dtype)
+        out = np.empty(tuple(t.shape), dtype=np_dtype)
     nbytes = t.numel() * t.element_size()
-    if not (t.is_cuda and nbytes >= _STAGE_MIN and out.flags.c_contiguous and out.nbytes == nbytes and
+    if not (t.is_cuda and nbytes >= _STAGE_MIN and out.flags.c_contiguous and out.dtype == np_dtype and out.nbytes == nbytes and
             _d2h_staged(t, out, t.device.index)):
         out[...] = t.cpu().numpy()
     return out
