@@ -138,6 +138,8 @@ def host_copy(dst, src):
 def to_host(t, out=None):
     """Device tensor -> numpy array (`out`: a contiguous array of the same shape and dtype to fill).  Large tensors leave through
     the pinned ring."""
+    if out is None and t.ndim == 2 and not t.is_contiguous() and t.T.is_contiguous():
+        return to_host(t.T).T           # a transposed view (stft_dev's frame-major spectrogram) keeps its memory order, like .cpu()
     t = t.contiguous()
     np_dtype = torch.empty(0, dtype=t.dtype).numpy().dtype
     if out is None:

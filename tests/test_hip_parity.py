@@ -2779,6 +2779,9 @@ def test_staged_host_transfers_are_exact(par):
     assert np.array_equal(_dev.to_host(_dev.to_dev(a64, t.float64, 0)), a64)
     a2 = rng.standard_normal((5_000_001, 4)).astype(np.float32)
     assert np.array_equal(_dev.to_host(_dev.to_dev(a2[:, ::2], t.float32, 0)), a2[:, ::2])     # strided source, 2-D
+    tv = t.arange(30_000_000, dtype=t.float32, device="cuda").reshape(6_000_000, 5).T      # a transposed view comes back as one
+    hv = _dev.to_host(tv)
+    assert hv.shape == (5, 6_000_000) and hv.T.flags.c_contiguous and np.array_equal(hv, tv.cpu().numpy())
     res = [None, None]
 
     def up(k):
