@@ -10,59 +10,76 @@ import numpy as np
 
 
 def read_wav(path):
+    """RIFF/WAVE -> (float32 (frames, channels), sr, channels).  The chunk headers are walked with seeks and the data chunk is read
+    ONCE, straight into the array (r06: the whole file as bytes, a slice of it and a converted copy were three passes over 460 MB
+    for a 10-min file)."""
     with open(path, "rb") as f:
-        data = f.read()
-    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
-        raise ValueError(f"{path}: not a RIFF/WAVE file")
-    pos = 12
-    fmt = None
-    raw = None
-    while pos + 8 <= len(data):
-        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
-        body = data[pos + 8:pos + 8 + size]
-        if cid == b"fmt ":
-            tag, ch, sr, _, _, bits = struct.unpack("<HHIIHH", body[:16])
-            if tag == 0xFFFE and len(body) >= 26:          # WAVE_FORMAT_EXTENSIBLE: real tag in the GUID
-                tag = struct.unpack("<H", body[24:26])[0]
-            fmt = (tag, ch, sr, bits)
-        elif cid == b"data":
-            raw = body
-        pos += 8 + size + (size & 1)
-    if fmt is None or raw is None:
-        raise ValueError(f"{path}: missing fmt/data chunk")
-    tag, ch, sr, bits = fmt
+        head = f.read(12)
+        if head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+            raise ValueError(f"{path}: not a RIFF/WAVE file")
+        size_of_file = os.fstat(f.fileno()).st_size
+        fmt = None
+        data_at = data_size = None
+        pos = 12
+        while pos + 8 <= size_of_file:
+            f.seek(pos)
+            hdr = f.read(8)
+            if len(hdr) < 8:
+                break
+            cid, size = hdr[:4], struct.unpack("<I", hdr[4:8])[0]
+            if cid == b"fmt ":
+                body = f.read(min(size, 64))
+                tag, ch, sr, _, _, bits = struct.unpack("<HHIIHH", body[:16])
+                if tag == 0xFFFE and len(body) >= 26:          # WAVE_FORMAT_EXTENSIBLE: real tag in the GUID
+                    tag = struct.unpack("<H", body[24:26])[0]
+                fmt = (tag, ch, sr, bits)
+            elif cid == b"data":
+                data_at, data_size = pos + 8, min(size, size_of_file - pos - 8)      # (a truncated file: what is there)
+            pos += 8 + size + (size & 1)
+        if fmt is None or data_at is None:
+            raise ValueError(f"{path}: missing fmt/data chunk")
+        tag, ch, sr, bits = fmt
+        kinds = {(3, 32): "<f4", (3, 64): "<f8", (1, 16): "<i2", (1, 32): "<i4", (1, 24): np.uint8}
+        if (tag, bits) not in kinds:
+            raise ValueError(f"{path}: unsupported WAV format tag={tag} bits={bits}")
+        dt = np.dtype(kinds[(tag, bits)])
+        f.seek(data_at)
+        raw = np.fromfile(f, dtype=dt, count=data_size // dt.itemsize)
     if tag == 3 and bits == 32:
-        x = np.frombuffer(raw, dtype="<f4").astype(np.float32)
+        x = raw.astype(np.float32, copy=False)
     elif tag == 3 and bits == 64:
-        x = np.frombuffer(raw, dtype="<f8").astype(np.float32)
+        x = raw.astype(np.float32)
     elif tag == 1 and bits == 16:
-        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+        x = raw.astype(np.float32) / 32768.0
     elif tag == 1 and bits == 32:
-        x = (np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
-    elif tag == 1 and bits == 24:
-        b = np.frombuffer(raw[:len(raw) // 3 * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        x = (raw.astype(np.float64) / 2147483648.0).astype(np.float32)
+    else:                                                      # 24-bit PCM
+        b = raw[:len(raw) // 3 * 3].reshape(-1, 3).astype(np.int32)
         v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
         v = np.where(v & 0x800000, v - 0x1000000, v)
         x = (v / 8388608.0).astype(np.float32)
-    else:
-        raise ValueError(f"{path}: unsupported WAV format tag={tag} bits={bits}")
     frames = len(x) // ch
     return x[:frames * ch].reshape(frames, ch), sr, ch
 
 
 def write_wav_float(path, signal, sr):
-    """IEEE float32 WAV (what sf.SoundFile(..., subtype='FLOAT') writes)."""
+    """IEEE float32 WAV (what sf.SoundFile(..., subtype='FLOAT') writes): the header, then the samples from the array's own
+    memory (r06: no bytes copies of the payload)."""
     signal = np.asarray(signal, dtype=np.float32)
     if signal.ndim == 1:
         signal = signal[:, None]
     frames, ch = signal.shape
-    payload = np.ascontiguousarray(signal, dtype="<f4").tobytes()
+    payload = np.ascontiguousarray(signal, dtype="<f4")
+    nbytes = payload.nbytes
+    if nbytes + 50 >= 1 << 32:
+        raise ValueError(f"{path}: {nbytes} bytes of samples do not fit a RIFF/WAVE file (4 GiB)")
     fmt = struct.pack("<HHIIHH", 3, ch, int(sr), int(sr) * ch * 4, ch * 4, 32)
     fact = struct.pack("<I", frames)
-    body = (b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"fact" + struct.pack("<I", 4) + fact
-            + b"data" + struct.pack("<I", len(payload)) + payload)
+    head = (b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"fact" + struct.pack("<I", 4) + fact
+            + b"data" + struct.pack("<I", nbytes))
     with open(path, "wb") as f:
-        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+        f.write(b"RIFF" + struct.pack("<I", len(head) + nbytes) + head)
+        payload.tofile(f)
 
 
 def read_file(audio_path):

@@ -165,6 +165,37 @@ def test_wav_io_roundtrip(tmp_path):
     io_ops.write_file(p, x[:, 0], 44100, 1, suffix="_res")
     y, sr, ch = io_ops.read_file(str(tmp_path / "a_res.wav"))
     assert ch == 1 and np.array_equal(y[:, 0], x[:, 0])
+    # every sample format the reader takes (libsndfile's dtype="float32" scalings), an unknown chunk with an odd size in front of
+    # the data, WAVE_FORMAT_EXTENSIBLE, and a data chunk that claims more than the file holds
+    import struct
+    rng = np.random.default_rng(1)
+
+    def wav(tag, bits, ch, payload, extensible=False, junk=b"", claim=None):
+        fmt = struct.pack("<HHIIHH", 0xFFFE if extensible else tag, ch, 48000, 48000 * ch * bits // 8, ch * bits // 8, bits)
+        if extensible:
+            fmt += struct.pack("<HHI", 22, bits, 3) + struct.pack("<H", tag) + bytes(14)
+        body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt
+        if junk:
+            body += b"LIST" + struct.pack("<I", len(junk)) + junk + (b"\0" if len(junk) & 1 else b"")
+        body += b"data" + struct.pack("<I", len(payload) if claim is None else claim) + payload
+        q = str(tmp_path / "f.wav")
+        with open(q, "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+        return io_ops.read_file(q)
+    i16 = rng.integers(-32768, 32767, (500, 2), dtype=np.int16)
+    y, sr, ch = wav(1, 16, 2, i16.tobytes(), junk=b"odd")
+    assert sr == 48000 and ch == 2 and y.dtype == np.float32 and np.array_equal(y, i16.astype(np.float32) / 32768.0)
+    i32 = rng.integers(-2 ** 31, 2 ** 31 - 1, (300, 1), dtype=np.int32)
+    assert np.array_equal(wav(1, 32, 1, i32.tobytes())[0], (i32.astype(np.float64) / 2147483648.0).astype(np.float32))
+    i24 = rng.integers(-2 ** 23, 2 ** 23 - 1, (400, 3), dtype=np.int32)
+    b24 = np.stack([(i24 >> s) & 0xFF for s in (0, 8, 16)], axis=-1).astype(np.uint8).tobytes()
+    assert np.array_equal(wav(1, 24, 3, b24, extensible=True)[0], (i24 / 8388608.0).astype(np.float32))
+    f64 = rng.standard_normal((200, 2))
+    assert np.array_equal(wav(3, 64, 2, f64.tobytes())[0], f64.astype(np.float32))
+    y, _, _ = wav(3, 32, 2, x.tobytes(), claim=10 ** 9)
+    assert np.array_equal(y, x)
+    with pytest.raises(ValueError, match="unsupported"):
+        wav(1, 8, 1, bytes(100))
 
 
 def test_host_filter_design_matches_reference_branches():
