@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import inputs
 from pyaudiorestoration_amd import io_ops, resampling
-logging.basicConfig(level=logging.INFO, format="%(message)s")
+logging.basicConfig(level=logging.DEBUG, format="%(message)s")
 sr, seconds = 192000, float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
 ch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 n = int(sr * seconds)
