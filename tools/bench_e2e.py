@@ -67,6 +67,18 @@ dt, y3 = wall(lambda: resampling.sinc_wrapper(pos, sig, 0, 32), 2)
 res["sinc_wrapper(sample_at f64, signal) operator slot"] = {"s": round(dt, 4), "Msamples/s": round(len(y3) / dt / 1e6, 1)}
 assert np.array_equal(y, y2.numpy())
 
+# operator slot #1 at scale: numpy signal in, numpy magnitude spectrogram out (1024 / 256: 8 B down per sample in)
+from pyaudiorestoration_amd import fourier
+dt, m1 = wall(lambda: fourier.get_mag(sig, 1024, 256, "blackmanharris"), 2)
+res["get_mag(numpy signal) -> numpy magnitudes, 1024/256 (operator slot #1; staged transfers)"] = {"s": round(dt, 4), "Msamples/s": round(n / dt / 1e6, 1)}
+keep = _dev._STAGE_MIN
+_dev._STAGE_MIN = 1 << 62
+dt, m0 = wall(lambda: fourier.get_mag(sig, 1024, 256, "blackmanharris"), 2)
+_dev._STAGE_MIN = keep
+res["the same with the runtime's own pageable copies (r05)"  + " "] = {"s": round(dt, 4), "Msamples/s": round(n / dt / 1e6, 1)}
+assert np.array_equal(m1, m0)
+del m1, m0
+
 # a batch of host files through varispeed_batch_host: upload of file k+1 under the download of file k
 n_files = 12
 st_np, sp_np = curve[:, 0] * sr, np.ascontiguousarray(curve[:, 1])
