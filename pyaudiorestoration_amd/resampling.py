@@ -636,14 +636,14 @@ def sinc_wrapper_mt(output, sample_at, signal, lowpass, NT):
     """In-place variant: fills caller-owned `output` (may be a strided column view), returns None.
     Uses the canonical period definition (every chunk boundary reads the true next position), so the
     result does not depend on os.cpu_count() the way the reference's chunked threads do."""
-    output[:] = sinc_wrapper(sample_at, signal, lowpass, NT)
+    _dev.host_assign(output, sinc_wrapper(sample_at, signal, lowpass, NT))      # (a column view: scattered on the staging threads)
 
 
 def sinc_core(sample_at, signal, lowpass, output, win_func, N):
     """Reference-signature entry (util/resampling.py:52): NT from len(N); window/N are recomputed on
     the device side from NT exactly as sinc_wrapper builds them."""
     NT = (len(N) - 1) // 2
-    output[:] = sinc_wrapper(sample_at, signal, lowpass, NT)
+    _dev.host_assign(output, sinc_wrapper(sample_at, signal, lowpass, NT))
 
 
 # ----------------------------------------------------------------------------- run

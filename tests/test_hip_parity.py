@@ -2782,6 +2782,13 @@ def test_staged_host_transfers_are_exact(par):
     tv = t.arange(30_000_000, dtype=t.float32, device="cuda").reshape(6_000_000, 5).T      # a transposed view comes back as one
     hv = _dev.to_host(tv)
     assert hv.shape == (5, 6_000_000) and hv.T.flags.c_contiguous and np.array_equal(hv, tv.cpu().numpy())
+    # column views of an interleaved file (the reference's signal[:, ch] / output[:, k]): gathered and scattered on the staging threads
+    inter = rng.standard_normal((12_000_001, 2)).astype(np.float32)
+    assert np.array_equal(_dev.to_dev(inter[:, 1], t.float32, 0).cpu().numpy(), inter[:, 1])
+    assert np.array_equal(_dev.contiguous(inter[:, 0], np.float64), inter[:, 0].astype(np.float64))
+    back2 = np.zeros_like(inter)
+    _dev.host_assign(back2[:, 1], inter[:, 0])
+    assert np.array_equal(back2[:, 1], inter[:, 0]) and not back2[:, 0].any()
     res = [None, None]
 
     def up(k):
